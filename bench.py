@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Benchmark of the message-passing hot path: edges/sec (fwd+bwd), RGCN H=320 L=4 on an R-MAT batch
+shaped like BASELINE.json configs[1] (30k nodes, 900k edges, 4 edge types), 1..8 MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: bucket the batch's edges (ops.Graph), GNN
+forward (initial projection, 4 RGCN layers, dropout, the Dense after layer 0 - the op sequence of
+tf2_gnn_train RGCN PPI) and the full backward (all weight gradients).  Inputs are
+resident in HBM before the timed region.  Multi-GPU: graph batches are independent, each rank
+processes its own batch of the same shape (weak scaling, no data-path collective); one RCCL
+all-gather collects the per-rank edge counts / times for the metric.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel, measured live with HIP
+events on the launch stream; `cpu_baseline` times the CPU oracle (reference op sequence, torch-CPU)
+on rank 0 when N == 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_FP32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # BASELINE.json configs[1] shape + metric's model (RGCN H=320, 4 layers, PPI_RGCN.json hypers)
+    "rmat30k": dict(num_nodes=30000, num_edges=900000, num_edge_types=4, feature_dim=320, hidden_dim=320, num_layers=4),
+    # small variant for smoke runs
+    "tiny": dict(num_nodes=2000, num_edges=40000, num_edge_types=4, feature_dim=64, hidden_dim=64, num_layers=4),
+}
+
+
+def ppi_rgcn_params(hidden_dim, num_layers):
+    """tf2_gnn/cli_utils/default_hypers/PPI_RGCN.json:6-19 on top of GNN/RGCN defaults."""
+    from tf2_gnn_amd.layers import GNN
+
+    p = GNN.get_default_hyperparameters("rgcn")
+    p.update(
+        {
+            "num_layers": num_layers,
+            "hidden_dim": hidden_dim,
+            "use_target_state_as_input": False,
+            "normalize_by_num_incoming": True,
+            "num_edge_MLP_hidden_layers": 0,
+            "layer_input_dropout_rate": 0.1,
+            "dense_every_num_layers": 10000,
+            "residual_every_num_layers": 10000,
+            "global_exchange_every_num_layers": 10000,
+            "use_inter_layer_layernorm": False,
+            "initial_node_representation_activation": "tanh",
+            "dense_intermediate_layer_activation": "tanh",
+            "message_activation_function": "ReLU",
+            "aggregation_function": "sum",
+        }
+    )
+    return p
+
+
+def time_kernel(fn, iters=20, warmup=3):
+    """average launch duration in ms, HIP events on the current (= launch) stream"""
+    for _ in range(warmup):
+        fn()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def cpu_baseline(wl, feats, adjs, params, max_seconds=90.0):
+    """The reference's CPU cost structure: oracle restatement (per-edge gathers and matmuls, concat,
+    scatter-add; torch-CPU fp32, autograd for the backward), all host cores."""
+    from oracle import tf2gnn_oracle as orc
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    H, NL, L = wl["hidden_dim"], wl["num_layers"], wl["num_edge_types"]
+    g = torch.Generator().manual_seed(0)
+
+    def glorot(i, o):
+        lim = (6.0 / (i + o)) ** 0.5
+        return ((torch.rand((i, o), generator=g) * 2 - 1) * lim).requires_grad_(True)
+
+    weights = {
+        "initial_projection": glorot(wl["feature_dim"], H),
+        "mp": [{"edge_mlps": [[glorot(H, H)] for _ in range(L)]} for _ in range(NL)],
+        "dense": {0: glorot(H, H)},
+        "layernorm": [],
+    }
+    leaves = [weights["initial_projection"], weights["dense"][0]] + [w[0] for m in weights["mp"] for w in m["edge_mlps"]]
+    X = torch.from_numpy(feats)
+    adj_t = [torch.from_numpy(a) for a in adjs]
+    E = sum(a.shape[0] for a in adjs)
+
+    def step(layers):
+        p = dict(params, num_layers=layers)
+        out, _ = orc.gnn_internal_call(p, weights, X, adj_t)
+        torch.autograd.grad(out.sum(), leaves[:2] + leaves[2 : 2 + layers * L])
+
+    # calibrate on one layer, then time as many layers as fit the budget (scaled to the full stack)
+    t0 = time.perf_counter()
+    step(1)
+    t1 = time.perf_counter() - t0
+    layers = NL if t1 * NL * 1.2 < max_seconds else max(1, int(max_seconds / (1.2 * t1)))
+    t0 = time.perf_counter()
+    step(layers)
+    t = time.perf_counter() - t0
+    # the initial projection / dense glue is <2% of a layer: scale linearly in the number of layers
+    t_full = t * NL / layers
+    return {
+        "value": E / t_full,
+        "unit": "edges/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{layers} of {NL} RGCN layers fwd+bwd on the full batch ({t:.2f} s measured"
+        f"{'' if layers == NL else ', scaled to ' + str(NL) + ' layers'}); torch-CPU fp32 restatement of the "
+        "reference op sequence (TensorFlow unavailable offline)",
+        "seconds_per_step": t_full,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rmat30k", choices=sorted(WORKLOADS))
+    ap.add_argument("--reuse-graph", action="store_true", help="bucket the edges once, outside the timed steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a ROCm device (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    wl = WORKLOADS[args.workload]
+    V, E, L, D, H, NL = (wl[k] for k in ("num_nodes", "num_edges", "num_edge_types", "feature_dim", "hidden_dim", "num_layers"))
+    feats, adjs = make_synthetic_batch(V, E, L, D, seed=1 + rank)  # timing seeds 1..
+    X = torch.from_numpy(feats).to(dev)
+    adj_dev = tuple(torch.from_numpy(a).to(dev) for a in adjs)
+    n2g = torch.zeros(V, dtype=torch.int32, device=dev)
+    params = ppi_rgcn_params(H, NL)
+    set_seed(0)
+    gnn = GNN(params)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
+    graph = ops.Graph(adj_dev, V) if args.reuse_graph else None
+
+    def step():
+        g = graph if graph is not None else ops.Graph(adj_dev, V)
+        gnn(GNNInput(X, g, n2g, 1), training=True)
+        gnn.backward(dOut)
+        if graph is None:
+            g.close()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # final metric reduction: all-gather of the per-rank edge counts (north_star: the only collective)
+        mine = torch.tensor([float(E)], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        total_edges_per_step = float(sum(x.item() for x in gathered))
+    else:
+        total_edges_per_step = float(E)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = total_edges_per_step * args.steps / elapsed
+
+    result = {
+        "metric": "edges/sec (fwd+bwd) RGCN H=320 L=4, PPI-shaped batch",
+        "value": value,
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic R-MAT (0.57,0.19,0.19,0.05), N(0,1) features, Glorot weights",
+        "config": {
+            "workload": f"{args.workload}: V={V} E={E} edge_types={L} D={D} H={H} layers={NL} RGCN (PPI_RGCN.json hypers), "
+            f"step = edge bucketing{' (hoisted)' if args.reuse_graph else ''} + GNN fwd + full bwd, one batch per GPU",
+            "per_layer_traversal_rate_edges_per_s": value * NL,
+        },
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # ---- dominant kernels, measured live on the launch stream -------------------------------
+        g = graph if graph is not None else ops.Graph(adj_dev, V)
+        rowptr, col, rs = g.array(ops.G_ROWPTR_BY_DST), g.array(ops.G_COL_BY_DST), g.array(ops.G_INVDEG_BY_DST)
+        Hx = torch.randn((V, H), device=dev)
+        A = torch.empty((V * L, H), device=dev)
+        W = torch.randn((L * H, H), device=dev) * 0.05
+        out = torch.empty((V, H), device=dev)
+        ms_gather = time_kernel(lambda: ops.gather_reduce(rowptr, col, Hx, row_scale=rs, out=A))
+        ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
+        ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
+        # algorithmic bytes of one gather launch: one fp32 source row + one int32 col per
+        # edge, the row pointer and scale once, one output row per (node, type) bucket
+        gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4
+        gemm_flops = 2.0 * V * (L * H) * H
+        gather_gbs = gather_bytes / (ms_gather * 1e-3) / 1e9
+        gemm_tflops = gemm_flops / (ms_gemm * 1e-3) / 1e12
+        # per step: 2 gathers and 3 GEMM-equivalents per layer
+        share_gather = 2 * NL * ms_gather / ms_per_step
+        share_gemm = 3 * NL * ms_gemm / ms_per_step
+        roof_gather = {
+            "kernel": "csr_gather_reduce_kernel (aggregate source rows per (node, type) bucket)",
+            "bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gather_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_gather,
+            "algorithmic_bytes_per_launch": gather_bytes, "share_of_step": share_gather,
+        }
+        roof_gemm = {
+            "kernel": "gemm_mfma_kernel<1,5> ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": gemm_tflops / MFMA_FP32_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_gemm,
+            "algorithmic_flops_per_launch": gemm_flops, "share_of_step": share_gemm,
+        }
+        if share_gemm >= share_gather:
+            result["roofline"], result["roofline_secondary"] = roof_gemm, roof_gather
+        else:
+            result["roofline"], result["roofline_secondary"] = roof_gather, roof_gemm
+        result["config"]["ms_edge_bucketing"] = ms_graph
+        if graph is None:
+            g.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl, feats, adjs, params)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

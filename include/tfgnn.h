@@ -1,0 +1,236 @@
+/*
+ * tfgnn.h - C ABI of the MI355X-native (gfx950) message-passing hot path of microsoft/tf2-gnn.
+ *
+ * The reference (/root/reference, pure Python on TensorFlow 2) has no FFI of its own: every
+ * "kernel" on its hot path is a stock TensorFlow op dispatched from
+ * tf2_gnn/layers/message_passing/{message_passing,gnn_edge_mlp,rgcn,rgin,ggnn,rgat}.py and tf2_gnn/layers/nodes_to_graph_representation.py.
+ * This header therefore declares one entry point per TensorFlow op (or fused group of ops) that
+ * path dispatches; each declaration cites the reference call site it replaces (file:line relative
+ * to /root/reference).  A maintainer binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HIP), row-major, contiguous unless a leading
+ *     dimension (ld*, counted in elements) is given; floats are IEEE fp32, indices int32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it,
+ *     no entry point synchronises except tfgnn_graph_create (one small D2H validity read).
+ *   - return value: 0 on success, negative tfgnn_status otherwise; tfgnn_last_error() returns a
+ *     thread-local description of the last failure.
+ *   - inputs are never written; outputs must not alias inputs unless stated.
+ */
+#ifndef TFGNN_H
+#define TFGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TFGNN_OK = 0,
+  TFGNN_ERR_INVALID_ARGUMENT = -1, /* bad shape / null pointer / unknown enum           */
+  TFGNN_ERR_OUT_OF_RANGE = -2,     /* node index outside [0, V) (TF Gather: InvalidArgument) */
+  TFGNN_ERR_HIP = -3,              /* a HIP runtime call failed                          */
+  TFGNN_ERR_UNSUPPORTED = -4
+} tfgnn_status;
+
+/* tf2_gnn/utils/param_helpers.py:25-33 (+ "none" = identity, "sigmoid" for pooling weights,
+ * nodes_to_graph_representation.py:176) */
+typedef enum {
+  TFGNN_ACT_NONE = 0,
+  TFGNN_ACT_RELU = 1,
+  TFGNN_ACT_TANH = 2,
+  TFGNN_ACT_LEAKY_RELU = 3, /* alpha = 0.2 (tf.nn.leaky_relu default) */
+  TFGNN_ACT_ELU = 4,
+  TFGNN_ACT_SELU = 5,
+  TFGNN_ACT_GELU = 6, /* tanh approximation, tf2_gnn/utils/activation.py:7-14 */
+  TFGNN_ACT_SIGMOID = 7
+} tfgnn_activation;
+
+/* tf2_gnn/utils/param_helpers.py:9-14 */
+typedef enum {
+  TFGNN_REDUCE_SUM = 0,
+  TFGNN_REDUCE_MAX = 1 /* empty segment -> lowest finite float, like tf.math.unsorted_segment_max */
+} tfgnn_reduce;
+
+const char* tfgnn_last_error(void);
+/* "tfgnn <version> gfx950" */
+const char* tfgnn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph handle: the (dst, edge_type)- and (src, edge_type)-bucketed adjacency of one batch.
+ * Replaces, for all L layers and both passes of a step, the per-layer work of
+ *   message_passing.py:195-206 (slicing src/dst columns, embedding_lookup of the degree),
+ *   message_passing.py:230-263 calculate_type_to_num_incoming_edges (scatter_nd of ones),
+ *   message_passing.py:166-167 (concat of targets / messages over edge types).
+ * Row r = node * L + edge_type.  Within a row, columns ascend (canonical, deterministic).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tfgnn_graph tfgnn_graph;
+
+/* d_adjacency[l] : device int32 [num_edges[l], 2], row k = (source, target)  (gnn.py:241-244).
+ * The array of pointers and num_edges live on the HOST. */
+int tfgnn_graph_create(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                       const int64_t* num_edges, void* stream, tfgnn_graph** out_graph);
+int tfgnn_graph_destroy(tfgnn_graph* graph);
+
+typedef enum {
+  TFGNN_G_ROWPTR_BY_DST = 0, /* int32 [V*L+1]                                                  */
+  TFGNN_G_COL_BY_DST = 1,    /* int32 [E]  source node of each bucketed edge                  */
+  TFGNN_G_EID_BY_DST = 2,    /* int32 [E]  position of the edge in concat(adjacency_lists)    */
+  TFGNN_G_COLL_BY_DST = 3,   /* int32 [E]  source * L + edge_type (row of a [V*L, H] tensor)  */
+  TFGNN_G_ROWPTR_BY_SRC = 4, /* int32 [V*L+1]                                                  */
+  TFGNN_G_COL_BY_SRC = 5,    /* int32 [E]  target node                                        */
+  TFGNN_G_EID_BY_SRC = 6,    /* int32 [E]                                                     */
+  TFGNN_G_COLL_BY_SRC = 7,   /* int32 [E]  target * L + edge_type                             */
+  TFGNN_G_INVDEG_BY_DST = 8, /* float [V*L] 1/(in_degree[l,v] + 1e-7) (gnn_edge_mlp.py:102-106), 0 for empty rows */
+  TFGNN_G_INVDEG_EDGE_BY_SRC = 9, /* float [E] same quantity per edge, in by-src order        */
+  TFGNN_G_NODEPTR_BY_DST = 10,    /* int32 [V+1] = ROWPTR_BY_DST[::L] (all edge types of a target) */
+  TFGNN_G_NODEPTR_BY_SRC = 11,    /* int32 [V+1]                                               */
+  TFGNN_G_INVDEG_EDGE_BY_DST = 12, /* float [E] per edge, by-dst order                          */
+  TFGNN_G_SRC2DST_POS = 13        /* int32 [E] position in by-dst order of the edge at each by-src position */
+} tfgnn_graph_array_id;
+
+/* Borrow a device array owned by the handle (valid until tfgnn_graph_destroy). */
+int tfgnn_graph_array(const tfgnn_graph* graph, int array_id, const void** d_ptr, int64_t* count);
+int tfgnn_graph_dims(const tfgnn_graph* graph, int64_t* num_nodes, int* num_edge_types,
+                     int64_t* num_edges);
+
+/* Scales that fold the degree normalisation (gnn_edge_mlp.py:102-106) and the mean / sqrt_n
+ * aggregators (utils/param_helpers.py:12-13) into the gather kernel.
+ *   aggregation_mode 0 = sum, 1 = mean (1/max(N_v,1)), 2 = sqrt_n (1/sqrt(max(N_v,1))), N_v = number
+ *   of messages entering v over all edge types.
+ *   d_row_scale [V*L]          per bucket (v,l): (normalize ? 1/(c_lv+1e-7) : 1) * m_v
+ *   d_node_scale [V]           m_v
+ *   d_edge_weight_by_src [E]   per edge in by-src order: (normalize ? 1/(c_{l,tgt}+1e-7) : 1) * m_tgt
+ *   d_edge_weight_by_dst [E]   per edge in by-dst order: (normalize ? 1/(c_{l,tgt}+1e-7) : 1)          */
+int tfgnn_graph_scales(const tfgnn_graph* graph, int normalize_by_num_incoming, int aggregation_mode,
+                       float* d_row_scale, float* d_node_scale, float* d_edge_weight_by_src,
+                       float* d_edge_weight_by_dst, void* stream);
+
+/* Helper for use_target_state_as_input with a linear edge layer (gnn_edge_mlp.py:92-97):
+ * sum_e s_e [x_u | x_v] W = (sum_e s_e x_u) W_s + k_{l,v} x_v W_t with k = c_{l,v} * row_scale.
+ *   d_k [V*L], d_ident_ptr [V*L+1] = 0..V*L, d_node_of_row [V*L] = r / L                           */
+int tfgnn_graph_target_multiplier(const tfgnn_graph* graph, const float* d_row_scale, float* d_k,
+                                  int32_t* d_ident_ptr, int32_t* d_node_of_row, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather + segment reduce over a CSR (the hot kernel):
+ *   out[r, :] = post_act( row_scale[r] * REDUCE_{e in [rowptr[r], rowptr[r+1])}
+ *                                 pre_act( edge_weight[e] * in[col[e], :] ) )
+ * Replaces tf.nn.embedding_lookup (message_passing.py:197-206) fused with
+ * tf.math.unsorted_segment_{sum,max,mean,sqrt_n} (utils/param_helpers.py:9-14 via
+ * message_passing.py:172-174) and the per-message 1/(c+1e-7) scaling (gnn_edge_mlp.py:102-106);
+ * mean / sqrt_n are SUM with a row_scale.  d_edge_weight and d_row_scale may be NULL (= 1).
+ * width = number of floats per row; ld_in / ld_out = row strides in floats.
+ * ------------------------------------------------------------------------------------------ */
+int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d_col,
+                            const float* d_edge_weight, const float* d_row_scale,
+                            int64_t num_rows, const float* d_in, int64_t ld_in, int width,
+                            float* d_out, int64_t ld_out, int reduce_op, int pre_act, int post_act,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layer: C[M,N] = act( op(A)[M,K] @ op(B)[K,N] + bias[N] ) (+ C if accumulate)
+ * fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32).
+ * Replaces Keras Dense inside dpu_utils MLP (gnn_edge_mlp.py:100, rgin.py:104), rgat.py:102-109,
+ * gnn.py:279,324-327, the GRUCell matmuls (ggnn.py:84-87) and their tf.GradientTape gradients
+ * (models/graph_task_model.py:347-357).
+ *   trans_a = 0: A stored [M,K] (lda >= K);  1: A stored [K,M] (lda >= M)
+ *   trans_b = 0: B stored [K,N] (ldb >= N);  1: B stored [N,K] (ldb >= K)
+ * d_workspace: scratch for split-K partial sums (may be NULL / 0 -> no split-K).
+ * ------------------------------------------------------------------------------------------ */
+size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
+               int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+               const float* d_bias, int act, int accumulate, void* d_workspace,
+               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise: activations (utils/param_helpers.py:21-39) and their gradients.
+ * tfgnn_activation_backward: dx = dy * act'(.) where the derivative is evaluated from the saved
+ * OUTPUT y for relu/tanh/leaky_relu/elu/selu/sigmoid and from the saved INPUT x for gelu
+ * (pass the matching tensor as d_saved).
+ * ------------------------------------------------------------------------------------------ */
+int tfgnn_activation_forward(int act, const float* d_x, float* d_y, int64_t n, void* stream);
+int tfgnn_activation_backward(int act, const float* d_dy, const float* d_saved, float* d_dx,
+                              int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GRUCell gate math ([ext] tf.keras.layers.GRUCell TF2 defaults: reset_after=True, gates z|r|h,
+ * sigmoid / tanh), used by GGNN (ggnn.py:64,84-87).  The two matmuls are tfgnn_gemm calls:
+ *   mx = x @ kernel + bias[0]   mh = h @ recurrent_kernel + bias[1]      (both [V, 3H])
+ * forward:  z = s(mx_z+mh_z), r = s(mx_r+mh_r), c = tanh(mx_h + r*mh_h), h' = z*h + (1-z)*c;
+ *           d_gates (nullable) [V,3H] receives z|r|c for the backward pass.
+ * backward: d_dmx, d_dmh [V,3H] and d_dh_direct [V,H] = dh' * z.
+ * ------------------------------------------------------------------------------------------ */
+int tfgnn_gru_gates_forward(const float* d_mx, const float* d_mh, const float* d_h, float* d_h_new,
+                            float* d_gates, int64_t V, int H, void* stream);
+int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const float* d_mh,
+                             const float* d_h, float* d_dmx, float* d_dmh, float* d_dh_direct,
+                             int64_t V, int H, void* stream);
+
+/* out[n] = sum_m in[m, n] (bias gradients of Dense / GRUCell). */
+int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* stream);
+/* out = alpha * (x + y): residual averaging of the layer stack, gnn.py:291-296. */
+int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, float* d_out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RGAT (rgat.py:91-163).  Y = X @ [W_0 | ... | W_{L-1}] is a tfgnn_gemm call ([V*L, H] rows (v,l)).
+ * tfgnn_rgat_node_scores: the two halves of the attention logit (rgat.py:111-121) per (node,type,head):
+ *     s_src[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,:H/K]>   s_tgt[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,H/K:]>
+ *     d_alpha: [L, K, 2H/K] (the L "Edge_attention_parameters" stacked, rgat.py:82-86)
+ * tfgnn_rgat_aggregate: score_ek = leaky_relu(s_src[src,l,k] + s_tgt[tgt,l,k]); per head, softmax over
+ *     all edges entering a node (dpu_utils unsorted_segment_log_softmax + exp, rgat.py:147-151);
+ *     out[v,k,:] = post_act( sum_e a_ek Y[(src,l),k,:] ) (rgat.py:154-163).  d_att (nullable) [E,K]
+ *     receives a_ek in by-dst edge order for the backward pass.
+ * ------------------------------------------------------------------------------------------ */
+int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, int64_t num_nodes, int num_edge_types,
+                           int num_heads, int hidden_dim, float* d_s_src, float* d_s_tgt, void* stream);
+int tfgnn_rgat_aggregate(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst, const float* d_Y,
+                         const float* d_s_src, const float* d_s_tgt, int64_t num_nodes, int num_edge_types,
+                         int num_heads, int hidden_dim, int post_act, float* d_out, float* d_att,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Node -> graph pooling (layers/nodes_to_graph_representation.py:170-229).  node_to_graph_map is
+ * sorted (data/graph_dataset.py:211-217), so segments are ranges ptr[g]..ptr[g+1].
+ *   tfgnn_segment_offsets: ids [V] -> ptr [G+1]; synchronises once to report unsorted /
+ *       out-of-range ids (tf.math.segment_sum raises InvalidArgument for both).
+ *   tfgnn_segment_softmax: per (graph, head) dpu_utils unsorted_segment_softmax of the node scores
+ *       (:178-186): exp(s - max) / (sum + 1e-7).  scores/out: [V, heads] with row strides ld.
+ *   tfgnn_segment_weighted_sum: out[g,h,:] = sum_{v in g} w[v,h] * R[v,h,:] (:219-227); w NULL =
+ *       tf.math.segment_sum (:204-210); mean=1 = tf.math.segment_mean (:211-217).
+ *   *_backward: gradients of the two ops above (tf.GradientTape in the reference).
+ * ------------------------------------------------------------------------------------------ */
+int tfgnn_segment_offsets(const int32_t* d_ids, int64_t V, int64_t G, int32_t* d_ptr, void* stream);
+int tfgnn_segment_softmax(const float* d_scores, int64_t ld, int heads, const int32_t* d_ptr, int64_t G,
+                          float* d_out, int64_t ld_out, void* stream);
+int tfgnn_segment_weighted_sum(const float* d_R, const float* d_w, const int32_t* d_ptr, int64_t G, int GD,
+                               int heads, int mean, float* d_out, void* stream);
+int tfgnn_segment_weighted_sum_backward(const float* d_dOut, const float* d_R, const float* d_w,
+                                        const int32_t* d_ids, const int32_t* d_ptr, int64_t V, int GD,
+                                        int heads, int mean, float* d_dR, float* d_dW, void* stream);
+int tfgnn_segment_softmax_backward(const float* d_w, const float* d_dw, int heads, const int32_t* d_ptr,
+                                   int64_t G, float* d_ds, void* stream);
+
+/* Layer-input dropout of the GNN stack (gnn.py:285-288; [ext] tf.nn.dropout scales kept units by
+ * 1/(1-rate)).  d_mask receives 0 or 1/(1-rate) per element; the gradient is tfgnn_mul(dy, mask).
+ * The stream of random numbers is this library's own (counter-based), not TensorFlow's. */
+int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask, int64_t n, float rate,
+                          uint64_t seed, void* stream);
+int tfgnn_mul(const float* d_a, const float* d_b, float* d_out, int64_t n, void* stream);
+
+/* Inter-layer LayerNormalization of the GNN stack (gnn.py:157-161,318-321; [ext] Keras defaults
+ * axis=-1, epsilon=1e-3).  backward: d_dx, and d_dy_xhat = dy * xhat whose column sum is d gamma
+ * (d beta = column sum of dy; both via tfgnn_colsum). */
+int tfgnn_layernorm_forward(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
+                            int64_t rows, int H, float* d_y, float* d_mean, float* d_rstd, void* stream);
+int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, const float* d_gamma, const float* d_mean,
+                             const float* d_rstd, int64_t rows, int H, float* d_dx, float* d_dy_xhat,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFGNN_H */

@@ -1,0 +1,82 @@
+"""Integer-side oracle (numpy): adjacency preprocessing and the (dst, edge_type) bucketing.
+
+TEST INFRASTRUCTURE ONLY - see ``oracle/__init__.py``.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence, Set, Tuple, Union
+
+import numpy as np
+
+
+# --- tf2_gnn/data/utils.py:9-133 ---------------------------------------------------------------
+def get_tied_edge_types(tie_fwd_bkwd_edges: Union[bool, List[int]], num_fwd_edge_types: int) -> Set[int]:
+    """data/utils.py:61-78"""
+    if isinstance(tie_fwd_bkwd_edges, list):
+        return set(tie_fwd_bkwd_edges)
+    if tie_fwd_bkwd_edges:
+        return set(range(num_fwd_edge_types))
+    return set()
+
+
+def process_adjacency_lists(
+    adjacency_lists: Sequence[Sequence[Tuple[int, int]]],
+    num_nodes: int,
+    add_self_loop_edges: bool,
+    tied_fwd_bkwd_edge_types: Iterable[int],
+    self_loop_edge_type: int = 0,
+):
+    """data/utils.py:9-58: add backward edges (tied types share the forward type, others get a new
+    type appended in forward-type order, :99-113), then self loops inserted at ``self_loop_edge_type``
+    (negative values count from the end, :37-53, :88-96), then in-degree counts (:116-124)."""
+    tied = set(tied_fwd_bkwd_edge_types)
+    lists = [list(map(tuple, a)) for a in adjacency_lists]
+    n_fwd = len(lists)
+    for t in range(n_fwd):
+        flipped = [(d, s) for (s, d) in adjacency_lists[t]]
+        if t in tied:
+            lists[t] = lists[t] + flipped
+        else:
+            lists.append(flipped)
+    if add_self_loop_edges:
+        n = len(lists)
+        assert -(n + 1) <= self_loop_edge_type <= n
+        if self_loop_edge_type < 0:
+            self_loop_edge_type += n + 1
+        lists.insert(self_loop_edge_type, [(i, i) for i in range(num_nodes)])
+    counts = np.zeros((len(lists), num_nodes))
+    for t, edges in enumerate(lists):
+        for _, d in edges:
+            counts[t, d] += 1
+    arrays = [
+        np.array(a, dtype=np.int32) if len(a) > 0 else np.zeros((0, 2), dtype=np.int32) for a in lists
+    ]
+    return arrays, counts
+
+
+# --- bucketing used by the HIP path (ours; the reference has no equivalent, it concatenates edge
+# --- lists and scatter-adds, message_passing.py:166-174) -----------------------------------------
+def bucket_edges(adjacency_lists: Sequence[np.ndarray], num_nodes: int, by: str = "dst"):
+    """Canonical CSR over rows r = node * L + edge_type.
+
+    by="dst": row node = edge target, col = edge source   (forward gather)
+    by="src": row node = edge source, col = edge target   (backward / transposed gather)
+    Within a row, cols ascend (ties are identical values, so the order is canonical).
+    Returns rowptr int32 [V*L+1], col int32 [E], etype int32 [E]."""
+    L = len(adjacency_lists)
+    srcs, dsts, types = [], [], []
+    for l, adj in enumerate(adjacency_lists):
+        adj = np.asarray(adj, dtype=np.int64).reshape(-1, 2)
+        srcs.append(adj[:, 0])
+        dsts.append(adj[:, 1])
+        types.append(np.full(adj.shape[0], l, dtype=np.int64))
+    src = np.concatenate(srcs) if srcs else np.zeros(0, np.int64)
+    dst = np.concatenate(dsts) if dsts else np.zeros(0, np.int64)
+    typ = np.concatenate(types) if types else np.zeros(0, np.int64)
+    row_node, col = (dst, src) if by == "dst" else (src, dst)
+    key = row_node * L + typ
+    order = np.lexsort((col, key))
+    rowptr = np.zeros(num_nodes * L + 1, dtype=np.int64)
+    np.add.at(rowptr, key + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr.astype(np.int32), col[order].astype(np.int32), typ[order].astype(np.int32)

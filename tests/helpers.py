@@ -1,0 +1,71 @@
+"""Shared helpers of the parity tests: seeded graphs, weight transfer HIP layer <-> oracle."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def random_graph(num_nodes, num_edges, num_types, seed=0, empty_types=(), hub=None):
+    """Unsorted multigraph; ``hub`` = (node, extra_in_edges) adds a high in-degree target."""
+    rng = np.random.default_rng(seed)
+    adjs = []
+    for l in range(num_types):
+        if l in empty_types:
+            adjs.append(np.zeros((0, 2), dtype=np.int32))
+            continue
+        e = num_edges // max(1, num_types - len(empty_types))
+        a = rng.integers(0, num_nodes, size=(e, 2)).astype(np.int32)
+        if hub is not None and l == 0:
+            node, extra = hub
+            h = np.stack([rng.integers(0, num_nodes, size=extra), np.full(extra, node)], axis=1).astype(np.int32)
+            a = np.concatenate([a, h], axis=0)
+            rng.shuffle(a, axis=0)
+        adjs.append(a)
+    return adjs
+
+
+def to_dev(arrs, dev):
+    return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs)
+
+
+def edge_mlp_weights_from_layer(layer):
+    """HIP GNN_Edge_MLP-family layer -> oracle weights dict (CPU tensors, same values)."""
+    mlps = layer._edge_type_mlps
+    w = {"edge_mlps": [[k[l].detach().cpu().clone() for k in mlps.kernels] for l in range(mlps.L)]}
+    if getattr(layer, "_aggregation_mlp", None) is not None:
+        w["aggr_mlp"] = [k.detach().cpu().clone() for k in layer._aggregation_mlp]
+    else:
+        w["aggr_mlp"] = None
+    ru = getattr(layer, "_recurrent_unit", None)
+    if ru is not None:
+        w["gru_kernel"] = ru["kernel"].value.detach().cpu().clone()
+        w["gru_recurrent_kernel"] = ru["recurrent_kernel"].value.detach().cpu().clone()
+        w["gru_bias"] = ru["bias"].value.detach().cpu().clone()
+    return w
+
+
+def rgat_weights_from_layer(layer):
+    H = layer._hidden_dim
+    L = layer._num_edge_types
+    return {
+        "kernels": [layer._kernels[:, l * H : (l + 1) * H].detach().cpu().clone() for l in range(L)],
+        "attn": [layer._attn[l].detach().cpu().clone() for l in range(L)],
+    }
+
+
+def mp_weights_from_layer(layer):
+    if type(layer).__name__ == "RGAT":
+        return rgat_weights_from_layer(layer)
+    return edge_mlp_weights_from_layer(layer)
+
+
+def assert_close(actual: torch.Tensor, expected: torch.Tensor, tol=1e-5, what=""):
+    """|a - b| <= tol * max(1, |b|)  (SURVEY.md section 7 hard part 2: north_star's 1e-5 on fp32 node states)."""
+    a = actual.detach().cpu().double()
+    b = expected.detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if a.numel() == 0:
+        return
+    err = (a - b).abs() / b.abs().clamp(min=1.0)
+    worst = float(err.max())
+    assert worst <= tol, f"{what}: max scaled error {worst:.3e} > {tol:.1e} at {int(err.argmax())}"

@@ -1,0 +1,370 @@
+"""Parity of the HIP layers (through the C ABI) with the CPU oracle on identical inputs.
+Tolerance: fp32 node states within 1e-5 (north_star), scaled: |a-b| <= 1e-5 * max(1, |b|)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf2gnn_oracle as orc
+from tests.helpers import assert_close, mp_weights_from_layer, random_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cls_name, params, D, L):
+    import tf2_gnn_amd.layers.message_passing as mp
+
+    cls = getattr(mp, cls_name)
+    p = cls.get_default_hyperparameters()
+    p.update(params)
+    layer = cls(p)
+    layer.build(mp.MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
+    return layer, p
+
+
+# ---- the reference's own known-answer vectors, through the generic path on the GPU ---------------
+@pytest.mark.parametrize("idx", range(4))
+def test_message_passing_kats_on_gpu(dev, kats, idx):
+    """tf2_gnn/test/layers/test_message_passing.py:35-84 with a user subclass (PassSourceStates)."""
+    from tf2_gnn_amd.layers import MessagePassing, MessagePassingInput
+
+    class PassSourceStates(MessagePassing):
+        def __init__(self):
+            params = super().get_default_hyperparameters()
+            params["message_activation_function"] = "relu"
+            params["aggregation_function"] = "sum"
+            super().__init__(params)
+
+        def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message,
+                              edge_type_idx, training):
+            return edge_source_states
+
+    k = kats["message_passing_kats"][idx]
+    X = torch.tensor(k["node_embeddings"], dtype=torch.float32, device=dev)
+    adjs = tuple(torch.tensor(a, dtype=torch.int32, device=dev).reshape(-1, 2) for a in k["adjacency_lists"])
+    out = PassSourceStates()(MessagePassingInput(X, adjs), training=False)
+    expected = torch.tensor(k["aggregated_states"], dtype=torch.float32)
+    assert out.shape == expected.shape
+    np.testing.assert_array_almost_equal(out.cpu().numpy(), expected.numpy())
+
+
+CASES = [
+    # name, class, param overrides
+    ("rgcn", "RGCN", {}),
+    ("rgcn_tanh_mean", "RGCN", {"message_activation_function": "tanh", "aggregation_function": "mean"}),
+    ("rgcn_sqrt_n_nonorm", "RGCN", {"aggregation_function": "sqrt_n", "normalize_by_num_incoming": False}),
+    ("rgcn_gelu", "RGCN", {"message_activation_function": "gelu"}),
+    ("rgcn_max", "RGCN", {"aggregation_function": "max"}),
+    ("rgcn_act_before", "RGCN", {"message_activation_before_aggregation": True, "message_activation_function": "elu"}),
+    ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),
+    ("edge_mlp_ppi", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 0, "message_activation_function": "gelu"}),
+    ("edge_mlp_src_only", "GNN_Edge_MLP", {"use_target_state_as_input": False}),
+    ("rgin", "RGIN", {}),
+    ("rgin_norm_aggr_mlp", "RGIN", {"normalize_by_num_incoming": True, "num_aggr_MLP_hidden_layers": 1}),
+    ("ggnn", "GGNN", {}),
+    ("ggnn_nonorm", "GGNN", {"normalize_by_num_incoming": False}),
+    ("rgat", "RGAT", {"num_heads": 4}),
+    ("rgat_tanh_8", "RGAT", {"num_heads": 8, "message_activation_function": "tanh"}),
+]
+
+
+@pytest.mark.parametrize("name,cls_name,over", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("H", [16, 64])
+def test_layer_forward_parity(dev, name, cls_name, over, H):
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, D = 150, 3, H
+    adjs = random_graph(V, 1800, L, seed=H, empty_types=(1,) if "rgin" in name else (), hub=(3, 200))
+    layer, p = _build(cls_name, dict(over, hidden_dim=H), D, L)
+    g = torch.Generator().manual_seed(H)
+    X = torch.randn((V, D), generator=g)
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=False)
+    w = mp_weights_from_layer(layer)
+    adj_t = [torch.from_numpy(a) for a in adjs]
+    ref32 = orc.message_passing_call(cls_name, p, w, X, adj_t)
+    assert out.shape == (V, H)
+    assert_close(out.cpu(), ref32, tol=1e-5, what=name)
+    # and both fp32 results are equally close to the fp64 oracle
+    w64 = _to64(w)
+    ref64 = orc.message_passing_call(cls_name, p, w64, X.double(), adj_t)
+    assert_close(out.cpu(), ref64.float(), tol=1e-5, what=name + " vs fp64")
+
+
+def _to64(w):
+    if isinstance(w, dict):
+        return {k: _to64(v) for k, v in w.items()}
+    if isinstance(w, list):
+        return [_to64(v) for v in w]
+    if isinstance(w, torch.Tensor):
+        return w.double()
+    return w
+
+
+def test_rgcn_odd_dims_scalar_paths(dev):
+    """hidden_dim 7 / input dim 5 (the reference's default hidden_dim): unaligned kernels."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, D, H = 40, 2, 5, 7
+    adjs = random_graph(V, 300, L, seed=9)
+    layer, p = _build("RGCN", {"hidden_dim": H}, D, L)
+    X = torch.randn((V, D), generator=torch.Generator().manual_seed(9))
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)))
+    ref = orc.message_passing_call("rgcn", p, mp_weights_from_layer(layer), X, [torch.from_numpy(a) for a in adjs])
+    assert_close(out.cpu(), ref, tol=1e-5, what="rgcn odd dims")
+
+
+def test_layers_on_empty_and_isolated_inputs(dev):
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    H = 8
+    layer, p = _build("RGCN", {"hidden_dim": H}, H, 2)
+    X = torch.randn((6, H), generator=torch.Generator().manual_seed(0))
+    empty = [np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)]
+    out = layer(MessagePassingInput(X.to(dev), to_dev(empty, dev)))
+    assert torch.equal(out.cpu(), torch.zeros((6, H)))
+    # max aggregation over nodes without incoming edges: float32 lowest -> activation
+    layer, p = _build("RGCN", {"hidden_dim": H, "aggregation_function": "max", "message_activation_function": "tanh"}, H, 1)
+    adj = [np.array([[0, 1], [2, 1]], np.int32)]
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adj, dev)))
+    ref = orc.message_passing_call("rgcn", p, mp_weights_from_layer(layer), X, [torch.from_numpy(adj[0])])
+    assert_close(out.cpu(), ref, tol=1e-5, what="max empty segments")
+    assert torch.all(out.cpu()[0] == -1.0)
+
+
+BWD_CASES = [
+    ("rgcn", "RGCN", {}),
+    ("rgcn_tanh_mean", "RGCN", {"message_activation_function": "tanh", "aggregation_function": "mean"}),
+    ("rgcn_gelu_nonorm", "RGCN", {"message_activation_function": "gelu", "normalize_by_num_incoming": False}),
+    ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),
+    ("edge_mlp_src_only", "GNN_Edge_MLP", {"use_target_state_as_input": False}),
+    ("rgin", "RGIN", {}),
+    ("rgin_aggr_mlp", "RGIN", {"normalize_by_num_incoming": True, "num_aggr_MLP_hidden_layers": 1}),
+    ("ggnn", "GGNN", {}),
+]
+
+
+@pytest.mark.parametrize("name,cls_name,over", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_layer_backward_parity(dev, name, cls_name, over):
+    """explicit HIP backward == torch autograd through the fp64 oracle (stand-in for tf.GradientTape)."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, H = 120, 3, 32
+    adjs = random_graph(V, 1500, L, seed=4, hub=(2, 150))
+    layer, p = _build(cls_name, dict(over, hidden_dim=H), H, L)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn((V, H), generator=g)
+    dOut = torch.randn((V, H), generator=g)
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
+    dX = layer.backward(dOut.to(dev))
+
+    w64 = _to64(mp_weights_from_layer(layer))
+    leaves = []
+
+    def req(t):
+        t.requires_grad_(True)
+        leaves.append(t)
+        return t
+
+    for l in range(L):
+        w64["edge_mlps"][l] = [req(k) for k in w64["edge_mlps"][l]]
+    if w64.get("aggr_mlp") is not None:
+        w64["aggr_mlp"] = [req(k) for k in w64["aggr_mlp"]]
+    for k in ("gru_kernel", "gru_recurrent_kernel", "gru_bias"):
+        if k in w64:
+            w64[k] = req(w64[k])
+    X64 = X.double().requires_grad_(True)
+    ref = orc.message_passing_call(cls_name, p, w64, X64, [torch.from_numpy(a) for a in adjs])
+    assert_close(out.cpu(), ref.detach().float(), tol=1e-5, what=name + " fwd")
+    grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
+    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=name + " dX")
+    ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
+    pairs = []
+    for l in range(L):
+        for j, v in enumerate(layer._edge_type_mlps.vars[l]):
+            pairs.append((v, w64["edge_mlps"][l][j]))
+    if w64.get("aggr_mlp") is not None:
+        pairs += list(zip(layer._aggregation_mlp_vars, w64["aggr_mlp"]))
+    if "gru_kernel" in w64:
+        ru = layer._recurrent_unit
+        pairs += [(ru["kernel"], w64["gru_kernel"]), (ru["recurrent_kernel"], w64["gru_recurrent_kernel"]),
+                  (ru["bias"], w64["gru_bias"])]
+    assert len(pairs) == len(layer.trainable_variables) == len(leaves)
+    for v, t in pairs:
+        rv = ref_by_id[id(t)]
+        assert v.grad is not None, v.name
+        scale = max(1.0, float(rv.abs().max()))
+        assert_close(v.grad.cpu() / scale, (rv / scale).float(), tol=2e-5, what=f"{name} d{v.name}")
+
+
+def _gnn_oracle_weights(gnn):
+    w = {"initial_projection": gnn._initial_projection_layer.value.cpu().clone(), "mp": [], "dense": {}, "layernorm": []}
+    for i, mp in enumerate(gnn._mp_layers):
+        w["mp"].append(mp_weights_from_layer(mp))
+        if gnn._use_inter_layer_layernorm:
+            g_, b_ = gnn._inter_layer_layernorms[i]
+            w["layernorm"].append((g_.value.cpu().clone(), b_.value.cpu().clone()))
+        if str(i) in gnn._dense_layers:
+            w["dense"][i] = gnn._dense_layers[str(i)].value.cpu().clone()
+    return w
+
+
+@pytest.mark.parametrize(
+    "mp_style,over",
+    [
+        ("rgcn", {"dense_every_num_layers": 10000, "residual_every_num_layers": 10000}),  # PPI_RGCN.json shape
+        ("rgcn", {"dense_every_num_layers": 2, "residual_every_num_layers": 2, "use_inter_layer_layernorm": True}),
+        ("ggnn", {"dense_every_num_layers": 3, "residual_every_num_layers": 1}),
+        ("rgin", {"dense_every_num_layers": 1, "residual_every_num_layers": 2, "use_inter_layer_layernorm": True}),
+    ],
+)
+def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
+    """GNN._internal_call (gnn.py:276-329): forward, all representations, and weight gradients."""
+    from tf2_gnn_amd.layers import GNN, GNNInput
+
+    V, L, Din, H = 100, 3, 10, 24
+    params = GNN.get_default_hyperparameters(mp_style)
+    params.update({"hidden_dim": H, "num_layers": 4, "global_exchange_every_num_layers": 10000})
+    params.update(over)
+    adjs = random_graph(V, 1200, L, seed=21)
+    gnn = GNN(params)
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn((V, Din), generator=g)
+    dOut = torch.randn((V, H), generator=g)
+    inp = GNNInput(X.to(dev), to_dev(adjs, dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    out, all_reprs = gnn(inp, training=False, return_all_representations=True)
+    w = _gnn_oracle_weights(gnn)
+    ref, ref_all = orc.gnn_internal_call(params, w, X, [torch.from_numpy(a) for a in adjs])
+    assert len(all_reprs) == params["num_layers"] + 1
+    for a, b in zip(all_reprs, ref_all):
+        assert_close(a.cpu(), b, tol=2e-5, what="all_node_representations")
+    assert_close(out.cpu(), ref, tol=2e-5, what=f"gnn {mp_style}")
+
+    # backward vs autograd through the fp64 oracle
+    w64 = _to64(w)
+    leaves = []
+
+    def visit(obj):
+        if isinstance(obj, torch.Tensor):
+            obj.requires_grad_(True)
+            leaves.append(obj)
+        elif isinstance(obj, dict):
+            for k in obj:
+                visit(obj[k])
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                visit(v)
+
+    visit(w64)
+    ref64, _ = orc.gnn_internal_call(params, w64, X.double(), [torch.from_numpy(a) for a in adjs])
+    grads = torch.autograd.grad((ref64 * dOut.double()).sum(), leaves, allow_unused=True)
+    ref_by_id = {id(t): gr for t, gr in zip(leaves, grads)}
+    gnn(inp, training=False)
+    gnn.backward(dOut.to(dev))
+    # initial projection
+    gi = gnn._initial_projection_layer.grad
+    assert_close(gi.cpu(), ref_by_id[id(w64["initial_projection"])].float(), tol=5e-5, what="d initial projection")
+    for i, mp in enumerate(gnn._mp_layers):
+        ref_k = w64["mp"][i]["edge_mlps"]
+        for l in range(L):
+            for j, v in enumerate(mp._edge_type_mlps.vars[l]):
+                r = ref_by_id[id(ref_k[l][j])]
+                scale = max(1.0, float(r.abs().max()))
+                assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=5e-5, what=f"layer {i} {v.name}")
+        if str(i) in gnn._dense_layers:
+            r = ref_by_id[id(w64["dense"][i])]
+            scale = max(1.0, float(r.abs().max()))
+            assert_close(gnn._dense_layers[str(i)].grad.cpu() / scale, (r / scale).float(), tol=5e-5, what=f"dense {i}")
+        if params["use_inter_layer_layernorm"]:
+            gam, bet = gnn._inter_layer_layernorms[i]
+            r = ref_by_id[id(w64["layernorm"][i][0])]
+            scale = max(1.0, float(r.abs().max()))
+            assert_close(gam.grad.cpu() / scale, (r / scale).float(), tol=5e-5, what=f"ln gamma {i}")
+
+
+def test_gnn_training_dropout_matches_oracle_with_same_masks(dev):
+    from tf2_gnn_amd.layers import GNN, GNNInput
+
+    V, L, Din, H = 80, 2, 6, 16
+    params = GNN.get_default_hyperparameters("rgcn")
+    params.update({"hidden_dim": H, "num_layers": 3, "global_exchange_every_num_layers": 10000,
+                   "layer_input_dropout_rate": 0.25, "dense_every_num_layers": 2, "residual_every_num_layers": 2})
+    adjs = random_graph(V, 600, L, seed=2)
+    gnn = GNN(params)
+    X = torch.randn((V, Din), generator=torch.Generator().manual_seed(1))
+    inp = GNNInput(X.to(dev), to_dev(adjs, dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    out = gnn(inp, training=True)
+    masks = [st["mask"].cpu() for st in gnn._ctx["steps"]]
+    assert all(0.6 < float((m > 0).float().mean()) < 0.9 for m in masks)
+    ref, _ = orc.gnn_internal_call(params, _gnn_oracle_weights(gnn), X, [torch.from_numpy(a) for a in adjs], dropout_masks=masks)
+    assert_close(out.cpu(), ref, tol=2e-5, what="gnn training dropout")
+    out_eval = gnn(inp, training=False)
+    ref_eval, _ = orc.gnn_internal_call(params, _gnn_oracle_weights(gnn), X, [torch.from_numpy(a) for a in adjs])
+    assert_close(out_eval.cpu(), ref_eval, tol=2e-5, what="gnn eval")
+
+
+def _pool_weights(layer):
+    def mlp(m):
+        return [k.value.cpu().clone() for k in m.kernels], [None if b is None else b.value.cpu().clone() for b in m.biases]
+
+    w = {"transformation": mlp(layer._transformation_mlp)}
+    if layer._weighting_fun not in ("none", "average"):
+        w["scoring"] = mlp(layer._scoring_mlp)
+    return w
+
+
+@pytest.mark.parametrize("wf", ["softmax", "sigmoid", "average", "none"])
+def test_weighted_sum_graph_representation_parity(dev, wf):
+    """nodes_to_graph_representation.py:170-229 forward, and backward vs autograd on the oracle."""
+    from tf2_gnn_amd.layers import NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
+
+    g = torch.Generator().manual_seed(3)
+    sizes = [5, 1, 9, 3, 7, 12]
+    ids = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)])
+    V, VD, GD, heads = int(ids.numel()), 20, 16, 4
+    X = torch.randn((V, VD), generator=g)
+    layer = WeightedSumGraphRepresentation(GD, heads, weighting_fun=wf, scoring_mlp_layers=[24],
+                                           transformation_mlp_layers=[24], scoring_mlp_use_biases=True,
+                                           transformation_mlp_activation_fun="tanh")
+    out = layer(NodesToGraphRepresentationInput(X.to(dev), ids.to(dev), len(sizes)))
+    for v in layer.trainable_variables:  # make biases non-trivial, then recompute
+        if v.name.endswith("bias"):
+            v.value.copy_(torch.randn(v.shape, generator=g))
+    out = layer(NodesToGraphRepresentationInput(X.to(dev), ids.to(dev), len(sizes)))
+    cfg = {"graph_representation_size": GD, "num_heads": heads, "weighting_fun": wf,
+           "scoring_mlp_activation_fun": "ReLU", "transformation_mlp_activation_fun": "tanh"}
+    w = _pool_weights(layer)
+    ref = orc.weighted_sum_graph_representation(cfg, w, X, ids, len(sizes))
+    assert_close(out.cpu(), ref, tol=1e-5, what=f"pool {wf}")
+    # backward
+    dOut = torch.randn((len(sizes), GD), generator=g)
+    dX = layer.backward(dOut.to(dev))
+    X64 = X.double().requires_grad_(True)
+    w64 = {k: ([t.double() for t in ks], [None if b is None else b.double() for b in bs]) for k, (ks, bs) in w.items()}
+    ref64 = orc.weighted_sum_graph_representation(cfg, w64, X64, ids, len(sizes))
+    (gx,) = torch.autograd.grad((ref64 * dOut.double()).sum(), X64)
+    assert_close(dX.cpu(), gx.float(), tol=2e-5, what=f"pool {wf} dX")
+
+
+def test_was_graph_representation_parity(dev):
+    from tf2_gnn_amd.layers import NodesToGraphRepresentationInput, WASGraphRepresentation
+
+    g = torch.Generator().manual_seed(8)
+    sizes = [4, 6, 2]
+    ids = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)])
+    X = torch.randn((int(ids.numel()), 12), generator=g)
+    layer = WASGraphRepresentation(graph_representation_size=8, num_heads=2, pooling_mlp_layers=[16, 16])
+    out = layer(NodesToGraphRepresentationInput(X.to(dev), ids.to(dev), 3))
+    cfg = {"graph_representation_size": 8, "num_heads": 2, "scoring_mlp_activation_fun": "elu",
+           "transformation_mlp_activation_fun": "elu"}
+    w = {"avg": _pool_weights(layer._weighted_avg_graph_repr_layer), "sum": _pool_weights(layer._weighted_sum_graph_repr_layer),
+         "out_projection": layer._out_projection.value.cpu().clone()}
+    ref = orc.was_graph_representation(cfg, w, X, ids, 3)
+    assert_close(out.cpu(), ref, tol=1e-5, what="WAS")
+
+
+def test_unsorted_node_to_graph_map_raises(dev):
+    from tf2_gnn_amd.layers import NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
+
+    layer = WeightedSumGraphRepresentation(4, 2)
+    X = torch.randn((4, 6), device=dev)
+    with pytest.raises(ValueError, match="sorted"):
+        layer(NodesToGraphRepresentationInput(X, torch.tensor([0, 1, 0, 1], dtype=torch.int32, device=dev), 2))

@@ -1,0 +1,212 @@
+"""HIP primitives against plain fp32/fp64 references (run through the C ABI via ctypes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adjacency_oracle as ao
+from oracle import tf2gnn_oracle as orc
+from tests.helpers import assert_close, random_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+ACTS = ["relu", "tanh", "leaky_relu", "elu", "selu", "gelu", "sigmoid"]
+
+
+def _ref_act(name):
+    return torch.sigmoid if name == "sigmoid" else orc.get_activation_function(name)
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize(
+    "M,N,K",
+    [(64, 64, 32), (130, 320, 96), (257, 128, 1280), (33, 7, 50), (5, 121, 3), (1, 1, 1), (300, 640, 64), (100, 12, 17)],
+)
+def test_gemm_matches_fp64(dev, ta, tb, M, N, K):
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    out = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    scale = max(1.0, float(K) ** 0.5)
+    assert_close(out.cpu() / scale, (ref / scale).float(), tol=2e-6, what=f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
+
+
+def test_gemm_asymmetric_identity(dev):
+    """transpose-detecting check (A = I, asymmetric B)."""
+    from tf2_gnn_amd import ops
+
+    n = 96
+    B = torch.arange(n * 80, dtype=torch.float32).reshape(n, 80) / 7.0
+    out = ops.gemm(torch.eye(n).to(dev), B.to(dev))
+    assert torch.equal(out.cpu(), B)
+
+
+@pytest.mark.parametrize("act", [None] + ACTS)
+def test_gemm_epilogue_bias_act_accumulate_strided(dev, act):
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn((70, 48), generator=g)
+    B = torch.randn((48, 36), generator=g)
+    bias = torch.randn(36, generator=g)
+    ref = A.double() @ B.double() + bias.double()
+    if act is not None:
+        ref = _ref_act(act)(ref)
+    # strided output (a column block of a wider matrix) + accumulate
+    wide = torch.ones((70, 100), device=dev)
+    ops.gemm(A.to(dev), B.to(dev), bias=bias.to(dev), act=act, out=wide[:, 10:46], accumulate=True)
+    assert_close(wide[:, 10:46].cpu(), (ref + 1.0).float(), tol=5e-6, what=f"epilogue {act}")
+    assert torch.all(wide[:, :10] == 1) and torch.all(wide[:, 46:] == 1)
+
+
+def test_gemm_split_k_weight_gradient_shape(dev):
+    """dW = X^T G with K = number of nodes: split-K path, deterministic."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn((20000, 64), generator=g)
+    G = torch.randn((20000, 96), generator=g)
+    ref = X.double().t() @ G.double()
+    o1 = ops.gemm(X.to(dev), G.to(dev), trans_a=True)
+    o2 = ops.gemm(X.to(dev), G.to(dev), trans_a=True)
+    assert torch.equal(o1, o2)
+    assert_close(o1.cpu() / 141.0, (ref / 141.0).float(), tol=3e-6, what="split-k")
+
+
+@pytest.mark.parametrize("width", [3, 7, 12, 32, 64, 128, 256, 320, 512, 1280])
+@pytest.mark.parametrize("reduce", ["sum", "max"])
+def test_gather_reduce_matches_oracle(dev, width, reduce):
+    from tf2_gnn_amd import ops
+
+    V, L = 200, 3
+    adjs = random_graph(V, 3000, L, seed=width, empty_types=(2,), hub=(5, 300))
+    rowptr, col, _ = ao.bucket_edges(adjs, V, by="dst")
+    g = torch.Generator().manual_seed(width)
+    X = torch.randn((V, width), generator=g)
+    ew = torch.rand(col.shape[0], generator=g) + 0.5
+    rs = torch.rand(V * L, generator=g) + 0.5
+    seg = torch.from_numpy(np.repeat(np.arange(V * L), np.diff(rowptr))).int()
+    msgs = X.double()[torch.from_numpy(col).long()] * ew.double().unsqueeze(-1)
+    if reduce == "sum":
+        ref = orc.unsorted_segment_sum(msgs, seg, V * L) * rs.double().unsqueeze(-1)
+    else:
+        ref = orc.unsorted_segment_max(msgs.float(), seg, V * L).double()
+        nonempty = torch.from_numpy(np.diff(rowptr) > 0)
+        ref[nonempty] = ref[nonempty] * rs.double()[nonempty].unsqueeze(-1)
+    out = ops.gather_reduce(
+        torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), X.to(dev),
+        edge_weight=ew.to(dev), row_scale=rs.to(dev),
+        reduce=ops.REDUCE_MAX if reduce == "max" else ops.REDUCE_SUM,
+    )
+    assert_close(out.cpu(), ref.float(), tol=2e-6, what=f"gather {reduce} w={width}")
+
+
+def test_gather_reduce_pre_post_activation_and_strides(dev):
+    from tf2_gnn_amd import ops
+
+    V = 64
+    adjs = random_graph(V, 500, 1, seed=1)
+    rowptr, col, _ = ao.bucket_edges(adjs, V, by="dst")
+    X = torch.randn((V, 40))
+    wide_in = torch.zeros((V, 64))
+    wide_in[:, 8:48] = X
+    seg = torch.from_numpy(np.repeat(np.arange(V), np.diff(rowptr))).int()
+    ref = torch.tanh(orc.unsorted_segment_sum(torch.relu(X.double()[torch.from_numpy(col).long()]), seg, V))
+    out_wide = torch.full((V, 100), 9.0, device=dev)
+    ops.gather_reduce(torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), wide_in.to(dev)[:, 8:48],
+                      pre_act="relu", post_act="tanh", out=out_wide[:, 20:60])
+    assert_close(out_wide[:, 20:60].cpu(), ref.float(), tol=2e-6, what="pre/post act")
+    assert torch.all(out_wide[:, :20] == 9) and torch.all(out_wide[:, 60:] == 9)
+
+
+@pytest.mark.parametrize("name", ["sum", "max", "mean", "sqrt_n"])
+def test_aggregation_function_semantics(dev, name):
+    """get_aggregation_function(name)(data, segment_ids, num_segments) == tf.math.unsorted_segment_*"""
+    from tf2_gnn_amd.utils import get_aggregation_function
+
+    g = torch.Generator().manual_seed(2)
+    data = torch.randn((37, 5), generator=g)
+    ids = torch.randint(0, 9, (37,), generator=g).int()
+    ids[ids == 4] = 3  # segment 4 is empty
+    ref = orc.get_aggregation_function(name)(data, ids, 11)
+    out = get_aggregation_function(name)(data=data.to(dev), segment_ids=ids.to(dev), num_segments=11)
+    assert_close(out.cpu(), ref, tol=2e-6, what=name)
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_activation_forward_backward(dev, act):
+    from tf2_gnn_amd import ops
+
+    x = torch.linspace(-6, 6, 1003, dtype=torch.float64).requires_grad_(True)
+    y = _ref_act(act)(x)
+    (gx,) = torch.autograd.grad(y.sum(), x)
+    xd = x.detach().float().to(dev)
+    yd = ops.activation_forward(act, xd)
+    assert_close(yd.cpu(), y.detach().float(), tol=2e-6, what=f"{act} fwd")
+    dy = torch.ones_like(xd)
+    saved = xd if act == "gelu" else yd
+    dx = ops.activation_backward(act, dy, saved)
+    assert_close(dx.cpu(), gx.float(), tol=5e-6, what=f"{act} bwd")
+
+
+def test_gru_gates_forward_backward(dev):
+    from tf2_gnn_amd import ops
+
+    V, H = 50, 12
+    g = torch.Generator().manual_seed(0)
+    mx = torch.randn((V, 3 * H), generator=g, dtype=torch.float64).requires_grad_(True)
+    mh = torch.randn((V, 3 * H), generator=g, dtype=torch.float64).requires_grad_(True)
+    h = torch.randn((V, H), generator=g, dtype=torch.float64).requires_grad_(True)
+    z = torch.sigmoid(mx[:, :H] + mh[:, :H])
+    r = torch.sigmoid(mx[:, H:2 * H] + mh[:, H:2 * H])
+    c = torch.tanh(mx[:, 2 * H:] + r * mh[:, 2 * H:])
+    out = z * h + (1 - z) * c
+    dout = torch.randn((V, H), generator=g, dtype=torch.float64)
+    gmx, gmh, gh = torch.autograd.grad((out * dout).sum(), [mx, mh, h])
+    f = lambda t: t.detach().float().to(dev)
+    h_new, gates = ops.gru_gates_forward(f(mx), f(mh), f(h))
+    assert_close(h_new.cpu(), out.detach().float(), tol=2e-6, what="gru fwd")
+    dmx, dmh, dh = ops.gru_gates_backward(f(dout), gates, f(mh), f(h))
+    assert_close(dmx.cpu(), gmx.float(), tol=5e-6, what="gru dmx")
+    assert_close(dmh.cpu(), gmh.float(), tol=5e-6, what="gru dmh")
+    assert_close(dh.cpu(), gh.float(), tol=5e-6, what="gru dh")
+
+
+def test_layernorm_forward_backward(dev):
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((33, 70), generator=g, dtype=torch.float64).requires_grad_(True)
+    gamma = torch.randn(70, generator=g, dtype=torch.float64).requires_grad_(True)
+    beta = torch.randn(70, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = orc.layer_norm(x, gamma, beta, 1e-3)
+    dy = torch.randn((33, 70), generator=g, dtype=torch.float64)
+    gx, gg, gb = torch.autograd.grad((y * dy).sum(), [x, gamma, beta])
+    f = lambda t: t.detach().float().to(dev)
+    yd, mean, rstd = ops.layernorm_forward(f(x), f(gamma), f(beta), 1e-3)
+    assert_close(yd.cpu(), y.detach().float(), tol=5e-6, what="ln fwd")
+    dx, dgam, dbet = ops.layernorm_backward(f(dy), f(x), f(gamma), mean, rstd)
+    assert_close(dx.cpu(), gx.float(), tol=1e-5, what="ln dx")
+    assert_close(dgam.cpu(), gg.float(), tol=1e-5, what="ln dgamma")
+    assert_close(dbet.cpu(), gb.float(), tol=1e-5, what="ln dbeta")
+
+
+def test_dropout_mask_statistics_and_scaling(dev):
+    from tf2_gnn_amd import ops
+
+    x = torch.ones(200000, device=dev)
+    y, mask = ops.dropout_forward(x, 0.1, seed=7)
+    kept = (mask > 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    vals = torch.unique(mask).cpu()
+    assert vals.numel() == 2 and vals[0] == 0 and abs(float(vals[1]) - 1 / 0.9) < 1e-6
+    assert torch.equal(y, mask)
+    y2, mask2 = ops.dropout_forward(x, 0.1, seed=7)
+    assert torch.equal(mask, mask2)
+    _, mask3 = ops.dropout_forward(x, 0.1, seed=8)
+    assert not torch.equal(mask, mask3)
+    with pytest.raises(ValueError):
+        ops.dropout_forward(x, 1.0, seed=0)

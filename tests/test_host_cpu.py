@@ -1,0 +1,159 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/tfgnn.h declares,
+argument validation that needs no GPU, and the host-side mirror of the reference interface
+(registry, hyper-parameter dictionaries, parameter shapes)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "tfgnn.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfgnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tf2_gnn_amd import _lib
+
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"libtfgnn.so does not export {name}"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
+    assert b"gfx950" in lib.tfgnn_version()
+
+
+def test_argument_validation_without_gpu():
+    from tf2_gnn_amd import _lib
+
+    lib = _lib.load()
+    # negative sizes / bad enums are rejected before any HIP call
+    assert lib.tfgnn_gemm(0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None) == -1
+    assert b"negative" in lib.tfgnn_last_error()
+    assert lib.tfgnn_csr_gather_reduce(None, None, None, None, 4, None, 8, 8, None, 8, 7, 0, 0, None) == -1
+    assert lib.tfgnn_activation_forward(99, None, None, 4, None) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1)
+    # empty problems are no-ops
+    assert lib.tfgnn_gemm(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None) == 0
+    assert lib.tfgnn_rgat_aggregate(None, None, None, None, None, 0, 2, 2, 4, 0, None, None, None) == 0
+    assert lib.tfgnn_rgat_aggregate(None, None, None, None, None, 4, 2, 3, 4, 0, None, None, None) == -1  # 4 % 3
+
+
+def test_ops_refuse_cpu_tensors():
+    from tf2_gnn_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.Graph([torch.zeros((1, 2), dtype=torch.int32)], 2)
+
+
+def test_registry_and_errors(kats):
+    """tf2_gnn/layers/message_passing/__init__.py:9-13, message_passing.py:221-227, utils/param_helpers.py"""
+    from tf2_gnn_amd.layers import get_known_message_passing_classes, get_message_passing_class
+    from tf2_gnn_amd.utils import get_activation_function, get_aggregation_function
+
+    assert get_message_passing_class("RGCN").__name__ == "RGCN"
+    assert get_message_passing_class("gnn_edge_mlp").__name__ == "GNN_Edge_MLP"
+    assert set(get_known_message_passing_classes()) >= {"RGCN", "RGAT", "RGIN", "GGNN", "GNN_Edge_MLP"}
+    with pytest.raises(ValueError, match="Unknown message passing type"):
+        get_message_passing_class("nope")
+    with pytest.raises(ValueError, match="Unknown aggregation function"):
+        get_aggregation_function("median")
+    with pytest.raises(ValueError, match="Unknown activation function"):
+        get_activation_function("swish")
+    with pytest.raises(ValueError):  # the reference raises for "linear" too (param_helpers.py:28,36-38)
+        get_activation_function("linear")
+    assert get_activation_function(None) is None
+    assert get_activation_function("ReLU").tfgnn_name == "relu"
+
+
+@pytest.mark.parametrize("cls_name", ["MessagePassing", "GNN_Edge_MLP", "RGCN", "RGIN", "GGNN", "RGAT"])
+def test_default_hyperparameters_match_reference(kats, cls_name):
+    import tf2_gnn_amd.layers.message_passing as mp
+
+    cls = getattr(mp, cls_name)
+    got = cls.get_default_hyperparameters()
+    ref_own = kats["default_hyperparameters"][cls_name]
+    for k, v in ref_own.items():
+        assert got[k] == v, (cls_name, k)
+    # inherited keys of the base class are present everywhere
+    for k in kats["default_hyperparameters"]["MessagePassing"]:
+        assert k in got
+
+
+def test_gnn_default_hyperparameters_match_reference(kats):
+    from tf2_gnn_amd.layers import GNN
+
+    got = GNN.get_default_hyperparameters()
+    for k, v in kats["default_hyperparameters"]["GNN"].items():
+        assert got[k] == v, k
+    assert got["use_target_state_as_input"] is False  # merged from RGCN (gnn.py:74-78)
+    assert GNN.get_default_hyperparameters("ggnn")["message_calculation_class"] == "ggnn"
+    bad = dict(got, global_exchange_mode="nope")
+    with pytest.raises(ValueError, match="global_exchange_mode"):
+        GNN(bad)
+
+
+@pytest.mark.parametrize("use_target", [False, True])
+def test_rgcn_trainable_variable_shapes(kats, use_target):
+    """tf2_gnn/test/layers/test_RGCN.py:15-65: exactly L bias-free kernels of shape (D or 2D, H)."""
+    from tf2_gnn_amd.layers import MessagePassingInput, RGCN
+
+    for D, L, H in kats["rgcn_shape_cases"]:
+        params = RGCN.get_default_hyperparameters()
+        params["hidden_dim"] = H
+        params["use_target_state_as_input"] = use_target
+        layer = RGCN(params)
+        layer.build(MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
+        tv = layer.trainable_variables
+        assert len(tv) == L and len(layer.variables) == L
+        for v in tv:
+            assert tuple(v.shape) == ((2 * D if use_target else D), H)
+
+
+def test_rgat_trainable_variable_shapes(kats):
+    """tf2_gnn/test/layers/test_RGAT.py:35-64"""
+    from tf2_gnn_amd.layers import MessagePassingInput, RGAT
+
+    for D, L, H, K in kats["rgat_shape_cases"]:
+        params = RGAT.get_default_hyperparameters()
+        params["hidden_dim"] = H
+        params["num_heads"] = K
+        layer = RGAT(params)
+        layer.build(MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
+        tv = layer.trainable_variables
+        assert len(tv) == 2 * L and len(layer.variables) == 2 * L
+        for v in tv:
+            if "kernel" in v.name:
+                assert tuple(v.shape) == (D, H)
+            elif "attention" in v.name:
+                assert tuple(v.shape) == (K, 2 * H // K)
+            else:
+                raise AssertionError(v.name)
+
+
+def test_gnn_build_creates_reference_layer_set():
+    """gnn.py:117-232 / SURVEY 3.3: with dense_every_num_layers=10000 there is exactly one Dense (layer 0)."""
+    from tf2_gnn_amd.layers import GNN, GNNInput
+
+    params = GNN.get_default_hyperparameters()
+    params.update({"hidden_dim": 8, "num_layers": 4, "dense_every_num_layers": 10000,
+                   "residual_every_num_layers": 10000, "global_exchange_every_num_layers": 10000})
+    gnn = GNN(params)
+    gnn.build(GNNInput((None, 5), tuple((None, 2) for _ in range(3)), (None,), ()))
+    names = [v.name for v in gnn.trainable_variables]
+    assert sum("Dense/kernel" in n for n in names) == 1
+    assert sum("MessagePassing" in n for n in names) == 4 * 3
+    assert tuple(gnn.trainable_variables[0].shape) == (5, 8)
+    # default GNN params enable global exchange at layer 2: explicitly out of scope
+    with pytest.raises(NotImplementedError, match="global exchange"):
+        g2 = GNN(GNN.get_default_hyperparameters())
+        g2.build(GNNInput((None, 5), ((None, 2),), (None,), ()))

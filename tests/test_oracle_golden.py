@@ -1,0 +1,112 @@
+"""Pin the CPU oracle against every known-answer vector the reference's own tests hold for the path
+(SURVEY.md section 8c).  Runs on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adjacency_oracle as ao
+from oracle import tf2gnn_oracle as orc
+
+
+@pytest.mark.parametrize("idx", range(4))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_message_passing_kats(kats, idx, dtype):
+    """tf2_gnn/test/layers/test_message_passing.py:35-84 (PassSourceStates: message = source state,
+    sum aggregation, relu after aggregation)."""
+    k = kats["message_passing_kats"][idx]
+    X = torch.tensor(k["node_embeddings"], dtype=dtype)
+    adjs = [torch.tensor(a, dtype=torch.int32).reshape(-1, 2) for a in k["adjacency_lists"]]
+    params = {"aggregation_function": "sum", "message_activation_function": "relu", "hidden_dim": 3}
+    out = orc.message_passing_call("pass_source_states", params, {}, X, adjs)
+    expected = torch.tensor(k["aggregated_states"], dtype=dtype)
+    assert out.shape == expected.shape
+    np.testing.assert_array_almost_equal(out.numpy(), expected.numpy())
+
+
+def test_num_incoming_doctest(kats):
+    """tf2_gnn/layers/message_passing/message_passing.py:238-249"""
+    d = kats["num_incoming_doctest"]
+    X = torch.zeros((d["num_nodes"], 3))
+    adjs = [torch.tensor(a, dtype=torch.int32) for a in d["adjacency_lists"]]
+    got = orc.calculate_type_to_num_incoming_edges(X, adjs)
+    assert got.dtype == torch.float32
+    np.testing.assert_array_equal(got.numpy(), np.array(d["expected"], dtype=np.float32))
+    # the bucketing used by the HIP path must give the same counts (row lengths)
+    rowptr, _, _ = ao.bucket_edges([np.array(a, dtype=np.int32) for a in d["adjacency_lists"]], d["num_nodes"])
+    lens = np.diff(rowptr).reshape(d["num_nodes"], 3).T
+    np.testing.assert_array_equal(lens, np.array(d["expected"]))
+
+
+@pytest.mark.parametrize("idx", range(14))
+def test_process_adjacency_lists(kats, idx):
+    """tf2_gnn/test/data/test_utils.py:50-137 + 6 extra cases executed through the reference code"""
+    c = kats["adjacency_cases"][idx]
+    tied = ao.get_tied_edge_types(c["tie_fwd_bkwd_edges"], len(c["adjacency_lists"]))
+    adj, counts = ao.process_adjacency_lists(
+        [list(map(tuple, a)) for a in c["adjacency_lists"]],
+        c["num_nodes"], c["add_self_loop_edges"], tied, c["self_loop_edge_type"],
+    )
+    assert len(adj) == len(c["expected_adjacency_lists"])
+    for got, exp in zip(adj, c["expected_adjacency_lists"]):
+        assert got.dtype == np.int32
+        assert np.array_equal(got, np.array(exp, dtype=np.int32).reshape(-1, 2))
+    assert np.array_equal(counts, np.array(c["expected_counts"]).reshape(len(adj), c["num_nodes"]))
+
+
+def test_segment_op_semantics():
+    """[ext] tf.math.unsorted_segment_*: empty segments -> 0 (sum/mean/sqrt_n) or float32 lowest (max)."""
+    data = torch.tensor([[1.0, -2.0], [3.0, 4.0], [5.0, -6.0]])
+    ids = torch.tensor([2, 0, 2], dtype=torch.int32)
+    assert torch.equal(orc.unsorted_segment_sum(data, ids, 4), torch.tensor([[3.0, 4.0], [0, 0], [6.0, -8.0], [0, 0]]))
+    assert torch.equal(orc.unsorted_segment_mean(data, ids, 4), torch.tensor([[3.0, 4.0], [0, 0], [3.0, -4.0], [0, 0]]))
+    got = orc.unsorted_segment_sqrt_n(data, ids, 4)
+    np.testing.assert_allclose(got[2].numpy(), np.array([6.0, -8.0]) / np.sqrt(2.0), rtol=1e-6)
+    mx = orc.unsorted_segment_max(data, ids, 4)
+    lowest = torch.finfo(torch.float32).min
+    assert torch.equal(mx, torch.tensor([[3.0, 4.0], [lowest, lowest], [5.0, -2.0], [lowest, lowest]]))
+
+
+def test_segment_softmax_matches_dense_softmax():
+    logits = torch.tensor([0.5, -1.0, 2.0, 0.0, 3.0])
+    ids = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32)
+    p = torch.exp(orc.unsorted_segment_log_softmax(logits, ids, 2))
+    np.testing.assert_allclose(p[[0, 2]].numpy(), torch.softmax(logits[[0, 2]], 0).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(p[[1, 3, 4]].numpy(), torch.softmax(logits[[1, 3, 4]], 0).numpy(), rtol=1e-6)
+    q = orc.unsorted_segment_softmax(logits, ids, 2)
+    np.testing.assert_allclose(q.numpy(), p.numpy(), rtol=1e-6)
+
+
+def test_rgcn_restatement_equals_node_side_algebra():
+    """The reference's per-edge form (gather, per-edge matmul, scale, scatter-add) equals the
+    node-side form the HIP path uses, in float64 to 1e-12."""
+    rng = np.random.default_rng(0)
+    V, D, H, L = 40, 6, 5, 3
+    X = torch.tensor(rng.standard_normal((V, D)))
+    adjs = [torch.tensor(rng.integers(0, V, size=(60, 2)).astype(np.int32)) for _ in range(L)]
+    Ws = [torch.tensor(rng.standard_normal((D, H))) for _ in range(L)]
+    params = {
+        "aggregation_function": "sum", "message_activation_function": "relu", "hidden_dim": H,
+        "use_target_state_as_input": False, "normalize_by_num_incoming": True, "num_edge_MLP_hidden_layers": 0,
+    }
+    ref = orc.message_passing_call("rgcn", params, {"edge_mlps": [[w] for w in Ws]}, X, adjs)
+    cnt = orc.calculate_type_to_num_incoming_edges(X, adjs)
+    pre = torch.zeros((V, H), dtype=torch.float64)
+    for l in range(L):
+        A = orc.unsorted_segment_sum(X[adjs[l][:, 0].long()], adjs[l][:, 1], V)
+        A = A * torch.where(cnt[l] > 0, 1.0 / (cnt[l] + 1e-7), torch.zeros_like(cnt[l])).unsqueeze(-1)
+        pre += A @ Ws[l]
+    np.testing.assert_allclose(torch.relu(pre).numpy(), ref.numpy(), atol=1e-12)
+
+
+def test_gru_cell_gate_order_and_shapes():
+    """[ext] Keras GRUCell reset_after=True: with zero kernels h' = 0.5*h + 0.5*tanh(0) = 0.5*h."""
+    H = 4
+    h = torch.arange(8, dtype=torch.float32).reshape(2, H)
+    z = torch.zeros
+    out = orc.gru_cell(z(2, H), h, z(H, 3 * H), z(H, 3 * H), z(2, 3 * H))
+    np.testing.assert_allclose(out.numpy(), 0.5 * h.numpy())
+    # a large positive z-gate input bias keeps the state
+    b = z(2, 3 * H)
+    b[0, :H] = 50.0
+    out = orc.gru_cell(z(2, H), h, z(H, 3 * H), z(H, 3 * H), b)
+    np.testing.assert_allclose(out.numpy(), h.numpy(), rtol=1e-6)

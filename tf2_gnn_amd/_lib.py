@@ -1,0 +1,120 @@
+"""ctypes binding of libtfgnn.so (the C ABI declared in include/tfgnn.h).
+
+There is deliberately NO fallback: if the HIP library has not been built (``python -m
+tf2_gnn_amd.build``) or cannot be loaded, every op raises ``RuntimeError``.  PyTorch is used for
+device allocation and the current HIP stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libtfgnn.so"
+
+# (name, restype, argtypes) - one row per symbol declared in include/tfgnn.h
+_SIGNATURES = [
+    ("tfgnn_last_error", c_char_p, []),
+    ("tfgnn_version", c_char_p, []),
+    (
+        "tfgnn_graph_create",
+        c_int,
+        [c_int, c_int64, POINTER(c_void_p), POINTER(c_int64), c_void_p, POINTER(c_void_p)],
+    ),
+    ("tfgnn_graph_destroy", c_int, [c_void_p]),
+    ("tfgnn_graph_array", c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
+    ("tfgnn_graph_dims", c_int, [c_void_p, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
+    ("tfgnn_graph_scales", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("tfgnn_graph_target_multiplier", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    (
+        "tfgnn_csr_gather_reduce",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
+         c_int, c_int, c_int, c_void_p],
+    ),
+    ("tfgnn_gemm_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64]),
+    (
+        "tfgnn_gemm",
+        c_int,
+        [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+         c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    ),
+    ("tfgnn_activation_forward", c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_activation_backward", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_gru_gates_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    (
+        "tfgnn_gru_gates_backward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    ),
+    ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_add_scale", c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_rgat_node_scores", c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    (
+        "tfgnn_rgat_aggregate",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    (
+        "tfgnn_layernorm_forward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_layernorm_backward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    ),
+    ("tfgnn_segment_offsets", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_segment_softmax", c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_segment_weighted_sum", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    (
+        "tfgnn_segment_weighted_sum_backward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    ),
+    ("tfgnn_segment_softmax_backward", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_dropout_forward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p]),
+    ("tfgnn_mul", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+]
+
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+class TfgnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtfgnn.so (once).  Raises RuntimeError when it is missing - never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run `python -m tf2_gnn_amd.build` "
+            "(hipcc --offload-arch=gfx950). tf2_gnn_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(str(LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status == 0:
+        return
+    msg = load().tfgnn_last_error().decode("utf-8", "replace")
+    if status in (-1, -2):
+        # same convention as the reference's Python layer: bad arguments / indices -> ValueError
+        raise ValueError(f"tfgnn: {msg}")
+    raise TfgnnError(f"tfgnn (status {status}): {msg}")

@@ -1,0 +1,349 @@
+// Element-wise kernels of the hot path: activations (tf2_gnn/utils/param_helpers.py:21-39,
+// applied at message_passing.py:169-177) and their gradients.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace tfgnn {
+
+__global__ void __launch_bounds__(256)
+act_forward_kernel(int act, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (; i + 3 < n; i += stride * 4) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    v.x = act_apply(act, v.x);
+    v.y = act_apply(act, v.y);
+    v.z = act_apply(act, v.z);
+    v.w = act_apply(act, v.w);
+    *reinterpret_cast<float4*>(y + i) = v;
+  }
+  for (; i < n; ++i) {  // at most one thread lands here with a partial tail
+    y[i] = act_apply(act, x[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+act_backward_kernel(int act, const float* __restrict__ dy, const float* __restrict__ saved,
+                    float* __restrict__ dx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (; i + 3 < n; i += stride * 4) {
+    float4 g = *reinterpret_cast<const float4*>(dy + i);
+    float4 s = *reinterpret_cast<const float4*>(saved + i);
+    g.x *= act_grad(act, s.x);
+    g.y *= act_grad(act, s.y);
+    g.z *= act_grad(act, s.z);
+    g.w *= act_grad(act, s.w);
+    *reinterpret_cast<float4*>(dx + i) = g;
+  }
+  for (; i < n; ++i) dx[i] = dy[i] * act_grad(act, saved[i]);
+}
+
+__global__ void act_forward_scalar_kernel(int act, const float* x, float* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = act_apply(act, x[i]);
+}
+__global__ void act_backward_scalar_kernel(int act, const float* dy, const float* saved, float* dx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * act_grad(act, saved[i]);
+}
+
+// ---- GRUCell gates ([ext] tf.keras.layers.GRUCell, reset_after=True; ggnn.py:84-87) -----------
+// mx = x @ kernel + bias[0], mh = h @ recurrent_kernel + bias[1]  (both [V, 3H], gate order z|r|h)
+//   z = sigmoid(mx_z + mh_z); r = sigmoid(mx_r + mh_r); c = tanh(mx_h + r * mh_h); h' = z*h + (1-z)*c
+// gates (optional) receives z|r|c for the backward pass.
+__global__ void __launch_bounds__(256)
+gru_gates_forward_kernel(const float* __restrict__ mx, const float* __restrict__ mh, const float* __restrict__ h,
+                         float* __restrict__ h_new, float* __restrict__ gates, int64_t V, int H) {
+  const int64_t total = V * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / H;
+    const int j = (int)(i - v * H);
+    const float* px = mx + v * 3 * H;
+    const float* ph = mh + v * 3 * H;
+    const float z = 1.f / (1.f + expf(-(px[j] + ph[j])));
+    const float r = 1.f / (1.f + expf(-(px[H + j] + ph[H + j])));
+    const float c = tanhf(px[2 * H + j] + r * ph[2 * H + j]);
+    const float hv = h[i];
+    h_new[i] = z * hv + (1.f - z) * c;
+    if (gates) {
+      float* pg = gates + v * 3 * H;
+      pg[j] = z;
+      pg[H + j] = r;
+      pg[2 * H + j] = c;
+    }
+  }
+}
+
+// dmx, dmh [V,3H], dh_direct [V,H] = dh_new * z
+__global__ void __launch_bounds__(256)
+gru_gates_backward_kernel(const float* __restrict__ dh_new, const float* __restrict__ gates,
+                          const float* __restrict__ mh, const float* __restrict__ h, float* __restrict__ dmx,
+                          float* __restrict__ dmh, float* __restrict__ dh_direct, int64_t V, int H) {
+  const int64_t total = V * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / H;
+    const int j = (int)(i - v * H);
+    const float* pg = gates + v * 3 * H;
+    const float z = pg[j], r = pg[H + j], c = pg[2 * H + j];
+    const float hh = mh[v * 3 * H + 2 * H + j];
+    const float g = dh_new[i];
+    const float dc = g * (1.f - z);
+    const float dz = g * (h[i] - c);
+    const float dpc = dc * (1.f - c * c);
+    const float dpz = dz * z * (1.f - z);
+    const float dpr = dpc * hh * r * (1.f - r);
+    float* ox = dmx + v * 3 * H;
+    float* oh = dmh + v * 3 * H;
+    ox[j] = dpz;
+    ox[H + j] = dpr;
+    ox[2 * H + j] = dpc;
+    oh[j] = dpz;
+    oh[H + j] = dpr;
+    oh[2 * H + j] = dpc * r;
+    dh_direct[i] = g * z;
+  }
+}
+
+// out[n] = sum_m in[m, n]   (bias gradients).  One block per 64 columns, deterministic tree.
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ in, int64_t M, int N, int64_t ld, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int64_t m = w; m < M; m += 4) s += in[m * ld + c];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// y = a * x + b * y' style helpers used by the layer stack (gnn.py:291-296 residual averaging):
+// out = alpha * (x + y)
+__global__ void __launch_bounds__(256)
+add_scale_kernel(const float* __restrict__ x, const float* __restrict__ y, float alpha, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = alpha * (x[i] + y[i]);
+}
+
+// ---- dropout (gnn.py:285-288, [ext] tf.nn.dropout: keep with prob 1-rate, scale by 1/(1-rate)) ---
+// counter-based generator (splitmix64 finaliser over seed ^ index): reproducible for a given seed,
+// independent of the launch geometry.  The mask (0 or 1/(1-rate)) is stored for the backward pass.
+__device__ __forceinline__ uint32_t mix_hash(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+__global__ void __launch_bounds__(256)
+dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n,
+                       float rate, uint64_t seed) {
+  const float scale = 1.f / (1.f - rate);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float u = (float)(mix_hash(seed * 0xD1342543DE82EF95ull + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+    const float m = u >= rate ? scale : 0.f;
+    mask[i] = m;
+    y[i] = x[i] * m;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * b[i];
+}
+
+// ---- LayerNormalization ([ext] tf.keras.layers.LayerNormalization defaults: axis=-1, eps=1e-3;
+// gnn.py:157-161,318-321).  One wave per row.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+layernorm_forward_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         float eps, int64_t rows, int H, float* __restrict__ y, float* __restrict__ mean_out,
+                         float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * H;
+  float s = 0.f;
+  for (int j = lane; j < H; j += 64) s += xr[j];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+  for (int j = lane; j < H; j += 64) {
+    const float d = xr[j] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  float* yr = y + row * H;
+  for (int j = lane; j < H; j += 64) yr[j] = (xr[j] - mean) * rstd * gamma[j] + beta[j];
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dy_xhat = dy * xhat (for d gamma)
+__global__ void __launch_bounds__(256)
+layernorm_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in, int64_t rows, int H,
+                          float* __restrict__ dx, float* __restrict__ dy_xhat) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mean = mean_in[row], rstd = rstd_in[row];
+  const float* xr = x + row * H;
+  const float* dr = dy + row * H;
+  float sg = 0.f, sgx = 0.f;
+  for (int j = lane; j < H; j += 64) {
+    const float xh = (xr[j] - mean) * rstd;
+    const float g = dr[j] * gamma[j];
+    sg += g;
+    sgx += g * xh;
+  }
+  sg = wave_sum(sg) / (float)H;
+  sgx = wave_sum(sgx) / (float)H;
+  for (int j = lane; j < H; j += 64) {
+    const float xh = (xr[j] - mean) * rstd;
+    const float g = dr[j] * gamma[j];
+    dx[row * H + j] = rstd * (g - sg - xh * sgx);
+    dy_xhat[row * H + j] = dr[j] * xh;
+  }
+}
+
+static unsigned ew_blocks(int64_t n_vec) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_vec, 256), 256 * 16));
+}
+
+}  // namespace tfgnn
+
+extern "C" int tfgnn_activation_forward(int act, const float* d_x, float* d_y, int64_t n, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_y, "NULL pointer");
+  TFGNN_REQUIRE(act >= TFGNN_ACT_NONE && act <= TFGNN_ACT_SIGMOID, "unknown activation %d", act);
+  hipStream_t s = (hipStream_t)stream;
+  if ((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0)
+    hipLaunchKernelGGL(act_forward_kernel, dim3(ew_blocks(ceil_div(n, 4))), dim3(256), 0, s, act, d_x, d_y, n);
+  else
+    hipLaunchKernelGGL(act_forward_scalar_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, act, d_x, d_y, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_activation_backward(int act, const float* d_dy, const float* d_saved, float* d_dx,
+                                         int64_t n, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_dy && d_saved && d_dx, "NULL pointer");
+  TFGNN_REQUIRE(act >= TFGNN_ACT_NONE && act <= TFGNN_ACT_SIGMOID, "unknown activation %d", act);
+  hipStream_t s = (hipStream_t)stream;
+  if ((((uintptr_t)d_dy | (uintptr_t)d_saved | (uintptr_t)d_dx) & 15) == 0)
+    hipLaunchKernelGGL(act_backward_kernel, dim3(ew_blocks(ceil_div(n, 4))), dim3(256), 0, s, act, d_dy, d_saved, d_dx, n);
+  else
+    hipLaunchKernelGGL(act_backward_scalar_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, act, d_dy, d_saved, d_dx, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_gru_gates_forward(const float* d_mx, const float* d_mh, const float* d_h, float* d_h_new,
+                                       float* d_gates, int64_t V, int H, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
+  if (V == 0 || H == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_mx && d_mh && d_h && d_h_new, "NULL pointer");
+  hipLaunchKernelGGL(gru_gates_forward_kernel, dim3(ew_blocks(V * H)), dim3(256), 0, (hipStream_t)stream, d_mx, d_mh,
+                     d_h, d_h_new, d_gates, V, H);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const float* d_mh,
+                                        const float* d_h, float* d_dmx, float* d_dmh, float* d_dh_direct,
+                                        int64_t V, int H, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
+  if (V == 0 || H == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_dh_new && d_gates && d_mh && d_h && d_dmx && d_dmh && d_dh_direct, "NULL pointer");
+  hipLaunchKernelGGL(gru_gates_backward_kernel, dim3(ew_blocks(V * H)), dim3(256), 0, (hipStream_t)stream, d_dh_new,
+                     d_gates, d_mh, d_h, d_dmx, d_dmh, d_dh_direct, V, H);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(M >= 0 && N >= 0, "negative size");
+  if (N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_out && (M == 0 || d_in) && ld >= N, "bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, d_in, M, N, ld, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, float* d_out, int64_t n, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_y && d_out, "NULL pointer");
+  hipLaunchKernelGGL(add_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, alpha, d_out, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask, int64_t n, float rate,
+                                     uint64_t seed, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  TFGNN_REQUIRE(rate >= 0.f && rate < 1.f, "dropout rate must be in [0, 1), got %f", (double)rate);
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_y && d_mask, "NULL pointer");
+  hipLaunchKernelGGL(dropout_forward_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask,
+                     n, rate, seed);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_mul(const float* d_a, const float* d_b, float* d_out, int64_t n, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_a && d_b && d_out, "NULL pointer");
+  hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_a, d_b, d_out, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_layernorm_forward(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
+                                       int64_t rows, int H, float* d_y, float* d_mean, float* d_rstd, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(rows >= 0 && H > 0, "bad sizes");
+  if (rows == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_gamma && d_beta && d_y && d_mean && d_rstd, "NULL pointer");
+  hipLaunchKernelGGL(layernorm_forward_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_x, d_gamma, d_beta, eps, rows, H, d_y, d_mean, d_rstd);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, const float* d_gamma, const float* d_mean,
+                                        const float* d_rstd, int64_t rows, int H, float* d_dx, float* d_dy_xhat,
+                                        void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(rows >= 0 && H > 0, "bad sizes");
+  if (rows == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_dy && d_x && d_gamma && d_mean && d_rstd && d_dx && d_dy_xhat, "NULL pointer");
+  hipLaunchKernelGGL(layernorm_backward_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_dy, d_x, d_gamma, d_mean, d_rstd, rows, H, d_dx, d_dy_xhat);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

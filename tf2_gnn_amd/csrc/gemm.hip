@@ -1,0 +1,319 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+//   C[M,N] = act( op(A)[M,K] @ op(B)[K,N] + bias[N] )  (+ C)
+//
+// This is the compute-bound half of the hot path: the per-relation weight multiply of
+// RGCN / GGNN / RGIN / GNN_Edge_MLP (Keras Dense inside dpu_utils MLP, gnn_edge_mlp.py:100),
+// RGAT's Dense (rgat.py:102-109), the GNN glue Dense layers (gnn.py:279,324-327), GRUCell's two
+// matmuls (ggnn.py:84-87) and every MatMul gradient TensorFlow would run for them.
+//
+// Structure: 256 threads = 4 waves arranged 2 x 2; each wave owns TM x TN tiles of 32 x 32
+// (block tile 64*TM x 64*TN), BK = 32.  Global -> registers -> LDS staging with the next tile's
+// global loads in flight while the current tile is multiplied (the fp32 MFMA takes 64 cycles per
+// instruction, so one tile of prefetch covers HBM latency).  LDS layouts are chosen so that every
+// fragment read is bank-conflict free: operands whose K index is contiguous in memory are stored
+// [mn][BK+1] (padded, ds_write_b32), operands whose M/N index is contiguous are stored [k][mn]
+// (ds_write_b128).  Split-K (blockIdx.z) with a deterministic second-pass reduction covers the
+// weight-gradient shapes (small M x N, K = number of nodes).
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace tfgnn {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+struct GemmArgs {
+  int64_t M, N, K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float* C;
+  int64_t ldc;
+  const float* bias;
+  int act;
+  int accumulate;
+  int64_t k_chunk;  // K range per blockIdx.z (multiple of BK)
+  int splits;
+  float* partial;  // [splits][M][N] when splits > 1
+  int vec_a, vec_b;
+  unsigned n_tiles;
+};
+
+// ---- staging of one operand tile -------------------------------------------------------------
+// KCONTIG: source is [MN_total, K] row-major (ld), tile = MN x BK;  LDS [MN][BK+1]
+// else   : source is [K, MN_total] row-major (ld), tile = BK x MN;  LDS [BK][MN]
+template <int MN, bool KCONTIG>
+struct Stage {
+  static constexpr int NV = MN / 32;  // float4 per thread per tile
+  float4 r[NV];
+
+  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t mn0,
+                                       int64_t mn_total, int64_t k0, int64_t k_end, int vec, int tid) {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      int64_t mn, k;
+      if (KCONTIG) {
+        mn = mn0 + (tid >> 3) + 32 * p;
+        k = k0 + (tid & 7) * 4;
+      } else {
+        int q = tid + 256 * p;
+        k = k0 + q / (MN / 4);
+        mn = mn0 + (q % (MN / 4)) * 4;
+      }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KCONTIG) {
+        if (mn < mn_total) {
+          const float* ptr = src + mn * ld + k;
+          if (vec) {
+            if (k < k_end) v = *reinterpret_cast<const float4*>(ptr);
+          } else {
+            if (k + 0 < k_end) v.x = ptr[0];
+            if (k + 1 < k_end) v.y = ptr[1];
+            if (k + 2 < k_end) v.z = ptr[2];
+            if (k + 3 < k_end) v.w = ptr[3];
+          }
+        }
+      } else {
+        if (k < k_end) {
+          const float* ptr = src + k * ld + mn;
+          if (vec) {
+            if (mn < mn_total) v = *reinterpret_cast<const float4*>(ptr);
+          } else {
+            if (mn + 0 < mn_total) v.x = ptr[0];
+            if (mn + 1 < mn_total) v.y = ptr[1];
+            if (mn + 2 < mn_total) v.z = ptr[2];
+            if (mn + 3 < mn_total) v.w = ptr[3];
+          }
+        }
+      }
+      r[p] = v;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      if (KCONTIG) {
+        float* d = lds + ((tid >> 3) + 32 * p) * (BK + 1) + (tid & 7) * 4;
+        d[0] = r[p].x;
+        d[1] = r[p].y;
+        d[2] = r[p].z;
+        d[3] = r[p].w;
+      } else {
+        int q = tid + 256 * p;
+        float* d = lds + (q / (MN / 4)) * MN + (q % (MN / 4)) * 4;
+        *reinterpret_cast<float4*>(d) = r[p];
+      }
+    }
+  }
+
+  // fragment element for MFMA 32x32x2: lane (i = lane & 31, kk = lane >> 5)
+  static __device__ __forceinline__ float frag(const float* __restrict__ lds, int mn, int k) {
+    return KCONTIG ? lds[mn * (BK + 1) + k] : lds[k * MN + mn];
+  }
+  static constexpr int LDS_FLOATS = KCONTIG ? MN * (BK + 1) : BK * MN;
+};
+
+template <int TM, int TN, bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  using SA = Stage<BM, !TA>;  // A stored [M,K] -> K contiguous unless transposed
+  using SB = Stage<BN, TB>;   // B stored [K,N] -> N contiguous unless transposed
+  __shared__ __attribute__((aligned(16))) float lds_a[SA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_b[SB::LDS_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * BM;
+  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  SA sa;
+  SB sb;
+  const int li = lane & 31, lk = lane >> 5;
+
+  if (k_begin < k_end) {
+    sa.load(g.A, g.lda, m0, g.M, k_begin, k_end, g.vec_a, tid);
+    sb.load(g.B, g.ldb, n0, g.N, k_begin, k_end, g.vec_b, tid);
+    sa.store(lds_a, tid);
+    sb.store(lds_b, tid);
+    __syncthreads();
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+      const bool more = k0 + BK < k_end;
+      if (more) {
+        sa.load(g.A, g.lda, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
+        sb.load(g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, 2 * kk + lk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, 2 * kk + lk);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        sa.store(lds_a, tid);
+        sb.store(lds_b, tid);
+        __syncthreads();
+      }
+    }
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const bool split = g.splits > 1;
+  float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldo = split ? g.N : g.ldc;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + (wn * TN + j) * 32 + li;
+      if (col < g.N) {
+        const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < g.M) {
+            float v = acc[i][j][r];
+            if (!split) {
+              v = act_apply(g.act, v + bv);
+              if (g.accumulate) v += outp[row * ldo + col];
+            }
+            outp[row * ldo + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < g.splits; ++z) s += g.partial[(int64_t)z * total + i];
+    const int64_t row = i / g.N, col = i - row * g.N;
+    if (g.bias) s += g.bias[col];
+    s = act_apply(g.act, s);
+    float* c = g.C + row * g.ldc + col;
+    if (g.accumulate) s += *c;
+    *c = s;
+  }
+}
+
+struct GemmPlan {
+  int tm, tn;  // tile config
+  int splits;
+  int64_t k_chunk;
+};
+
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_bytes) {
+  GemmPlan p;
+  if (N % 320 == 0 || (N > 256 && N <= 320)) {
+    p.tm = 1;
+    p.tn = 5;
+  } else if (N > 64 && M > 64) {
+    p.tm = 2;
+    p.tn = 2;
+  } else {
+    p.tm = 1;
+    p.tn = 1;
+  }
+  const int64_t tiles = ceil_div(M, 64 * p.tm) * ceil_div(N, 64 * p.tn);
+  p.splits = 1;
+  p.k_chunk = ceil_div(K > 0 ? K : 1, BK) * BK;
+  // split-K only when the output grid cannot fill the chip and K is long
+  if (tiles < 192 && K >= 1024) {
+    int64_t want = ceil_div(512, tiles);
+    int64_t max_by_k = K / (4 * BK);
+    int64_t s = want < max_by_k ? want : max_by_k;
+    if (s > 64) s = 64;
+    int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4 + 1));
+    if (s > max_by_ws) s = max_by_ws;
+    if (s > 1) {
+      p.k_chunk = ceil_div(ceil_div(K, s), BK) * BK;
+      p.splits = (int)ceil_div(K, p.k_chunk);
+    }
+  }
+  return p;
+}
+
+template <int TM, int TN>
+static void launch_cfg(const GemmArgs& g, int ta, int tb, dim3 grid, hipStream_t s) {
+  dim3 block(256);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, false, false>), grid, block, 0, s, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, false, true>), grid, block, 0, s, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, true, false>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, true, true>), grid, block, 0, s, g);
+}
+
+}  // namespace tfgnn
+
+extern "C" size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  using namespace tfgnn;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  GemmPlan p = plan_gemm(M, N, K, (size_t)1 << 40);
+  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * 4 : 0;
+}
+
+extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
+                          int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                          const float* d_bias, int act, int accumulate, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative GEMM size");
+  if (M == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_C != nullptr, "C is NULL");
+  TFGNN_REQUIRE(K == 0 || (d_A && d_B), "A or B is NULL");
+  TFGNN_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
+  hipStream_t s = (hipStream_t)stream;
+  GemmPlan p = plan_gemm(M, N, K, d_workspace ? workspace_bytes : 0);
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K;
+  g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
+  g.bias = d_bias; g.act = act; g.accumulate = accumulate;
+  g.k_chunk = p.k_chunk; g.splits = p.splits; g.partial = (float*)d_workspace;
+  // float4 staging needs 16-byte aligned rows and the vectorised index to be a multiple of 4
+  const bool a16 = ((uintptr_t)d_A % 16 == 0) && (lda % 4 == 0);
+  const bool b16 = ((uintptr_t)d_B % 16 == 0) && (ldb % 4 == 0);
+  g.vec_a = a16 && ((trans_a ? M : K) % 4 == 0);
+  g.vec_b = b16 && ((trans_b ? K : N) % 4 == 0);
+  g.n_tiles = (unsigned)ceil_div(N, 64 * p.tn);
+  const int64_t tiles = ceil_div(M, 64 * p.tm) * (int64_t)g.n_tiles;
+  TFGNN_REQUIRE(tiles < ((int64_t)1 << 31), "GEMM grid too large");
+  dim3 grid((unsigned)tiles, 1, (unsigned)p.splits);
+  if (p.tm == 1 && p.tn == 5) launch_cfg<1, 5>(g, trans_a, trans_b, grid, s);
+  else if (p.tm == 2 && p.tn == 2) launch_cfg<2, 2>(g, trans_a, trans_b, grid, s);
+  else launch_cfg<1, 1>(g, trans_a, trans_b, grid, s);
+  TFGNN_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    int64_t total = M * N;
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
+    TFGNN_LAUNCH_CHECK();
+  }
+  return TFGNN_OK;
+}

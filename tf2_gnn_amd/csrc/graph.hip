@@ -1,0 +1,675 @@
+// Graph handle: bucket the edges of one batch by (target, edge_type) and by (source, edge_type).
+//
+// Replaces, once per batch instead of once per layer and pass, the index work the reference does
+// inside MessagePassing.call (tf2_gnn/layers/message_passing/message_passing.py:166-167,195-206,
+// 230-263): slicing the src/dst columns of every adjacency list, counting incoming edges per
+// (type, node) with scatter_nd, gathering those counts per edge, and concatenating the per-type
+// target lists.  Row r = node * L + edge_type; the in-degree c[l, v] is the length of row v*L+l.
+//
+// Pipeline (all on the caller's stream; deterministic result):
+//   count keys (int atomics) -> exclusive scan -> scatter (col<<32 | edge_id) with an atomic cursor
+//   -> per-row sort of the 64-bit composites (canonical order) -> unpack + derived arrays.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace tfgnn {
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (thread-local)
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace tfgnn
+
+extern "C" const char* tfgnn_last_error(void) { return tfgnn::g_err; }
+extern "C" const char* tfgnn_version(void) { return "tfgnn 0.1 gfx950"; }
+
+namespace tfgnn {
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of int32 (device wide, 3-phase, recursive on block totals)
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048
+
+// out[i] = exclusive prefix within the tile; block_sums[b] = tile total
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_tiles_kernel(const int32_t* in, int32_t* out, int32_t* block_sums, int64_t n) {  // in may alias out
+  __shared__ int32_t wave_tot[SCAN_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)tid * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    v[i] = idx < n ? in[idx] : 0;
+    sum += v[i];
+  }
+  // inclusive scan of `sum` across the wave
+  const int lane = tid & 63;
+  int32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int32_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  int32_t wave_off = 0;
+  for (int w = 0; w < (tid >> 6); ++w) wave_off += wave_tot[w];
+  int32_t excl = wave_off + incl - sum;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    if (idx < n) out[idx] = excl;
+    excl += v[i];
+  }
+  if (tid == SCAN_THREADS - 1 && block_sums) block_sums[blockIdx.x] = wave_off + incl;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_add_offsets_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ block_offs, int64_t n) {
+  const int32_t off = block_offs[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+  for (int i = threadIdx.x; i < SCAN_TILE; i += SCAN_THREADS) {
+    int64_t idx = base + i;
+    if (idx < n) out[idx] += off;
+  }
+}
+
+static size_t scan_scratch_elems(int64_t n) {
+  size_t total = 0;
+  while (n > SCAN_TILE) {
+    n = ceil_div(n, SCAN_TILE);
+    total += (size_t)n;
+  }
+  return total + 1;
+}
+
+// in/out may alias.  scratch: scan_scratch_elems(n) int32.
+static int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* scratch,
+                              hipStream_t s) {
+  if (n <= 0) return TFGNN_OK;
+  int64_t nb = ceil_div(n, SCAN_TILE);
+  if (nb == 1) {
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, in, out, (int32_t*)nullptr, n);
+    TFGNN_LAUNCH_CHECK();
+    return TFGNN_OK;
+  }
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, scratch, n);
+  TFGNN_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32(scratch, scratch, nb, scratch + nb, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(scan_add_offsets_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, out, scratch, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+struct EdgeLists {
+  const int32_t* const* adj;  // device array of L device pointers
+  const int64_t* edge_off;    // device [L+1]
+  int L;
+};
+
+__device__ __forceinline__ int find_type(const int64_t* __restrict__ edge_off, int L, int64_t g) {
+  int lo = 0, hi = L;  // edge_off[lo] <= g < edge_off[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (edge_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void count_keys_kernel(EdgeLists el, int64_t E, int64_t V, int32_t* __restrict__ cnt_d,
+                                  int32_t* __restrict__ cnt_s, int32_t* __restrict__ err_flag) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    int l = find_type(el.edge_off, el.L, g);
+    const int32_t* a = el.adj[l] + 2 * (g - el.edge_off[l]);
+    int32_t src = a[0], dst = a[1];
+    if (src < 0 || src >= V || dst < 0 || dst >= V) {
+      atomicOr(err_flag, 1);
+      continue;
+    }
+    atomicAdd(&cnt_d[(int64_t)dst * el.L + l], 1);
+    atomicAdd(&cnt_s[(int64_t)src * el.L + l], 1);
+  }
+}
+
+__global__ void scatter_kernel(EdgeLists el, int64_t E, int64_t V, const int32_t* __restrict__ rowptr_d,
+                               const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ cur_d,
+                               int32_t* __restrict__ cur_s, uint64_t* __restrict__ comp_d,
+                               uint64_t* __restrict__ comp_s, int32_t* __restrict__ rowid_d,
+                               int32_t* __restrict__ rowid_s) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    int l = find_type(el.edge_off, el.L, g);
+    const int32_t* a = el.adj[l] + 2 * (g - el.edge_off[l]);
+    int32_t src = a[0], dst = a[1];
+    if (src < 0 || src >= V || dst < 0 || dst >= V) continue;
+    int64_t kd = (int64_t)dst * el.L + l;
+    int64_t ks = (int64_t)src * el.L + l;
+    int32_t pd = rowptr_d[kd] + atomicAdd(&cur_d[kd], 1);
+    int32_t ps = rowptr_s[ks] + atomicAdd(&cur_s[ks], 1);
+    comp_d[pd] = ((uint64_t)(uint32_t)src << 32) | (uint32_t)g;
+    comp_s[ps] = ((uint64_t)(uint32_t)dst << 32) | (uint32_t)g;
+    rowid_d[pd] = (int32_t)kd;
+    rowid_s[ps] = (int32_t)ks;
+  }
+}
+
+// rows of length 2 are fixed in place; 3..64 -> list_a (wave sort); > 64 -> list_b (block sort)
+__global__ void classify_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R,
+                                     uint64_t* __restrict__ comp, int32_t* __restrict__ list_a,
+                                     int32_t* __restrict__ list_b, int32_t* __restrict__ counters) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    int32_t b = rowptr[r], e = rowptr[r + 1];
+    int32_t len = e - b;
+    if (len == 2) {
+      uint64_t x = comp[b], y = comp[b + 1];
+      if (y < x) {
+        comp[b] = y;
+        comp[b + 1] = x;
+      }
+    } else if (len > 2 && len <= 64) {
+      list_a[atomicAdd(&counters[0], 1)] = (int32_t)r;
+    } else if (len > 64) {
+      list_b[atomicAdd(&counters[1], 1)] = (int32_t)r;
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// one wave per listed row (len <= 64): normalized bitonic network over the 64 lanes
+__global__ void __launch_bounds__(256)
+sort_wave_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ list,
+                      const int32_t* __restrict__ count, uint64_t* __restrict__ comp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int32_t n = *count;
+  for (int64_t i = wave; i < n; i += nwaves) {
+    int32_t r = list[i];
+    int32_t b = rowptr[r], len = rowptr[r + 1] - b;
+    uint64_t v = lane < len ? comp[b + lane] : ~0ull;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+      {
+        int m = k - 1;
+        uint64_t o = shfl_xor_u64(v, m);
+        const bool lower = (lane ^ m) > lane;
+        v = lower ? (o < v ? o : v) : (o > v ? o : v);
+      }
+#pragma unroll
+      for (int j = k >> 2; j > 0; j >>= 1) {
+        uint64_t o = shfl_xor_u64(v, j);
+        bool lower = (lane & j) == 0;
+        v = lower ? (o < v ? o : v) : (o > v ? o : v);
+      }
+    }
+    if (lane < len) comp[b + lane] = v;
+  }
+}
+
+constexpr int SORT_LDS_CAP = 4096;  // 32 KiB of composites
+
+// one block per listed row (len > 64): normalized bitonic network in LDS (or in place in global
+// memory for rows longer than SORT_LDS_CAP)
+__global__ void __launch_bounds__(256)
+sort_block_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ list,
+                       const int32_t* __restrict__ count, uint64_t* __restrict__ comp) {
+  __shared__ uint64_t lds[SORT_LDS_CAP];
+  const int tid = threadIdx.x;
+  const int32_t n_rows = *count;
+  for (int32_t li = blockIdx.x; li < n_rows; li += gridDim.x) {
+    int32_t r = list[li];
+    int32_t b = rowptr[r], n = rowptr[r + 1] - b;
+    uint64_t* g = comp + b;
+    const bool use_lds = n <= SORT_LDS_CAP;
+    uint64_t* a = use_lds ? lds : g;
+    if (use_lds) {
+      for (int i = tid; i < n; i += 256) lds[i] = g[i];
+    }
+    __syncthreads();
+    int N = 1;
+    while (N < n) N <<= 1;
+    for (int k = 2; k <= N; k <<= 1) {
+      // flip step
+      for (int idx = tid; idx < (N >> 1); idx += 256) {
+        int hb = k >> 1;
+        int blk = idx / hb, t = idx - blk * hb;
+        int i = blk * k + t, p = blk * k + (k - 1 - t);
+        if (p < n) {
+          uint64_t x = a[i], y = a[p];
+          if (y < x) {
+            a[i] = y;
+            a[p] = x;
+          }
+        }
+      }
+      __syncthreads();
+      for (int j = k >> 2; j > 0; j >>= 1) {
+        for (int idx = tid; idx < (N >> 1); idx += 256) {
+          int blk = idx / j, t = idx - blk * j;
+          int i = blk * 2 * j + t, p = i + j;
+          if (p < n) {
+            uint64_t x = a[i], y = a[p];
+            if (y < x) {
+              a[i] = y;
+              a[p] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (use_lds) {
+      for (int i = tid; i < n; i += 256) g[i] = lds[i];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void invdeg_rows_kernel(const int32_t* __restrict__ rowptr_d, int64_t R, int L,
+                                   float* __restrict__ invdeg_d, int32_t* __restrict__ nodeptr_d,
+                                   const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ nodeptr_s) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    if (r < R) {
+      int32_t len = rowptr_d[r + 1] - rowptr_d[r];
+      // gnn_edge_mlp.py:102-106: 1.0 / (num_incoming + SMALL_NUMBER), evaluated in fp32 like TF
+      invdeg_d[r] = len > 0 ? 1.0f / ((float)len + kSmallNumber) : 0.f;
+    }
+    if (r % L == 0) {
+      nodeptr_d[r / L] = rowptr_d[r];
+      nodeptr_s[r / L] = rowptr_s[r];
+    }
+  }
+}
+
+__global__ void unpack_kernel(const uint64_t* __restrict__ comp, const int32_t* __restrict__ rowid,
+                              int64_t E, int L, int32_t* __restrict__ col, int32_t* __restrict__ eid,
+                              int32_t* __restrict__ coll, const float* __restrict__ invdeg_d,
+                              float* __restrict__ invdeg_edge, int by_src,
+                              int32_t* __restrict__ eid_to_pos) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t c = comp[p];
+    int32_t other = (int32_t)(c >> 32);
+    int32_t id = (int32_t)(c & 0xffffffffu);
+    int32_t row = rowid[p];
+    int l = row % L;
+    col[p] = other;
+    eid[p] = id;
+    int64_t cl = (int64_t)other * L + l;
+    coll[p] = (int32_t)cl;
+    // the degree that normalises an edge is always the in-degree of its TARGET for its type
+    invdeg_edge[p] = by_src ? invdeg_d[cl] : invdeg_d[row];
+    if (eid_to_pos) eid_to_pos[id] = (int32_t)p;
+  }
+}
+
+__global__ void src2dst_kernel(const int32_t* __restrict__ eid_s, const int32_t* __restrict__ eid_to_pos_d,
+                               int64_t E, int32_t* __restrict__ src2dst) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
+       p += (int64_t)gridDim.x * blockDim.x)
+    src2dst[p] = eid_to_pos_d[eid_s[p]];
+}
+
+}  // namespace tfgnn
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct tfgnn_graph {
+  int L = 0;
+  int64_t V = 0, E = 0, R = 0;
+  void* slab = nullptr;
+  int32_t *rowptr_d = nullptr, *col_d = nullptr, *eid_d = nullptr, *coll_d = nullptr;
+  int32_t *rowptr_s = nullptr, *col_s = nullptr, *eid_s = nullptr, *coll_s = nullptr;
+  int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr;
+  float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
+};
+
+namespace {
+struct SlabPlan {
+  size_t total = 0;
+  size_t take(size_t bytes) {
+    size_t off = total;
+    total += (bytes + 255) & ~(size_t)255;
+    return off;
+  }
+};
+}  // namespace
+
+extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
+                                  const int32_t* const* d_adjacency, const int64_t* num_edges,
+                                  void* stream, tfgnn_graph** out_graph) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(out_graph != nullptr, "out_graph is NULL");
+  *out_graph = nullptr;
+  TFGNN_REQUIRE(num_edge_types >= 0 && num_nodes >= 0, "negative sizes");
+  TFGNN_REQUIRE(num_edge_types == 0 || (d_adjacency && num_edges), "adjacency arrays are NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = num_edge_types;
+  const int64_t V = num_nodes;
+  std::vector<int64_t> edge_off(L + 1, 0);
+  for (int l = 0; l < L; ++l) {
+    TFGNN_REQUIRE(num_edges[l] >= 0, "num_edges[%d] < 0", l);
+    TFGNN_REQUIRE(num_edges[l] == 0 || d_adjacency[l] != nullptr, "adjacency list %d is NULL", l);
+    edge_off[l + 1] = edge_off[l] + num_edges[l];
+  }
+  const int64_t E = edge_off[L];
+  const int64_t R = V * (int64_t)L;
+  TFGNN_REQUIRE(R < ((int64_t)1 << 31) - 1 && E < ((int64_t)1 << 31) - 1,
+                "graph too large for int32 indexing (V*L=%lld, E=%lld)", (long long)R, (long long)E);
+
+  tfgnn_graph* g = new tfgnn_graph();
+  g->L = L;
+  g->V = V;
+  g->E = E;
+  g->R = R;
+
+  // persistent arrays
+  SlabPlan plan;
+  const size_t o_rowptr_d = plan.take((R + 1) * 4), o_rowptr_s = plan.take((R + 1) * 4);
+  const size_t o_col_d = plan.take(E * 4), o_eid_d = plan.take(E * 4), o_coll_d = plan.take(E * 4);
+  const size_t o_col_s = plan.take(E * 4), o_eid_s = plan.take(E * 4), o_coll_s = plan.take(E * 4);
+  const size_t o_nodeptr_d = plan.take((V + 1) * 4), o_nodeptr_s = plan.take((V + 1) * 4);
+  const size_t o_src2dst = plan.take(E * 4);
+  const size_t o_invdeg_d = plan.take((R + 1) * 4);
+  const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
+  const size_t persistent = plan.total;
+  // build-time scratch (freed with a second allocation)
+  SlabPlan tmp;
+  const size_t t_cur_d = tmp.take((R + 1) * 4), t_cur_s = tmp.take((R + 1) * 4);
+  const size_t t_comp_d = tmp.take(E * 8), t_comp_s = tmp.take(E * 8);
+  const size_t t_rowid_d = tmp.take(E * 4), t_rowid_s = tmp.take(E * 4);
+  const size_t t_list_a = tmp.take((E / 3 + 1) * 4), t_list_b = tmp.take((E / 65 + 1) * 4);
+  const size_t t_counters = tmp.take(16 * 4);
+  const size_t t_scan = tmp.take(scan_scratch_elems(R + 1) * 4 + 16);
+  const size_t t_eid2pos = tmp.take(E * 4);
+  const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
+
+  char* slab = nullptr;
+  char* scratch = nullptr;
+  hipError_t he = hipMalloc((void**)&slab, persistent ? persistent : 256);
+  if (he != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", persistent, hipGetErrorString(he));
+    delete g;
+    return TFGNN_ERR_HIP;
+  }
+  he = hipMalloc((void**)&scratch, tmp.total);
+  if (he != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", tmp.total, hipGetErrorString(he));
+    (void)hipFree(slab);
+    delete g;
+    return TFGNN_ERR_HIP;
+  }
+  g->slab = slab;
+  g->rowptr_d = (int32_t*)(slab + o_rowptr_d);
+  g->rowptr_s = (int32_t*)(slab + o_rowptr_s);
+  g->col_d = (int32_t*)(slab + o_col_d);
+  g->eid_d = (int32_t*)(slab + o_eid_d);
+  g->coll_d = (int32_t*)(slab + o_coll_d);
+  g->col_s = (int32_t*)(slab + o_col_s);
+  g->eid_s = (int32_t*)(slab + o_eid_s);
+  g->coll_s = (int32_t*)(slab + o_coll_s);
+  g->nodeptr_d = (int32_t*)(slab + o_nodeptr_d);
+  g->nodeptr_s = (int32_t*)(slab + o_nodeptr_s);
+  g->src2dst = (int32_t*)(slab + o_src2dst);
+  g->invdeg_d = (float*)(slab + o_invdeg_d);
+  g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
+  g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
+
+  int32_t* cur_d = (int32_t*)(scratch + t_cur_d);
+  int32_t* cur_s = (int32_t*)(scratch + t_cur_s);
+  uint64_t* comp_d = (uint64_t*)(scratch + t_comp_d);
+  uint64_t* comp_s = (uint64_t*)(scratch + t_comp_s);
+  int32_t* rowid_d = (int32_t*)(scratch + t_rowid_d);
+  int32_t* rowid_s = (int32_t*)(scratch + t_rowid_s);
+  int32_t* list_a = (int32_t*)(scratch + t_list_a);
+  int32_t* list_b = (int32_t*)(scratch + t_list_b);
+  int32_t* counters = (int32_t*)(scratch + t_counters);
+  int32_t* scan_tmp = (int32_t*)(scratch + t_scan);
+  int32_t* eid2pos = (int32_t*)(scratch + t_eid2pos);
+  const int32_t** d_ptrs = (const int32_t**)(scratch + t_ptrs);
+  int64_t* d_off = (int64_t*)(scratch + t_off);
+
+  int rc = TFGNN_OK;
+  int32_t h_counters[16] = {0};
+  auto fail = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    (void)hipFree(slab);
+    delete g;
+    return code;
+  };
+#define G_CHECK(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);    \
+      return fail(TFGNN_ERR_HIP);                                                              \
+    }                                                                                          \
+  } while (0)
+
+  // rowptr arrays double as the count arrays (shifted by one: count of row r at index r)
+  G_CHECK(hipMemsetAsync(g->rowptr_d, 0, (R + 1) * 4, s));
+  G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
+  G_CHECK(hipMemsetAsync(cur_d, 0, (R + 1) * 4, s));
+  G_CHECK(hipMemsetAsync(cur_s, 0, (R + 1) * 4, s));
+  G_CHECK(hipMemsetAsync(counters, 0, 16 * 4, s));
+  if (L > 0) {
+    G_CHECK(hipMemcpyAsync(d_ptrs, d_adjacency, (size_t)L * 8, hipMemcpyHostToDevice, s));
+  }
+  G_CHECK(hipMemcpyAsync(d_off, edge_off.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
+  // the two host arrays above are read by the async copies: make sure they are consumed before
+  // this function returns (edge_off is a local; d_adjacency belongs to the caller)
+  G_CHECK(hipStreamSynchronize(s));
+
+  EdgeLists el{d_ptrs, d_off, L};
+  const int threads = 256;
+  auto blocks_for = [&](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, threads), 8192)); };
+
+  if (E > 0) {
+    hipLaunchKernelGGL(count_keys_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V,
+                       g->rowptr_d, g->rowptr_s, counters + 2);
+  }
+  rc = exclusive_scan_i32(g->rowptr_d, g->rowptr_d, R + 1, scan_tmp, s);
+  if (rc) return fail(rc);
+  rc = exclusive_scan_i32(g->rowptr_s, g->rowptr_s, R + 1, scan_tmp, s);
+  if (rc) return fail(rc);
+  if (E > 0) {
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V, g->rowptr_d,
+                       g->rowptr_s, cur_d, cur_s, comp_d, comp_s, rowid_d, rowid_s);
+    // canonicalise rows: by-dst
+    hipLaunchKernelGGL(classify_rows_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, g->rowptr_d, R,
+                       comp_d, list_a, list_b, counters + 0);
+    hipLaunchKernelGGL(sort_wave_rows_kernel, dim3(2048), dim3(256), 0, s, g->rowptr_d, list_a,
+                       counters + 0, comp_d);
+    hipLaunchKernelGGL(sort_block_rows_kernel, dim3(1024), dim3(256), 0, s, g->rowptr_d, list_b,
+                       counters + 1, comp_d);
+    // by-src (separate counters 4,5; the lists are reused after the by-dst sorts were enqueued)
+    hipLaunchKernelGGL(classify_rows_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, g->rowptr_s, R,
+                       comp_s, list_a, list_b, counters + 4);
+    hipLaunchKernelGGL(sort_wave_rows_kernel, dim3(2048), dim3(256), 0, s, g->rowptr_s, list_a,
+                       counters + 4, comp_s);
+    hipLaunchKernelGGL(sort_block_rows_kernel, dim3(1024), dim3(256), 0, s, g->rowptr_s, list_b,
+                       counters + 5, comp_s);
+  }
+  if (L > 0) {
+    hipLaunchKernelGGL(invdeg_rows_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, g->rowptr_d, R, L,
+                       g->invdeg_d, g->nodeptr_d, g->rowptr_s, g->nodeptr_s);
+  } else {
+    G_CHECK(hipMemsetAsync(g->nodeptr_d, 0, (V + 1) * 4, s));
+    G_CHECK(hipMemsetAsync(g->nodeptr_s, 0, (V + 1) * 4, s));
+  }
+  if (E > 0) {
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_d, rowid_d, E, L,
+                       g->col_d, g->eid_d, g->coll_d, g->invdeg_d, g->invdeg_edge_d, 0, eid2pos);
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_s, rowid_s, E, L,
+                       g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr);
+    hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
+                       g->src2dst);
+  }
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      set_error("graph build kernel launch failed: %s", hipGetErrorString(le));
+      return fail(TFGNN_ERR_HIP);
+    }
+  }
+  G_CHECK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));
+  G_CHECK(hipStreamSynchronize(s));
+  G_CHECK(hipFree(scratch));
+  scratch = nullptr;
+#undef G_CHECK
+  if (h_counters[2] != 0) {
+    set_error("adjacency list contains a node index outside [0, %lld)", (long long)V);
+    (void)hipFree(slab);
+    delete g;
+    return TFGNN_ERR_OUT_OF_RANGE;
+  }
+  *out_graph = g;
+  return TFGNN_OK;
+}
+
+
+namespace tfgnn {
+// mode: 0 = sum, 1 = mean (1/max(N_v,1)), 2 = sqrt_n (1/sqrt(max(N_v,1))); N_v = all in-edges of v
+__device__ __forceinline__ float node_mult(const int32_t* __restrict__ nodeptr_d, int64_t v, int mode) {
+  if (mode == 0) return 1.f;
+  float n = (float)(nodeptr_d[v + 1] - nodeptr_d[v]);
+  n = n < 1.f ? 1.f : n;
+  return mode == 1 ? 1.f / n : 1.f / sqrtf(n);
+}
+
+__global__ void graph_scales_kernel(const int32_t* __restrict__ nodeptr_d, const float* __restrict__ invdeg_d,
+                                    const float* __restrict__ invdeg_edge_s, const float* __restrict__ invdeg_edge_d,
+                                    const int32_t* __restrict__ col_s, int64_t V, int L, int64_t E,
+                                    int normalize, int mode, float* __restrict__ row_scale,
+                                    float* __restrict__ node_scale, float* __restrict__ ew_s,
+                                    float* __restrict__ ew_d) {
+  const int64_t R = V * L;
+  const int64_t n = R > E ? R : E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < R) {
+      const int64_t v = i / L;
+      const float m = node_mult(nodeptr_d, v, mode);
+      row_scale[i] = (normalize ? invdeg_d[i] : 1.f) * m;
+      if (i % L == 0) node_scale[v] = m;
+    }
+    if (i < E) {
+      ew_s[i] = (normalize ? invdeg_edge_s[i] : 1.f) * node_mult(nodeptr_d, col_s[i], mode);
+      ew_d[i] = normalize ? invdeg_edge_d[i] : 1.f;
+    }
+  }
+}
+
+__global__ void target_multiplier_kernel(const int32_t* __restrict__ rowptr_d, const float* __restrict__ row_scale,
+                                         int64_t R, int L, float* __restrict__ k, int32_t* __restrict__ ident_ptr,
+                                         int32_t* __restrict__ node_of_row) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R; r += (int64_t)gridDim.x * blockDim.x) {
+    ident_ptr[r] = (int32_t)r;
+    if (r < R) {
+      const float c = (float)(rowptr_d[r + 1] - rowptr_d[r]);
+      k[r] = row_scale ? c * row_scale[r] : c;
+      node_of_row[r] = (int32_t)(r / L);
+    }
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_graph_scales(const tfgnn_graph* g, int normalize_by_num_incoming, int aggregation_mode,
+                                  float* d_row_scale, float* d_node_scale, float* d_edge_weight_by_src,
+                                  float* d_edge_weight_by_dst, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  TFGNN_REQUIRE(aggregation_mode >= 0 && aggregation_mode <= 2, "unknown aggregation mode %d", aggregation_mode);
+  const int64_t R = g->R, E = g->E;
+  const int64_t n = R > E ? R : E;
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE((R == 0 || (d_row_scale && d_node_scale)) && (E == 0 || (d_edge_weight_by_src && d_edge_weight_by_dst)),
+                "NULL output");
+  unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256), 8192);
+  hipLaunchKernelGGL(graph_scales_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->nodeptr_d,
+                     g->invdeg_d, g->invdeg_edge_s, g->invdeg_edge_d, g->col_s, g->V, g->L, E,
+                     normalize_by_num_incoming, aggregation_mode, d_row_scale, d_node_scale,
+                     d_edge_weight_by_src, d_edge_weight_by_dst);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_target_multiplier(const tfgnn_graph* g, const float* d_row_scale, float* d_k,
+                                             int32_t* d_ident_ptr, int32_t* d_node_of_row, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr && d_ident_ptr != nullptr, "NULL argument");
+  TFGNN_REQUIRE(g->R == 0 || (d_k && d_node_of_row), "NULL output");
+  unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(g->R + 1, 256), 8192);
+  hipLaunchKernelGGL(target_multiplier_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->rowptr_d,
+                     d_row_scale, g->R, g->L > 0 ? g->L : 1, d_k, d_ident_ptr, d_node_of_row);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_destroy(tfgnn_graph* graph) {
+  if (!graph) return TFGNN_OK;
+  if (graph->slab) TFGNN_HIP_CHECK(hipFree(graph->slab));
+  delete graph;
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_dims(const tfgnn_graph* g, int64_t* num_nodes, int* num_edge_types,
+                                int64_t* num_edges) {
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  if (num_nodes) *num_nodes = g->V;
+  if (num_edge_types) *num_edge_types = g->L;
+  if (num_edges) *num_edges = g->E;
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void** d_ptr, int64_t* count) {
+  TFGNN_REQUIRE(g != nullptr && d_ptr != nullptr && count != nullptr, "NULL argument");
+  switch (array_id) {
+    case TFGNN_G_ROWPTR_BY_DST: *d_ptr = g->rowptr_d; *count = g->R + 1; break;
+    case TFGNN_G_COL_BY_DST: *d_ptr = g->col_d; *count = g->E; break;
+    case TFGNN_G_EID_BY_DST: *d_ptr = g->eid_d; *count = g->E; break;
+    case TFGNN_G_COLL_BY_DST: *d_ptr = g->coll_d; *count = g->E; break;
+    case TFGNN_G_ROWPTR_BY_SRC: *d_ptr = g->rowptr_s; *count = g->R + 1; break;
+    case TFGNN_G_COL_BY_SRC: *d_ptr = g->col_s; *count = g->E; break;
+    case TFGNN_G_EID_BY_SRC: *d_ptr = g->eid_s; *count = g->E; break;
+    case TFGNN_G_COLL_BY_SRC: *d_ptr = g->coll_s; *count = g->E; break;
+    case TFGNN_G_INVDEG_BY_DST: *d_ptr = g->invdeg_d; *count = g->R; break;
+    case TFGNN_G_INVDEG_EDGE_BY_SRC: *d_ptr = g->invdeg_edge_s; *count = g->E; break;
+    case TFGNN_G_NODEPTR_BY_DST: *d_ptr = g->nodeptr_d; *count = g->V + 1; break;
+    case TFGNN_G_NODEPTR_BY_SRC: *d_ptr = g->nodeptr_s; *count = g->V + 1; break;
+    case TFGNN_G_INVDEG_EDGE_BY_DST: *d_ptr = g->invdeg_edge_d; *count = g->E; break;
+    case TFGNN_G_SRC2DST_POS: *d_ptr = g->src2dst; *count = g->E; break;
+    default:
+      tfgnn::set_error("unknown graph array id %d", array_id);
+      return TFGNN_ERR_INVALID_ARGUMENT;
+  }
+  return TFGNN_OK;
+}

@@ -1,0 +1,18 @@
+from .gnn import GNN, GNNInput
+from .message_passing import (
+    GGNN,
+    GNN_Edge_MLP,
+    MessagePassing,
+    MessagePassingInput,
+    RGAT,
+    RGCN,
+    RGIN,
+    get_known_message_passing_classes,
+    get_message_passing_class,
+)
+from .nodes_to_graph_representation import (
+    NodesToGraphRepresentation,
+    NodesToGraphRepresentationInput,
+    WASGraphRepresentation,
+    WeightedSumGraphRepresentation,
+)

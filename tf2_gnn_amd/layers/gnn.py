@@ -1,0 +1,252 @@
+"""GNN encoder - mirror of tf2_gnn/layers/gnn.py (GNNInput, GNN: hyper-parameters, build, call
+signature, op order of ``_internal_call`` gnn.py:276-329).
+
+The layer stack is the caller of the hot path; its glue (bias-free Dense + activation, dropout,
+residual averaging, LayerNorm) runs on the same HIP library so that a whole forward+backward step
+stays on the device without a second framework in the loop.  The batch's edges are bucketed once
+(ops.Graph) and shared by all message passing layers and both passes.
+
+Out of scope (raises): graph global exchange (layers/graph_global_exchange.py) - disabled in every
+PPI / QM9 default_hypers file; see DESIGN.md.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, NamedTuple, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..utils.param_helpers import get_activation_function
+from .message_passing import MessagePassing, MessagePassingInput, get_message_passing_class
+from .message_passing.message_passing import Variable, _num_edge_types, default_device, get_graph, glorot_uniform
+
+
+class GNNInput(NamedTuple):
+    """Input named tuple for the GNN (gnn.py:21-27)."""
+
+    node_features: torch.Tensor
+    adjacency_lists: Tuple[torch.Tensor, ...]
+    node_to_graph_map: torch.Tensor
+    num_graphs: Any
+
+
+class GNN:
+    """Encode graph states using a combination of graph message passing layers and dense layers."""
+
+    @classmethod
+    def get_default_hyperparameters(cls, mp_style: Optional[str] = None) -> Dict[str, Any]:
+        """Get the default hyperparameter dictionary for the class (gnn.py:53-79)."""
+        these_hypers = {
+            "message_calculation_class": "rgcn",
+            "initial_node_representation_activation": "tanh",
+            "dense_intermediate_layer_activation": "tanh",
+            "num_layers": 4,
+            "dense_every_num_layers": 2,
+            "residual_every_num_layers": 2,
+            "use_inter_layer_layernorm": False,
+            "hidden_dim": 16,
+            "layer_input_dropout_rate": 0.0,
+            "global_exchange_mode": "gru",  # One of "mean", "mlp", "gru"
+            "global_exchange_every_num_layers": 2,
+            "global_exchange_weighting_fun": "softmax",  # One of "softmax", "sigmoid"
+            "global_exchange_num_heads": 4,
+            "global_exchange_dropout_rate": 0.2,
+        }  # type: Dict[str, Any]
+        if mp_style is not None:
+            these_hypers["message_calculation_class"] = mp_style
+        message_passing_class = get_message_passing_class(these_hypers["message_calculation_class"])
+        message_passing_hypers = message_passing_class.get_default_hyperparameters()
+        message_passing_hypers.update(these_hypers)
+        return message_passing_hypers
+
+    def __init__(self, params: Dict[str, Any]):
+        """Initialise the layer (gnn.py:81-115)."""
+        self._params = params
+        self._hidden_dim = params["hidden_dim"]
+        self._num_layers = params["num_layers"]
+        self._dense_every_num_layers = params["dense_every_num_layers"]
+        self._residual_every_num_layers = params["residual_every_num_layers"]
+        self._use_inter_layer_layernorm = params["use_inter_layer_layernorm"]
+        self._initial_node_representation_activation_fn = get_activation_function(
+            params["initial_node_representation_activation"]
+        )
+        self._dense_intermediate_layer_activation_fn = get_activation_function(
+            params["dense_intermediate_layer_activation"]
+        )
+        self._init_act = _act_name(self._initial_node_representation_activation_fn)
+        self._dense_act = _act_name(self._dense_intermediate_layer_activation_fn)
+        self._message_passing_class = get_message_passing_class(params["message_calculation_class"])
+
+        if not params["global_exchange_mode"].lower() in {"mean", "mlp", "gru"}:
+            raise ValueError(
+                f"Unknown global_exchange_mode mode {params['global_exchange_mode']} - has to be one of 'mean', 'mlp', 'gru'!"
+            )
+        self._global_exchange_every_num_layers = params["global_exchange_every_num_layers"]
+
+        self._initial_projection_layer: Optional[Variable] = None
+        self._mp_layers: List[MessagePassing] = []
+        self._inter_layer_layernorms: List[Tuple[Variable, Variable]] = []
+        self._dense_layers: Dict[str, Variable] = {}
+        self.built = False
+        self._ctx = None
+        self._dropout_calls = 0
+        self.dropout_seed = 0
+
+    # ---- Keras-like plumbing ----------------------------------------------------------------
+    @property
+    def trainable_variables(self) -> List[Variable]:
+        out = [self._initial_projection_layer]
+        for i, mp in enumerate(self._mp_layers):
+            out.extend(mp.trainable_variables)
+            if self._use_inter_layer_layernorm:
+                out.extend(self._inter_layer_layernorms[i])
+            if str(i) in self._dense_layers:
+                out.append(self._dense_layers[str(i)])
+        return out
+
+    variables = trainable_variables
+
+    def zero_grad(self):
+        for v in self.trainable_variables:
+            v.grad = None
+
+    def build(self, tensor_shapes: GNNInput):
+        """gnn.py:117-232."""
+        dev = default_device()
+        D_in = int(tensor_shapes.node_features[-1])
+        adjacency_list_shapes = tuple(tensor_shapes.adjacency_lists)
+        H = self._hidden_dim
+        embedded_shape = (None, H)
+        name = f"{self._message_passing_class.__name__}_GNN"
+        self._initial_projection_layer = Variable(
+            f"{name}/gnn_initial_node_projection/kernel", glorot_uniform((D_in, H), device=dev)
+        )
+        for layer_idx in range(self._num_layers):
+            mp = self._message_passing_class(self._params)
+            mp.build(MessagePassingInput(embedded_shape, adjacency_list_shapes))
+            for v in mp.variables:
+                v.name = f"{name}/Layer_{layer_idx}/MessagePassing/{v.name}"
+            self._mp_layers.append(mp)
+            if self._use_inter_layer_layernorm:
+                self._inter_layer_layernorms.append(
+                    (
+                        Variable(f"{name}/Layer_{layer_idx}/LayerNorm/gamma", torch.ones(H, dtype=torch.float32, device=dev)),
+                        Variable(f"{name}/Layer_{layer_idx}/LayerNorm/beta", torch.zeros(H, dtype=torch.float32, device=dev)),
+                    )
+                )
+            if layer_idx % self._dense_every_num_layers == 0:
+                self._dense_layers[str(layer_idx)] = Variable(
+                    f"{name}/Layer_{layer_idx}/Dense/kernel", glorot_uniform((H, H), device=dev)
+                )
+            if layer_idx and layer_idx % self._global_exchange_every_num_layers == 0:
+                raise NotImplementedError(
+                    "graph global exchange (layers/graph_global_exchange.py) is out of scope of the MI355X hot "
+                    "path; set global_exchange_every_num_layers > num_layers (as all PPI/QM9 default_hypers do)"
+                )
+        self.built = True
+
+    def __call__(self, inputs: GNNInput, training: bool = False, return_all_representations: bool = False):
+        if not self.built:
+            self.build(
+                GNNInput(
+                    tuple(inputs.node_features.shape),
+                    tuple((None, 2) for _ in range(_num_edge_types(inputs.adjacency_lists))),
+                    (None,),
+                    (),
+                )
+            )
+        return self.call(inputs, training, return_all_representations)
+
+    def call(self, inputs: GNNInput, training: bool = False, return_all_representations: bool = False):
+        """gnn.py:234-274: [V, hidden_dim], or (that, tuple of num_layers+1 x [V, hidden_dim])."""
+        cur, all_reprs = self._internal_call(inputs, training)
+        if return_all_representations:
+            return cur, all_reprs
+        return cur
+
+    def _dense(self, x, w: Variable, act_name):
+        """bias-free Dense + activation (gnn.py:136-141,163-170); gelu keeps its pre-activation."""
+        if act_name == "gelu":
+            pre = ops.gemm(x, w.value)
+            return ops.activation_forward("gelu", pre), pre
+        return ops.gemm(x, w.value, act=act_name), None
+
+    def _internal_call(self, inputs: GNNInput, training: bool = False):
+        """gnn.py:276-329, same op order."""
+        X = inputs.node_features
+        V = X.shape[0]
+        graph = get_graph(inputs.adjacency_lists, V)
+        rate = float(self._params["layer_input_dropout_rate"])
+        steps = []
+        cur, pre0 = self._dense(X, self._initial_projection_layer, self._init_act)
+        ctx = {"X": X, "h0": cur, "pre0": pre0, "steps": steps}
+        last = cur
+        all_reprs = [cur]
+        for layer_idx, mp_layer in enumerate(self._mp_layers):
+            st = {}
+            if training and rate > 0.0:
+                self._dropout_calls += 1
+                cur, st["mask"] = ops.dropout_forward(cur, rate, self.dropout_seed * 1000003 + self._dropout_calls)
+            if layer_idx % self._residual_every_num_layers == 0:
+                tmp = cur
+                if layer_idx > 0:
+                    cur = ops.add_scale(cur, last, 0.5)
+                last = tmp
+            cur = mp_layer(MessagePassingInput(node_embeddings=cur, adjacency_lists=graph), training=training)
+            all_reprs.append(cur)
+            if self._use_inter_layer_layernorm:
+                g_, b_ = self._inter_layer_layernorms[layer_idx]
+                st["ln_in"] = cur
+                cur, st["ln_mean"], st["ln_rstd"] = ops.layernorm_forward(cur, g_.value, b_.value, 1e-3)
+            if layer_idx % self._dense_every_num_layers == 0:
+                st["dense_in"] = cur
+                cur, st["dense_pre"] = self._dense(cur, self._dense_layers[str(layer_idx)], self._dense_act)
+                st["dense_out"] = cur
+            steps.append(st)
+        self._ctx = ctx
+        return cur, tuple(all_reprs)
+
+    # ---- backward (stands in for tf.GradientTape, models/graph_task_model.py:347-357) ---------
+    def _dense_backward(self, grad, x_in, w: Variable, act_name, out, pre):
+        if act_name is not None:
+            grad = ops.activation_backward(act_name, grad, pre if act_name == "gelu" else out)
+        w.grad = ops.gemm(x_in, grad, trans_a=True)
+        return grad
+
+    def backward(self, grad_output: torch.Tensor, need_input_grad: bool = False):
+        """Back-propagate d(loss)/d(final node representations) through the stack; fills ``.grad``
+        of every trainable variable; returns d(loss)/d(node_features) if requested."""
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        g = grad_output
+        g_last = None
+        for layer_idx in range(self._num_layers - 1, -1, -1):
+            st = ctx["steps"][layer_idx]
+            if layer_idx % self._dense_every_num_layers == 0:
+                w = self._dense_layers[str(layer_idx)]
+                gpre = self._dense_backward(g, st["dense_in"], w, self._dense_act, st["dense_out"], st["dense_pre"])
+                g = ops.gemm(gpre, w.value, trans_b=True)
+            if self._use_inter_layer_layernorm:
+                gam, bet = self._inter_layer_layernorms[layer_idx]
+                g, gam.grad, bet.grad = ops.layernorm_backward(g, st["ln_in"], gam.value, st["ln_mean"], st["ln_rstd"])
+            g = self._mp_layers[layer_idx].backward(g)
+            if layer_idx % self._residual_every_num_layers == 0:
+                if layer_idx > 0:
+                    half = ops.add_scale(g, g, 0.25)  # 0.5 * g
+                    g = half if g_last is None else ops.add_scale(half, g_last, 1.0)
+                    g_last = half
+                else:
+                    if g_last is not None:
+                        g = ops.add_scale(g, g_last, 1.0)
+                    g_last = None
+            if "mask" in st:
+                g = ops.mul(g, st["mask"])
+        gpre = self._dense_backward(g, ctx["X"], self._initial_projection_layer, self._init_act, ctx["h0"], ctx["pre0"])
+        if need_input_grad:
+            return ops.gemm(gpre, self._initial_projection_layer.value, trans_b=True)
+        return None
+
+
+def _act_name(fn):
+    return None if fn is None else fn.tfgnn_name

@@ -1,0 +1,85 @@
+"""Gated Graph Neural Network layer - mirror of tf2_gnn/layers/message_passing/ggnn.py."""
+from typing import Any, Dict
+
+import torch
+
+from ... import ops
+from .gnn_edge_mlp import GNN_Edge_MLP
+from .message_passing import (
+    MessagePassingInput,
+    _INIT_GEN,
+    default_device,
+    glorot_uniform,
+    register_message_passing_implementation,
+)
+
+
+@register_message_passing_implementation
+class GGNN(GNN_Edge_MLP):
+    """h^{t+1}_v := GRU( sum_l sum_{(u,v) in A_l} W_l h^t_u , h^t_v )   (ggnn.py:12-89).
+    No message activation; requires hidden_dim == input dim (ggnn.py:30).
+    GRUCell = [ext] tf.keras.layers.GRUCell(units=H) TF2 defaults (reset_after=True): kernel [D,3H]
+    glorot_uniform, recurrent_kernel [H,3H] orthogonal, bias [2,3H] zeros, gate order z|r|h."""
+
+    @classmethod
+    def get_default_hyperparameters(cls):
+        these_hypers = {
+            "use_target_state_as_input": False,
+            "normalize_by_num_incoming": True,
+            "num_edge_MLP_hidden_layers": 0,
+        }
+        mp_hypers = super().get_default_hyperparameters()
+        mp_hypers.update(these_hypers)
+        return mp_hypers
+
+    def __init__(self, params: Dict[str, Any], **kwargs):
+        super().__init__(params, **kwargs)
+        self._recurrent_unit = None
+
+    def build(self, input_shapes: MessagePassingInput):
+        D = int(input_shapes.node_embeddings[-1])
+        H = self._hidden_dim
+        dev = default_device()
+        kernel = glorot_uniform((H, 3 * H), device=dev)  # GRUCell input = aggregated messages [V, H]
+        a = torch.randn((3 * H, H), generator=_INIT_GEN, dtype=torch.float32)
+        q, _ = torch.linalg.qr(a)  # [ext] orthogonal initialiser
+        recurrent = q.t().contiguous().to(dev)
+        if D != H:
+            raise ValueError("GGNN requires hidden_dim == node embedding dimension (GRU state size)")
+        bias = torch.zeros((2, 3 * H), dtype=torch.float32, device=dev)
+        self._recurrent_unit = {
+            "kernel": self.add_weight("gru_cell/kernel", kernel),
+            "recurrent_kernel": self.add_weight("gru_cell/recurrent_kernel", recurrent),
+            "bias": self.add_weight("gru_cell/bias", bias),
+        }
+        super().build(input_shapes)
+
+    def _uses_base_aggregation(self) -> bool:
+        return False
+
+    def _post_activation_name(self):
+        return None  # ggnn.py:80-89: aggregated messages go straight into the GRU
+
+    def _finish(self, agg, X, ctx, training):
+        ru = self._recurrent_unit
+        b = ru["bias"].value
+        mx = ops.gemm(agg, ru["kernel"].value, bias=b[0])
+        mh = ops.gemm(X, ru["recurrent_kernel"].value, bias=b[1])
+        h_new, gates = ops.gru_gates_forward(mx, mh, X)
+        ctx.update({"agg": agg, "mh": mh, "gates": gates, "out": h_new})
+        return h_new
+
+    def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        ru = self._recurrent_unit
+        X = ctx["X"]
+        dmx, dmh, dh_direct = ops.gru_gates_backward(grad_output, ctx["gates"], ctx["mh"], X)
+        ru["kernel"].grad = ops.gemm(ctx["agg"], dmx, trans_a=True)
+        ru["recurrent_kernel"].grad = ops.gemm(X, dmh, trans_a=True)
+        ru["bias"].grad = torch.stack([ops.colsum(dmx), ops.colsum(dmh)], dim=0)
+        d_agg = ops.gemm(dmx, ru["kernel"].value, trans_b=True)
+        dX_state = ops.gemm(dmh, ru["recurrent_kernel"].value, trans_b=True, out=dh_direct, accumulate=True)
+        dX_msgs = self._backward_messages(d_agg, ctx)
+        return ops.add_scale(dX_msgs, dX_state, 1.0)

@@ -1,0 +1,325 @@
+"""GNN_Edge_MLP and its hyper-parameter specialisations - mirror of
+tf2_gnn/layers/message_passing/gnn_edge_mlp.py (class, hyper-parameters, weights: one bias-free
+MLP per edge type, gnn_edge_mlp.py:64-82, pinned by test/layers/test_RGCN.py).
+
+The reference computes, per edge type l and per EDGE (gnn_edge_mlp.py:84-107):
+    m_e = MLP_l([x_src | x_tgt] or x_src) ;  m_e *= 1 / (c_{l,tgt} + 1e-7)   (optional)
+and then concat -> unsorted_segment_<agg> -> activation (message_passing.py:135-179).
+Here the same function is evaluated with the per-edge matmul moved to the node side:
+
+  path A (0 hidden layers, sum/mean/sqrt_n, activation after aggregation - RGCN, GGNN):
+      A[v, l, :] = scale_{l,v} * sum_{(u,v) in A_l} x_u          gather kernel over rows (v, l)
+      out        = act( [A_0 | ... | A_{L-1}] @ [W_0; ...; W_{L-1}] )     one MFMA GEMM
+      (+ target states: sum_e [x_u|x_v] W = (sum x_u) W_s + c_{l,v} x_v W_t)
+  path B (>= 1 hidden layer, or max aggregation, or activation before aggregation, source-only):
+      Y[u, l, :] = MLP_l(x_u) for every node        MFMA GEMMs, [V, L, H]
+      out[v]     = post( agg_{(u,v,l)} pre( w_e * Y[u, l, :] ) )         gather kernel over rows v
+  path C (target states AND >= 1 hidden layer): genuine per-edge MLP (first layer separable:
+      x_u W_s + x_v W_t), evaluated per edge in edge-list order.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from ... import ops
+from .message_passing import (
+    MessagePassing,
+    MessagePassingInput,
+    Variable,
+    default_device,
+    get_graph,
+    glorot_uniform,
+    register_message_passing_implementation,
+)
+
+
+def mlp_hidden_sizes(out_size: int, hidden_layers) -> List[int]:
+    """[ext] dpu_utils.tf2utils.MLP: an int n means n hidden layers of ``out_size`` units."""
+    if isinstance(hidden_layers, int):
+        return [out_size] * hidden_layers
+    return list(hidden_layers)
+
+
+class StackedEdgeMLPs:
+    """L bias-free MLPs (one per edge type) stored layer-wise as [L, in, out] tensors so that the
+    per-type kernels of one layer are contiguous ([L*in, out] is the vertical stack)."""
+
+    def __init__(self, owner: MessagePassing, num_types: int, in_size: int, out_size: int, hidden_layers, device):
+        sizes = mlp_hidden_sizes(out_size, hidden_layers) + [out_size]
+        self.L = num_types
+        self.kernels: List[torch.Tensor] = []  # per MLP layer j: [L, in_j, out_j]
+        self.vars: List[List[Variable]] = [[] for _ in range(num_types)]
+        last = in_size
+        for j, size in enumerate(sizes):
+            w = torch.empty((num_types, last, size), dtype=torch.float32, device=device)
+            self.kernels.append(w)
+            last = size
+        # create in the reference's order (all layers of type 0, then type 1, ...) so that seeded
+        # initialisation and variable order match a per-type construction (gnn_edge_mlp.py:73-81)
+        for l in range(num_types):
+            for j, w in enumerate(self.kernels):
+                w[l].copy_(glorot_uniform(w[l].shape, device=device))
+                tag = f"dense_{j}" if j < len(sizes) - 1 else "final_layer"
+                self.vars[l].append(owner.add_weight(f"edge_type_{l}/MLP_{tag}/kernel", w[l]))
+        self.grads: List[Optional[torch.Tensor]] = [None] * len(self.kernels)
+
+    @property
+    def num_layers(self):
+        return len(self.kernels)
+
+    def publish_grads(self):
+        for j, g in enumerate(self.grads):
+            for l in range(self.L):
+                self.vars[l][j].grad = None if g is None else g[l]
+
+
+@register_message_passing_implementation
+class GNN_Edge_MLP(MessagePassing):
+    """Compute new graph states by neural message passing using an edge MLP (gnn_edge_mlp.py:12-107):
+        h^{t+1}_v := sigma( sum_l sum_{(u,v) in A_l} MLP_l(h^t_u || h^t_v) )
+    """
+
+    @classmethod
+    def get_default_hyperparameters(cls):
+        these_hypers = {
+            "use_target_state_as_input": True,
+            "normalize_by_num_incoming": False,
+            "num_edge_MLP_hidden_layers": 1,
+        }
+        mp_hypers = super().get_default_hyperparameters()
+        mp_hypers.update(these_hypers)
+        return mp_hypers
+
+    def __init__(self, params: Dict[str, Any], **kwargs):
+        super().__init__(params, **kwargs)
+        self._use_target_state_as_input = params["use_target_state_as_input"]
+        self._normalize_by_num_incoming = params["normalize_by_num_incoming"]
+        self._num_edge_MLP_hidden_layers = params["num_edge_MLP_hidden_layers"]
+        self._edge_type_mlps: Optional[StackedEdgeMLPs] = None
+        self._in_dim = None
+        self._num_edge_types = None
+
+    def build(self, input_shapes: MessagePassingInput):
+        node_embedding_shapes = input_shapes.node_embeddings
+        adjacency_list_shapes = input_shapes.adjacency_lists
+        num_edge_types = len(adjacency_list_shapes)
+        D = int(node_embedding_shapes[-1])
+        edge_layer_input_size = 2 * D if self._use_target_state_as_input else D
+        self._in_dim = D
+        self._num_edge_types = num_edge_types
+        self._edge_type_mlps = StackedEdgeMLPs(
+            self, num_edge_types, edge_layer_input_size, self._hidden_dim,
+            self._num_edge_MLP_hidden_layers, default_device(),
+        )
+        super().build(input_shapes)
+
+    # the reference's per-edge definition, kept for user subclasses / documentation of semantics
+    def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message,
+                          edge_type_idx, training):
+        raise NotImplementedError(
+            "GNN_Edge_MLP evaluates its message function on the node side (see module docstring); "
+            "the per-edge form lives in oracle/tf2gnn_oracle.py:_edge_mlp_message"
+        )
+
+    # ---- which formulation ------------------------------------------------------------------
+    def _path(self) -> str:
+        linear = self._edge_type_mlps.num_layers == 1
+        sum_like = self._aggregation_name in ("sum", "mean", "sqrt_n")
+        if linear and sum_like and not self._pre_activation():
+            return "A"
+        if not self._use_target_state_as_input:
+            return "B"
+        return "C"
+
+    def _pre_activation(self) -> bool:
+        """activation applied per message before aggregation? (base class only, message_passing.py:169)"""
+        return bool(self._message_activation_before_aggregation) and self._uses_base_aggregation()
+
+    def _uses_base_aggregation(self) -> bool:
+        return True  # RGIN / GGNN override _compute_new_node_embeddings and ignore the flag
+
+    def _post_activation_name(self) -> Optional[str]:
+        """activation fused after the aggregation of messages (message_passing.py:176-177)."""
+        return None if self._pre_activation() else self._activation_name
+
+    # ---- scale helpers ----------------------------------------------------------------------
+    def _scales(self, g: "ops.Graph"):
+        """(row_scale over rows (v,l) | None, edge weights by-dst | None, edge weights by-src | None,
+        node scale [V] | None) for the configured normalisation / aggregation."""
+        from ..graph_scales import graph_scales
+
+        return graph_scales(g, bool(self._normalize_by_num_incoming), self._aggregation_name)
+
+    # ---- forward ----------------------------------------------------------------------------
+    def call(self, inputs: MessagePassingInput, training: bool = False):
+        X = inputs.node_embeddings
+        V = X.shape[0]
+        g = get_graph(inputs.adjacency_lists, V)
+        if g.num_edge_types != self._num_edge_types:
+            raise ValueError(
+                f"layer was built for {self._num_edge_types} edge types, got {g.num_edge_types}"
+            )
+        agg, ctx = self._aggregate_messages(X, g, fuse_act=self._post_activation_name())
+        ctx["graph"] = g
+        ctx["X"] = X
+        self._ctx = ctx
+        return self._finish(agg, X, ctx, training)
+
+    def _finish(self, agg, X, ctx, training):
+        """base class: the activation was fused into the aggregation step."""
+        ctx["out"] = agg
+        return agg
+
+    def _aggregate_messages(self, X, g, fuse_act):
+        """-> (act?(aggregated messages) [V, H], ctx)"""
+        path = self._path()
+        if path == "A":
+            return self._forward_A(X, g, fuse_act)
+        if path == "B":
+            return self._forward_B(X, g, fuse_act)
+        return self._forward_C(X, g, fuse_act)
+
+    def _forward_A(self, X, g, fuse_act):
+        V, D = X.shape
+        L, H = g.num_edge_types, self._hidden_dim
+        T = self._use_target_state_as_input
+        row_scale, _, _, _ = self._scales(g)
+        W = self._edge_type_mlps.kernels[0]  # [L, Din, H]
+        Din = W.shape[1]
+        rowptr = g.array(ops.G_ROWPTR_BY_DST)
+        col = g.array(ops.G_COL_BY_DST)
+        A = torch.empty((V, L * Din), dtype=torch.float32, device=X.device)
+        Arows = A.view(V * L, Din)
+        ops.gather_reduce(rowptr, col, X, row_scale=row_scale, out=Arows[:, :D])
+        if T:
+            # sum_e s_e [x_u | x_v] W = (sum_e s_e x_u) W_s + (c * s) x_v W_t
+            from ..graph_scales import target_multiplier
+
+            k, ident_ptr, node_of_row = target_multiplier(g, row_scale)
+            ops.gather_reduce(ident_ptr, node_of_row, X, edge_weight=k, out=Arows[:, D:])
+        gelu_split = fuse_act == "gelu"
+        pre = ops.gemm(A, W.view(L * Din, H), act=None if gelu_split else fuse_act)
+        ctx = {"path": "A", "A": A, "fused_act": fuse_act}
+        if gelu_split:
+            ctx["pre"] = pre
+            return ops.activation_forward("gelu", pre), ctx
+        return pre, ctx
+
+    def _mlp_all_types(self, X, L, ctx):
+        """Y[:, l, :] = MLP_l(X) for all nodes -> [V, L, H]; hidden activations saved in ctx."""
+        V = X.shape[0]
+        mlps = self._edge_type_mlps
+        acts = []
+        cur = None
+        for j, W in enumerate(mlps.kernels):
+            out_j = W.shape[2]
+            Z = torch.empty((V, L, out_j), dtype=torch.float32, device=X.device)
+            last = j == mlps.num_layers - 1
+            for l in range(L):
+                inp = X if j == 0 else cur[:, l, :]
+                ops.gemm(inp, W[l], act=None if last else "relu", out=Z[:, l, :])
+            acts.append(Z)
+            cur = Z
+        ctx["mlp_acts"] = acts
+        return cur
+
+    def _forward_B(self, X, g, fuse_act):
+        V = X.shape[0]
+        L, H = g.num_edge_types, self._hidden_dim
+        _, ew_d, _, node_scale = self._scales(g)
+        ctx = {"path": "B", "fused_act": fuse_act}
+        Y = self._mlp_all_types(X, L, ctx)
+        is_max = self._aggregation_name == "max"
+        pre = self._activation_name if self._pre_activation() else None
+        gelu_split = fuse_act == "gelu"
+        out = ops.gather_reduce(
+            g.array(ops.G_NODEPTR_BY_DST), g.array(ops.G_COLL_BY_DST), Y.view(V * L, H),
+            edge_weight=ew_d, row_scale=node_scale,
+            reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM,
+            pre_act=pre, post_act=None if gelu_split else fuse_act,
+        )
+        if gelu_split:
+            ctx["pre"] = out
+            return ops.activation_forward("gelu", out), ctx
+        return out, ctx
+
+    def _forward_C(self, X, g, fuse_act):
+        raise NotImplementedError(
+            "GNN_Edge_MLP with use_target_state_as_input=True and hidden edge-MLP layers (per-edge MLP) "
+            "is not implemented yet"
+        )
+
+    # ---- backward ---------------------------------------------------------------------------
+    def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        d_agg = self._backward_finish(grad_output, ctx)
+        return self._backward_messages(d_agg, ctx)
+
+    def _backward_finish(self, grad_output, ctx):
+        """base class: undo the fused activation."""
+        act = ctx["fused_act"]
+        if act is None:
+            return grad_output
+        saved = ctx["pre"] if act == "gelu" else ctx["out"]
+        return ops.activation_backward(act, grad_output, saved)
+
+    def _backward_messages(self, d_agg, ctx):
+        """d(aggregated messages) [V, H] -> dX [V, D]; fills the edge-MLP kernel gradients."""
+        g = ctx["graph"]
+        X = ctx["X"]
+        V, D = X.shape
+        L, H = g.num_edge_types, self._hidden_dim
+        mlps = self._edge_type_mlps
+        if self._aggregation_name == "max" or self._pre_activation():
+            raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
+        row_scale, _, ew_s, _ = self._scales(g)
+        # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]
+        G = ops.gather_reduce(
+            g.array(ops.G_ROWPTR_BY_SRC), g.array(ops.G_COL_BY_SRC), d_agg, edge_weight=ew_s
+        ).view(V, L, H)
+        dX = torch.empty_like(X)
+        if ctx["path"] == "A":
+            W = mlps.kernels[0]  # [L, Din, H]
+            dW = torch.empty_like(W)
+            for l in range(L):
+                ops.gemm(G[:, l, :], W[l, :D, :], trans_b=True, out=dX, accumulate=l > 0)
+                ops.gemm(X, G[:, l, :], trans_a=True, out=dW[l, :D, :])
+            if self._use_target_state_as_input:
+                # target part: pre += (k_{l,v} x_v) W_t  ->  dW_t = (k x)^T d_agg ; dX_v += k d_agg W_t^T
+                from ..graph_scales import target_multiplier
+
+                k, ident_ptr, node_of_row = target_multiplier(g, row_scale)
+                A = ctx["A"].view(V, L, 2 * D)
+                for l in range(L):
+                    ops.gemm(A[:, l, D:], d_agg, trans_a=True, out=dW[l, D:, :])
+                # dX_v += sum_l k_{l,v} * (d_agg[v] @ W_t[l]^T)
+                kd = ops.gather_reduce(ident_ptr, node_of_row, d_agg, edge_weight=k).view(V, L, H)
+                for l in range(L):
+                    ops.gemm(kd[:, l, :], W[l, D:, :], trans_b=True, out=dX, accumulate=True)
+            mlps.grads = [dW]
+        else:
+            acts = ctx["mlp_acts"]
+            grads = [torch.empty_like(W) for W in mlps.kernels]
+            dcur = G  # gradient w.r.t. the MLP outputs Y [V, L, H]
+            for j in range(mlps.num_layers - 1, -1, -1):
+                W = mlps.kernels[j]
+                inp_all = None if j == 0 else acts[j - 1]
+                if j > 0:
+                    dprev = torch.empty_like(inp_all)
+                for l in range(L):
+                    inp = X if j == 0 else inp_all[:, l, :]
+                    ops.gemm(inp, dcur[:, l, :], trans_a=True, out=grads[j][l])
+                    if j > 0:
+                        ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dprev[:, l, :])
+                    else:
+                        ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dX, accumulate=l > 0)
+                if j > 0:
+                    # hidden layers use relu ([ext] dpu_utils MLP default activation)
+                    dcur = ops.activation_backward("relu", dprev, inp_all)
+            mlps.grads = grads
+        mlps.publish_grads()
+        return dX

@@ -1,0 +1,293 @@
+"""Message passing layer - MI355X-native mirror of
+tf2_gnn/layers/message_passing/message_passing.py (same class / method names, hyper-parameter
+keys, call signature and error behaviour; the compute runs in libtfgnn.so).
+
+Differences a caller can observe, by design:
+  * tensors are torch tensors on a ROCm device (fp32 node states, int32 adjacency lists);
+  * the edges of a batch are bucketed once into a ``Graph`` (ops.Graph) that all layers and both
+    passes of a step share; ``MessagePassingInput.adjacency_lists`` may be that Graph directly;
+  * gradients come from explicit ``backward`` methods (the reference relies on tf.GradientTape,
+    models/graph_task_model.py:347-357).
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from collections import OrderedDict
+from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple, Union
+
+import torch
+
+from ... import ops
+from ...utils.param_helpers import get_activation_function, get_aggregation_function
+
+
+class MessagePassingInput(NamedTuple):
+    """A named tuple to hold input to the message passing layer (message_passing.py:13-17)."""
+
+    node_embeddings: torch.Tensor
+    adjacency_lists: Union[Tuple[torch.Tensor, ...], "ops.Graph"]
+
+
+class Variable:
+    """A named trainable tensor (stand-in for tf.Variable: ``.name``, ``.shape``, ``.value``)."""
+
+    def __init__(self, name: str, value: torch.Tensor, trainable: bool = True):
+        self.name = name
+        self.value = value
+        self.trainable = trainable
+        self.grad: Optional[torch.Tensor] = None
+
+    @property
+    def shape(self):
+        return tuple(self.value.shape)
+
+    def __repr__(self):
+        return f"Variable({self.name!r}, shape={self.shape})"
+
+
+_PARAM_DEVICE = [None]
+
+
+def default_device() -> torch.device:
+    if _PARAM_DEVICE[0] is not None:
+        return _PARAM_DEVICE[0]
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")  # shape/plumbing tests only; every op raises on CPU tensors
+
+
+def set_default_device(device):
+    _PARAM_DEVICE[0] = None if device is None else torch.device(device)
+
+
+_INIT_GEN = torch.Generator(device="cpu")
+_INIT_GEN.manual_seed(0)
+
+
+def set_seed(seed: int):
+    _INIT_GEN.manual_seed(seed)
+
+
+def glorot_uniform(shape, fan_in=None, fan_out=None, device=None) -> torch.Tensor:
+    """[ext] Keras default kernel initializer (glorot_uniform): U(-l, l), l = sqrt(6/(fan_in+fan_out))."""
+    if fan_in is None:
+        fan_in, fan_out = shape[-2], shape[-1]
+    limit = (6.0 / max(fan_in + fan_out, 1)) ** 0.5
+    t = (torch.rand(tuple(shape), generator=_INIT_GEN, dtype=torch.float32) * 2.0 - 1.0) * limit
+    return t.to(device or default_device())
+
+
+# --------------------------------------------------------------------------------------------
+# graph cache: GNN builds the Graph once per batch; stand-alone layer calls share it too
+# --------------------------------------------------------------------------------------------
+_GRAPH_CACHE: "OrderedDict[tuple, ops.Graph]" = OrderedDict()
+_GRAPH_CACHE_SIZE = 4
+
+
+def get_graph(adjacency_lists, num_nodes: int) -> "ops.Graph":
+    if isinstance(adjacency_lists, ops.Graph):
+        if adjacency_lists.num_nodes != num_nodes:
+            raise ValueError("Graph was built for a different number of nodes")
+        return adjacency_lists
+    key = (int(num_nodes),) + tuple((a.data_ptr(), tuple(a.shape), a._version) for a in adjacency_lists)
+    g = _GRAPH_CACHE.get(key)
+    if g is None:
+        g = ops.Graph(adjacency_lists, num_nodes)
+        _GRAPH_CACHE[key] = g
+        while len(_GRAPH_CACHE) > _GRAPH_CACHE_SIZE:
+            _, old = _GRAPH_CACHE.popitem(last=False)
+            old.close()
+    else:
+        _GRAPH_CACHE.move_to_end(key)
+    return g
+
+
+def clear_graph_cache():
+    while _GRAPH_CACHE:
+        _, g = _GRAPH_CACHE.popitem()
+        g.close()
+
+
+class MessagePassing:
+    """Abstract class to compute new graph states by neural message passing
+    (message_passing.py:20-218).
+
+    Users create a specific type of message passing layer by implementing ``_message_function``
+    (and optionally overriding ``_compute_new_node_embeddings``), exactly as in the reference.
+    A subclass that only implements ``_message_function`` runs on the generic path: per-edge source
+    / target states are gathered by the HIP gather kernel and handed to the user function, whose
+    result is aggregated by the HIP segment kernels.  The built-in subclasses override ``call``
+    with fused node-side formulations.
+
+    Shape abbreviations as in the reference: V nodes, D input dim, L edge types, E edges of a
+    type, H = hidden_dim.
+    """
+
+    @classmethod
+    def get_default_hyperparameters(cls):
+        return {
+            "aggregation_function": "sum",  # One of sum, mean, max, sqrt_n
+            "message_activation_function": "relu",  # One of relu, leaky_relu, elu, gelu, tanh
+            "message_activation_before_aggregation": False,  # Change to True to apply activation _before_ aggregation.
+            "hidden_dim": 7,
+        }
+
+    def __init__(self, params: Dict[str, Any], **kwargs):
+        self.name = kwargs.get("name", type(self).__name__)
+        self._hidden_dim = int(params["hidden_dim"])
+
+        aggregation_fn_name = params["aggregation_function"]
+        self._aggregation_fn = get_aggregation_function(aggregation_fn_name)
+        self._aggregation_name = aggregation_fn_name
+
+        self._message_activation_before_aggregation = params.get(
+            "message_activation_before_aggregation", False
+        )
+
+        activation_fn_name = params["message_activation_function"]
+        self._activation_fn = get_activation_function(activation_fn_name)
+        self._activation_name = None if activation_fn_name is None else activation_fn_name.lower()
+
+        self.built = False
+        self._variables: List[Variable] = []
+        self._ctx = None  # saved tensors of the last recorded forward
+
+    # ---- Keras-like plumbing ----------------------------------------------------------------
+    @property
+    def trainable_variables(self) -> List[Variable]:
+        return [v for v in self._variables if v.trainable]
+
+    @property
+    def variables(self) -> List[Variable]:
+        return list(self._variables)
+
+    def add_weight(self, name: str, value: torch.Tensor, trainable: bool = True) -> Variable:
+        v = Variable(name, value, trainable)
+        self._variables.append(v)
+        return v
+
+    def zero_grad(self):
+        for v in self._variables:
+            v.grad = None
+
+    def build(self, input_shapes: MessagePassingInput):
+        self.built = True
+
+    def __call__(self, inputs: MessagePassingInput, training: bool = False):
+        if not self.built:
+            self.build(
+                MessagePassingInput(
+                    tuple(inputs.node_embeddings.shape),
+                    tuple((None, 2) for _ in range(_num_edge_types(inputs.adjacency_lists))),
+                )
+            )
+        return self.call(inputs, training=training)
+
+    # ---- the reference's extension points ---------------------------------------------------
+    @abstractmethod
+    def _message_function(
+        self,
+        edge_source_states: torch.Tensor,
+        edge_target_states: torch.Tensor,
+        num_incoming_to_node_per_message: torch.Tensor,
+        edge_type_idx: int,
+        training: bool,
+    ) -> torch.Tensor:
+        """Calculate the messages passed from source nodes to target nodes for ONE edge type
+        (message_passing.py:64-93): [E, D], [E, D], [E] -> [E, H]."""
+
+    def call(self, inputs: MessagePassingInput, training: bool = False):
+        """message_passing.py:95-133 (generic path).  Returns float32 [V, hidden_dim]."""
+        node_embeddings, adjacency_lists = inputs.node_embeddings, inputs.adjacency_lists
+        if isinstance(adjacency_lists, ops.Graph):
+            raise ValueError("the generic MessagePassing path needs the adjacency list tensors")
+        num_nodes = node_embeddings.shape[0]
+        messages_per_type = self._calculate_messages_per_type(adjacency_lists, node_embeddings, training)
+        edge_type_to_message_targets = [adj[:, 1] for adj in adjacency_lists]
+        return self._compute_new_node_embeddings(
+            node_embeddings, messages_per_type, edge_type_to_message_targets, num_nodes, training
+        )
+
+    def _compute_new_node_embeddings(
+        self,
+        cur_node_embeddings: torch.Tensor,
+        messages_per_type: List[torch.Tensor],
+        edge_type_to_message_targets: List[torch.Tensor],
+        num_nodes: int,
+        training: bool,
+    ):
+        """message_passing.py:135-179: concat, (activation), aggregation, (activation)."""
+        message_targets = torch.cat(list(edge_type_to_message_targets), dim=0)  # [M]
+        messages = torch.cat(list(messages_per_type), dim=0)  # [M, H]
+        if self._message_activation_before_aggregation:
+            messages = self._activation_fn(messages)
+        aggregated_messages = self._aggregation_fn(
+            data=messages, segment_ids=message_targets, num_segments=num_nodes
+        )
+        if not self._message_activation_before_aggregation:
+            aggregated_messages = self._activation_fn(aggregated_messages)
+        return aggregated_messages
+
+    def _calculate_messages_per_type(self, adjacency_lists, node_embeddings, training: bool = False):
+        """message_passing.py:181-218; the three embedding_lookups are HIP row gathers."""
+        messages_per_type = []
+        type_to_num_incoming_edges = calculate_type_to_num_incoming_edges(node_embeddings, adjacency_lists)
+        for edge_type_idx, adj in enumerate(adjacency_lists):
+            edge_sources = adj[:, 0].contiguous()
+            edge_targets = adj[:, 1].contiguous()
+            edge_source_states = gather_rows(node_embeddings, edge_sources)
+            edge_target_states = gather_rows(node_embeddings, edge_targets)
+            num_incoming = gather_rows(
+                type_to_num_incoming_edges[edge_type_idx].reshape(-1, 1), edge_targets
+            ).reshape(-1)
+            messages_per_type.append(
+                self._message_function(
+                    edge_source_states, edge_target_states, num_incoming, edge_type_idx, training
+                )
+            )
+        return messages_per_type
+
+    def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            f"{type(self).__name__} runs on the generic message-passing path, which has no backward; "
+            "the built-in layers (RGCN, RGAT, RGIN, GGNN, GNN_Edge_MLP) implement it"
+        )
+
+
+def _num_edge_types(adjacency_lists) -> int:
+    if isinstance(adjacency_lists, ops.Graph):
+        return adjacency_lists.num_edge_types
+    return len(adjacency_lists)
+
+
+def gather_rows(params: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """tf.nn.embedding_lookup(params, ids) (message_passing.py:197-206) through the gather kernel
+    (identity row pointer: one edge per output row)."""
+    n = ids.shape[0]
+    if params.shape[0] == 0 and n:
+        raise ValueError("gather from an empty tensor")
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=params.device)
+    if n and (int(ids.min()) < 0 or int(ids.max()) >= params.shape[0]):
+        raise ValueError("index out of range in gather")  # TF: InvalidArgumentError
+    return ops.gather_reduce(rowptr, ids.to(torch.int32).contiguous(), params.reshape(params.shape[0], -1))
+
+
+MESSAGE_PASSING_IMPLEMENTATIONS: Dict[str, type] = {}
+
+
+def register_message_passing_implementation(cls):
+    """Decorator used to register a message passing class implementation (message_passing.py:224-227)."""
+    MESSAGE_PASSING_IMPLEMENTATIONS[cls.__name__.lower()] = cls
+    return cls
+
+
+def calculate_type_to_num_incoming_edges(node_embeddings, adjacency_lists):
+    """float32 tensor [L, V]: number of incoming edges of each type per node
+    (message_passing.py:230-263).  Here it is read off the bucketed graph: the count for (l, v) is
+    the length of row v*L+l."""
+    num_nodes = node_embeddings.shape[0]
+    g = get_graph(adjacency_lists, num_nodes)
+    L = g.num_edge_types
+    rowptr = g.array(ops.G_ROWPTR_BY_DST)
+    counts = (rowptr[1:] - rowptr[:-1]).reshape(num_nodes, L)
+    return counts.t().to(torch.float32).contiguous()

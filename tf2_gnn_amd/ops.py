@@ -1,0 +1,360 @@
+"""Tensor-level wrappers over the C ABI (include/tfgnn.h).
+
+Inputs/outputs are torch tensors living on a ROCm device; torch supplies device memory and the
+current HIP stream, every FLOP and byte of the hot path runs in libtfgnn.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LEAKY_RELU, ACT_ELU, ACT_SELU, ACT_GELU, ACT_SIGMOID = range(8)
+REDUCE_SUM, REDUCE_MAX = 0, 1
+
+_ACT_BY_NAME = {
+    "none": ACT_NONE,
+    "relu": ACT_RELU,
+    "tanh": ACT_TANH,
+    "leaky_relu": ACT_LEAKY_RELU,
+    "elu": ACT_ELU,
+    "selu": ACT_SELU,
+    "gelu": ACT_GELU,
+    "sigmoid": ACT_SIGMOID,
+}
+
+
+def act_id(name_or_id) -> int:
+    if name_or_id is None:
+        return ACT_NONE
+    if isinstance(name_or_id, int):
+        return name_or_id
+    try:
+        return _ACT_BY_NAME[name_or_id.lower()]
+    except KeyError:
+        raise ValueError(f"Unknown activation function: {name_or_id}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_dev(t: torch.Tensor, dtype, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"tf2_gnn_amd: {what} must live on a ROCm device (got {t.device}); there is no CPU fallback"
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"tf2_gnn_amd: {what} must be {dtype}, got {t.dtype}")
+
+
+def _rowmajor(t: torch.Tensor, what: str):
+    """2-D tensor with unit inner stride -> (tensor, leading dimension)."""
+    if t.dim() != 2:
+        raise ValueError(f"{what} must be 2-D, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    if ld < t.shape[1]:
+        t = t.contiguous()
+        ld = max(t.shape[1], 1)
+    return t, ld
+
+
+class _DevArray:
+    """Zero-copy view of a device array owned by the C library (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": (count,),
+            "typestr": typestr,
+            "data": (ptr, False),
+            "version": 2,
+            "strides": None,
+        }
+
+
+# graph array ids (include/tfgnn.h tfgnn_graph_array_id)
+(G_ROWPTR_BY_DST, G_COL_BY_DST, G_EID_BY_DST, G_COLL_BY_DST, G_ROWPTR_BY_SRC, G_COL_BY_SRC, G_EID_BY_SRC,
+ G_COLL_BY_SRC, G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_NODEPTR_BY_DST, G_NODEPTR_BY_SRC,
+ G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS) = range(14)
+_FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
+
+
+class Graph:
+    """Edge-bucketed adjacency of one batch (``tfgnn_graph``); build once, reuse for every layer
+    and for forward + backward.  ``adjacency_lists``: sequence of int32 device tensors [E_l, 2]
+    with rows (source, target), exactly ``GNNInput.adjacency_lists`` (layers/gnn.py:241-244)."""
+
+    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int):
+        lib = _lib.load()
+        adjs = []
+        for i, a in enumerate(adjacency_lists):
+            _require_dev(a, torch.int32, f"adjacency_lists[{i}]")
+            if a.dim() != 2 or a.shape[1] != 2:
+                if a.numel() == 0:
+                    a = a.reshape(0, 2)
+                else:
+                    raise ValueError(f"adjacency_lists[{i}] must have shape [E, 2], got {tuple(a.shape)}")
+            adjs.append(a.contiguous())
+        self._keep = adjs
+        L = len(adjs)
+        ptrs = (ctypes.c_void_p * max(L, 1))(*[a.data_ptr() if a.numel() else None for a in adjs])
+        counts = (ctypes.c_int64 * max(L, 1))(*[a.shape[0] for a in adjs])
+        handle = ctypes.c_void_p()
+        _lib.check(
+            lib.tfgnn_graph_create(L, int(num_nodes), ptrs, counts, _stream(), ctypes.byref(handle))
+        )
+        self._h = handle
+        self.num_nodes = int(num_nodes)
+        self.num_edge_types = L
+        self.num_edges = int(sum(a.shape[0] for a in adjs))
+        self.device = adjs[0].device if adjs else torch.device("cuda")
+        self._cache = {}
+        self._keep = None  # the handle owns copies of everything it needs
+
+    def array(self, array_id: int) -> torch.Tensor:
+        if array_id in self._cache:
+            return self._cache[array_id]
+        lib = _lib.load()
+        p = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        _lib.check(lib.tfgnn_graph_array(self._h, array_id, ctypes.byref(p), ctypes.byref(n)))
+        if n.value == 0 or not p.value:
+            t = torch.empty(0, dtype=torch.float32 if array_id in _FLOAT_ARRAYS else torch.int32, device=self.device)
+        else:
+            typestr = "<f4" if array_id in _FLOAT_ARRAYS else "<i4"
+            t = torch.as_tensor(_DevArray(p.value, n.value, typestr, self), device=self.device)
+        self._cache[array_id] = t
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._cache = {}
+            _lib.check(_lib.load().tfgnn_graph_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def gather_reduce(
+    rowptr: torch.Tensor,
+    col: torch.Tensor,
+    inp: torch.Tensor,
+    *,
+    edge_weight: Optional[torch.Tensor] = None,
+    row_scale: Optional[torch.Tensor] = None,
+    reduce: int = REDUCE_SUM,
+    pre_act=ACT_NONE,
+    post_act=ACT_NONE,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """out[r] = post_act(row_scale[r] * REDUCE_{e in row r} pre_act(edge_weight[e] * inp[col[e]]))."""
+    lib = _lib.load()
+    _require_dev(inp, torch.float32, "inp")
+    _require_dev(rowptr, torch.int32, "rowptr")
+    num_rows = rowptr.numel() - 1
+    inp, ld_in = _rowmajor(inp, "inp")
+    width = inp.shape[1]
+    if out is None:
+        out = torch.empty((num_rows, width), dtype=torch.float32, device=inp.device)
+    out2, ld_out = _rowmajor(out, "out")
+    if out2 is not out:
+        raise ValueError("out must have unit inner stride")
+    if out.shape[0] != num_rows or out.shape[1] != width:
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(num_rows, width)}")
+    _lib.check(
+        lib.tfgnn_csr_gather_reduce(
+            _ptr(rowptr), _ptr(col), _ptr(edge_weight), _ptr(row_scale), num_rows, _ptr(inp), ld_in, width,
+            _ptr(out), ld_out, int(reduce), act_id(pre_act), act_id(post_act), _stream(),
+        )
+    )
+    return out
+
+
+def gemm(
+    a: torch.Tensor,
+    b: torch.Tensor,
+    *,
+    trans_a: bool = False,
+    trans_b: bool = False,
+    bias: Optional[torch.Tensor] = None,
+    act=ACT_NONE,
+    out: Optional[torch.Tensor] = None,
+    accumulate: bool = False,
+) -> torch.Tensor:
+    """out = act(op(a) @ op(b) + bias) (+ out).  a, b: 2-D fp32 device tensors, unit inner stride."""
+    lib = _lib.load()
+    _require_dev(a, torch.float32, "a")
+    _require_dev(b, torch.float32, "b")
+    a, lda = _rowmajor(a, "a")
+    b, ldb = _rowmajor(b, "b")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    out2, ldc = _rowmajor(out, "out")
+    if out2 is not out or tuple(out.shape) != (M, N):
+        raise ValueError(f"out must be [{M},{N}] with unit inner stride")
+    if bias is not None:
+        _require_dev(bias, torch.float32, "bias")
+        if bias.numel() != N:
+            raise ValueError("bias must have N elements")
+        bias = bias.contiguous()
+    ws_bytes = lib.tfgnn_gemm_workspace_bytes(M, N, K)
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_gemm(
+            int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias),
+            act_id(act), int(accumulate), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    return out
+
+
+def activation_forward(act, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _require_dev(x, torch.float32, "x")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.tfgnn_activation_forward(act_id(act), _ptr(x), _ptr(out), x.numel(), _stream()))
+    return out
+
+
+def activation_backward(act, dy: torch.Tensor, saved: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """dx = dy * act'(.), derivative evaluated from the saved output (saved input for gelu)."""
+    lib = _lib.load()
+    _require_dev(dy, torch.float32, "dy")
+    dy = dy.contiguous()
+    saved = saved.contiguous()
+    if out is None:
+        out = torch.empty_like(dy)
+    _lib.check(
+        lib.tfgnn_activation_backward(act_id(act), _ptr(dy), _ptr(saved), _ptr(out), dy.numel(), _stream())
+    )
+    return out
+
+
+def gru_gates_forward(mx, mh, h, save_gates: bool = True):
+    """h' = GRU gate math on the two pre-computed matmuls ([ext] Keras GRUCell reset_after=True)."""
+    lib = _lib.load()
+    V, H = h.shape
+    h = h.contiguous()
+    h_new = torch.empty_like(h)
+    gates = torch.empty((V, 3 * H), dtype=torch.float32, device=h.device) if save_gates else None
+    _lib.check(
+        lib.tfgnn_gru_gates_forward(_ptr(mx), _ptr(mh), _ptr(h), _ptr(h_new), _ptr(gates), V, H, _stream())
+    )
+    return h_new, gates
+
+
+def gru_gates_backward(dh_new, gates, mh, h):
+    lib = _lib.load()
+    V, H = h.shape
+    dh_new = dh_new.contiguous()
+    dmx = torch.empty((V, 3 * H), dtype=torch.float32, device=h.device)
+    dmh = torch.empty_like(dmx)
+    dh_direct = torch.empty_like(h)
+    _lib.check(
+        lib.tfgnn_gru_gates_backward(
+            _ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx), _ptr(dmh), _ptr(dh_direct),
+            V, H, _stream(),
+        )
+    )
+    return dmx, dmh, dh_direct
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x, ld = _rowmajor(x, "x")
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.tfgnn_colsum(_ptr(x), x.shape[0], x.shape[1], ld, _ptr(out), _stream()))
+    return out
+
+
+def add_scale(x: torch.Tensor, y: torch.Tensor, alpha: float) -> torch.Tensor:
+    """alpha * (x + y)"""
+    lib = _lib.load()
+    x = x.contiguous()
+    y = y.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(lib.tfgnn_add_scale(_ptr(x), _ptr(y), float(alpha), _ptr(out), x.numel(), _stream()))
+    return out
+
+
+def dropout_forward(x: torch.Tensor, rate: float, seed: int):
+    """-> (y, mask) with mask in {0, 1/(1-rate)}"""
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    mask = torch.empty_like(x)
+    _lib.check(
+        lib.tfgnn_dropout_forward(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & (2**64 - 1), _stream())
+    )
+    return y, mask
+
+
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a = a.contiguous()
+    b = b.contiguous()
+    out = torch.empty_like(a)
+    _lib.check(lib.tfgnn_mul(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()))
+    return out
+
+
+def layernorm_forward(x, gamma, beta, eps: float = 1e-3):
+    lib = _lib.load()
+    x = x.contiguous()
+    rows, H = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(
+        lib.tfgnn_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), float(eps), rows, H, _ptr(y), _ptr(mean),
+                                    _ptr(rstd), _stream())
+    )
+    return y, mean, rstd
+
+
+def layernorm_backward(dy, x, gamma, mean, rstd):
+    """-> (dx, dgamma, dbeta)"""
+    lib = _lib.load()
+    dy = dy.contiguous()
+    rows, H = x.shape
+    dx = torch.empty_like(x)
+    dy_xhat = torch.empty_like(x)
+    _lib.check(
+        lib.tfgnn_layernorm_backward(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), rows, H, _ptr(dx),
+                                     _ptr(dy_xhat), _stream())
+    )
+    return dx, colsum(dy_xhat), colsum(dy)
