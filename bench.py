@@ -233,12 +233,12 @@ def main():
     if rank == 0 and not args.no_roofline:
         # ---- dominant kernels, measured live on the launch stream -------------------------------
         g = graph if graph is not None else ops.Graph(adj_dev, V)
-        rowptr, col, rs = g.array(ops.G_ROWPTR_BY_DST), g.array(ops.G_COL_BY_DST), g.array(ops.G_INVDEG_BY_DST)
+        rs = g.array(ops.G_INVDEG_BY_DST)
         Hx = torch.randn((V, H), device=dev)
         A = torch.empty((V * L, H), device=dev)
         W = torch.randn((L * H, H), device=dev) * 0.05
         out = torch.empty((V, H), device=dev)
-        ms_gather = time_kernel(lambda: ops.gather_reduce(rowptr, col, Hx, row_scale=rs, out=A))
+        ms_gather = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
         ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
         ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
         # algorithmic bytes of one gather launch: one fp32 source row + one int32 col per

@@ -130,6 +130,29 @@ int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d_col,
                             float* d_out, int64_t ld_out, int reduce_op, int pre_act, int post_act,
                             void* stream);
 
+/* The same reduction over one of the graph handle's four bucketed views, with the handle's plan for
+ * long rows (rows with more than 32 edges are cut into 256-edge items, one workgroup each, combined
+ * deterministically) - the form the layers use:
+ *   TFGNN_VIEW_BY_DST_TYPED  rows (v,l) -> col = source             (aggregate-first forward)
+ *   TFGNN_VIEW_BY_DST_NODE   rows v     -> col = source*L + type    (transform-first forward, RGAT)
+ *   TFGNN_VIEW_BY_SRC_TYPED  rows (u,l) -> col = target             (backward: scatter by source)
+ *   TFGNN_VIEW_BY_SRC_NODE   rows u     -> col = target*L + type
+ * d_col_override (nullable) replaces the view's column array (same edge order).  d_edge_weight is
+ * [E] (ew_heads == 1) or [E, ew_heads] applied per head of width/ew_heads floats (RGAT attention,
+ * rgat.py:154-160).  d_workspace must hold tfgnn_graph_gather_workspace_bytes(graph, view, width). */
+typedef enum {
+  TFGNN_VIEW_BY_DST_TYPED = 0,
+  TFGNN_VIEW_BY_DST_NODE = 1,
+  TFGNN_VIEW_BY_SRC_TYPED = 2,
+  TFGNN_VIEW_BY_SRC_NODE = 3
+} tfgnn_graph_view;
+size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* graph, int view, int width);
+int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
+                              const float* d_edge_weight, int ew_heads, const float* d_row_scale,
+                              const float* d_in, int64_t ld_in, int width, float* d_out, int64_t ld_out,
+                              int reduce_op, int pre_act, int post_act, void* d_workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense layer: C[M,N] = act( op(A)[M,K] @ op(B)[K,N] + bias[N] ) (+ C if accumulate)
  * fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32).

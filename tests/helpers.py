@@ -69,3 +69,11 @@ def assert_close(actual: torch.Tensor, expected: torch.Tensor, tol=1e-5, what=""
     err = (a - b).abs() / b.abs().clamp(min=1.0)
     worst = float(err.max())
     assert worst <= tol, f"{what}: max scaled error {worst:.3e} > {tol:.1e} at {int(err.argmax())}"
+
+
+def scaled_error(actual: torch.Tensor, expected: torch.Tensor) -> float:
+    a = actual.detach().cpu().double()
+    b = expected.detach().cpu().double()
+    if a.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp(min=1.0)).max())

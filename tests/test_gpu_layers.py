@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import tf2gnn_oracle as orc
-from tests.helpers import assert_close, mp_weights_from_layer, random_graph, to_dev
+from tests.helpers import assert_close, mp_weights_from_layer, random_graph, scaled_error, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -82,11 +82,15 @@ def test_layer_forward_parity(dev, name, cls_name, over, H):
     adj_t = [torch.from_numpy(a) for a in adjs]
     ref32 = orc.message_passing_call(cls_name, p, w, X, adj_t)
     assert out.shape == (V, H)
-    assert_close(out.cpu(), ref32, tol=1e-5, what=name)
-    # and both fp32 results are equally close to the fp64 oracle
+    # The fp64 oracle is the arbiter: the HIP result must be within 1e-5 of it.  The reference-order
+    # fp32 result is held to the same yardstick; where ITS rounding error already exceeds 1e-5 (long
+    # un-normalised sums with cancellation) the HIP path may not be worse than twice that.
     w64 = _to64(w)
     ref64 = orc.message_passing_call(cls_name, p, w64, X.double(), adj_t)
-    assert_close(out.cpu(), ref64.float(), tol=1e-5, what=name + " vs fp64")
+    err_ref32 = scaled_error(ref32, ref64)
+    err_hip = scaled_error(out.cpu(), ref64)
+    assert err_hip <= max(1e-5, 2 * err_ref32), f"{name}: HIP vs fp64 {err_hip:.3e}, reference-order fp32 vs fp64 {err_ref32:.3e}"
+    assert scaled_error(out.cpu(), ref32) <= max(1e-5, 2 * (err_hip + err_ref32)), name
 
 
 def _to64(w):

@@ -101,7 +101,11 @@ def test_gather_reduce_matches_oracle(dev, width, reduce):
         edge_weight=ew.to(dev), row_scale=rs.to(dev),
         reduce=ops.REDUCE_MAX if reduce == "max" else ops.REDUCE_SUM,
     )
-    assert_close(out.cpu(), ref.float(), tol=2e-6, what=f"gather {reduce} w={width}")
+    # fp32 summation error is bounded by (row length) * eps * sum|terms|: compare relative to the
+    # L1 mass of each row (hub rows hold 300+ terms)
+    l1 = orc.unsorted_segment_sum(msgs.abs(), seg, V * L).clamp(min=1.0) * rs.double().unsqueeze(-1).clamp(min=1.0)
+    err = ((out.cpu().double() - ref).abs() / (l1 if reduce == "sum" else ref.abs().clamp(min=1.0))).max()
+    assert float(err) <= 2e-6, f"gather {reduce} w={width}: {float(err):.3e}"
 
 
 def test_gather_reduce_pre_post_activation_and_strides(dev):

@@ -7,14 +7,19 @@
 // RGAT's Dense (rgat.py:102-109), the GNN glue Dense layers (gnn.py:279,324-327), GRUCell's two
 // matmuls (ggnn.py:84-87) and every MatMul gradient TensorFlow would run for them.
 //
-// Structure: 256 threads = 4 waves arranged 2 x 2; each wave owns TM x TN tiles of 32 x 32
-// (block tile 64*TM x 64*TN), BK = 32.  Global -> registers -> LDS staging with the next tile's
+// Structure: WM x WN waves per workgroup, each wave owns TM x TN tiles of 32 x 32 (block tile
+// 32*WM*TM x 32*WN*TN), BK = 32.  N = 320-family shapes use 8 waves (4 x 2) on a 128 x 320 tile: the
+// 40 KB weight tile is staged once per CU and two waves share each SIMD, so one wave's LDS fragment
+// reads hide under the other's MFMAs.  Global -> registers -> LDS staging with the next tile's
 // global loads in flight while the current tile is multiplied (the fp32 MFMA takes 64 cycles per
 // instruction, so one tile of prefetch covers HBM latency).  LDS layouts are chosen so that every
 // fragment read is bank-conflict free: operands whose K index is contiguous in memory are stored
 // [mn][BK+1] (padded, ds_write_b32), operands whose M/N index is contiguous are stored [k][mn]
-// (ds_write_b128).  Split-K (blockIdx.z) with a deterministic second-pass reduction covers the
-// weight-gradient shapes (small M x N, K = number of nodes).
+// (ds_write_b128).  The staging code is specialised at compile time for 16-byte aligned operands
+// (VEC: one global_load_dwordx4 per staged vector, pointers advanced by a constant per K tile) so
+// that the steady-state loop is a few hundred instructions; a scalar variant covers odd shapes.
+// Split-K (blockIdx.z) with a deterministic second-pass reduction covers the weight-gradient
+// shapes (small M x N, K = number of nodes).
 #include <algorithm>
 
 #include "common.hpp"
@@ -39,58 +44,73 @@ struct GemmArgs {
   int64_t k_chunk;  // K range per blockIdx.z (multiple of BK)
   int splits;
   float* partial;  // [splits][M][N] when splits > 1
-  int vec_a, vec_b;
   unsigned n_tiles;
 };
 
 // ---- staging of one operand tile -------------------------------------------------------------
 // KCONTIG: source is [MN_total, K] row-major (ld), tile = MN x BK;  LDS [MN][BK+1]
 // else   : source is [K, MN_total] row-major (ld), tile = BK x MN;  LDS [BK][MN]
-template <int MN, bool KCONTIG>
+// Thread t stages NV vectors of 4 floats per tile; vector p covers
+//   KCONTIG : row mn = (t >> 3) + (NT/8) p, k = (t & 7) * 4 .. +3
+//   else    : q = t + NT p, k = q / (MN/4), mn = (q % (MN/4)) * 4 .. +3
+template <int MN, bool KCONTIG, bool VEC, int NT>
 struct Stage {
-  static constexpr int NV = MN / 32;  // float4 per thread per tile
+  static constexpr int NV = MN * BK / 4 / NT;  // vectors per thread per tile
+  static_assert(MN * BK / 4 % NT == 0, "tile must divide evenly over the workgroup");
   float4 r[NV];
+  const float* ptr[NV];  // current global address of vector p (advances by one K tile per load)
+  bool row_ok[NV];       // mn inside the matrix (VEC: whole vector in or out)
+  int koff[NV];          // k offset of the vector inside the tile
+  int mn_rem[NV];        // scalar path: number of valid mn (non-KCONTIG) elements in the vector
 
-  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t mn0,
-                                       int64_t mn_total, int64_t k0, int64_t k_end, int vec, int tid) {
+  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t mn0, int64_t mn_total,
+                                       int64_t k_begin, int tid) {
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
-      int64_t mn, k;
+      int64_t mn;
+      int k;
       if (KCONTIG) {
-        mn = mn0 + (tid >> 3) + 32 * p;
-        k = k0 + (tid & 7) * 4;
+        mn = mn0 + (tid >> 3) + (NT / 8) * p;
+        k = (tid & 7) * 4;
+        ptr[p] = src + mn * ld + k_begin + k;
+        mn_rem[p] = 4;
       } else {
-        int q = tid + 256 * p;
-        k = k0 + q / (MN / 4);
+        const int q = tid + NT * p;
+        k = q / (MN / 4);
         mn = mn0 + (q % (MN / 4)) * 4;
+        ptr[p] = src + (k_begin + k) * ld + mn;
+        const int64_t rem = mn_total - mn;
+        mn_rem[p] = rem > 4 ? 4 : (rem < 0 ? 0 : (int)rem);
       }
+      koff[p] = k;
+      row_ok[p] = mn < mn_total;
+    }
+  }
+
+  // k_left = number of valid k from the start of this tile
+  __device__ __forceinline__ void load(int64_t k_left, int64_t ld) {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KCONTIG) {
-        if (mn < mn_total) {
-          const float* ptr = src + mn * ld + k;
-          if (vec) {
-            if (k < k_end) v = *reinterpret_cast<const float4*>(ptr);
-          } else {
-            if (k + 0 < k_end) v.x = ptr[0];
-            if (k + 1 < k_end) v.y = ptr[1];
-            if (k + 2 < k_end) v.z = ptr[2];
-            if (k + 3 < k_end) v.w = ptr[3];
-          }
-        }
-      } else {
-        if (k < k_end) {
-          const float* ptr = src + k * ld + mn;
-          if (vec) {
-            if (mn < mn_total) v = *reinterpret_cast<const float4*>(ptr);
-          } else {
-            if (mn + 0 < mn_total) v.x = ptr[0];
-            if (mn + 1 < mn_total) v.y = ptr[1];
-            if (mn + 2 < mn_total) v.z = ptr[2];
-            if (mn + 3 < mn_total) v.w = ptr[3];
-          }
+      if (row_ok[p]) {
+        if (VEC) {
+          if (koff[p] < k_left) v = *reinterpret_cast<const float4*>(ptr[p]);
+        } else if (KCONTIG) {
+          const int64_t n = k_left - koff[p];
+          if (n > 0) v.x = ptr[p][0];
+          if (n > 1) v.y = ptr[p][1];
+          if (n > 2) v.z = ptr[p][2];
+          if (n > 3) v.w = ptr[p][3];
+        } else if (koff[p] < k_left) {
+          const int n = mn_rem[p];
+          if (n > 0) v.x = ptr[p][0];
+          if (n > 1) v.y = ptr[p][1];
+          if (n > 2) v.z = ptr[p][2];
+          if (n > 3) v.w = ptr[p][3];
         }
       }
       r[p] = v;
+      ptr[p] += KCONTIG ? (int64_t)BK : (int64_t)BK * ld;
     }
   }
 
@@ -98,13 +118,13 @@ struct Stage {
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       if (KCONTIG) {
-        float* d = lds + ((tid >> 3) + 32 * p) * (BK + 1) + (tid & 7) * 4;
+        float* d = lds + ((tid >> 3) + (NT / 8) * p) * (BK + 1) + (tid & 7) * 4;
         d[0] = r[p].x;
         d[1] = r[p].y;
         d[2] = r[p].z;
         d[3] = r[p].w;
       } else {
-        int q = tid + 256 * p;
+        const int q = tid + NT * p;
         float* d = lds + (q / (MN / 4)) * MN + (q % (MN / 4)) * 4;
         *reinterpret_cast<float4*>(d) = r[p];
       }
@@ -118,18 +138,19 @@ struct Stage {
   static constexpr int LDS_FLOATS = KCONTIG ? MN * (BK + 1) : BK * MN;
 };
 
-template <int TM, int TN, bool TA, bool TB>
-__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  using SA = Stage<BM, !TA>;  // A stored [M,K] -> K contiguous unless transposed
-  using SB = Stage<BN, TB>;   // B stored [K,N] -> N contiguous unless transposed
+template <int WM_, int WN_, int TM, int TN, bool TA, bool TB, bool VEC>
+__global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WM_ * WN_;
+  constexpr int BM = 32 * WM_ * TM, BN = 32 * WN_ * TN;
+  using SA = Stage<BM, !TA, VEC, NT>;  // A stored [M,K] -> K contiguous unless transposed
+  using SB = Stage<BN, TB, VEC, NT>;   // B stored [K,N] -> N contiguous unless transposed
   __shared__ __attribute__((aligned(16))) float lds_a[SA::LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float lds_b[SB::LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN_, wn = wave % WN_;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * BM;
   const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
@@ -143,34 +164,44 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  SA sa;
-  SB sb;
   const int li = lane & 31, lk = lane >> 5;
 
   if (k_begin < k_end) {
-    sa.load(g.A, g.lda, m0, g.M, k_begin, k_end, g.vec_a, tid);
-    sb.load(g.B, g.ldb, n0, g.N, k_begin, k_end, g.vec_b, tid);
+    SA sa;
+    SB sb;
+    sa.init(g.A, g.lda, m0, g.M, k_begin, tid);
+    sb.init(g.B, g.ldb, n0, g.N, k_begin, tid);
+    sa.load(k_end - k_begin, g.lda);
+    sb.load(k_end - k_begin, g.ldb);
     sa.store(lds_a, tid);
     sb.store(lds_b, tid);
     __syncthreads();
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
       const bool more = k0 + BK < k_end;
       if (more) {
-        sa.load(g.A, g.lda, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
-        sb.load(g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+        sa.load(k_end - k0 - BK, g.lda);
+        sb.load(k_end - k0 - BK, g.ldb);
       }
+      // fragments of k-step kk+1 are fetched from LDS while the MFMAs of k-step kk run
+      float fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, lk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, lk);
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float fa[TM], fb[TN];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, 2 * kk + lk);
+          for (int i = 0; i < TM; ++i) fa[nxt][i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, 2 * (kk + 1) + lk);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, 2 * kk + lk);
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, 2 * (kk + 1) + lk);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
       if (more) {
@@ -224,25 +255,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// tile configurations: {waves_m, waves_n, tm, tn} -> block tile (32*wm*tm) x (32*wn*tn)
+enum { CFG_128x320 = 0, CFG_128x128 = 1, CFG_64x64 = 2 };
 struct GemmPlan {
-  int tm, tn;  // tile config
+  int cfg;
+  int bm, bn;
   int splits;
   int64_t k_chunk;
 };
 
-static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_bytes) {
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_bytes, bool vec) {
   GemmPlan p;
-  if (N % 320 == 0 || (N > 256 && N <= 320)) {
-    p.tm = 1;
-    p.tn = 5;
+  if (!vec) {
+    p.cfg = CFG_64x64;
+  } else if (N % 320 == 0 || (N > 256 && N <= 320)) {
+    p.cfg = CFG_128x320;
   } else if (N > 64 && M > 64) {
-    p.tm = 2;
-    p.tn = 2;
+    p.cfg = CFG_128x128;
   } else {
-    p.tm = 1;
-    p.tn = 1;
+    p.cfg = CFG_64x64;
   }
-  const int64_t tiles = ceil_div(M, 64 * p.tm) * ceil_div(N, 64 * p.tn);
+  p.bm = p.cfg == CFG_64x64 ? 64 : 128;
+  p.bn = p.cfg == CFG_128x320 ? 320 : (p.cfg == CFG_128x128 ? 128 : 64);
+  const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
   p.splits = 1;
   p.k_chunk = ceil_div(K > 0 ? K : 1, BK) * BK;
   // split-K only when the output grid cannot fill the chip and K is long
@@ -261,13 +296,21 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_byte
   return p;
 }
 
-template <int TM, int TN>
+template <int WM_, int WN_, int TM, int TN, bool VEC>
 static void launch_cfg(const GemmArgs& g, int ta, int tb, dim3 grid, hipStream_t s) {
-  dim3 block(256);
-  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, false, false>), grid, block, 0, s, g);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, false, true>), grid, block, 0, s, g);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, true, false>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN, true, true>), grid, block, 0, s, g);
+  dim3 block(64 * WM_ * WN_);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, false, false, VEC>), grid, block, 0, s, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, false, true, VEC>), grid, block, 0, s, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, true, false, VEC>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, true, true, VEC>), grid, block, 0, s, g);
+}
+
+// float4 staging needs 16-byte aligned rows and the vectorised index to be a multiple of 4
+static bool operands_vectorisable(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A,
+                                  int64_t lda, const float* B, int64_t ldb) {
+  const bool a16 = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+  const bool b16 = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+  return a16 && b16 && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0);
 }
 
 }  // namespace tfgnn
@@ -275,8 +318,11 @@ static void launch_cfg(const GemmArgs& g, int ta, int tb, dim3 grid, hipStream_t
 extern "C" size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   using namespace tfgnn;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  GemmPlan p = plan_gemm(M, N, K, (size_t)1 << 40);
-  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * 4 : 0;
+  // upper bound over both staging variants
+  GemmPlan p1 = plan_gemm(M, N, K, (size_t)1 << 40, true);
+  GemmPlan p2 = plan_gemm(M, N, K, (size_t)1 << 40, false);
+  const int s = std::max(p1.splits, p2.splits);
+  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
 }
 
 extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
@@ -290,24 +336,21 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   TFGNN_REQUIRE(K == 0 || (d_A && d_B), "A or B is NULL");
   TFGNN_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
   hipStream_t s = (hipStream_t)stream;
-  GemmPlan p = plan_gemm(M, N, K, d_workspace ? workspace_bytes : 0);
+  const bool vec = K > 0 && operands_vectorisable(trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb);
+  GemmPlan p = plan_gemm(M, N, K, d_workspace ? workspace_bytes : 0, vec);
   GemmArgs g;
   g.M = M; g.N = N; g.K = K;
   g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
   g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.k_chunk = p.k_chunk; g.splits = p.splits; g.partial = (float*)d_workspace;
-  // float4 staging needs 16-byte aligned rows and the vectorised index to be a multiple of 4
-  const bool a16 = ((uintptr_t)d_A % 16 == 0) && (lda % 4 == 0);
-  const bool b16 = ((uintptr_t)d_B % 16 == 0) && (ldb % 4 == 0);
-  g.vec_a = a16 && ((trans_a ? M : K) % 4 == 0);
-  g.vec_b = b16 && ((trans_b ? K : N) % 4 == 0);
-  g.n_tiles = (unsigned)ceil_div(N, 64 * p.tn);
-  const int64_t tiles = ceil_div(M, 64 * p.tm) * (int64_t)g.n_tiles;
+  g.n_tiles = (unsigned)ceil_div(N, p.bn);
+  const int64_t tiles = ceil_div(M, p.bm) * (int64_t)g.n_tiles;
   TFGNN_REQUIRE(tiles < ((int64_t)1 << 31), "GEMM grid too large");
   dim3 grid((unsigned)tiles, 1, (unsigned)p.splits);
-  if (p.tm == 1 && p.tn == 5) launch_cfg<1, 5>(g, trans_a, trans_b, grid, s);
-  else if (p.tm == 2 && p.tn == 2) launch_cfg<2, 2>(g, trans_a, trans_b, grid, s);
-  else launch_cfg<1, 1>(g, trans_a, trans_b, grid, s);
+  if (!vec) launch_cfg<2, 2, 1, 1, false>(g, trans_a, trans_b, grid, s);
+  else if (p.cfg == CFG_128x320) launch_cfg<4, 2, 1, 5, true>(g, trans_a, trans_b, grid, s);
+  else if (p.cfg == CFG_128x128) launch_cfg<2, 2, 2, 2, true>(g, trans_a, trans_b, grid, s);
+  else launch_cfg<2, 2, 1, 1, true>(g, trans_a, trans_b, grid, s);
   TFGNN_LAUNCH_CHECK();
   if (p.splits > 1) {
     int64_t total = M * N;

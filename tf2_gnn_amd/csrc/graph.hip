@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "graph.hpp"
 
 namespace tfgnn {
 
@@ -291,6 +292,34 @@ sort_block_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __rest
   }
 }
 
+// work items for rows longer than LONG_ROW_THRESHOLD (see graph.hpp / spmm.hip); counters = {items,
+// multi-item rows, partial slots}.  The order in which rows claim their slots is irrelevant: a row's
+// items are contiguous and are always combined in chunk order.
+__global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, int32_t* __restrict__ counters,
+                                 int32_t* __restrict__ item_row, int32_t* __restrict__ item_chunk,
+                                 int32_t* __restrict__ item_slot, int32_t* __restrict__ multi_row,
+                                 int32_t* __restrict__ multi_base, int32_t* __restrict__ multi_n) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t len = rowptr[r + 1] - rowptr[r];
+    if (len <= LONG_ROW_THRESHOLD) continue;
+    const int32_t n = (len + ITEM_CHUNK - 1) / ITEM_CHUNK;
+    const int32_t base = atomicAdd(&counters[0], n);
+    int32_t pb = -1;
+    if (n > 1) {
+      const int32_t m = atomicAdd(&counters[1], 1);
+      pb = atomicAdd(&counters[2], n);
+      multi_row[m] = (int32_t)r;
+      multi_base[m] = pb;
+      multi_n[m] = n;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+      item_row[base + i] = (int32_t)r;
+      item_chunk[base + i] = i;
+      item_slot[base + i] = n > 1 ? pb + i : -1;
+    }
+  }
+}
+
 __global__ void invdeg_rows_kernel(const int32_t* __restrict__ rowptr_d, int64_t R, int L,
                                    float* __restrict__ invdeg_d, int32_t* __restrict__ nodeptr_d,
                                    const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ nodeptr_s) {
@@ -342,15 +371,6 @@ __global__ void src2dst_kernel(const int32_t* __restrict__ eid_s, const int32_t*
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
-struct tfgnn_graph {
-  int L = 0;
-  int64_t V = 0, E = 0, R = 0;
-  void* slab = nullptr;
-  int32_t *rowptr_d = nullptr, *col_d = nullptr, *eid_d = nullptr, *coll_d = nullptr;
-  int32_t *rowptr_s = nullptr, *col_s = nullptr, *eid_s = nullptr, *coll_s = nullptr;
-  int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr;
-  float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
-};
 
 namespace {
 struct SlabPlan {
@@ -400,6 +420,12 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   const size_t o_src2dst = plan.take(E * 4);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
+  const size_t max_items = (size_t)(E / LONG_ROW_THRESHOLD + 1), max_multi = (size_t)(E / ITEM_CHUNK + 1);
+  size_t o_item[4][3], o_multi[4][3];
+  for (int v = 0; v < 4; ++v) {
+    for (int k = 0; k < 3; ++k) o_item[v][k] = plan.take(max_items * 4);
+    for (int k = 0; k < 3; ++k) o_multi[v][k] = plan.take(max_multi * 4);
+  }
   const size_t persistent = plan.total;
   // build-time scratch (freed with a second allocation)
   SlabPlan tmp;
@@ -407,7 +433,7 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   const size_t t_comp_d = tmp.take(E * 8), t_comp_s = tmp.take(E * 8);
   const size_t t_rowid_d = tmp.take(E * 4), t_rowid_s = tmp.take(E * 4);
   const size_t t_list_a = tmp.take((E / 3 + 1) * 4), t_list_b = tmp.take((E / 65 + 1) * 4);
-  const size_t t_counters = tmp.take(16 * 4);
+  const size_t t_counters = tmp.take(64 * 4);
   const size_t t_scan = tmp.take(scan_scratch_elems(R + 1) * 4 + 16);
   const size_t t_eid2pos = tmp.take(E * 4);
   const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
@@ -458,7 +484,7 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   int64_t* d_off = (int64_t*)(scratch + t_off);
 
   int rc = TFGNN_OK;
-  int32_t h_counters[16] = {0};
+  int32_t h_counters[64] = {0};
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(s);
     (void)hipFree(scratch);
@@ -480,7 +506,7 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
   G_CHECK(hipMemsetAsync(cur_d, 0, (R + 1) * 4, s));
   G_CHECK(hipMemsetAsync(cur_s, 0, (R + 1) * 4, s));
-  G_CHECK(hipMemsetAsync(counters, 0, 16 * 4, s));
+  G_CHECK(hipMemsetAsync(counters, 0, 64 * 4, s));
   if (L > 0) {
     G_CHECK(hipMemcpyAsync(d_ptrs, d_adjacency, (size_t)L * 8, hipMemcpyHostToDevice, s));
   }
@@ -534,6 +560,25 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
                        g->src2dst);
   }
+  // gather views + long-row plans (tfgnn_graph_view order)
+  g->views[0].rowptr = g->rowptr_d;  g->views[0].num_rows = R; g->views[0].col = g->col_d;
+  g->views[1].rowptr = g->nodeptr_d; g->views[1].num_rows = V; g->views[1].col = g->coll_d;
+  g->views[2].rowptr = g->rowptr_s;  g->views[2].num_rows = R; g->views[2].col = g->col_s;
+  g->views[3].rowptr = g->nodeptr_s; g->views[3].num_rows = V; g->views[3].col = g->coll_s;
+  for (int v = 0; v < 4; ++v) {
+    CsrPlan& pl = g->views[v].plan;
+    pl.item_row = (int32_t*)(slab + o_item[v][0]);
+    pl.item_chunk = (int32_t*)(slab + o_item[v][1]);
+    pl.item_slot = (int32_t*)(slab + o_item[v][2]);
+    pl.multi_row = (int32_t*)(slab + o_multi[v][0]);
+    pl.multi_base = (int32_t*)(slab + o_multi[v][1]);
+    pl.multi_n = (int32_t*)(slab + o_multi[v][2]);
+    if (E > 0 && g->views[v].num_rows > 0) {
+      hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks_for(g->views[v].num_rows)), dim3(threads), 0, s,
+                         g->views[v].rowptr, g->views[v].num_rows, counters + 16 + 4 * v, pl.item_row,
+                         pl.item_chunk, pl.item_slot, pl.multi_row, pl.multi_base, pl.multi_n);
+    }
+  }
   {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
@@ -546,6 +591,11 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   G_CHECK(hipFree(scratch));
   scratch = nullptr;
 #undef G_CHECK
+  for (int v = 0; v < 4; ++v) {
+    g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
+    g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
+    g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
+  }
   if (h_counters[2] != 0) {
     set_error("adjacency list contains a node index outside [0, %lld)", (long long)V);
     (void)hipFree(slab);

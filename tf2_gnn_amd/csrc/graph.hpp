@@ -1,0 +1,43 @@
+// Internal layout of the graph handle (shared by graph.hip and spmm.hip).
+#pragma once
+#include <cstdint>
+
+namespace tfgnn {
+
+// Rows longer than LONG_ROW_THRESHOLD edges are not walked by a single lane group: they are cut
+// into items of ITEM_CHUNK consecutive edges, one workgroup per item (deterministic partial sums,
+// combined in item order).  Keeps the tail of the gather kernel bounded on skewed (R-MAT) graphs.
+constexpr int LONG_ROW_THRESHOLD = 32;
+constexpr int ITEM_CHUNK = 256;
+
+struct CsrPlan {
+  int32_t num_items = 0;     // host copies of the device counters
+  int32_t num_multi = 0;     // rows with more than one item
+  int32_t num_partials = 0;  // items belonging to multi-item rows (scratch slots)
+  int32_t* item_row = nullptr;    // [num_items]
+  int32_t* item_chunk = nullptr;  // [num_items] chunk index within the row
+  int32_t* item_slot = nullptr;   // [num_items] scratch slot, or -1: the item is the whole row
+  int32_t* multi_row = nullptr;   // [num_multi]
+  int32_t* multi_base = nullptr;  // [num_multi] first scratch slot
+  int32_t* multi_n = nullptr;     // [num_multi] number of items
+};
+
+struct GraphView {
+  const int32_t* rowptr = nullptr;
+  int64_t num_rows = 0;
+  const int32_t* col = nullptr;
+  CsrPlan plan;
+};
+
+}  // namespace tfgnn
+
+struct tfgnn_graph {
+  int L = 0;
+  int64_t V = 0, E = 0, R = 0;
+  void* slab = nullptr;
+  int32_t *rowptr_d = nullptr, *col_d = nullptr, *eid_d = nullptr, *coll_d = nullptr;
+  int32_t *rowptr_s = nullptr, *col_s = nullptr, *eid_s = nullptr, *coll_s = nullptr;
+  int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr;
+  float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
+  tfgnn::GraphView views[4];  // tfgnn_graph_view order
+};

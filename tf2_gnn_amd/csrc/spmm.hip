@@ -1,12 +1,13 @@
 // Gather + segment reduce over a CSR: the bandwidth-bound half of the message-passing hot path.
 //
-//   out[r, :] = post_act( row_scale[r] * REDUCE_{e in row r} pre_act( edge_weight[e] * in[col[e], :] ) )
+//   out[r, :] = post_act( row_scale[r] * REDUCE_{e in row r} pre_act( w_e * in[col[e], :] ) )
 //
 // One call replaces, for one edge-bucketed view of the graph,
 //   tf.nn.embedding_lookup(node_embeddings, edge_sources)          message_passing.py:197-199
 //   the per-message 1/(c + 1e-7) scaling                             gnn_edge_mlp.py:102-106
 //   tf.concat over edge types                                        message_passing.py:166-167
 //   tf.math.unsorted_segment_{sum,max,mean,sqrt_n}                   utils/param_helpers.py:9-14
+//   (RGAT) attention-weighted per-head unsorted_segment_sum          rgat.py:154-160
 // without ever materialising the [E, D] gathered tensor (1.15 GB per layer at cfg-2).
 //
 // Work decomposition (wave64): a wave is split into 64/LPR groups of LPR lanes; a group owns one
@@ -16,9 +17,17 @@
 // UNROLL*VPL 16-byte loads in flight per lane.  Accumulation order inside a row is the CSR order
 // (cols ascending) -> bit-reproducible, no atomics.
 //
-// blockIdx.y walks feature windows ("slices"): windows narrower than the row let the working set
-// V * window_bytes of one pass sit in the 4 MiB L2 of an XCD.
+// Skew (R-MAT hubs): with a plan (graph views), rows longer than LONG_ROW_THRESHOLD are skipped by
+// the row kernel and cut into items of ITEM_CHUNK edges; one workgroup per item, its groups each
+// take a contiguous slice of the item, partial sums are combined through LDS in group order.  Rows
+// made of several items go through a scratch buffer and a third, tiny combine kernel (item order).
+// Everything stays deterministic.
+//
+// blockIdx.y walks feature windows.
+#include <algorithm>
+
 #include "common.hpp"
+#include "graph.hpp"
 
 namespace tfgnn {
 
@@ -69,10 +78,15 @@ __device__ __forceinline__ void vunpack<1>(const float& v, float* o) {
   o[0] = v;
 }
 
+// MODE 0: sum, optional scalar edge weight          (RGCN / GGNN / RGIN forward and backward)
+// MODE 1: sum, per-head edge weights ew[e, K]       (RGAT)
+// MODE 2: general: runtime max / pre-activation, optional scalar edge weight
+enum { MODE_SUM = 0, MODE_HEADS = 1, MODE_GENERAL = 2 };
+
 struct GatherArgs {
   const int32_t* rowptr;
   const int32_t* col;
-  const float* ew;         // nullable
+  const float* ew;         // nullable; [E] or [E, ew_heads]
   const float* row_scale;  // nullable
   int64_t num_rows;
   const float* in;
@@ -82,36 +96,37 @@ struct GatherArgs {
   int64_t ld_out;
   int pre_act;
   int post_act;
+  int is_max;
+  int ew_heads;    // K (MODE_HEADS)
+  int head_width;  // floats per head (MODE_HEADS)
+  int long_threshold;  // rows longer than this are left to the item kernels (0 = never)
+  // item pass
+  const int32_t* item_row;
+  const int32_t* item_chunk;
+  const int32_t* item_slot;
+  float* partial;  // [num_partials, width]
+  int item_chunk_edges;
+  // combine pass
+  const int32_t* multi_row;
+  const int32_t* multi_base;
+  const int32_t* multi_n;
+  int num_multi;
 };
 
-template <int LPR, int VPL, int VEC, int UNROLL, bool IS_MAX, bool HAS_PRE>
-__global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
-  constexpr int GROUPS_PER_BLOCK = 256 / LPR;
-  constexpr int WINDOW = LPR * VPL * VEC;  // floats covered per pass
+// accumulate edges [beg, end) into acc (lane-private chunks)
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+__device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t beg, int32_t end, int f0,
+                                                 const bool (&live)[VPL], float (&acc)[VPL][VEC]) {
   using V = typename VecT<VEC>::type;
-
-  const int tid = threadIdx.x;
-  const int group = tid / LPR;
-  const int gl = tid % LPR;
-  const int64_t row = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + group;
-  if (row >= a.num_rows) return;
-  const int f0 = blockIdx.y * WINDOW + gl * VEC;  // first float of this lane's chunk 0
-
-  const int32_t beg = a.rowptr[row];
-  const int32_t end = a.rowptr[row + 1];
-
-  float acc[VPL][VEC];
+  const bool is_max = MODE == MODE_GENERAL && a.is_max;
+  int hidx[VPL];
+  if (MODE == MODE_HEADS) {
 #pragma unroll
-  for (int i = 0; i < VPL; ++i)
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) acc[i][c] = IS_MAX ? kFloatLowest : 0.f;
-
-  bool live[VPL];
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) live[i] = (f0 + i * LPR * VEC) < a.width;
-
+    for (int i = 0; i < VPL; ++i) hidx[i] = live[i] ? (f0 + i * LPR * VEC) / a.head_width : 0;
+  }
   for (int32_t e = beg; e < end; e += UNROLL) {
     int32_t idx[UNROLL];
+    int32_t eid[UNROLL];
     float w[UNROLL];
     bool ok[UNROLL];
 #pragma unroll
@@ -119,16 +134,22 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
       int32_t ee = e + u;
       ok[u] = ee < end;
       ee = ok[u] ? ee : end - 1;
+      eid[u] = ee;
       idx[u] = a.col[ee];
-      w[u] = a.ew ? a.ew[ee] : 1.f;
+      w[u] = (MODE != MODE_HEADS && a.ew) ? a.ew[ee] : 1.f;
     }
     V v[UNROLL][VPL];
+    float wh[UNROLL][VPL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const float* src = a.in + (int64_t)idx[u] * a.ld_in + f0;
 #pragma unroll
-      for (int i = 0; i < VPL; ++i)
-        if (live[i]) v[u][i] = vload<VEC>(src + i * LPR * VEC);
+      for (int i = 0; i < VPL; ++i) {
+        if (live[i]) {
+          v[u][i] = vload<VEC>(src + i * LPR * VEC);
+          if (MODE == MODE_HEADS) wh[u][i] = a.ew[(int64_t)eid[u] * a.ew_heads + hidx[i]];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -138,17 +159,48 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
           if (live[i]) {
             float x[VEC];
             vunpack<VEC>(v[u][i], x);
+            const float wt = MODE == MODE_HEADS ? wh[u][i] : w[u];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-              float m = w[u] * x[c];
-              if (HAS_PRE) m = act_apply(a.pre_act, m);
-              acc[i][c] = IS_MAX ? fmaxf(acc[i][c], m) : acc[i][c] + m;
+              float m = wt * x[c];
+              if (MODE == MODE_GENERAL) {
+                m = act_apply(a.pre_act, m);
+                acc[i][c] = is_max ? fmaxf(acc[i][c], m) : acc[i][c] + m;
+              } else {
+                acc[i][c] += m;
+              }
             }
           }
         }
       }
     }
   }
+}
+
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+__global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
+  constexpr int GROUPS_PER_BLOCK = 256 / LPR;
+  constexpr int WINDOW = LPR * VPL * VEC;  // floats covered per pass
+  const int tid = threadIdx.x;
+  const int group = tid / LPR;
+  const int gl = tid % LPR;
+  const int64_t row = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + group;
+  if (row >= a.num_rows) return;
+  const int f0 = blockIdx.y * WINDOW + gl * VEC;  // first float of this lane's chunk 0
+  const int32_t beg = a.rowptr[row];
+  const int32_t end = a.rowptr[row + 1];
+  if (a.long_threshold > 0 && end - beg > a.long_threshold) return;  // handled by the item kernels
+  const bool is_max = MODE == MODE_GENERAL && a.is_max;
+
+  float acc[VPL][VEC];
+  bool live[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    live[i] = (f0 + i * LPR * VEC) < a.width;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[i][c] = is_max ? kFloatLowest : 0.f;
+  }
+  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
 
   const float rs = a.row_scale ? a.row_scale[row] : 1.f;
   float* dst = a.out + row * a.ld_out + f0;
@@ -160,8 +212,8 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
       for (int c = 0; c < VEC; ++c) {
         float y = acc[i][c];
         // an empty max-segment keeps the lowest float (tf.math.unsorted_segment_max); scaling it
-        // would overflow to -inf, so the scale only touches real sums
-        if (!IS_MAX || end > beg) y *= rs;
+        // would overflow to -inf, so the scale only touches real results
+        if (!is_max || end > beg) y *= rs;
         o[c] = act_apply(a.post_act, y);
       }
       vstore<VEC>(dst + i * LPR * VEC, o);
@@ -169,21 +221,133 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
   }
 }
 
-template <int LPR, int VPL, int VEC, int UNROLL>
-static int launch_variant(const GatherArgs& a, bool is_max, bool has_pre, hipStream_t s) {
+// one workgroup per item (a run of <= item_chunk_edges edges of a long row)
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+__global__ void __launch_bounds__(256) csr_gather_items_kernel(GatherArgs a) {
+  constexpr int GROUPS = 256 / LPR;
+  constexpr int WINDOW = LPR * VPL * VEC;
+  __shared__ float red[GROUPS][WINDOW];
+  const int tid = threadIdx.x;
+  const int group = tid / LPR;
+  const int gl = tid % LPR;
+  const int item = blockIdx.x;
+  const int64_t row = a.item_row[item];
+  const int32_t rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+  const int32_t ibeg = rbeg + a.item_chunk[item] * a.item_chunk_edges;
+  const int32_t iend = min(rend, ibeg + a.item_chunk_edges);
+  const int per = (a.item_chunk_edges + GROUPS - 1) / GROUPS;
+  const int32_t beg = min(iend, ibeg + group * per);
+  const int32_t end = min(iend, beg + per);
+  const int w0 = blockIdx.y * WINDOW;
+  const int f0 = w0 + gl * VEC;
+  const bool is_max = MODE == MODE_GENERAL && a.is_max;
+
+  float acc[VPL][VEC];
+  bool live[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    live[i] = (f0 + i * LPR * VEC) < a.width;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[i][c] = is_max ? kFloatLowest : 0.f;
+  }
+  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) red[group][(gl + i * LPR) * VEC + c] = acc[i][c];
+  __syncthreads();
+  const int32_t slot = a.item_slot[item];
+  const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+  for (int f = tid; f < WINDOW; f += 256) {
+    if (w0 + f >= a.width) break;
+    float s = red[0][f];
+#pragma unroll
+    for (int g = 1; g < GROUPS; ++g) s = is_max ? fmaxf(s, red[g][f]) : s + red[g][f];
+    if (slot < 0) {
+      a.out[row * a.ld_out + w0 + f] = act_apply(a.post_act, s * rs);
+    } else {
+      a.partial[(int64_t)slot * a.width + w0 + f] = s;
+    }
+  }
+}
+
+// rows made of several items: combine their partial results in item order
+__global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
+  const int64_t total = (int64_t)a.num_multi * a.width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / a.width);
+    const int f = (int)(i - (int64_t)m * a.width);
+    const int64_t row = a.multi_row[m];
+    const int32_t base = a.multi_base[m], n = a.multi_n[m];
+    float s = a.partial[(int64_t)base * a.width + f];
+    for (int k = 1; k < n; ++k) {
+      const float p = a.partial[(int64_t)(base + k) * a.width + f];
+      s = a.is_max ? fmaxf(s, p) : s + p;
+    }
+    const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+    a.out[row * a.ld_out + f] = act_apply(a.post_act, s * rs);
+  }
+}
+
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+static int launch_mode(const GatherArgs& a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
-  dim3 grid((unsigned)ceil_div(a.num_rows, GROUPS_PER_BLOCK), (unsigned)ceil_div(a.width, WINDOW));
+  const unsigned windows = (unsigned)ceil_div(a.width, WINDOW);
   dim3 block(256);
-  if (!is_max && !has_pre)
-    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, false, false>), grid, block, 0, s, a);
-  else if (!is_max && has_pre)
-    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, false, true>), grid, block, 0, s, a);
-  else if (is_max && !has_pre)
-    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, true, false>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, true, true>), grid, block, 0, s, a);
+  if (num_items > 0) {  // longest work first
+    hipLaunchKernelGGL((csr_gather_items_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3((unsigned)num_items, windows), block, 0, s, a);
+    TFGNN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>),
+                     dim3((unsigned)ceil_div(a.num_rows, GROUPS_PER_BLOCK), windows), block, 0, s, a);
   TFGNN_LAUNCH_CHECK();
+  if (a.num_multi > 0) {
+    const int64_t total = (int64_t)a.num_multi * a.width;
+    hipLaunchKernelGGL(csr_gather_combine_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), block, 0, s, a);
+    TFGNN_LAUNCH_CHECK();
+  }
+  return TFGNN_OK;
+}
+
+template <int LPR, int VPL, int VEC, int UNROLL>
+static int launch_variant(const GatherArgs& a, int mode, int num_items, hipStream_t s) {
+  if (mode == MODE_SUM) return launch_mode<LPR, VPL, VEC, UNROLL, MODE_SUM>(a, num_items, s);
+  if (mode == MODE_HEADS) return launch_mode<LPR, VPL, VEC, UNROLL, MODE_HEADS>(a, num_items, s);
+  return launch_mode<LPR, VPL, VEC, UNROLL, MODE_GENERAL>(a, num_items, s);
+}
+
+static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
+  int mode = MODE_SUM;
+  if (a.is_max || a.pre_act != TFGNN_ACT_NONE) mode = MODE_GENERAL;
+  if (a.ew && a.ew_heads > 1) {
+    TFGNN_REQUIRE(mode == MODE_SUM, "per-head edge weights only support plain sums");
+    TFGNN_REQUIRE(a.head_width > 0 && a.width % a.head_width == 0 && a.width / a.head_width == a.ew_heads,
+                  "width %d is not ew_heads %d x head_width %d", a.width, a.ew_heads, a.head_width);
+    mode = MODE_HEADS;
+  }
+  const bool vec4 = (a.width % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) &&
+                    (((uintptr_t)a.in | (uintptr_t)a.out) % 16 == 0) &&
+                    (mode != MODE_HEADS || a.head_width % 4 == 0);
+  if (!vec4) {
+    // scalar path (odd widths: unit tests, tiny models): 16 lanes x 4 floats per pass
+    return launch_variant<16, 4, 1, 2>(a, mode, num_items, s);
+  }
+  const int chunks = a.width / 4;
+  if (chunks <= 8) return launch_variant<8, 1, 4, 8>(a, mode, num_items, s);
+  if (chunks <= 16) return launch_variant<16, 1, 4, 8>(a, mode, num_items, s);
+  if (chunks <= 32) return launch_variant<16, 2, 4, 4>(a, mode, num_items, s);
+  if (chunks <= 64) return launch_variant<16, 4, 4, 2>(a, mode, num_items, s);
+  if (chunks % 80 == 0 || chunks <= 80) return launch_variant<16, 5, 4, 2>(a, mode, num_items, s);
+  return launch_variant<32, 4, 4, 2>(a, mode, num_items, s);
+}
+
+static int check_common(int64_t num_rows, const void* rowptr, const void* in, const void* out, int64_t ld_in,
+                        int64_t ld_out, int width, int reduce_op) {
+  TFGNN_REQUIRE(rowptr && in && out, "NULL pointer");
+  TFGNN_REQUIRE(ld_in >= width && ld_out >= width, "leading dimension smaller than width");
+  TFGNN_REQUIRE(reduce_op == TFGNN_REDUCE_SUM || reduce_op == TFGNN_REDUCE_MAX, "unknown reduce op %d", reduce_op);
+  TFGNN_REQUIRE(num_rows < ((int64_t)1 << 31), "too many rows");
   return TFGNN_OK;
 }
 
@@ -197,26 +361,45 @@ extern "C" int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d
   using namespace tfgnn;
   TFGNN_REQUIRE(num_rows >= 0 && width >= 0, "negative size");
   if (num_rows == 0 || width == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_rowptr && d_in && d_out, "NULL pointer");
-  TFGNN_REQUIRE(ld_in >= width && ld_out >= width, "leading dimension smaller than width");
-  TFGNN_REQUIRE(reduce_op == TFGNN_REDUCE_SUM || reduce_op == TFGNN_REDUCE_MAX, "unknown reduce op %d", reduce_op);
-  TFGNN_REQUIRE(num_rows < ((int64_t)1 << 31), "too many rows");
-  hipStream_t s = (hipStream_t)stream;
-  GatherArgs a{d_rowptr, d_col,  d_edge_weight, d_row_scale, num_rows, d_in,
-               ld_in,    width,  d_out,         ld_out,      pre_act,  post_act};
-  const bool is_max = reduce_op == TFGNN_REDUCE_MAX;
-  const bool has_pre = pre_act != TFGNN_ACT_NONE;
-  const bool vec4 = (width % 4 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
-                    (((uintptr_t)d_in | (uintptr_t)d_out) % 16 == 0);
-  if (!vec4) {
-    // scalar path (odd widths: unit tests, tiny models): 16 lanes x 4 floats per pass
-    return launch_variant<16, 4, 1, 2>(a, is_max, has_pre, s);
-  }
-  const int chunks = width / 4;
-  if (chunks <= 8) return launch_variant<8, 1, 4, 8>(a, is_max, has_pre, s);
-  if (chunks <= 16) return launch_variant<16, 1, 4, 8>(a, is_max, has_pre, s);
-  if (chunks <= 32) return launch_variant<16, 2, 4, 4>(a, is_max, has_pre, s);
-  if (chunks <= 64) return launch_variant<16, 4, 4, 2>(a, is_max, has_pre, s);
-  if (chunks % 80 == 0 || chunks <= 80) return launch_variant<16, 5, 4, 2>(a, is_max, has_pre, s);
-  return launch_variant<32, 4, 4, 2>(a, is_max, has_pre, s);
+  int rc = check_common(num_rows, d_rowptr, d_in, d_out, ld_in, ld_out, width, reduce_op);
+  if (rc) return rc;
+  GatherArgs a{};
+  a.rowptr = d_rowptr; a.col = d_col; a.ew = d_edge_weight; a.row_scale = d_row_scale;
+  a.num_rows = num_rows; a.in = d_in; a.ld_in = ld_in; a.width = width; a.out = d_out; a.ld_out = ld_out;
+  a.pre_act = pre_act; a.post_act = post_act; a.is_max = reduce_op == TFGNN_REDUCE_MAX;
+  a.ew_heads = 1; a.head_width = width;
+  return gather_dispatch(a, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int view, int width) {
+  if (!g || view < 0 || view > 3 || width <= 0) return 0;
+  return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
+}
+
+extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const int32_t* d_col_override,
+                                         const float* d_edge_weight, int ew_heads, const float* d_row_scale,
+                                         const float* d_in, int64_t ld_in, int width, float* d_out,
+                                         int64_t ld_out, int reduce_op, int pre_act, int post_act,
+                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  TFGNN_REQUIRE(view >= 0 && view <= 3, "unknown graph view %d", view);
+  TFGNN_REQUIRE(width >= 0 && ew_heads >= 1, "bad sizes");
+  const GraphView& gv = g->views[view];
+  if (gv.num_rows == 0 || width == 0) return TFGNN_OK;
+  int rc = check_common(gv.num_rows, gv.rowptr, d_in, d_out, ld_in, ld_out, width, reduce_op);
+  if (rc) return rc;
+  const CsrPlan& p = gv.plan;
+  TFGNN_REQUIRE(p.num_partials == 0 || (d_workspace && workspace_bytes >= (size_t)p.num_partials * width * 4),
+                "workspace too small: need %zu bytes", (size_t)p.num_partials * width * 4);
+  GatherArgs a{};
+  a.rowptr = gv.rowptr; a.col = d_col_override ? d_col_override : gv.col; a.ew = d_edge_weight;
+  a.row_scale = d_row_scale; a.num_rows = gv.num_rows; a.in = d_in; a.ld_in = ld_in; a.width = width;
+  a.out = d_out; a.ld_out = ld_out; a.pre_act = pre_act; a.post_act = post_act;
+  a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
+  a.long_threshold = LONG_ROW_THRESHOLD;
+  a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
+  a.partial = (float*)d_workspace; a.item_chunk_edges = ITEM_CHUNK;
+  a.multi_row = p.multi_row; a.multi_base = p.multi_base; a.multi_n = p.multi_n; a.num_multi = p.num_multi;
+  return gather_dispatch(a, p.num_items, (hipStream_t)stream);
 }

@@ -188,11 +188,9 @@ class GNN_Edge_MLP(MessagePassing):
         row_scale, _, _, _ = self._scales(g)
         W = self._edge_type_mlps.kernels[0]  # [L, Din, H]
         Din = W.shape[1]
-        rowptr = g.array(ops.G_ROWPTR_BY_DST)
-        col = g.array(ops.G_COL_BY_DST)
         A = torch.empty((V, L * Din), dtype=torch.float32, device=X.device)
         Arows = A.view(V * L, Din)
-        ops.gather_reduce(rowptr, col, X, row_scale=row_scale, out=Arows[:, :D])
+        ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, out=Arows[:, :D])
         if T:
             # sum_e s_e [x_u | x_v] W = (sum_e s_e x_u) W_s + (c * s) x_v W_t
             from ..graph_scales import target_multiplier
@@ -234,8 +232,8 @@ class GNN_Edge_MLP(MessagePassing):
         is_max = self._aggregation_name == "max"
         pre = self._activation_name if self._pre_activation() else None
         gelu_split = fuse_act == "gelu"
-        out = ops.gather_reduce(
-            g.array(ops.G_NODEPTR_BY_DST), g.array(ops.G_COLL_BY_DST), Y.view(V * L, H),
+        out = ops.graph_gather(
+            g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H),
             edge_weight=ew_d, row_scale=node_scale,
             reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM,
             pre_act=pre, post_act=None if gelu_split else fuse_act,
@@ -278,9 +276,7 @@ class GNN_Edge_MLP(MessagePassing):
             raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
         row_scale, _, ew_s, _ = self._scales(g)
         # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]
-        G = ops.gather_reduce(
-            g.array(ops.G_ROWPTR_BY_SRC), g.array(ops.G_COL_BY_SRC), d_agg, edge_weight=ew_s
-        ).view(V, L, H)
+        G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=ew_s).view(V, L, H)
         dX = torch.empty_like(X)
         if ctx["path"] == "A":
             W = mlps.kernels[0]  # [L, Din, H]

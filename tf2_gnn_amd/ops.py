@@ -196,6 +196,50 @@ def gather_reduce(
     return out
 
 
+VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE = range(4)
+
+
+def graph_gather(
+    graph: "Graph",
+    view: int,
+    inp: torch.Tensor,
+    *,
+    col: Optional[torch.Tensor] = None,
+    edge_weight: Optional[torch.Tensor] = None,
+    row_scale: Optional[torch.Tensor] = None,
+    reduce: int = REDUCE_SUM,
+    pre_act=ACT_NONE,
+    post_act=ACT_NONE,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """gather_reduce over one of the Graph's bucketed views (with its long-row plan).
+    edge_weight: [E] or [E, K] (K heads of width/K floats each)."""
+    lib = _lib.load()
+    _require_dev(inp, torch.float32, "inp")
+    num_rows = graph.num_nodes * (graph.num_edge_types if view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED) else 1)
+    inp, ld_in = _rowmajor(inp, "inp")
+    width = inp.shape[1]
+    if out is None:
+        out = torch.empty((num_rows, width), dtype=torch.float32, device=inp.device)
+    out2, ld_out = _rowmajor(out, "out")
+    if out2 is not out or out.shape[0] != num_rows or out.shape[1] != width:
+        raise ValueError(f"out must be [{num_rows},{width}] with unit inner stride, got {tuple(out.shape)}")
+    heads = 1
+    if edge_weight is not None:
+        edge_weight = edge_weight.contiguous()
+        heads = edge_weight.shape[1] if edge_weight.dim() == 2 else 1
+    ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, width)
+    ws = _workspace(inp.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_graph_gather_reduce(
+            graph._h, view, _ptr(col), _ptr(edge_weight), heads, _ptr(row_scale), _ptr(inp), ld_in, width,
+            _ptr(out), ld_out, int(reduce), act_id(pre_act), act_id(post_act), _ptr(ws),
+            ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    return out
+
+
 def gemm(
     a: torch.Tensor,
     b: torch.Tensor,
