@@ -88,7 +88,8 @@ typedef enum {
   TFGNN_G_NODEPTR_BY_DST = 10,    /* int32 [V+1] = ROWPTR_BY_DST[::L] (all edge types of a target) */
   TFGNN_G_NODEPTR_BY_SRC = 11,    /* int32 [V+1]                                               */
   TFGNN_G_INVDEG_EDGE_BY_DST = 12, /* float [E] per edge, by-dst order                          */
-  TFGNN_G_SRC2DST_POS = 13        /* int32 [E] position in by-dst order of the edge at each by-src position */
+  TFGNN_G_SRC2DST_POS = 13,       /* int32 [E] position in by-dst order of the edge at each by-src position */
+  TFGNN_G_TARGET_BY_DST = 14      /* int32 [E] target node of each bucketed edge, by-dst order */
 } tfgnn_graph_array_id;
 
 /* Borrow a device array owned by the handle (valid until tfgnn_graph_destroy). */
@@ -203,17 +204,30 @@ int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, float* d_ou
  * tfgnn_rgat_node_scores: the two halves of the attention logit (rgat.py:111-121) per (node,type,head):
  *     s_src[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,:H/K]>   s_tgt[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,H/K:]>
  *     d_alpha: [L, K, 2H/K] (the L "Edge_attention_parameters" stacked, rgat.py:82-86)
- * tfgnn_rgat_aggregate: score_ek = leaky_relu(s_src[src,l,k] + s_tgt[tgt,l,k]); per head, softmax over
- *     all edges entering a node (dpu_utils unsorted_segment_log_softmax + exp, rgat.py:147-151);
- *     out[v,k,:] = post_act( sum_e a_ek Y[(src,l),k,:] ) (rgat.py:154-163).  d_att (nullable) [E,K]
- *     receives a_ek in by-dst edge order for the backward pass.
+ * tfgnn_rgat_edge_attention: score_ek = leaky_relu(s_src[src,l,k] + s_tgt[tgt,l,k]); per head, softmax
+ *     over all edges entering a node (dpu_utils unsorted_segment_log_softmax + exp, rgat.py:147-151);
+ *     d_att [E,K] receives a_ek in by-dst edge order.  The weighted sum out[v,k,:] = sum_e a_ek
+ *     Y[(src,l),k,:] (rgat.py:154-163) is tfgnn_graph_gather_reduce(view BY_DST_NODE, ew_heads = K).
  * ------------------------------------------------------------------------------------------ */
 int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, int64_t num_nodes, int num_edge_types,
                            int num_heads, int hidden_dim, float* d_s_src, float* d_s_tgt, void* stream);
-int tfgnn_rgat_aggregate(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst, const float* d_Y,
-                         const float* d_s_src, const float* d_s_tgt, int64_t num_nodes, int num_edge_types,
-                         int num_heads, int hidden_dim, int post_act, float* d_out, float* d_att,
-                         void* stream);
+int tfgnn_rgat_edge_attention(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
+                              const float* d_s_src, const float* d_s_tgt, int64_t num_nodes,
+                              int num_edge_types, int num_heads, float* d_att, void* stream);
+/* backward pieces (tf.GradientTape in the reference):
+ *   tfgnn_rgat_edge_dot:           da[e,k] = < d_agg[tgt_e,k,:], Y[(src_e,l_e),k,:] >
+ *   tfgnn_rgat_attention_backward: dz[e,k] = a_ek (da_ek - sum_e' a_e'k da_e'k) * leaky_relu'(z_ek)
+ *   tfgnn_rgat_scores_backward:    dY[(v,l),k,:] += ds_src[(v,l),k] alpha[l,k,:H/K] + ds_tgt[(v,l),k] alpha[l,k,H/K:] */
+int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst, const float* d_Y,
+                        const float* d_dagg, int64_t num_edges, int num_heads, int hidden_dim, float* d_da,
+                        void* stream);
+int tfgnn_rgat_attention_backward(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
+                                  const float* d_s_src, const float* d_s_tgt, const float* d_att,
+                                  const float* d_da, int64_t num_nodes, int num_edge_types, int num_heads,
+                                  float* d_dz, void* stream);
+int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha,
+                               int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
+                               float* d_dY, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node -> graph pooling (layers/nodes_to_graph_representation.py:170-229).  node_to_graph_map is
@@ -252,6 +266,11 @@ int tfgnn_layernorm_forward(const float* d_x, const float* d_gamma, const float*
 int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, const float* d_gamma, const float* d_mean,
                              const float* d_rstd, int64_t rows, int H, float* d_dx, float* d_dy_xhat,
                              void* stream);
+
+/* dst[b, a, :] = src[a, b, :]: re-pack the stacked per-edge-type kernels [L, D, H] <-> [D, L, H]
+ * (one bias-free kernel per edge type, gnn_edge_mlp.py:73-81) so that a layer's backward pass is two
+ * large GEMMs. */
+int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float* d_dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,8 +42,8 @@ def test_argument_validation_without_gpu():
         _lib.check(-1)
     # empty problems are no-ops
     assert lib.tfgnn_gemm(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None) == 0
-    assert lib.tfgnn_rgat_aggregate(None, None, None, None, None, 0, 2, 2, 4, 0, None, None, None) == 0
-    assert lib.tfgnn_rgat_aggregate(None, None, None, None, None, 4, 2, 3, 4, 0, None, None, None) == -1  # 4 % 3
+    assert lib.tfgnn_rgat_node_scores(None, None, 0, 2, 2, 4, None, None, None) == 0
+    assert lib.tfgnn_rgat_node_scores(None, None, 4, 2, 3, 4, None, None, None) == -1  # 4 % 3
 
 
 def test_ops_refuse_cpu_tensors():

@@ -57,12 +57,14 @@ _SIGNATURES = [
     ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     ("tfgnn_add_scale", c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     ("tfgnn_rgat_node_scores", c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("tfgnn_rgat_edge_attention", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    ("tfgnn_rgat_edge_dot", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     (
-        "tfgnn_rgat_aggregate",
+        "tfgnn_rgat_attention_backward",
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-         c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
     ),
+    ("tfgnn_rgat_scores_backward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     (
         "tfgnn_layernorm_forward",
         c_int,
@@ -83,6 +85,7 @@ _SIGNATURES = [
     ),
     ("tfgnn_segment_softmax_backward", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     ("tfgnn_dropout_forward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p]),
+    ("tfgnn_permute_021", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_mul", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 ]
 

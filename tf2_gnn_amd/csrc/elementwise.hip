@@ -347,3 +347,29 @@ extern "C" int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, con
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
+
+// dst[b, a, :] = src[a, b, :]  ([A, B, C] -> [B, A, C]).  Re-packs the per-edge-type kernels
+// [L, D, H] (vertical stack, forward operand) into [D, L*H] (horizontal stack) so that the backward
+// pass of a layer is two large GEMMs instead of 2*L small ones, and back for the gradients.
+namespace tfgnn {
+__global__ void __launch_bounds__(256)
+permute_021_kernel(const float* __restrict__ src, int64_t A, int64_t B, int64_t C, float* __restrict__ dst) {
+  const int64_t total = A * B * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % C;
+    const int64_t ab = i / C;
+    const int64_t b = ab % B, a = ab / B;
+    dst[(b * A + a) * C + c] = src[i];
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float* d_dst, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(A >= 0 && B >= 0 && C >= 0, "negative size");
+  if (A * B * C == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_src && d_dst, "NULL pointer");
+  hipLaunchKernelGGL(permute_021_kernel, dim3(ew_blocks(A * B * C)), dim3(256), 0, (hipStream_t)stream, d_src, A, B, C, d_dst);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

@@ -144,8 +144,9 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   constexpr int BM = 32 * WM_ * TM, BN = 32 * WN_ * TN;
   using SA = Stage<BM, !TA, VEC, NT>;  // A stored [M,K] -> K contiguous unless transposed
   using SB = Stage<BN, TB, VEC, NT>;   // B stored [K,N] -> N contiguous unless transposed
-  __shared__ __attribute__((aligned(16))) float lds_a[SA::LDS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float lds_b[SB::LDS_FLOATS];
+  // two LDS stages: tile t+1 is written while tile t is being multiplied -> one barrier per K tile
+  __shared__ __attribute__((aligned(16))) float lds_a[2][SA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_b[2][SB::LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -173,29 +174,32 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
     sb.init(g.B, g.ldb, n0, g.N, k_begin, tid);
     sa.load(k_end - k_begin, g.lda);
     sb.load(k_end - k_begin, g.ldb);
-    sa.store(lds_a, tid);
-    sb.store(lds_b, tid);
+    sa.store(lds_a[0], tid);
+    sb.store(lds_b[0], tid);
     __syncthreads();
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+    int stage = 0;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK, stage ^= 1) {
       const bool more = k0 + BK < k_end;
       if (more) {
         sa.load(k_end - k0 - BK, g.lda);
         sb.load(k_end - k0 - BK, g.ldb);
       }
+      const float* la = lds_a[stage];
+      const float* lb = lds_b[stage];
       // fragments of k-step kk+1 are fetched from LDS while the MFMAs of k-step kk run
       float fa[2][TM], fb[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, lk);
+      for (int i = 0; i < TM; ++i) fa[0][i] = SA::frag(la, (wm * TM + i) * 32 + li, lk);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, lk);
+      for (int j = 0; j < TN; ++j) fb[0][j] = SB::frag(lb, (wn * TN + j) * 32 + li, lk);
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
         if (kk + 1 < BK / 2) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) fa[nxt][i] = SA::frag(lds_a, (wm * TM + i) * 32 + li, 2 * (kk + 1) + lk);
+          for (int i = 0; i < TM; ++i) fa[nxt][i] = SA::frag(la, (wm * TM + i) * 32 + li, 2 * (kk + 1) + lk);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) fb[nxt][j] = SB::frag(lds_b, (wn * TN + j) * 32 + li, 2 * (kk + 1) + lk);
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = SB::frag(lb, (wn * TN + j) * 32 + li, 2 * (kk + 1) + lk);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -203,12 +207,12 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       }
-      __syncthreads();
       if (more) {
-        sa.store(lds_a, tid);
-        sb.store(lds_b, tid);
-        __syncthreads();
+        // the other stage was last read before the previous barrier: safe to overwrite now
+        sa.store(lds_a[stage ^ 1], tid);
+        sb.store(lds_b[stage ^ 1], tid);
       }
+      __syncthreads();
     }
   }
 

@@ -341,7 +341,7 @@ __global__ void unpack_kernel(const uint64_t* __restrict__ comp, const int32_t* 
                               int64_t E, int L, int32_t* __restrict__ col, int32_t* __restrict__ eid,
                               int32_t* __restrict__ coll, const float* __restrict__ invdeg_d,
                               float* __restrict__ invdeg_edge, int by_src,
-                              int32_t* __restrict__ eid_to_pos) {
+                              int32_t* __restrict__ eid_to_pos, int32_t* __restrict__ row_node) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
        p += (int64_t)gridDim.x * blockDim.x) {
     uint64_t c = comp[p];
@@ -353,6 +353,7 @@ __global__ void unpack_kernel(const uint64_t* __restrict__ comp, const int32_t* 
     eid[p] = id;
     int64_t cl = (int64_t)other * L + l;
     coll[p] = (int32_t)cl;
+    if (row_node) row_node[p] = row / L;
     // the degree that normalises an edge is always the in-degree of its TARGET for its type
     invdeg_edge[p] = by_src ? invdeg_d[cl] : invdeg_d[row];
     if (eid_to_pos) eid_to_pos[id] = (int32_t)p;
@@ -418,6 +419,7 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   const size_t o_col_s = plan.take(E * 4), o_eid_s = plan.take(E * 4), o_coll_s = plan.take(E * 4);
   const size_t o_nodeptr_d = plan.take((V + 1) * 4), o_nodeptr_s = plan.take((V + 1) * 4);
   const size_t o_src2dst = plan.take(E * 4);
+  const size_t o_tgt_d = plan.take(E * 4);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
   const size_t max_items = (size_t)(E / LONG_ROW_THRESHOLD + 1), max_multi = (size_t)(E / ITEM_CHUNK + 1);
@@ -465,6 +467,7 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   g->nodeptr_d = (int32_t*)(slab + o_nodeptr_d);
   g->nodeptr_s = (int32_t*)(slab + o_nodeptr_s);
   g->src2dst = (int32_t*)(slab + o_src2dst);
+  g->tgt_d = (int32_t*)(slab + o_tgt_d);
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
   g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
@@ -554,9 +557,10 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   }
   if (E > 0) {
     hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_d, rowid_d, E, L,
-                       g->col_d, g->eid_d, g->coll_d, g->invdeg_d, g->invdeg_edge_d, 0, eid2pos);
+                       g->col_d, g->eid_d, g->coll_d, g->invdeg_d, g->invdeg_edge_d, 0, eid2pos, g->tgt_d);
     hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_s, rowid_s, E, L,
-                       g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr);
+                       g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
                        g->src2dst);
   }
@@ -717,6 +721,7 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     case TFGNN_G_NODEPTR_BY_SRC: *d_ptr = g->nodeptr_s; *count = g->V + 1; break;
     case TFGNN_G_INVDEG_EDGE_BY_DST: *d_ptr = g->invdeg_edge_d; *count = g->E; break;
     case TFGNN_G_SRC2DST_POS: *d_ptr = g->src2dst; *count = g->E; break;
+    case TFGNN_G_TARGET_BY_DST: *d_ptr = g->tgt_d; *count = g->E; break;
     default:
       tfgnn::set_error("unknown graph array id %d", array_id);
       return TFGNN_ERR_INVALID_ARGUMENT;

@@ -9,17 +9,20 @@
 // (rgat_node_scores) from Y = X W (one MFMA GEMM), so an edge costs two scalar loads and one row
 // gather instead of two [E,D]x[D,H] matmuls.
 //
-// rgat_aggregate: one wave per target node.  Pass 1 (lanes over edges): per-head max and
-// sum-exp of the scores.  Pass 2 (lanes over features, edges in CSR order): a_ek recomputed per
-// lane for the head its features belong to, accumulated into registers; a_ek is also written out
-// ([E, K], by-dst order) for the backward pass.
+//   tfgnn_rgat_node_scores     s_src / s_tgt [V*L, K]
+//   tfgnn_rgat_edge_attention  a[e, k] for every bucketed edge (by-dst order); one wave per target
+//                              node, lanes over its incoming edges (hub nodes stay parallel)
+//   the weighted sum of source rows is the generic gather kernel with per-head edge weights
+//   (tfgnn_graph_gather_reduce, ew_heads = K) - see spmm.hip.
+// Backward (stand-in for tf.GradientTape): tfgnn_rgat_edge_dot, tfgnn_rgat_attention_backward,
+// tfgnn_rgat_scores_backward + generic gathers / GEMMs (layers/message_passing/rgat.py).
 #include <algorithm>
 
 #include "common.hpp"
 
 namespace tfgnn {
 
-constexpr int MAX_HEADS = 32;
+constexpr int MAX_HEADS = 64;
 
 // s_src[(v,l), k] = <Y[(v,l), k, :], alpha[l, k, :Hk]> ; s_tgt with alpha[l, k, Hk:]
 __global__ void __launch_bounds__(256)
@@ -45,107 +48,112 @@ rgat_node_scores_kernel(const float* __restrict__ Y, const float* __restrict__ a
 
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : 0.2f * z; }
 
-struct RgatArgs {
-  const int32_t* nodeptr;  // [V+1] by-dst
-  const int32_t* coll;     // [E]  src*L + type, by-dst order
-  const float* Y;          // [V*L, H]
-  const float* s_src;      // [V*L, K]
-  const float* s_tgt;      // [V*L, K]
-  int64_t V;
-  int L, K, H, Hk;
-  int post_act;
-  float* out;  // [V, H]
-  float* att;  // [E, K] (nullable)
-};
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_add(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
 
-// VEC = 4: each lane owns float4 chunks lane, lane+64, ... (requires Hk % 4 == 0); VEC = 1: floats
-template <int VEC, int VPL>
-__global__ void __launch_bounds__(256) rgat_aggregate_kernel(RgatArgs a) {
-  __shared__ float sm_max[4][MAX_HEADS];
-  __shared__ float sm_den[4][MAX_HEADS];
+// one wave per target node: per head, max and sum-exp over the incoming edges, then the
+// normalised attention of every edge.  log_softmax then exp (rgat.py:147-151):
+// exp(s - m - log(sum)) == exp(s - m) / sum.
+__global__ void __launch_bounds__(256)
+rgat_edge_attention_kernel(const int32_t* __restrict__ nodeptr, const int32_t* __restrict__ coll,
+                           const float* __restrict__ s_src, const float* __restrict__ s_tgt, int64_t V, int L,
+                           int K, float* __restrict__ att) {
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  const int64_t v = (int64_t)blockIdx.x * 4 + w;
-  const bool active = v < a.V;
-  const int32_t beg = active ? a.nodeptr[v] : 0;
-  const int32_t end = active ? a.nodeptr[v + 1] : 0;
-  const int K = a.K, L = a.L;
-
-  // ---- pass 1: per-head max / sum-exp over the incoming edges (lanes over edges) ------------
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int32_t beg = nodeptr[v], end = nodeptr[v + 1];
   for (int k = 0; k < K; ++k) {
     float m = kFloatLowest;
     for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = a.coll[e];
-      const int l = cl % L;
-      m = fmaxf(m, leaky(a.s_src[(int64_t)cl * K + k] + a.s_tgt[(v * L + l) * K + k]));
+      const int32_t cl = coll[e];
+      m = fmaxf(m, leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]));
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    m = wave_max(m);
     float s = 0.f;
     for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = a.coll[e];
-      const int l = cl % L;
-      s += expf(leaky(a.s_src[(int64_t)cl * K + k] + a.s_tgt[(v * L + l) * K + k]) - m);
+      const int32_t cl = coll[e];
+      s += expf(leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]) - m);
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) {
-      sm_max[w][k] = m;
-      sm_den[w][k] = s;
+    s = wave_add(s);
+    const float inv = 1.f / s;
+    for (int32_t e = beg + lane; e < end; e += 64) {
+      const int32_t cl = coll[e];
+      att[(int64_t)e * K + k] = expf(leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]) - m) * inv;
     }
   }
-  __syncthreads();
-  if (!active) return;
+}
 
-  // ---- pass 2: weighted sum of the source rows (lanes over features) -------------------------
-  int head[VPL];
-  bool live[VPL], writer[VPL];
-  float mx[VPL], inv_den[VPL];
-  float acc[VPL][VEC];
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int f = (lane + 64 * i) * VEC;
-    live[i] = f < a.H;
-    head[i] = live[i] ? f / a.Hk : 0;
-    writer[i] = live[i] && (f % a.Hk == 0);
-    mx[i] = sm_max[w][head[i]];
-    // log_softmax then exp (rgat.py:147-151): exp(s - m - log(sum)) == exp(s - m) / sum
-    inv_den[i] = 1.f / sm_den[w][head[i]];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) acc[i][c] = 0.f;
+// da[e, k] = < d_agg[tgt_e, k, :], Y[(src_e, l_e), k, :] >    (thread per (edge, head))
+__global__ void __launch_bounds__(256)
+rgat_edge_dot_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict__ tgt, const float* __restrict__ Y,
+                     const float* __restrict__ d_agg, int64_t E, int K, int Hk, float* __restrict__ da) {
+  const int64_t total = E * K;
+  const int H = K * Hk;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / K;
+    const int k = (int)(i - e * K);
+    const float* y = Y + (int64_t)coll[e] * H + k * Hk;
+    const float* g = d_agg + (int64_t)tgt[e] * H + k * Hk;
+    float s = 0.f;
+    for (int j = 0; j < Hk; ++j) s += y[j] * g[j];
+    da[i] = s;
   }
-  for (int32_t e = beg; e < end; ++e) {
-    const int32_t cl = a.coll[e];
-    const int l = cl % L;
-    const float* yrow = a.Y + (int64_t)cl * a.H;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      if (live[i]) {
-        const int f = (lane + 64 * i) * VEC;
-        const float sc = leaky(a.s_src[(int64_t)cl * K + head[i]] + a.s_tgt[(v * L + l) * K + head[i]]);
-        const float p = expf(sc - mx[i]) * inv_den[i];
-        if (writer[i] && a.att) a.att[(int64_t)e * K + head[i]] = p;
-        if (VEC == 4) {
-          const float4 y = *reinterpret_cast<const float4*>(yrow + f);
-          acc[i][0] += p * y.x;
-          acc[i][1 % VEC] += p * y.y;
-          acc[i][2 % VEC] += p * y.z;
-          acc[i][3 % VEC] += p * y.w;
-        } else {
-          acc[i][0] += p * yrow[f];
-        }
-      }
+}
+
+// softmax + leaky_relu backward per target node: dz[e,k] = a (da - sum_e' a da) * lrelu'(z)
+__global__ void __launch_bounds__(256)
+rgat_attention_backward_kernel(const int32_t* __restrict__ nodeptr, const int32_t* __restrict__ coll,
+                               const float* __restrict__ s_src, const float* __restrict__ s_tgt,
+                               const float* __restrict__ att, const float* __restrict__ da, int64_t V, int L, int K,
+                               float* __restrict__ dz) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int32_t beg = nodeptr[v], end = nodeptr[v + 1];
+  for (int k = 0; k < K; ++k) {
+    float t = 0.f;
+    for (int32_t e = beg + lane; e < end; e += 64) t += att[(int64_t)e * K + k] * da[(int64_t)e * K + k];
+    t = wave_add(t);
+    for (int32_t e = beg + lane; e < end; e += 64) {
+      const int32_t cl = coll[e];
+      const float z = s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k];
+      const float ds = att[(int64_t)e * K + k] * (da[(int64_t)e * K + k] - t);
+      dz[(int64_t)e * K + k] = ds * (z > 0.f ? 1.f : 0.2f);
     }
   }
-  float* orow = a.out + v * a.H;
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    if (live[i]) {
-      const int f = (lane + 64 * i) * VEC;
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) orow[f + c] = act_apply(a.post_act, acc[i][c]);
-    }
+}
+
+// dY[(v,l), k, i] += ds_src[(v,l),k] * alpha[l,k,i] + ds_tgt[(v,l),k] * alpha[l,k,Hk+i]
+__global__ void __launch_bounds__(256)
+rgat_scores_backward_kernel(const float* __restrict__ ds_src, const float* __restrict__ ds_tgt,
+                            const float* __restrict__ alpha, int64_t rows, int L, int K, int Hk,
+                            float* __restrict__ dY) {
+  const int H = K * Hk;
+  const int64_t total = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / H;
+    const int f = (int)(i - row * H);
+    const int k = f / Hk, j = f - k * Hk;
+    const int l = (int)(row % L);
+    const float* a = alpha + ((int64_t)l * K + k) * 2 * Hk;
+    dY[i] += ds_src[row * K + k] * a[j] + ds_tgt[row * K + k] * a[Hk + j];
   }
+}
+
+static unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 16384)); }
+
+static int check_heads(int num_heads, int hidden_dim) {
+  TFGNN_REQUIRE(num_heads > 0 && num_heads <= MAX_HEADS && hidden_dim > 0, "bad sizes");
+  TFGNN_REQUIRE(hidden_dim % num_heads == 0, "hidden_dim %d is not divisible by num_heads %d", hidden_dim, num_heads);
+  return TFGNN_OK;
 }
 
 }  // namespace tfgnn
@@ -154,45 +162,75 @@ extern "C" int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, in
                                       int num_edge_types, int num_heads, int hidden_dim, float* d_s_src,
                                       float* d_s_tgt, void* stream) {
   using namespace tfgnn;
-  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0 && num_heads > 0 && hidden_dim > 0, "bad sizes");
-  TFGNN_REQUIRE(hidden_dim % num_heads == 0, "hidden_dim %d is not divisible by num_heads %d", hidden_dim, num_heads);
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0, "bad sizes");
+  int rc = check_heads(num_heads, hidden_dim);
+  if (rc) return rc;
   const int64_t rows = num_nodes * num_edge_types;
   if (rows == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_Y && d_alpha && d_s_src && d_s_tgt, "NULL pointer");
-  unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(rows * num_heads, 256), 16384);
-  hipLaunchKernelGGL(rgat_node_scores_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_Y, d_alpha, rows,
-                     num_edge_types, num_heads, hidden_dim / num_heads, d_s_src, d_s_tgt);
+  hipLaunchKernelGGL(rgat_node_scores_kernel, dim3(grid_for(rows * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                     d_Y, d_alpha, rows, num_edge_types, num_heads, hidden_dim / num_heads, d_s_src, d_s_tgt);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_rgat_aggregate(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
-                                    const float* d_Y, const float* d_s_src, const float* d_s_tgt,
-                                    int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
-                                    int post_act, float* d_out, float* d_att, void* stream) {
+extern "C" int tfgnn_rgat_edge_attention(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
+                                         const float* d_s_src, const float* d_s_tgt, int64_t num_nodes,
+                                         int num_edge_types, int num_heads, float* d_att, void* stream) {
   using namespace tfgnn;
-  TFGNN_REQUIRE(num_nodes >= 0 && num_heads > 0 && num_heads <= MAX_HEADS && hidden_dim > 0, "bad sizes");
-  TFGNN_REQUIRE(hidden_dim % num_heads == 0, "hidden_dim %d is not divisible by num_heads %d", hidden_dim, num_heads);
+  TFGNN_REQUIRE(num_nodes >= 0 && num_heads > 0 && num_heads <= MAX_HEADS, "bad sizes");
   if (num_nodes == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_nodeptr_by_dst && d_out, "NULL pointer");
-  RgatArgs a{d_nodeptr_by_dst, d_coll_by_dst, d_Y, d_s_src, d_s_tgt, num_nodes, num_edge_types > 0 ? num_edge_types : 1,
-             num_heads, hidden_dim, hidden_dim / num_heads, post_act, d_out, d_att};
-  dim3 grid((unsigned)ceil_div(num_nodes, 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  const int Hk = hidden_dim / num_heads;
-  const bool vec4 = (Hk % 4 == 0) && ((uintptr_t)d_Y % 16 == 0);
-  if (vec4) {
-    const int chunks = hidden_dim / 4;
-    TFGNN_REQUIRE(chunks <= 64 * 4, "hidden_dim %d too large for the RGAT kernel (max 1024)", hidden_dim);
-    if (chunks <= 64) hipLaunchKernelGGL((rgat_aggregate_kernel<4, 1>), grid, block, 0, s, a);
-    else if (chunks <= 128) hipLaunchKernelGGL((rgat_aggregate_kernel<4, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((rgat_aggregate_kernel<4, 4>), grid, block, 0, s, a);
-  } else {
-    TFGNN_REQUIRE(hidden_dim <= 64 * 8, "hidden_dim %d with head size %d not a multiple of 4 is limited to 512", hidden_dim, Hk);
-    if (hidden_dim <= 64) hipLaunchKernelGGL((rgat_aggregate_kernel<1, 1>), grid, block, 0, s, a);
-    else if (hidden_dim <= 128) hipLaunchKernelGGL((rgat_aggregate_kernel<1, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((rgat_aggregate_kernel<1, 8>), grid, block, 0, s, a);
-  }
+  TFGNN_REQUIRE(d_nodeptr_by_dst, "NULL pointer");
+  hipLaunchKernelGGL(rgat_edge_attention_kernel, dim3((unsigned)ceil_div(num_nodes, 4)), dim3(256), 0,
+                     (hipStream_t)stream, d_nodeptr_by_dst, d_coll_by_dst, d_s_src, d_s_tgt, num_nodes,
+                     num_edge_types > 0 ? num_edge_types : 1, num_heads, d_att);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst, const float* d_Y,
+                                   const float* d_dagg, int64_t num_edges, int num_heads, int hidden_dim,
+                                   float* d_da, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0, "bad sizes");
+  int rc = check_heads(num_heads, hidden_dim);
+  if (rc) return rc;
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_coll_by_dst && d_target_by_dst && d_Y && d_dagg && d_da, "NULL pointer");
+  hipLaunchKernelGGL(rgat_edge_dot_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                     d_coll_by_dst, d_target_by_dst, d_Y, d_dagg, num_edges, num_heads, hidden_dim / num_heads, d_da);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_attention_backward(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
+                                             const float* d_s_src, const float* d_s_tgt, const float* d_att,
+                                             const float* d_da, int64_t num_nodes, int num_edge_types,
+                                             int num_heads, float* d_dz, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_heads > 0 && num_heads <= MAX_HEADS, "bad sizes");
+  if (num_nodes == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_nodeptr_by_dst, "NULL pointer");
+  hipLaunchKernelGGL(rgat_attention_backward_kernel, dim3((unsigned)ceil_div(num_nodes, 4)), dim3(256), 0,
+                     (hipStream_t)stream, d_nodeptr_by_dst, d_coll_by_dst, d_s_src, d_s_tgt, d_att, d_da, num_nodes,
+                     num_edge_types > 0 ? num_edge_types : 1, num_heads, d_dz);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha,
+                                          int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
+                                          float* d_dY, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0, "bad sizes");
+  int rc = check_heads(num_heads, hidden_dim);
+  if (rc) return rc;
+  const int64_t rows = num_nodes * num_edge_types;
+  if (rows == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_ds_src && d_ds_tgt && d_alpha && d_dY, "NULL pointer");
+  hipLaunchKernelGGL(rgat_scores_backward_kernel, dim3(grid_for(rows * hidden_dim)), dim3(256), 0,
+                     (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, rows, num_edge_types, num_heads,
+                     hidden_dim / num_heads, d_dY);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -178,13 +178,13 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
 }
 
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
-__global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
+__device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned row_block) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;  // floats covered per pass
   const int tid = threadIdx.x;
   const int group = tid / LPR;
   const int gl = tid % LPR;
-  const int64_t row = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + group;
+  const int64_t row = (int64_t)row_block * GROUPS_PER_BLOCK + group;
   if (row >= a.num_rows) return;
   const int f0 = blockIdx.y * WINDOW + gl * VEC;  // first float of this lane's chunk 0
   const int32_t beg = a.rowptr[row];
@@ -223,14 +223,13 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a) {
 
 // one workgroup per item (a run of <= item_chunk_edges edges of a long row)
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
-__global__ void __launch_bounds__(256) csr_gather_items_kernel(GatherArgs a) {
+__device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
+                                                  float (&red)[256 / LPR][LPR * VPL * VEC]) {
   constexpr int GROUPS = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
-  __shared__ float red[GROUPS][WINDOW];
   const int tid = threadIdx.x;
   const int group = tid / LPR;
   const int gl = tid % LPR;
-  const int item = blockIdx.x;
   const int64_t row = a.item_row[item];
   const int32_t rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
   const int32_t ibeg = rbeg + a.item_chunk[item] * a.item_chunk_edges;
@@ -289,18 +288,26 @@ __global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
   }
 }
 
+// One launch covers both kinds of work: workgroups [0, num_items) each take one item of a long row
+// (longest work first), the remaining workgroups take 256/LPR short rows each.
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+__global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a, int num_items) {
+  __shared__ float red[256 / LPR][LPR * VPL * VEC];
+  if ((int)blockIdx.x < num_items)
+    gather_item_block<LPR, VPL, VEC, UNROLL, MODE>(a, (int)blockIdx.x, red);
+  else
+    gather_rows_block<LPR, VPL, VEC, UNROLL, MODE>(a, blockIdx.x - (unsigned)num_items);
+}
+
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
 static int launch_mode(const GatherArgs& a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
   const unsigned windows = (unsigned)ceil_div(a.width, WINDOW);
   dim3 block(256);
-  if (num_items > 0) {  // longest work first
-    hipLaunchKernelGGL((csr_gather_items_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3((unsigned)num_items, windows), block, 0, s, a);
-    TFGNN_LAUNCH_CHECK();
-  }
   hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>),
-                     dim3((unsigned)ceil_div(a.num_rows, GROUPS_PER_BLOCK), windows), block, 0, s, a);
+                     dim3((unsigned)(num_items + ceil_div(a.num_rows, GROUPS_PER_BLOCK)), windows), block, 0, s, a,
+                     num_items);
   TFGNN_LAUNCH_CHECK();
   if (a.num_multi > 0) {
     const int64_t total = (int64_t)a.num_multi * a.width;

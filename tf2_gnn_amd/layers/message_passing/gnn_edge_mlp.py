@@ -280,23 +280,29 @@ class GNN_Edge_MLP(MessagePassing):
         dX = torch.empty_like(X)
         if ctx["path"] == "A":
             W = mlps.kernels[0]  # [L, Din, H]
-            dW = torch.empty_like(W)
-            for l in range(L):
-                ops.gemm(G[:, l, :], W[l, :D, :], trans_b=True, out=dX, accumulate=l > 0)
-                ops.gemm(X, G[:, l, :], trans_a=True, out=dW[l, :D, :])
-            if self._use_target_state_as_input:
+            Din = W.shape[1]
+            # horizontal stack [Din, L*H] of the L kernels: the backward pass becomes two large GEMMs
+            #   dX = [G_0|...|G_{L-1}] @ [W_0|...|W_{L-1}]^T      dW_h = X^T @ [G_0|...|G_{L-1}]
+            Wh = ops.permute_021(W)  # [Din, L, H]
+            G2 = G.view(V, L * H)
+            dWh = torch.empty((Din, L, H), dtype=torch.float32, device=X.device)
+            if L == 0:
+                dX.zero_()
+            else:
+                ops.gemm(G2, Wh[:D].view(D, L * H), trans_b=True, out=dX)
+                ops.gemm(X, G2, trans_a=True, out=dWh[:D].view(D, L * H))
+            if self._use_target_state_as_input and L > 0:
                 # target part: pre += (k_{l,v} x_v) W_t  ->  dW_t = (k x)^T d_agg ; dX_v += k d_agg W_t^T
                 from ..graph_scales import target_multiplier
 
                 k, ident_ptr, node_of_row = target_multiplier(g, row_scale)
                 A = ctx["A"].view(V, L, 2 * D)
                 for l in range(L):
-                    ops.gemm(A[:, l, D:], d_agg, trans_a=True, out=dW[l, D:, :])
+                    ops.gemm(A[:, l, D:], d_agg, trans_a=True, out=dWh[D:, l, :])
                 # dX_v += sum_l k_{l,v} * (d_agg[v] @ W_t[l]^T)
-                kd = ops.gather_reduce(ident_ptr, node_of_row, d_agg, edge_weight=k).view(V, L, H)
-                for l in range(L):
-                    ops.gemm(kd[:, l, :], W[l, D:, :], trans_b=True, out=dX, accumulate=True)
-            mlps.grads = [dW]
+                kd = ops.gather_reduce(ident_ptr, node_of_row, d_agg, edge_weight=k).view(V, L * H)
+                ops.gemm(kd, Wh[D:].view(D, L * H), trans_b=True, out=dX, accumulate=True)
+            mlps.grads = [ops.permute_021(dWh)]
         else:
             acts = ctx["mlp_acts"]
             grads = [torch.empty_like(W) for W in mlps.kernels]

@@ -1,5 +1,5 @@
 """Relational Graph Attention Network layer - mirror of tf2_gnn/layers/message_passing/rgat.py."""
-from typing import Any, Dict, List
+from typing import Any, Dict
 
 import torch
 
@@ -22,6 +22,11 @@ class RGAT(MessagePassing):
     kernel [D, H] and one attention parameter [K, 2H/K].  The L kernels live side by side in one
     [D, L*H] buffer so that Y = X W for all types is a single GEMM.
 
+    Forward on the device (csrc/rgat.hip, csrc/spmm.hip):
+      Y = X @ [W_0|...|W_{L-1}]                                     MFMA GEMM, rows (v,l) of width H
+      s_src, s_tgt [V*L, K]   the two halves of every attention logit, per (node, type, head)
+      a [E, K]                per-head softmax over all edges entering a node (all types)
+      out = act( sum_e a_e * Y[(src_e, l_e)] )                      gather kernel, per-head edge weights
     The layer ignores ``aggregation_function`` and ``message_activation_before_aggregation``
     (rgat.py:125-163), like the reference."""
 
@@ -89,17 +94,21 @@ class RGAT(MessagePassing):
                 ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
             )
         )
-        out = torch.empty((V, H), dtype=torch.float32, device=dev)
         att = torch.empty((g.num_edges, K), dtype=torch.float32, device=dev)
-        act = self._activation_name
-        fused = None if act == "gelu" else act
         _lib.check(
-            lib.tfgnn_rgat_aggregate(
-                ops._ptr(g.array(ops.G_NODEPTR_BY_DST)), ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(Y),
-                ops._ptr(s_src), ops._ptr(s_tgt), V, L, K, H, ops.act_id(fused), ops._ptr(out), ops._ptr(att),
-                ops._stream(),
+            lib.tfgnn_rgat_edge_attention(
+                ops._ptr(g.array(ops.G_NODEPTR_BY_DST)), ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(s_src),
+                ops._ptr(s_tgt), V, L, K, ops._ptr(att), ops._stream(),
             )
         )
+        act = self._activation_name
+        fused = None if act == "gelu" else act
+        if L == 0 or g.num_edges == 0:
+            out = torch.zeros((V, H), dtype=torch.float32, device=dev)
+            if fused is not None:
+                out = ops.activation_forward(fused, out)
+        else:
+            out = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=att, post_act=fused)
         ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act}
         if act == "gelu":
             ctx["pre"] = out
@@ -109,4 +118,74 @@ class RGAT(MessagePassing):
         return out
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("RGAT backward is not implemented yet")
+        """d(loss)/d(out) -> d(loss)/d(node_embeddings); fills the kernel / attention gradients."""
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        lib = _lib.load()
+        g, X, Y, att = ctx["graph"], ctx["X"], ctx["Y"], ctx["att"]
+        s_src, s_tgt = ctx["s_src"], ctx["s_tgt"]
+        V, D = X.shape
+        L, H, K = g.num_edge_types, self._hidden_dim, self._num_heads
+        E = g.num_edges
+        dev = X.device
+        act = ctx["fused_act"]
+        d_agg = grad_output
+        if act is not None:
+            d_agg = ops.activation_backward(act, grad_output, ctx["pre"] if act == "gelu" else ctx["out"])
+        d_agg = d_agg.contiguous()
+        if L == 0 or E == 0:
+            for v in self._variables:
+                v.grad = torch.zeros_like(v.value)
+            return torch.zeros_like(X)
+        s2d = g.array(ops.G_SRC2DST_POS)
+        ident_e = g._cache.get("ident_e")
+        if ident_e is None:
+            ident_e = torch.arange(E + 1, dtype=torch.int32, device=dev)
+            g._cache["ident_e"] = ident_e
+        # (1) dY[(u,l),k,:] = sum over out-edges e of (u,l): a_ek * d_agg[tgt_e, k, :]
+        att_s = ops.gather_reduce(ident_e, s2d, att)  # attention re-ordered to the by-src edge order
+        dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]
+        # (2) gradient w.r.t. the attention values, softmax + leaky_relu backward
+        da = torch.empty((E, K), dtype=torch.float32, device=dev)
+        _lib.check(
+            lib.tfgnn_rgat_edge_dot(
+                ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(Y),
+                ops._ptr(d_agg), E, K, H, ops._ptr(da), ops._stream(),
+            )
+        )
+        dz = torch.empty((E, K), dtype=torch.float32, device=dev)
+        _lib.check(
+            lib.tfgnn_rgat_attention_backward(
+                ops._ptr(g.array(ops.G_NODEPTR_BY_DST)), ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(s_src),
+                ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), V, L, K, ops._ptr(dz), ops._stream(),
+            )
+        )
+        # (3) logits are s_src[(src,l)] + s_tgt[(tgt,l)]: segment sums of dz over both bucketings
+        ds_tgt = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, dz, col=ident_e[:E])  # [V*L, K]
+        ds_src = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dz, col=s2d)  # [V*L, K]
+        # (4) through the inner products with alpha
+        #     d alpha[l,k,:Hk] = sum_v ds_src[(v,l),k] * Y[(v,l),k,:]   (block diagonal of a small GEMM)
+        Hk = H // K
+        Yv = Y.view(V, L * H)
+        full_s = ops.gemm(ds_src.view(V, L * K), Yv, trans_a=True)  # [L*K, L*H]
+        full_t = ops.gemm(ds_tgt.view(V, L * K), Yv, trans_a=True)
+        d_attn = torch.empty_like(self._attn)
+        idx = torch.arange(L * K, device=dev)
+        blocks_s = full_s.view(L * K, L * K, Hk)[idx, idx]  # [(l,k), Hk]
+        blocks_t = full_t.view(L * K, L * K, Hk)[idx, idx]
+        d_attn[:, :, :Hk].copy_(blocks_s.view(L, K, Hk))
+        d_attn[:, :, Hk:].copy_(blocks_t.view(L, K, Hk))
+        _lib.check(
+            lib.tfgnn_rgat_scores_backward(
+                ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
+            )
+        )
+        # (5) Y = X @ W
+        dYv = dY.view(V, L * H)
+        d_kernels = ops.gemm(X, dYv, trans_a=True)  # [D, L*H]
+        dX = ops.gemm(dYv, self._kernels, trans_b=True)
+        for i in range(L):
+            self._edge_type_to_message_computation_layer[i].grad = d_kernels[:, i * H : (i + 1) * H]
+            self._edge_type_to_attention_parameters[i].grad = d_attn[i]
+        return dX

@@ -85,7 +85,7 @@ class _DevArray:
 # graph array ids (include/tfgnn.h tfgnn_graph_array_id)
 (G_ROWPTR_BY_DST, G_COL_BY_DST, G_EID_BY_DST, G_COLL_BY_DST, G_ROWPTR_BY_SRC, G_COL_BY_SRC, G_EID_BY_SRC,
  G_COLL_BY_SRC, G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_NODEPTR_BY_DST, G_NODEPTR_BY_SRC,
- G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS) = range(14)
+ G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS, G_TARGET_BY_DST) = range(15)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
 
 
@@ -402,3 +402,13 @@ def layernorm_backward(dy, x, gamma, mean, rstd):
                                      _ptr(dy_xhat), _stream())
     )
     return dx, colsum(dy_xhat), colsum(dy)
+
+
+def permute_021(x: torch.Tensor) -> torch.Tensor:
+    """[A, B, C] -> [B, A, C] (contiguous copy)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    A, B, C = x.shape
+    out = torch.empty((B, A, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.tfgnn_permute_021(_ptr(x), A, B, C, _ptr(out), _stream()))
+    return out
