@@ -73,6 +73,17 @@ typedef struct tfgnn_graph tfgnn_graph;
 int tfgnn_graph_create(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
                        const int64_t* num_edges, void* stream, tfgnn_graph** out_graph);
 int tfgnn_graph_destroy(tfgnn_graph* graph);
+/* Pipelined form (the reference prepares batches in a background thread + tf.data prefetch,
+ * data/graph_dataset.py:292-295, cli_utils/training_utils.py:114-115): enqueue the whole build on
+ * `stream` and return at once; tfgnn_graph_wait blocks the HOST until the build has finished, then
+ * reports bad indices.  Consumers on other streams must order themselves after `stream` (event /
+ * stream wait) and call tfgnn_graph_wait before the first gather.  tfgnn_graph_destroy_async returns
+ * the handle's memory to the library's pool, to be reused only after the work already enqueued on
+ * `last_use_stream` (tfgnn_graph_destroy waits for the device instead). */
+int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                             const int64_t* num_edges, void* stream, tfgnn_graph** out_graph);
+int tfgnn_graph_wait(tfgnn_graph* graph);
+int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stream);
 
 typedef enum {
   TFGNN_G_ROWPTR_BY_DST = 0, /* int32 [V*L+1]                                                  */

@@ -22,6 +22,13 @@ _SIGNATURES = [
         [c_int, c_int64, POINTER(c_void_p), POINTER(c_int64), c_void_p, POINTER(c_void_p)],
     ),
     ("tfgnn_graph_destroy", c_int, [c_void_p]),
+    (
+        "tfgnn_graph_create_async",
+        c_int,
+        [c_int, c_int64, POINTER(c_void_p), POINTER(c_int64), c_void_p, POINTER(c_void_p)],
+    ),
+    ("tfgnn_graph_wait", c_int, [c_void_p]),
+    ("tfgnn_graph_destroy_async", c_int, [c_void_p, c_void_p]),
     ("tfgnn_graph_array", c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
     ("tfgnn_graph_dims", c_int, [c_void_p, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
     ("tfgnn_graph_scales", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

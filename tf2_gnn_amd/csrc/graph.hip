@@ -10,6 +10,7 @@
 //   count keys (int atomics) -> exclusive scan -> scatter (col<<32 | edge_id) with an atomic cursor
 //   -> per-row sort of the 64-bit composites (canonical order) -> unpack + derived arrays.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -373,6 +374,82 @@ __global__ void src2dst_kernel(const int32_t* __restrict__ eid_s, const int32_t*
 // handle
 // ------------------------------------------------------------------------------------------
 
+namespace tfgnn {
+// Small cache of device / pinned-host blocks so that building a graph per batch does not pay a
+// hipMalloc + hipFree (both synchronise the device) every step.
+struct PoolEntry {
+  void* ptr;
+  size_t bytes;
+  hipEvent_t ready;  // nullable: work that may still be using the block (recorded at release)
+};
+static std::mutex g_pool_mutex;
+static std::vector<PoolEntry> g_dev_pool, g_pinned_pool;
+constexpr size_t POOL_MAX_ENTRIES = 12;
+
+static void* pool_take(std::vector<PoolEntry>& pool, size_t bytes, size_t* got, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  int best = -1;
+  for (int i = 0; i < (int)pool.size(); ++i)
+    if (pool[i].bytes >= bytes && pool[i].bytes <= 2 * bytes + 4096 && (best < 0 || pool[i].bytes < pool[best].bytes)) best = i;
+  if (best < 0) return nullptr;
+  void* p = pool[best].ptr;
+  *got = pool[best].bytes;
+  if (pool[best].ready) {  // the new owner's stream waits for the previous owner's last use
+    (void)hipStreamWaitEvent(s, pool[best].ready, 0);
+    (void)hipEventDestroy(pool[best].ready);
+  }
+  pool.erase(pool.begin() + best);
+  return p;
+}
+
+static hipError_t dev_alloc(void** p, size_t bytes, size_t* got, hipStream_t s) {
+  if (bytes == 0) bytes = 256;
+  *p = pool_take(g_dev_pool, bytes, got, s);
+  if (*p) return hipSuccess;
+  *got = bytes;
+  return hipMalloc(p, bytes);
+}
+// last_use: stream on which the block may still be in use (nullptr + sync=false: known idle)
+static void dev_release(void* p, size_t bytes, hipStream_t last_use = nullptr, bool in_use = false) {
+  if (!p) return;
+  hipEvent_t ev = nullptr;
+  if (in_use) {
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, last_use) != hipSuccess) {
+      (void)hipStreamSynchronize(last_use);
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_dev_pool.size() < POOL_MAX_ENTRIES) {
+      g_dev_pool.push_back({p, bytes, ev});
+      return;
+    }
+  }
+  if (ev) (void)hipEventDestroy(ev);
+  (void)hipFree(p);  // synchronises
+}
+static hipError_t pinned_alloc(void** p, size_t bytes, size_t* got) {
+  if (bytes < 4096) bytes = 4096;
+  *p = pool_take(g_pinned_pool, bytes, got, nullptr);
+  if (*p) return hipSuccess;
+  *got = bytes;
+  return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+static void pinned_release(void* p, size_t bytes) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pinned_pool.size() < POOL_MAX_ENTRIES) {
+      g_pinned_pool.push_back({p, bytes, nullptr});
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+}  // namespace tfgnn
+
 namespace {
 struct SlabPlan {
   size_t total = 0;
@@ -384,9 +461,19 @@ struct SlabPlan {
 };
 }  // namespace
 
-extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
-                                  const int32_t* const* d_adjacency, const int64_t* num_edges,
-                                  void* stream, tfgnn_graph** out_graph) {
+static void graph_release_all(tfgnn_graph* g, hipStream_t last_use = nullptr, bool in_use = false) {
+  using namespace tfgnn;
+  if (!g) return;
+  if (g->event) (void)hipEventDestroy((hipEvent_t)g->event);
+  dev_release(g->scratch, g->scratch_bytes, last_use, in_use);
+  dev_release(g->slab, g->slab_bytes, last_use, in_use);
+  pinned_release(g->pinned, g->pinned_bytes);
+  delete g;
+}
+
+extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
+                                        const int32_t* const* d_adjacency, const int64_t* num_edges,
+                                        void* stream, tfgnn_graph** out_graph) {
   using namespace tfgnn;
   TFGNN_REQUIRE(out_graph != nullptr, "out_graph is NULL");
   *out_graph = nullptr;
@@ -442,17 +529,24 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
 
   char* slab = nullptr;
   char* scratch = nullptr;
-  hipError_t he = hipMalloc((void**)&slab, persistent ? persistent : 256);
-  if (he != hipSuccess) {
-    set_error("hipMalloc(%zu) failed: %s", persistent, hipGetErrorString(he));
-    delete g;
-    return TFGNN_ERR_HIP;
+  const size_t pinned_need = 256 + (size_t)(L + 1) * 16;
+  hipError_t he = dev_alloc((void**)&slab, persistent, &g->slab_bytes, s);
+  if (he == hipSuccess) {
+    g->slab = slab;
+    he = dev_alloc((void**)&scratch, tmp.total, &g->scratch_bytes, s);
   }
-  he = hipMalloc((void**)&scratch, tmp.total);
+  if (he == hipSuccess) {
+    g->scratch = scratch;
+    he = pinned_alloc(&g->pinned, pinned_need, &g->pinned_bytes);
+  }
+  if (he == hipSuccess) {
+    hipEvent_t ev;
+    he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (he == hipSuccess) g->event = ev;
+  }
   if (he != hipSuccess) {
-    set_error("hipMalloc(%zu) failed: %s", tmp.total, hipGetErrorString(he));
-    (void)hipFree(slab);
-    delete g;
+    set_error("graph allocation failed (%zu + %zu bytes): %s", persistent, tmp.total, hipGetErrorString(he));
+    graph_release_all(g);
     return TFGNN_ERR_HIP;
   }
   g->slab = slab;
@@ -487,12 +581,9 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   int64_t* d_off = (int64_t*)(scratch + t_off);
 
   int rc = TFGNN_OK;
-  int32_t h_counters[64] = {0};
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(s);
-    (void)hipFree(scratch);
-    (void)hipFree(slab);
-    delete g;
+    graph_release_all(g);
     return code;
   };
 #define G_CHECK(expr)                                                                          \
@@ -510,13 +601,16 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
   G_CHECK(hipMemsetAsync(cur_d, 0, (R + 1) * 4, s));
   G_CHECK(hipMemsetAsync(cur_s, 0, (R + 1) * 4, s));
   G_CHECK(hipMemsetAsync(counters, 0, 64 * 4, s));
-  if (L > 0) {
-    G_CHECK(hipMemcpyAsync(d_ptrs, d_adjacency, (size_t)L * 8, hipMemcpyHostToDevice, s));
+  // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
+  {
+    char* hp = (char*)g->pinned + 256;
+    const int32_t** h_ptrs = (const int32_t**)hp;
+    int64_t* h_off = (int64_t*)(hp + (size_t)(L + 1) * 8);
+    for (int l = 0; l < L; ++l) h_ptrs[l] = d_adjacency[l];
+    for (int l = 0; l <= L; ++l) h_off[l] = edge_off[l];
+    if (L > 0) G_CHECK(hipMemcpyAsync(d_ptrs, h_ptrs, (size_t)L * 8, hipMemcpyHostToDevice, s));
+    G_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
   }
-  G_CHECK(hipMemcpyAsync(d_off, edge_off.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
-  // the two host arrays above are read by the async copies: make sure they are consumed before
-  // this function returns (edge_off is a local; d_adjacency belongs to the caller)
-  G_CHECK(hipStreamSynchronize(s));
 
   EdgeLists el{d_ptrs, d_off, L};
   const int threads = 256;
@@ -590,24 +684,47 @@ extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
       return fail(TFGNN_ERR_HIP);
     }
   }
-  G_CHECK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));
-  G_CHECK(hipStreamSynchronize(s));
-  G_CHECK(hipFree(scratch));
-  scratch = nullptr;
+  G_CHECK(hipMemcpyAsync(g->pinned, counters, 64 * 4, hipMemcpyDeviceToHost, s));
+  G_CHECK(hipEventRecord((hipEvent_t)g->event, s));
 #undef G_CHECK
+  g->pending = true;
+  *out_graph = g;
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_wait(tfgnn_graph* g) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  if (!g->pending) return TFGNN_OK;
+  TFGNN_HIP_CHECK(hipEventSynchronize((hipEvent_t)g->event));
+  g->pending = false;
+  const int32_t* h_counters = (const int32_t*)g->pinned;
   for (int v = 0; v < 4; ++v) {
     g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
     g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
     g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
   }
-  if (h_counters[2] != 0) {
-    set_error("adjacency list contains a node index outside [0, %lld)", (long long)V);
-    (void)hipFree(slab);
-    delete g;
+  const bool bad_index = h_counters[2] != 0;
+  dev_release(g->scratch, g->scratch_bytes);  // build-time scratch is no longer needed
+  g->scratch = nullptr;
+  if (bad_index) {
+    set_error("adjacency list contains a node index outside [0, %lld)", (long long)g->V);
     return TFGNN_ERR_OUT_OF_RANGE;
   }
-  *out_graph = g;
   return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_create(int num_edge_types, int64_t num_nodes,
+                                  const int32_t* const* d_adjacency, const int64_t* num_edges,
+                                  void* stream, tfgnn_graph** out_graph) {
+  int rc = tfgnn_graph_create_async(num_edge_types, num_nodes, d_adjacency, num_edges, stream, out_graph);
+  if (rc) return rc;
+  rc = tfgnn_graph_wait(*out_graph);
+  if (rc) {
+    graph_release_all(*out_graph);
+    *out_graph = nullptr;
+  }
+  return rc;
 }
 
 
@@ -690,8 +807,16 @@ extern "C" int tfgnn_graph_target_multiplier(const tfgnn_graph* g, const float* 
 
 extern "C" int tfgnn_graph_destroy(tfgnn_graph* graph) {
   if (!graph) return TFGNN_OK;
-  if (graph->slab) TFGNN_HIP_CHECK(hipFree(graph->slab));
-  delete graph;
+  // no stream given: anything may still be reading the arrays -> wait for the whole device
+  (void)hipDeviceSynchronize();
+  graph_release_all(graph);
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stream) {
+  if (!graph) return TFGNN_OK;
+  if (graph->pending) (void)hipEventSynchronize((hipEvent_t)graph->event);
+  graph_release_all(graph, (hipStream_t)last_use_stream, true);
   return TFGNN_OK;
 }
 

@@ -1,5 +1,6 @@
 // Internal layout of the graph handle (shared by graph.hip and spmm.hip).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace tfgnn {
@@ -40,4 +41,12 @@ struct tfgnn_graph {
   int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *tgt_d = nullptr;
   float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
   tfgnn::GraphView views[4];  // tfgnn_graph_view order
+  // asynchronous build state (tfgnn_graph_create_async / tfgnn_graph_wait)
+  size_t slab_bytes = 0;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void* pinned = nullptr;  // host staging: [0,256) counters read back, then pointer / offset tables
+  size_t pinned_bytes = 0;
+  void* event = nullptr;   // hipEvent_t recorded after the last build command
+  bool pending = false;
 };

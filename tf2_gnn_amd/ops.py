@@ -94,7 +94,10 @@ class Graph:
     and for forward + backward.  ``adjacency_lists``: sequence of int32 device tensors [E_l, 2]
     with rows (source, target), exactly ``GNNInput.adjacency_lists`` (layers/gnn.py:241-244)."""
 
-    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int):
+    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, wait: bool = True):
+        """wait=False: the build is only enqueued on the current stream (pipelining the next batch's
+        bucketing behind the current step, like the reference's prefetching input pipeline); call
+        ``wait()`` - and order the consuming stream after the build stream - before using it."""
         lib = _lib.load()
         adjs = []
         for i, a in enumerate(adjacency_lists):
@@ -105,21 +108,36 @@ class Graph:
                 else:
                     raise ValueError(f"adjacency_lists[{i}] must have shape [E, 2], got {tuple(a.shape)}")
             adjs.append(a.contiguous())
-        self._keep = adjs
+        self._keep = adjs  # the edge lists must stay alive until the build has run
         L = len(adjs)
         ptrs = (ctypes.c_void_p * max(L, 1))(*[a.data_ptr() if a.numel() else None for a in adjs])
         counts = (ctypes.c_int64 * max(L, 1))(*[a.shape[0] for a in adjs])
         handle = ctypes.c_void_p()
+        self._h = None
         _lib.check(
-            lib.tfgnn_graph_create(L, int(num_nodes), ptrs, counts, _stream(), ctypes.byref(handle))
+            lib.tfgnn_graph_create_async(L, int(num_nodes), ptrs, counts, _stream(), ctypes.byref(handle))
         )
         self._h = handle
+        self._pending = True
         self.num_nodes = int(num_nodes)
         self.num_edge_types = L
         self.num_edges = int(sum(a.shape[0] for a in adjs))
         self.device = adjs[0].device if adjs else torch.device("cuda")
         self._cache = {}
-        self._keep = None  # the handle owns copies of everything it needs
+        if wait:
+            self.wait()
+
+    def wait(self):
+        """Block the host until the bucketing has finished; raises ValueError for bad node indices."""
+        if self._pending:
+            self._pending = False
+            self._keep = None
+            try:
+                _lib.check(_lib.load().tfgnn_graph_wait(self._h))
+            except Exception:
+                self.close()
+                raise
+        return self
 
     def array(self, array_id: int) -> torch.Tensor:
         if array_id in self._cache:
@@ -137,10 +155,12 @@ class Graph:
         return t
 
     def close(self):
+        """Return the handle's memory to the library; work already enqueued on the current stream may
+        still read it (the memory is only reused after that work)."""
         if getattr(self, "_h", None) is not None and self._h:
             self._cache = {}
-            _lib.check(_lib.load().tfgnn_graph_destroy(self._h))
-            self._h = None
+            h, self._h = self._h, None
+            _lib.check(_lib.load().tfgnn_graph_destroy_async(h, _stream()))
 
     def __del__(self):
         try:
