@@ -143,21 +143,15 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm device (there is no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from tf2_gnn_amd import parallel
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    rank, world, dist = parallel.init_distributed(device=dev)  # nccl == RCCL over xGMI on ROCm
 
     from tf2_gnn_amd import ops
     from tf2_gnn_amd.data import make_synthetic_batch
@@ -207,10 +201,7 @@ def main():
             g.close()
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        parallel.barrier(dist)
 
     for _ in range(args.warmup):
         step()
@@ -224,17 +215,9 @@ def main():
         g_.wait()
         g_.close()
     pending.clear()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # final metric reduction: all-gather of the per-rank edge counts (north_star: the only collective)
-        mine = torch.tensor([float(E)], dtype=torch.float64, device=dev)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        total_edges_per_step = float(sum(x.item() for x in gathered))
-    else:
-        total_edges_per_step = float(E)
+    elapsed = parallel.reduce_max(elapsed, dist, dev)
+    # final metric reduction: all-gather of the per-rank edge counts (north_star: the only collective)
+    total_edges_per_step = float(parallel.all_gather_scalars([float(E)], dist, dev)[:, 0].sum())
     ms_per_step = 1000.0 * elapsed / args.steps
     value = total_edges_per_step * args.steps / elapsed
 

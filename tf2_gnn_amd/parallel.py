@@ -1,0 +1,136 @@
+"""Multi-GPU support for the hot path: one process per GPU, graph batches sharded by graph.
+
+A tf2-gnn batch is a disjoint union of graphs with per-graph node-id offsets and no cross-graph
+edges (tf2_gnn/data/graph_dataset.py:202-222), so the message-passing path shards by graph with NO
+data-path collective: every rank runs the full layer stack on its own graphs.  The only collectives
+are control-plane ones (barrier, MAX of the step time, all-gather of per-rank metric terms), issued
+through ``torch.distributed`` - backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU (tests).
+
+The reference itself has no distributed code; this module is new.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, world_size, dist-or-None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        return rank, 1, None
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, **kwargs)
+    return rank, world, dist
+
+
+def partition_graphs(cost_per_graph: Sequence[int], world_size: int) -> List[List[int]]:
+    """Longest-processing-time assignment of graphs to ranks by cost (edge count): graphs sorted by
+    decreasing cost (ties by index), each given to the currently lightest rank (ties by rank).
+    Deterministic; every rank computes the same partition.  Graph order inside a rank is ascending,
+    so concatenating rank outputs by ``graph ids`` restores the batch order."""
+    order = sorted(range(len(cost_per_graph)), key=lambda g: (-int(cost_per_graph[g]), g))
+    loads = [0] * world_size
+    parts: List[List[int]] = [[] for _ in range(world_size)]
+    for g in order:
+        r = min(range(world_size), key=lambda i: (loads[i], i))
+        parts[r].append(g)
+        loads[r] += int(cost_per_graph[g])
+    return [sorted(p) for p in parts]
+
+
+def shard_batch(
+    node_features: np.ndarray,
+    adjacency_lists: Sequence[np.ndarray],
+    node_to_graph_map: np.ndarray,
+    num_graphs: int,
+    world_size: int,
+    rank: int,
+) -> Tuple[np.ndarray, List[np.ndarray], np.ndarray, int, np.ndarray, np.ndarray]:
+    """Host-side (numpy) sharding of one batch by graph.
+
+    Returns (local node_features, local adjacency_lists with re-based node ids, local
+    node_to_graph_map (0..G_local-1), G_local, global ids of the local graphs, global ids of the
+    local nodes).  The node_to_graph_map must be sorted (graph_dataset.py:211-217)."""
+    n2g = np.asarray(node_to_graph_map)
+    V = n2g.shape[0]
+    assert np.all(n2g[1:] >= n2g[:-1]), "node_to_graph_map must be sorted"
+    starts = np.searchsorted(n2g, np.arange(num_graphs), side="left")
+    ends = np.searchsorted(n2g, np.arange(num_graphs), side="right")
+    edges_per_graph = np.zeros(num_graphs, dtype=np.int64)
+    for adj in adjacency_lists:
+        if adj.shape[0]:
+            np.add.at(edges_per_graph, n2g[adj[:, 1]], 1)
+    # cost = edges (gather traffic) + nodes (dense work): both scale the per-rank step time
+    cost = edges_per_graph + (ends - starts)
+    mine = partition_graphs(cost.tolist(), world_size)[rank]
+    mine_arr = np.asarray(mine, dtype=np.int64)
+    node_ids = (
+        np.concatenate([np.arange(starts[g], ends[g]) for g in mine]) if mine else np.zeros(0, dtype=np.int64)
+    )
+    new_id = np.full(V, -1, dtype=np.int64)
+    new_id[node_ids] = np.arange(node_ids.shape[0])
+    local_adj = []
+    for adj in adjacency_lists:
+        if adj.shape[0]:
+            keep = new_id[adj[:, 1]] >= 0  # edges never cross graphs: the target decides
+            a = adj[keep]
+            src = new_id[a[:, 0]]
+            assert np.all(src >= 0), "edge crosses graph boundaries"
+            local_adj.append(np.stack([src, new_id[a[:, 1]]], axis=1).astype(np.int32))
+        else:
+            local_adj.append(np.zeros((0, 2), dtype=np.int32))
+    local_graph_of = np.full(num_graphs, -1, dtype=np.int64)
+    local_graph_of[mine_arr] = np.arange(len(mine))
+    local_n2g = local_graph_of[n2g[node_ids]].astype(np.int32)
+    return (
+        np.ascontiguousarray(node_features[node_ids]),
+        local_adj,
+        local_n2g,
+        len(mine),
+        mine_arr,
+        node_ids,
+    )
+
+
+def barrier(dist) -> None:
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def reduce_max(value: float, dist, device=None) -> float:
+    """MAX over ranks of a host scalar (step time)."""
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_scalars(values: Sequence[float], dist, device=None) -> np.ndarray:
+    """all-gather of a few per-rank scalars (edge counts, loss sums, ...) -> [world, len(values)].
+    This is the 'final metric reduction' of the north star: the only data any rank sends."""
+    mine = torch.tensor(list(values), dtype=torch.float64, device=device or "cpu")
+    if dist is None:
+        return mine.cpu().numpy()[None, :]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.stack(out).cpu().numpy()
