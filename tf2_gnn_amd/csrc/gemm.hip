@@ -21,6 +21,7 @@
 // Split-K (blockIdx.z) with a deterministic second-pass reduction covers the weight-gradient
 // shapes (small M x N, K = number of nodes).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -45,6 +46,8 @@ struct GemmArgs {
   int splits;
   float* partial;  // [splits][M][N] when splits > 1
   unsigned n_tiles;
+  int wide_store;  // C rows are 16-byte aligned and N % 4 == 0: float4 epilogue
+  int debug;  // probe knobs (TFGNN_GEMM_DEBUG): 1 = no staging after the first tile, 2 = no fragment reads
 };
 
 // ---- staging of one operand tile -------------------------------------------------------------
@@ -145,8 +148,11 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   using SA = Stage<BM, !TA, VEC, NT>;  // A stored [M,K] -> K contiguous unless transposed
   using SB = Stage<BN, TB, VEC, NT>;   // B stored [K,N] -> N contiguous unless transposed
   // two LDS stages: tile t+1 is written while tile t is being multiplied -> one barrier per K tile
-  __shared__ __attribute__((aligned(16))) float lds_a[2][SA::LDS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float lds_b[2][SB::LDS_FLOATS];
+  constexpr int PATCH_FLOATS = (NT / 64) * 32 * 36;  // epilogue staging, one 32 x 36 patch per wave
+  constexpr int STAGE_FLOATS = 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+  __shared__ __attribute__((aligned(16))) float lds_raw[STAGE_FLOATS > PATCH_FLOATS ? STAGE_FLOATS : PATCH_FLOATS];
+  float(*lds_a)[SA::LDS_FLOATS] = reinterpret_cast<float(*)[SA::LDS_FLOATS]>(lds_raw);
+  float(*lds_b)[SB::LDS_FLOATS] = reinterpret_cast<float(*)[SB::LDS_FLOATS]>(lds_raw + 2 * SA::LDS_FLOATS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -166,6 +172,11 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int li = lane & 31, lk = lane >> 5;
+  long long probe_c0 = 0, probe_w0 = 0;
+  if (g.debug & 4) {
+    probe_c0 = clock64();
+    probe_w0 = wall_clock64();
+  }
 
   if (k_begin < k_end) {
     SA sa;
@@ -179,7 +190,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
     __syncthreads();
     int stage = 0;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK, stage ^= 1) {
-      const bool more = k0 + BK < k_end;
+      const bool more = k0 + BK < k_end && !(g.debug & 1);
       if (more) {
         sa.load(k_end - k0 - BK, g.lda);
         sb.load(k_end - k0 - BK, g.ldb);
@@ -195,7 +206,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2) {
+        if (kk + 1 < BK / 2 && !(g.debug & 2)) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[nxt][i] = SA::frag(la, (wm * TM + i) * 32 + li, 2 * (kk + 1) + lk);
 #pragma unroll
@@ -216,32 +227,83 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
     }
   }
 
+  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0) {
+    // probe: per workgroup {shader clocks of the main loop, wall start, wall end of loop} (100 MHz wall clock)
+    long long* pr = reinterpret_cast<long long*>(g.partial) + 4 * blockIdx.x;
+    pr[0] = clock64() - probe_c0;
+    pr[1] = probe_w0;
+    pr[2] = wall_clock64();
+  }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
+  if (VEC && g.wide_store) {
+    // Wide epilogue: every 32x32 accumulator tile goes through a wave-private LDS patch so that each
+    // lane stores 16 contiguous bytes (4x fewer store instructions than the per-register layout).
+    constexpr int PS = 36;  // patch row stride (floats): 16-byte aligned rows, conflict-free writes
+    __syncthreads();        // the staging buffers are free now
+    float* patch = lds_raw + wave * 32 * PS;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + (wn * TN + j) * 32 + li;
-      if (col < g.N) {
-        const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row < g.M) {
-            float v = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PS + li] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pr = (lane >> 3) + 8 * q;
+          const int64_t row = m0 + (wm * TM + i) * 32 + pr;
+          float4 v = *reinterpret_cast<const float4*>(patch + pr * PS + (lane & 7) * 4);
+          if (row < g.M && col < g.N) {  // N % 4 == 0 in this mode: the vector is fully in or out
+            float* dst = outp + row * ldo + col;
             if (!split) {
-              v = act_apply(g.act, v + bv);
-              if (g.accumulate) v += outp[row * ldo + col];
+              if (g.bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(g.bias + col);
+                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              }
+              v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y);
+              v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+              if (g.accumulate) {
+                const float4 c4 = *reinterpret_cast<const float4*>(dst);
+                v.x += c4.x; v.y += c4.y; v.z += c4.z; v.w += c4.w;
+              }
             }
-            outp[row * ldo + col] = v;
+            *reinterpret_cast<float4*>(dst) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + (wn * TN + j) * 32 + li;
+        if (col < g.N) {
+          const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < g.M) {
+              float v = acc[i][j][r];
+              if (!split) {
+                v = act_apply(g.act, v + bv);
+                if (g.accumulate) v += outp[row * ldo + col];
+              }
+              outp[row * ldo + col] = v;
+            }
           }
         }
       }
     }
   }
+  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0)
+    reinterpret_cast<long long*>(g.partial)[4 * blockIdx.x + 3] = wall_clock64();
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g) {
@@ -347,6 +409,17 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
   g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.k_chunk = p.k_chunk; g.splits = p.splits; g.partial = (float*)d_workspace;
+  {
+    static const int dbg = [] { const char* e = getenv("TFGNN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    g.debug = dbg;
+  }
+  {
+    const bool split = p.splits > 1;
+    const float* cbase = split ? (const float*)d_workspace : d_C;
+    const int64_t ldo = split ? N : ldc;
+    g.wide_store = vec && (N % 4 == 0) && (ldo % 4 == 0) && ((uintptr_t)cbase % 16 == 0) &&
+                   (d_bias == nullptr || (uintptr_t)d_bias % 16 == 0);
+  }
   g.n_tiles = (unsigned)ceil_div(N, p.bn);
   const int64_t tiles = ceil_div(M, p.bm) * (int64_t)g.n_tiles;
   TFGNN_REQUIRE(tiles < ((int64_t)1 << 31), "GEMM grid too large");
