@@ -165,6 +165,18 @@ int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t*
                               int reduce_op, int pre_act, int post_act, void* d_workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Per-edge pieces of GNN_Edge_MLP with target states AND hidden layers (gnn_edge_mlp.py:92-100): the
+ * first Dense is separable, [x_u|x_v] W = x_u W_s + x_v W_t, computed per node; per edge only
+ *   out[e,:] = act( P[index_a[e],:] + Q[index_b[e],:] )
+ * remains.  tfgnn_graph_original_order gives, in the order of the concatenated adjacency lists
+ * (type-contiguous, so later Dense layers are GEMMs over [E_l, H] blocks): source*L+type, target*L+type,
+ * target node, and (optional) a per-edge weight array re-ordered from by-dst order. */
+int tfgnn_edge_pair_combine(const int32_t* d_index_a, const int32_t* d_index_b, const float* d_P,
+                            const float* d_Q, int64_t num_edges, int width, int act, float* d_out,
+                            void* stream);
+int tfgnn_graph_original_order(const tfgnn_graph* graph, const float* d_weight_by_dst, int32_t* d_src_l,
+                               int32_t* d_tgt_l, int32_t* d_tgt_node, float* d_weight, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense layer: C[M,N] = act( op(A)[M,K] @ op(B)[K,N] + bias[N] ) (+ C if accumulate)
  * fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32).

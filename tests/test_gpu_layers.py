@@ -58,6 +58,9 @@ CASES = [
     ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),
     ("edge_mlp_ppi", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 0, "message_activation_function": "gelu"}),
     ("edge_mlp_src_only", "GNN_Edge_MLP", {"use_target_state_as_input": False}),
+    ("edge_mlp_default", "GNN_Edge_MLP", {}),  # target states + 1 hidden layer: per-edge MLP (path C)
+    ("edge_mlp_2hidden_norm_mean", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 2, "normalize_by_num_incoming": True,
+                                                    "aggregation_function": "mean", "message_activation_function": "tanh"}),
     ("rgin", "RGIN", {}),
     ("rgin_norm_aggr_mlp", "RGIN", {"normalize_by_num_incoming": True, "num_aggr_MLP_hidden_layers": 1}),
     ("ggnn", "GGNN", {}),
@@ -145,6 +148,9 @@ BWD_CASES = [
     ("rgcn_gelu_nonorm", "RGCN", {"message_activation_function": "gelu", "normalize_by_num_incoming": False}),
     ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),
     ("edge_mlp_src_only", "GNN_Edge_MLP", {"use_target_state_as_input": False}),
+    ("edge_mlp_default", "GNN_Edge_MLP", {}),
+    ("edge_mlp_2hidden_norm_mean", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 2, "normalize_by_num_incoming": True,
+                                                    "aggregation_function": "mean", "message_activation_function": "tanh"}),
     ("rgin", "RGIN", {}),
     ("rgin_aggr_mlp", "RGIN", {"normalize_by_num_incoming": True, "num_aggr_MLP_hidden_layers": 1}),
     ("ggnn", "GGNN", {}),

@@ -1,0 +1,93 @@
+// Per-edge kernels for the one configuration whose edge MLP cannot be moved to the node side:
+// GNN_Edge_MLP with use_target_state_as_input=True AND hidden layers (gnn_edge_mlp.py:92-100, the
+// class defaults): relu sits between the first and second Dense, per edge.  The first Dense is still
+// separable, [x_u | x_v] W = x_u W_s + x_v W_t, so both products are computed per NODE (two MFMA
+// GEMMs) and an edge only adds two rows:
+//     z0[e] = act( P[(src_e, l_e)] + Q[(tgt_e, l_e)] )        tfgnn_edge_pair_combine
+// Edges are processed in the order of the concatenated adjacency lists (type-contiguous), so the
+// remaining Dense layers are plain GEMMs over contiguous [E_l, H] blocks.
+#include <algorithm>
+
+#include "common.hpp"
+#include "graph.hpp"
+
+namespace tfgnn {
+
+// out[e, :] = act(P[ia[e], :] + Q[ib[e], :]);  16 lanes x float4 per edge row when width % 4 == 0
+__global__ void __launch_bounds__(256)
+edge_pair_combine_kernel(const int32_t* __restrict__ ia, const int32_t* __restrict__ ib, const float* __restrict__ P,
+                         const float* __restrict__ Q, int64_t E, int width, int act, float* __restrict__ out) {
+  const int vec = (width & 3) == 0;
+  if (vec) {
+    const int chunks = width >> 2;
+    const int64_t total = E * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e = i / chunks;
+      const int c = (int)(i - e * chunks) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(P + (int64_t)ia[e] * width + c);
+      const float4 b = *reinterpret_cast<const float4*>(Q + (int64_t)ib[e] * width + c);
+      float4 o;
+      o.x = act_apply(act, a.x + b.x);
+      o.y = act_apply(act, a.y + b.y);
+      o.z = act_apply(act, a.z + b.z);
+      o.w = act_apply(act, a.w + b.w);
+      *reinterpret_cast<float4*>(out + e * width + c) = o;
+    }
+  } else {
+    const int64_t total = E * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e = i / width;
+      const int c = (int)(i - e * width);
+      out[i] = act_apply(act, P[(int64_t)ia[e] * width + c] + Q[(int64_t)ib[e] * width + c]);
+    }
+  }
+}
+
+// index arrays in the order of the concatenated adjacency lists, derived from the by-dst bucketing
+__global__ void __launch_bounds__(256)
+original_order_kernel(const int32_t* __restrict__ eid_d, const int32_t* __restrict__ coll_d,
+                      const int32_t* __restrict__ tgt_d, const float* __restrict__ w_by_dst, int64_t E, int L,
+                      int32_t* __restrict__ src_l, int32_t* __restrict__ tgt_l, int32_t* __restrict__ tgt_node,
+                      float* __restrict__ w) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t g = eid_d[p];
+    const int32_t cl = coll_d[p];
+    const int32_t t = tgt_d[p];
+    src_l[g] = cl;
+    tgt_l[g] = t * L + cl % L;
+    tgt_node[g] = t;
+    if (w) w[g] = w_by_dst ? w_by_dst[p] : 1.f;
+  }
+}
+
+}  // namespace tfgnn
+
+extern "C" int tfgnn_edge_pair_combine(const int32_t* d_index_a, const int32_t* d_index_b, const float* d_P,
+                                       const float* d_Q, int64_t num_edges, int width, int act, float* d_out,
+                                       void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && width >= 0, "negative size");
+  if (num_edges == 0 || width == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_index_a && d_index_b && d_P && d_Q && d_out, "NULL pointer");
+  TFGNN_REQUIRE((width & 3) != 0 || (((uintptr_t)d_P | (uintptr_t)d_Q | (uintptr_t)d_out) & 15) == 0,
+                "operands must be 16-byte aligned when width is a multiple of 4");
+  const int64_t work = num_edges * ((width & 3) == 0 ? width / 4 : width);
+  unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256), 65536));
+  hipLaunchKernelGGL(edge_pair_combine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_index_a, d_index_b,
+                     d_P, d_Q, num_edges, width, act, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_graph_original_order(const tfgnn_graph* g, const float* d_weight_by_dst, int32_t* d_src_l,
+                                          int32_t* d_tgt_l, int32_t* d_tgt_node, float* d_weight, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  if (g->E == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_src_l && d_tgt_l && d_tgt_node, "NULL output");
+  unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(g->E, 256), 8192);
+  hipLaunchKernelGGL(original_order_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->eid_d, g->coll_d,
+                     g->tgt_d, d_weight_by_dst, g->E, g->L, d_src_l, d_tgt_l, d_tgt_node, d_weight);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

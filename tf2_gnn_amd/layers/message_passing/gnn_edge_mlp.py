@@ -243,11 +243,139 @@ class GNN_Edge_MLP(MessagePassing):
             return ops.activation_forward("gelu", out), ctx
         return out, ctx
 
+    def _original_order(self, g, ew_d):
+        """index arrays in concatenated-adjacency-list order (type-contiguous), cached on the Graph."""
+        from ... import _lib
+
+        key = ("orig", None if ew_d is None else ew_d.data_ptr())
+        cached = g._cache.get(key)
+        if cached is None:
+            E, dev = g.num_edges, g.device
+            src_l = torch.empty(E, dtype=torch.int32, device=dev)
+            tgt_l = torch.empty(E, dtype=torch.int32, device=dev)
+            tgt_node = torch.empty(E, dtype=torch.int32, device=dev)
+            w = torch.empty(E, dtype=torch.float32, device=dev) if ew_d is not None else None
+            _lib.check(
+                _lib.load().tfgnn_graph_original_order(
+                    g._h, ops._ptr(ew_d), ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(tgt_node), ops._ptr(w), ops._stream()
+                )
+            )
+            # edges of type l occupy [off[l], off[l+1]) in this order: row lengths of the by-dst buckets
+            rowptr = g.array(ops.G_ROWPTR_BY_DST)
+            counts = (rowptr[1:] - rowptr[:-1]).view(g.num_nodes, g.num_edge_types).sum(dim=0).tolist()
+            off = [0]
+            for c in counts:
+                off.append(off[-1] + int(c))
+            cached = (src_l, tgt_l, tgt_node, w, off, torch.arange(E + 1, dtype=torch.int32, device=dev))
+            g._cache[key] = cached
+        return cached
+
     def _forward_C(self, X, g, fuse_act):
-        raise NotImplementedError(
-            "GNN_Edge_MLP with use_target_state_as_input=True and hidden edge-MLP layers (per-edge MLP) "
-            "is not implemented yet"
+        """per-edge MLP (target states + hidden layers); see csrc/edge.hip."""
+        from ... import _lib
+
+        V, D = X.shape
+        L, H, E = g.num_edge_types, self._hidden_dim, g.num_edges
+        mlps = self._edge_type_mlps
+        _, ew_d, _, node_scale = self._scales(g)
+        src_l, tgt_l, tgt_node, _, off, _ = self._original_order(g, ew_d)
+        Wh = ops.permute_021(mlps.kernels[0])  # [2D, L, H0]
+        H0 = mlps.kernels[0].shape[2]
+        P = ops.gemm(X, Wh[:D].view(D, L * H0))  # x_u W_s for every (node, type)
+        Q = ops.gemm(X, Wh[D:].view(D, L * H0))  # x_v W_t
+        Z = torch.empty((E, H0), dtype=torch.float32, device=X.device)
+        _lib.check(
+            _lib.load().tfgnn_edge_pair_combine(
+                ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(P), ops._ptr(Q), E, H0, ops.act_id("relu"), ops._ptr(Z),
+                ops._stream(),
+            )
         )
+        acts = [Z]
+        cur = Z
+        for j in range(1, mlps.num_layers):
+            W = mlps.kernels[j]
+            last = j == mlps.num_layers - 1
+            nxt = torch.empty((E, W.shape[2]), dtype=torch.float32, device=X.device)
+            for l in range(L):
+                if off[l + 1] > off[l]:
+                    ops.gemm(cur[off[l] : off[l + 1]], W[l], act=None if last else "relu", out=nxt[off[l] : off[l + 1]])
+            acts.append(nxt)
+            cur = nxt
+        is_max = self._aggregation_name == "max"
+        pre = self._activation_name if self._pre_activation() else None
+        gelu_split = fuse_act == "gelu"
+        ctx = {"path": "C", "fused_act": fuse_act, "edge_acts": acts, "P_shape": (V, L * H0)}
+        if E == 0:
+            out = torch.zeros((V, H), dtype=torch.float32, device=X.device)
+            if is_max:
+                out.fill_(torch.finfo(torch.float32).min)
+            if fuse_act is not None and not gelu_split:
+                out = ops.activation_forward(fuse_act, out)
+        else:
+            out = ops.graph_gather(
+                g, ops.VIEW_BY_DST_NODE, cur, col=g.array(ops.G_EID_BY_DST), edge_weight=ew_d, row_scale=node_scale,
+                reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM, pre_act=pre,
+                post_act=None if gelu_split else fuse_act,
+            )
+        if gelu_split:
+            ctx["pre"] = out
+            return ops.activation_forward("gelu", out), ctx
+        return out, ctx
+
+    def _backward_C(self, d_agg, ctx):
+        g, X = ctx["graph"], ctx["X"]
+        V, D = X.shape
+        L, E = g.num_edge_types, g.num_edges
+        mlps = self._edge_type_mlps
+        if self._aggregation_name == "max" or self._pre_activation():
+            raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
+        if E == 0:
+            mlps.grads = [torch.zeros_like(W) for W in mlps.kernels]
+            mlps.publish_grads()
+            return torch.zeros_like(X)
+        _, ew_d, _, node_scale = self._scales(g)
+        # per-edge weight of the aggregation in by-dst order, including the mean / sqrt_n factor
+        if node_scale is not None:
+            tgt_d = g.array(ops.G_TARGET_BY_DST)
+            ident = g._cache.get("ident_e")
+            if ident is None:
+                ident = torch.arange(E + 1, dtype=torch.int32, device=X.device)
+                g._cache["ident_e"] = ident
+            m_e = ops.gather_reduce(ident, tgt_d, node_scale.view(-1, 1)).view(-1)
+            w_full = m_e if ew_d is None else ops.mul(m_e, ew_d)
+        else:
+            w_full = ew_d
+        src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, w_full)
+        acts = ctx["edge_acts"]
+        # d messages, in edge-list order: dM[e] = w_e * d_agg[target_e]
+        dcur = ops.gather_reduce(ident, tgt_node, d_agg, edge_weight=w_orig)
+        grads = [None] * mlps.num_layers
+        for j in range(mlps.num_layers - 1, 0, -1):
+            W = mlps.kernels[j]
+            inp = acts[j - 1]
+            gW = torch.zeros_like(W)
+            dprev = torch.empty_like(inp)
+            for l in range(L):
+                if off[l + 1] > off[l]:
+                    sl = slice(off[l], off[l + 1])
+                    ops.gemm(inp[sl], dcur[sl], trans_a=True, out=gW[l])
+                    ops.gemm(dcur[sl], W[l], trans_b=True, out=dprev[sl])
+            grads[j] = gW
+            dcur = ops.activation_backward("relu", dprev, inp)  # hidden layers are relu (dpu_utils MLP)
+        # first layer: z0[e] = relu(P[(src,l)] + Q[(tgt,l)]); dcur is d(P+Q) per edge
+        H0 = mlps.kernels[0].shape[2]
+        dP = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dcur, col=g.array(ops.G_EID_BY_SRC)).view(V, L * H0)
+        dQ = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, dcur, col=g.array(ops.G_EID_BY_DST)).view(V, L * H0)
+        Wh = ops.permute_021(mlps.kernels[0])  # [2D, L, H0]
+        dWh = torch.empty_like(Wh)
+        ops.gemm(X, dP, trans_a=True, out=dWh[:D].view(D, L * H0))
+        ops.gemm(X, dQ, trans_a=True, out=dWh[D:].view(D, L * H0))
+        dX = ops.gemm(dP, Wh[:D].view(D, L * H0), trans_b=True)
+        ops.gemm(dQ, Wh[D:].view(D, L * H0), trans_b=True, out=dX, accumulate=True)
+        grads[0] = ops.permute_021(dWh)
+        mlps.grads = grads
+        mlps.publish_grads()
+        return dX
 
     # ---- backward ---------------------------------------------------------------------------
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
@@ -267,6 +395,8 @@ class GNN_Edge_MLP(MessagePassing):
 
     def _backward_messages(self, d_agg, ctx):
         """d(aggregated messages) [V, H] -> dX [V, D]; fills the edge-MLP kernel gradients."""
+        if ctx["path"] == "C":
+            return self._backward_C(d_agg, ctx)
         g = ctx["graph"]
         X = ctx["X"]
         V, D = X.shape

@@ -1,0 +1,43 @@
+"""Turn the rocprofv3 --pmc CSVs of tools/pmc_probe.py into profiles/<tag>_pmc_traffic.json.
+
+usage: python tools/parse_pmc.py <fetch_dir> <write_dir> <out.json>
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  On gfx950 FETCH_SIZE counts 128-byte
+requests as 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section): the streaming
+calibration kernel in the probe (known 153.6 MB read / written) gives the correction factors that
+are applied to the other kernels (and are stored in the JSON)."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    per_kernel = defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter:
+                per_kernel[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in per_kernel.items()}
+
+
+def pick(d, needle):
+    for k, v in d.items():
+        if needle in k:
+            return v
+    return None
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+known = 30000 * 4 * 320 * 4.0  # bytes read and bytes written by the calibration kernel
+cal_f = pick(fetch, "act_forward_kernel") * 1024.0
+cal_w = pick(write, "act_forward_kernel") * 1024.0
+kf, kw = known / cal_f, known / cal_w
+res = {"calibration": {"known_bytes_each_way": known, "fetch_raw_bytes": cal_f, "write_raw_bytes": cal_w,
+                       "fetch_factor": kf, "write_factor": kw}}
+for name, needle in (("gather", "csr_gather_reduce_kernel"), ("gemm", "gemm_mfma_kernel")):
+    f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0
+    res[name] = {"fetch_raw_bytes": f, "write_raw_bytes": w, "hbm_bytes_per_launch": f * kf + w * kw}
+json.dump(res, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(res, indent=1))
