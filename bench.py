@@ -268,11 +268,19 @@ def main():
             "algorithmic_bytes_per_launch": gather_bytes, "share_of_step": share_gather,
         }
         roof_gemm = {
-            "kernel": "gemm_mfma_kernel<1,5> ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)",
+            "kernel": "gemm_mfma_kernel<4,2,1,5> 128x320 tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)",
             "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": gemm_tflops / MFMA_FP32_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_gemm,
             "algorithmic_flops_per_launch": gemm_flops, "share_of_step": share_gemm,
         }
+        # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_probe.py, tools/parse_pmc.py;
+        # FETCH_SIZE corrected x2 as calibrated on gfx950), committed under profiles/
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_{args.workload}.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            roof_gather["traffic"] = pmc["gather"]["hbm_bytes_per_launch"]
+            roof_gemm["traffic"] = pmc["gemm"]["hbm_bytes_per_launch"]
+            roof_gather["traffic_source"] = roof_gemm["traffic_source"] = os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))
         if share_gemm >= share_gather:
             result["roofline"], result["roofline_secondary"] = roof_gemm, roof_gather
         else:
