@@ -100,11 +100,28 @@ typedef enum {
   TFGNN_G_NODEPTR_BY_SRC = 11,    /* int32 [V+1]                                               */
   TFGNN_G_INVDEG_EDGE_BY_DST = 12, /* float [E] per edge, by-dst order                          */
   TFGNN_G_SRC2DST_POS = 13,       /* int32 [E] position in by-dst order of the edge at each by-src position */
-  TFGNN_G_TARGET_BY_DST = 14      /* int32 [E] target node of each bucketed edge, by-dst order */
+  TFGNN_G_TARGET_BY_DST = 14,     /* int32 [E] target node of each bucketed edge, by-dst order */
+  /* non-empty buckets in type-major order (compact index c): the per-relation multiply only has to
+   * visit buckets that received at least one edge (45 % of the (node,type) buckets of an R-MAT batch
+   * are empty) */
+  TFGNN_G_NZ_CPOS_BY_DST = 15,    /* int32 [V*L] bucket row -> compact index or -1            */
+  TFGNN_G_NZ_ROW_BY_DST = 16,     /* int32 [nz]  compact index -> bucket row                  */
+  TFGNN_G_NZ_NODE_BY_DST = 17,    /* int32 [nz]  compact index -> node                        */
+  TFGNN_G_NZ_OFF_BY_DST = 18,     /* int32 [L+1] first compact index of each edge type        */
+  TFGNN_G_NZ_NODEPTR_BY_DST = 19, /* int32 [V+1] CSR over nodes of their non-empty buckets    */
+  TFGNN_G_NZ_COL_BY_DST = 20,     /* int32 [nz]  compact indices grouped by node              */
+  TFGNN_G_NZ_CPOS_BY_SRC = 21,
+  TFGNN_G_NZ_ROW_BY_SRC = 22,
+  TFGNN_G_NZ_NODE_BY_SRC = 23,
+  TFGNN_G_NZ_OFF_BY_SRC = 24,
+  TFGNN_G_NZ_NODEPTR_BY_SRC = 25,
+  TFGNN_G_NZ_COL_BY_SRC = 26
 } tfgnn_graph_array_id;
 
 /* Borrow a device array owned by the handle (valid until tfgnn_graph_destroy). */
 int tfgnn_graph_array(const tfgnn_graph* graph, int array_id, const void** d_ptr, int64_t* count);
+/* host copy of TFGNN_G_NZ_OFF_* ([L+1] int32; offsets[L] = number of non-empty buckets) */
+int tfgnn_graph_nonempty_offsets(const tfgnn_graph* graph, int by_src, int32_t* h_offsets);
 int tfgnn_graph_dims(const tfgnn_graph* graph, int64_t* num_nodes, int* num_edge_types,
                      int64_t* num_edges);
 
@@ -156,7 +173,11 @@ typedef enum {
   TFGNN_VIEW_BY_DST_TYPED = 0,
   TFGNN_VIEW_BY_DST_NODE = 1,
   TFGNN_VIEW_BY_SRC_TYPED = 2,
-  TFGNN_VIEW_BY_SRC_NODE = 3
+  TFGNN_VIEW_BY_SRC_NODE = 3,
+  /* the two typed views with COMPACT output: row c of the output belongs to the c-th non-empty
+   * bucket in type-major order (TFGNN_G_NZ_* arrays); empty buckets produce no row */
+  TFGNN_VIEW_BY_DST_TYPED_COMPACT = 4,
+  TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5
 } tfgnn_graph_view;
 size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* graph, int view, int width);
 int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
@@ -192,6 +213,20 @@ int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const 
                int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                const float* d_bias, int act, int accumulate, void* d_workspace,
                size_t workspace_bytes, void* stream);
+
+/* Grouped forms of the Dense layer for the per-relation multiply over NON-EMPTY buckets only (rows of
+ * the stacked operand are grouped by edge type: group g owns rows [d_group_offsets[g],
+ * d_group_offsets[g+1]), TFGNN_G_NZ_OFF_*; max_group_rows bounds the launch grid):
+ *   tfgnn_gemm_grouped_rows: C[rows g] = act( A[rows g] @ op(B + g*stride_b) )   (A [rows,K], B_g [K,N] or [N,K])
+ *   tfgnn_gemm_grouped_k:    C + g*stride_c = A[rows g]^T @ B[rows g]             (A [rows,M], B [rows,N]; the
+ *                            weight gradient of relation g; split-K with a deterministic second pass) */
+int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows,
+                            int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
+                            int64_t stride_b, float* d_C, int64_t ldc, int act, void* stream);
+size_t tfgnn_gemm_grouped_k_workspace_bytes(int num_groups, int64_t max_group_rows, int64_t M, int64_t N);
+int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows, int64_t M,
+                         int64_t N, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
+                         int64_t ldc, int64_t stride_c, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise: activations (utils/param_helpers.py:21-39) and their gradients.

@@ -214,3 +214,53 @@ def test_dropout_mask_statistics_and_scaling(dev):
     assert not torch.equal(mask, mask3)
     with pytest.raises(ValueError):
         ops.dropout_forward(x, 1.0, seed=0)
+
+
+def test_compact_bucket_arrays_and_grouped_gemm(dev):
+    """Non-empty buckets in type-major order (graph.hip) + the grouped GEMMs that run over them."""
+    from tf2_gnn_amd import ops
+
+    V, L, D, H = 300, 3, 16, 24
+    adjs = random_graph(V, 500, L, seed=13, empty_types=(1,), hub=(4, 90))
+    g = ops.Graph(to_dev(adjs, dev), V)
+    for by, (ids, view) in {"dst": ((ops.G_NZ_CPOS_BY_DST, ops.G_NZ_ROW_BY_DST, ops.G_NZ_NODE_BY_DST, ops.G_NZ_OFF_BY_DST,
+                                      ops.G_NZ_NODEPTR_BY_DST, ops.G_NZ_COL_BY_DST), ops.VIEW_BY_DST_TYPED_COMPACT),
+                            "src": ((ops.G_NZ_CPOS_BY_SRC, ops.G_NZ_ROW_BY_SRC, ops.G_NZ_NODE_BY_SRC, ops.G_NZ_OFF_BY_SRC,
+                                      ops.G_NZ_NODEPTR_BY_SRC, ops.G_NZ_COL_BY_SRC), ops.VIEW_BY_SRC_TYPED_COMPACT)}.items():
+        rowptr, col, _ = ao.bucket_edges(adjs, V, by=by)
+        lens = np.diff(rowptr).reshape(V, L)
+        nzmask = lens > 0
+        # type-major enumeration of the non-empty buckets
+        exp_rows = [v * L + l for l in range(L) for v in range(V) if nzmask[v, l]]
+        off_h = g.nonempty_offsets(by == "src")
+        assert off_h == [int(nzmask[:, :l].sum()) for l in range(L)] + [int(nzmask.sum())]
+        np.testing.assert_array_equal(g.array(ids[1]).cpu().numpy(), np.array(exp_rows, dtype=np.int32))
+        np.testing.assert_array_equal(g.array(ids[2]).cpu().numpy(), np.array(exp_rows) // L)
+        cpos = g.array(ids[0]).cpu().numpy()
+        exp_cpos = np.full(V * L, -1)
+        exp_cpos[exp_rows] = np.arange(len(exp_rows))
+        np.testing.assert_array_equal(cpos, exp_cpos)
+        np.testing.assert_array_equal(g.array(ids[3]).cpu().numpy(), np.array(off_h))
+        nptr = g.array(ids[4]).cpu().numpy()
+        np.testing.assert_array_equal(nptr, np.concatenate([[0], np.cumsum(nzmask.sum(1))]))
+        cols = g.array(ids[5]).cpu().numpy()
+        for v in (0, 4, V - 1):
+            np.testing.assert_array_equal(cols[nptr[v]:nptr[v + 1]], [exp_cpos[v * L + l] for l in range(L) if nzmask[v, l]])
+        # compact gather == rows of the dense gather
+        X = torch.randn((V, D), generator=torch.Generator().manual_seed(1)).to(dev)
+        dense = ops.graph_gather(g, view - 4 if view == 4 else 2, X)
+        comp = ops.graph_gather(g, view, X)
+        assert comp.shape == (len(exp_rows), D)
+        assert torch.equal(comp.cpu(), dense.cpu()[exp_rows])
+        # grouped GEMMs vs per-group fp64
+        W = torch.randn((L, D, H), generator=torch.Generator().manual_seed(2))
+        out = ops.gemm_grouped_rows(comp, g.array(ids[3]), off_h, W.to(dev))
+        Gc = torch.randn((len(exp_rows), H), generator=torch.Generator().manual_seed(3))
+        outT = ops.gemm_grouped_rows(Gc.to(dev), g.array(ids[3]), off_h, W.to(dev), trans_b=True)
+        dW = ops.gemm_grouped_k(comp, Gc.to(dev), g.array(ids[3]), off_h, L)
+        for l in range(L):
+            sl = slice(off_h[l], off_h[l + 1])
+            assert_close(out[sl].cpu(), (comp[sl].cpu().double() @ W[l].double()).float(), tol=5e-6, what="grouped rows")
+            assert_close(outT[sl].cpu(), (Gc[sl].double() @ W[l].double().t()).float(), tol=5e-6, what="grouped rows T")
+            assert_close(dW[l].cpu() / 10, (comp[sl].cpu().double().t() @ Gc[sl].double()).float() / 10, tol=5e-6, what="grouped k")
+    g.close()

@@ -46,6 +46,13 @@ struct GemmArgs {
   int splits;
   float* partial;  // [splits][M][N] when splits > 1
   unsigned n_tiles;
+  // grouped variants (blockIdx.y = group g, rows [group_off[g], group_off[g+1]) of the stacked operand):
+  //   1: M-grouped  C[rows g] = act(A[rows g] @ op(B + g*strideB))          (per-relation multiply over the
+  //                                                                          non-empty buckets of one edge type)
+  //   2: K-grouped  C + g*strideC = A[rows g]^T @ B[rows g]  (trans_a = 1)   (its weight gradient)
+  int group_mode;
+  const int32_t* group_off;
+  int64_t strideB, strideC;
   int wide_store;  // C rows are 16-byte aligned and N % 4 == 0: float4 epilogue
   int debug;  // probe knobs (TFGNN_GEMM_DEBUG): 1 = no staging after the first tile, 2 = no fragment reads
 };
@@ -160,8 +167,29 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   const int wm = wave / WN_, wn = wave % WN_;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * BM;
   const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
-  const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
-  const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+  int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+  int64_t Mloc = g.M;
+  const float* Ap = g.A;
+  const float* Bp = g.B;
+  float* Cp = g.C;
+  int64_t partial_slab = blockIdx.z;
+  if (g.group_mode == 1) {
+    const int64_t gb = g.group_off[blockIdx.y], ge = g.group_off[blockIdx.y + 1];
+    Mloc = ge - gb;
+    if (m0 >= Mloc) return;  // uniform for the whole workgroup
+    Ap += gb * g.lda;
+    Cp += gb * g.ldc;
+    Bp += (int64_t)blockIdx.y * g.strideB;
+  } else if (g.group_mode == 2) {
+    const int64_t gb = g.group_off[blockIdx.y], ge = g.group_off[blockIdx.y + 1];
+    const int64_t per = (ge - gb + g.splits - 1) / g.splits;
+    const int64_t chunk = (per + BK - 1) / BK * BK;
+    k_begin = gb + (int64_t)blockIdx.z * chunk;
+    k_end = k_begin + chunk < ge ? k_begin + chunk : ge;
+    Cp += (int64_t)blockIdx.y * g.strideC;
+    partial_slab = (int64_t)blockIdx.y * g.splits + blockIdx.z;
+  }
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -181,8 +209,8 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   if (k_begin < k_end) {
     SA sa;
     SB sb;
-    sa.init(g.A, g.lda, m0, g.M, k_begin, tid);
-    sb.init(g.B, g.ldb, n0, g.N, k_begin, tid);
+    sa.init(Ap, g.lda, m0, Mloc, k_begin, tid);
+    sb.init(Bp, g.ldb, n0, g.N, k_begin, tid);
     sa.load(k_end - k_begin, g.lda);
     sb.load(k_end - k_begin, g.ldb);
     sa.store(lds_a[0], tid);
@@ -236,7 +264,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool split = g.splits > 1;
-  float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  float* outp = split ? g.partial + partial_slab * g.M * g.N : Cp;
   const int64_t ldo = split ? g.N : g.ldc;
   if (VEC && g.wide_store) {
     // Wide epilogue: every 32x32 accumulator tile goes through a wave-private LDS patch so that each
@@ -258,7 +286,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
           const int pr = (lane >> 3) + 8 * q;
           const int64_t row = m0 + (wm * TM + i) * 32 + pr;
           float4 v = *reinterpret_cast<const float4*>(patch + pr * PS + (lane & 7) * 4);
-          if (row < g.M && col < g.N) {  // N % 4 == 0 in this mode: the vector is fully in or out
+          if (row < Mloc && col < g.N) {  // N % 4 == 0 in this mode: the vector is fully in or out
             float* dst = outp + row * ldo + col;
             if (!split) {
               if (g.bias) {
@@ -289,7 +317,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < g.M) {
+            if (row < Mloc) {
               float v = acc[i][j][r];
               if (!split) {
                 v = act_apply(g.act, v + bv);
@@ -308,14 +336,16 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = g.M * g.N;
+  const float* part = g.partial + (int64_t)blockIdx.y * g.splits * total;  // blockIdx.y = group (0 if ungrouped)
+  float* C = g.C + (int64_t)blockIdx.y * g.strideC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int z = 0; z < g.splits; ++z) s += g.partial[(int64_t)z * total + i];
+    for (int z = 0; z < g.splits; ++z) s += part[(int64_t)z * total + i];
     const int64_t row = i / g.N, col = i - row * g.N;
     if (g.bias) s += g.bias[col];
     s = act_apply(g.act, s);
-    float* c = g.C + row * g.ldc + col;
+    float* c = C + row * g.ldc + col;
     if (g.accumulate) s += *c;
     *c = s;
   }
@@ -409,6 +439,7 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
   g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.k_chunk = p.k_chunk; g.splits = p.splits; g.partial = (float*)d_workspace;
+  g.group_mode = 0; g.group_off = nullptr; g.strideB = 0; g.strideC = 0;
   {
     static const int dbg = [] { const char* e = getenv("TFGNN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     g.debug = dbg;
@@ -433,6 +464,99 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     int64_t total = M * N;
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
+    TFGNN_LAUNCH_CHECK();
+  }
+  return TFGNN_OK;
+}
+
+// ---- grouped variants ---------------------------------------------------------------------------
+namespace tfgnn {
+static int grouped_splits(int num_groups, int64_t max_rows, int64_t M, int64_t N, int bm, int bn) {
+  const int64_t tiles = ceil_div(M, bm) * ceil_div(N, bn) * num_groups;
+  int64_t s = ceil_div(512, tiles > 0 ? tiles : 1);
+  const int64_t max_by_k = max_rows / (4 * BK);
+  if (s > max_by_k) s = max_by_k;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_t* d_group_offsets,
+                                       int64_t max_group_rows, int64_t N, int64_t K, const float* d_A, int64_t lda,
+                                       const float* d_B, int64_t ldb, int64_t stride_b, float* d_C, int64_t ldc,
+                                       int act, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_groups >= 0 && max_group_rows >= 0 && N >= 0 && K >= 0, "negative size");
+  if (num_groups == 0 || max_group_rows == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_group_offsets && d_A && d_B && d_C, "NULL pointer");
+  TFGNN_REQUIRE(lda >= K && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
+  TFGNN_REQUIRE(num_groups <= 65535, "too many groups");
+  const bool vec = K > 0 && operands_vectorisable(0, trans_b, 4, N, K, d_A, lda, d_B, ldb) && (stride_b % 4 == 0);
+  GemmPlan p = plan_gemm(max_group_rows, N, K, 0, vec);
+  GemmArgs g;
+  g.M = max_group_rows; g.N = N; g.K = K;
+  g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
+  g.bias = nullptr; g.act = act; g.accumulate = 0;
+  g.k_chunk = ceil_div(K > 0 ? K : 1, BK) * BK; g.splits = 1; g.partial = nullptr;
+  g.group_mode = 1; g.group_off = d_group_offsets; g.strideB = stride_b; g.strideC = 0;
+  g.wide_store = vec && (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)d_C % 16 == 0);
+  g.debug = 0;
+  g.n_tiles = (unsigned)ceil_div(N, p.bn);
+  dim3 grid((unsigned)(ceil_div(max_group_rows, p.bm) * g.n_tiles), (unsigned)num_groups, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (!vec) launch_cfg<2, 2, 1, 1, false>(g, 0, trans_b, grid, s);
+  else if (p.cfg == CFG_128x320) launch_cfg<4, 2, 1, 5, true>(g, 0, trans_b, grid, s);
+  else if (p.cfg == CFG_128x128) launch_cfg<2, 2, 2, 2, true>(g, 0, trans_b, grid, s);
+  else launch_cfg<2, 2, 1, 1, true>(g, 0, trans_b, grid, s);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" size_t tfgnn_gemm_grouped_k_workspace_bytes(int num_groups, int64_t max_group_rows, int64_t M, int64_t N) {
+  using namespace tfgnn;
+  if (num_groups <= 0 || M <= 0 || N <= 0) return 0;
+  GemmPlan p = plan_gemm(M, N, 0, 0, true);
+  GemmPlan p2 = plan_gemm(M, N, 0, 0, false);
+  const int s = std::max(grouped_splits(num_groups, max_group_rows, M, N, p.bm, p.bn),
+                         grouped_splits(num_groups, max_group_rows, M, N, p2.bm, p2.bn));
+  return s > 1 ? (size_t)s * num_groups * (size_t)M * (size_t)N * 4 : 0;
+}
+
+extern "C" int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows,
+                                    int64_t M, int64_t N, const float* d_A, int64_t lda, const float* d_B,
+                                    int64_t ldb, float* d_C, int64_t ldc, int64_t stride_c, void* d_workspace,
+                                    size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_groups >= 0 && max_group_rows >= 0 && M >= 0 && N >= 0, "negative size");
+  if (num_groups == 0 || M == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_group_offsets && d_C && (max_group_rows == 0 || (d_A && d_B)), "NULL pointer");
+  TFGNN_REQUIRE(lda >= M && ldb >= N && ldc >= N, "bad leading dimension");
+  TFGNN_REQUIRE(num_groups <= 65535, "too many groups");
+  const bool vec = operands_vectorisable(1, 0, M, N, 4, d_A, lda, d_B, ldb);
+  GemmPlan p = plan_gemm(M, N, 0, 0, vec);
+  int splits = grouped_splits(num_groups, max_group_rows, M, N, p.bm, p.bn);
+  if (splits > 1 && (!d_workspace || workspace_bytes < (size_t)splits * num_groups * M * N * 4)) splits = 1;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = max_group_rows;
+  g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
+  g.bias = nullptr; g.act = TFGNN_ACT_NONE; g.accumulate = 0;
+  g.k_chunk = 0; g.splits = splits; g.partial = (float*)d_workspace;
+  g.group_mode = 2; g.group_off = d_group_offsets; g.strideB = 0; g.strideC = stride_c;
+  g.wide_store = vec && (N % 4 == 0) && ((splits > 1) || ((ldc % 4 == 0) && (stride_c % 4 == 0) && ((uintptr_t)d_C % 16 == 0))) &&
+                 (splits == 1 || (uintptr_t)d_workspace % 16 == 0);
+  g.debug = 0;
+  g.n_tiles = (unsigned)ceil_div(N, p.bn);
+  dim3 grid((unsigned)(ceil_div(M, p.bm) * g.n_tiles), (unsigned)num_groups, (unsigned)splits);
+  hipStream_t s = (hipStream_t)stream;
+  if (!vec) launch_cfg<2, 2, 1, 1, false>(g, 1, 0, grid, s);
+  else if (p.cfg == CFG_128x320) launch_cfg<4, 2, 1, 5, true>(g, 1, 0, grid, s);
+  else if (p.cfg == CFG_128x128) launch_cfg<2, 2, 2, 2, true>(g, 1, 0, grid, s);
+  else launch_cfg<2, 2, 1, 1, true>(g, 1, 0, grid, s);
+  TFGNN_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t total = M * N;
+    dim3 rgrid((unsigned)std::min<int64_t>(ceil_div(total, 256), 1024), (unsigned)num_groups);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, s, g);
     TFGNN_LAUNCH_CHECK();
   }
   return TFGNN_OK;

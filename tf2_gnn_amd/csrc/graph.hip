@@ -321,6 +321,59 @@ __global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, 
   }
 }
 
+// ---- non-empty buckets, type-major (CompactBuckets) ---------------------------------------------
+// flags in type-major layout: i = l * V + v ; flags[R] = 0 ; node_cnt[v] = non-empty buckets of v
+__global__ void nz_flags_kernel(const int32_t* __restrict__ rowptr, int64_t V, int L, int32_t* __restrict__ flags,
+                                int32_t* __restrict__ node_cnt) {
+  const int64_t R = V * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= R; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < R) {
+      const int64_t l = i / V, v = i - l * V;
+      const int64_t r = v * L + l;
+      flags[i] = rowptr[r + 1] > rowptr[r] ? 1 : 0;
+    } else {
+      flags[i] = 0;
+    }
+    if (i <= V) {
+      int32_t c = 0;
+      if (i < V)
+        for (int l = 0; l < L; ++l) c += rowptr[i * L + l + 1] > rowptr[i * L + l] ? 1 : 0;
+      node_cnt[i] = c;
+    }
+  }
+}
+
+__global__ void nz_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ scan_t, int64_t V,
+                               int L, int32_t* __restrict__ cpos, int32_t* __restrict__ nzrow,
+                               int32_t* __restrict__ nz_node, int32_t* __restrict__ nz_off) {
+  const int64_t R = V * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t l = i / V, v = i - l * V;
+    const int64_t r = v * L + l;
+    const int32_t c = scan_t[i];
+    if (rowptr[r + 1] > rowptr[r]) {
+      cpos[r] = c;
+      nzrow[c] = (int32_t)r;
+      nz_node[c] = (int32_t)v;
+    } else {
+      cpos[r] = -1;
+    }
+    if (v == 0) nz_off[l] = c;
+    if (i == R - 1) nz_off[L] = scan_t[R];
+  }
+}
+
+__global__ void nz_cols_kernel(const int32_t* __restrict__ cpos, const int32_t* __restrict__ nodeptr_nz, int64_t V,
+                               int L, int32_t* __restrict__ col_nz) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    int32_t j = nodeptr_nz[v];
+    for (int l = 0; l < L; ++l) {
+      const int32_t c = cpos[v * L + l];
+      if (c >= 0) col_nz[j++] = c;
+    }
+  }
+}
+
 __global__ void invdeg_rows_kernel(const int32_t* __restrict__ rowptr_d, int64_t R, int L,
                                    float* __restrict__ invdeg_d, int32_t* __restrict__ nodeptr_d,
                                    const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ nodeptr_s) {
@@ -509,6 +562,15 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const size_t o_tgt_d = plan.take(E * 4);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
+  size_t o_cb[2][6];
+  for (int side = 0; side < 2; ++side) {
+    o_cb[side][0] = plan.take((R + 1) * 4);            // cpos
+    o_cb[side][1] = plan.take((R + 1) * 4);            // nzrow
+    o_cb[side][2] = plan.take((R + 1) * 4);            // nz_node
+    o_cb[side][3] = plan.take((size_t)(L + 1) * 4);    // nz_off
+    o_cb[side][4] = plan.take((V + 1) * 4);            // nodeptr_nz
+    o_cb[side][5] = plan.take((R + 1) * 4);            // col_nz
+  }
   const size_t max_items = (size_t)(E / LONG_ROW_THRESHOLD + 1), max_multi = (size_t)(E / ITEM_CHUNK + 1);
   size_t o_item[4][3], o_multi[4][3];
   for (int v = 0; v < 4; ++v) {
@@ -526,10 +588,12 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const size_t t_scan = tmp.take(scan_scratch_elems(R + 1) * 4 + 16);
   const size_t t_eid2pos = tmp.take(E * 4);
   const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
+  const size_t t_flags = tmp.take((R + 2) * 4);
 
   char* slab = nullptr;
   char* scratch = nullptr;
-  const size_t pinned_need = 256 + (size_t)(L + 1) * 16;
+  TFGNN_REQUIRE(L <= 256, "at most 256 edge types are supported (got %d)", L);
+  const size_t pinned_need = 256 + (size_t)(L + 1) * 16 + (size_t)(L + 1) * 8;
   hipError_t he = dev_alloc((void**)&slab, persistent, &g->slab_bytes, s);
   if (he == hipSuccess) {
     g->slab = slab;
@@ -565,6 +629,15 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
   g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
+  for (int side = 0; side < 2; ++side) {
+    CompactBuckets& cb = g->compact[side];
+    cb.cpos = (int32_t*)(slab + o_cb[side][0]);
+    cb.nzrow = (int32_t*)(slab + o_cb[side][1]);
+    cb.nz_node = (int32_t*)(slab + o_cb[side][2]);
+    cb.nz_off = (int32_t*)(slab + o_cb[side][3]);
+    cb.nodeptr_nz = (int32_t*)(slab + o_cb[side][4]);
+    cb.col_nz = (int32_t*)(slab + o_cb[side][5]);
+  }
 
   int32_t* cur_d = (int32_t*)(scratch + t_cur_d);
   int32_t* cur_s = (int32_t*)(scratch + t_cur_s);
@@ -658,6 +731,34 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
                        g->src2dst);
   }
+  // non-empty buckets in type-major order, for both bucketings
+  {
+    int32_t* flags = (int32_t*)(scratch + t_flags);
+    for (int side = 0; side < 2; ++side) {
+      CompactBuckets& cb = g->compact[side];
+      const int32_t* rp = side == 0 ? g->rowptr_d : g->rowptr_s;
+      if (L > 0) {
+        hipLaunchKernelGGL(nz_flags_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, rp, V, L, flags, cb.nodeptr_nz);
+        rc = exclusive_scan_i32(flags, flags, R + 1, scan_tmp, s);
+        if (rc) return fail(rc);
+        rc = exclusive_scan_i32(cb.nodeptr_nz, cb.nodeptr_nz, V + 1, scan_tmp, s);
+        if (rc) return fail(rc);
+        if (R > 0) {
+          hipLaunchKernelGGL(nz_fill_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, rp, flags, V, L, cb.cpos, cb.nzrow,
+                             cb.nz_node, cb.nz_off);
+          hipLaunchKernelGGL(nz_cols_kernel, dim3(blocks_for(V)), dim3(threads), 0, s, cb.cpos, cb.nodeptr_nz, V, L,
+                             cb.col_nz);
+        } else {
+          G_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
+        }
+      } else {
+        G_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
+        G_CHECK(hipMemsetAsync(cb.nodeptr_nz, 0, (V + 1) * 4, s));
+      }
+      G_CHECK(hipMemcpyAsync((char*)g->pinned + 256 + (size_t)(L + 1) * 16 + (size_t)side * (L + 1) * 4, cb.nz_off,
+                             (size_t)(L + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
+  }
   // gather views + long-row plans (tfgnn_graph_view order)
   g->views[0].rowptr = g->rowptr_d;  g->views[0].num_rows = R; g->views[0].col = g->col_d;
   g->views[1].rowptr = g->nodeptr_d; g->views[1].num_rows = V; g->views[1].col = g->coll_d;
@@ -703,6 +804,11 @@ extern "C" int tfgnn_graph_wait(tfgnn_graph* g) {
     g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
     g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
     g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
+  }
+  for (int side = 0; side < 2; ++side) {
+    const int32_t* h = (const int32_t*)((const char*)g->pinned + 256 + (size_t)(g->L + 1) * 16 + (size_t)side * (g->L + 1) * 4);
+    for (int l = 0; l <= g->L; ++l) g->compact[side].h_nz_off[l] = h[l];
+    g->compact[side].num_nz = h[g->L];
   }
   const bool bad_index = h_counters[2] != 0;
   dev_release(g->scratch, g->scratch_bytes);  // build-time scratch is no longer needed
@@ -820,6 +926,13 @@ extern "C" int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stre
   return TFGNN_OK;
 }
 
+extern "C" int tfgnn_graph_nonempty_offsets(const tfgnn_graph* g, int by_src, int32_t* h_offsets) {
+  TFGNN_REQUIRE(g != nullptr && h_offsets != nullptr, "NULL argument");
+  TFGNN_REQUIRE(!g->pending, "tfgnn_graph_wait has not been called");
+  for (int l = 0; l <= g->L; ++l) h_offsets[l] = g->compact[by_src ? 1 : 0].h_nz_off[l];
+  return TFGNN_OK;
+}
+
 extern "C" int tfgnn_graph_dims(const tfgnn_graph* g, int64_t* num_nodes, int* num_edge_types,
                                 int64_t* num_edges) {
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
@@ -847,6 +960,18 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     case TFGNN_G_INVDEG_EDGE_BY_DST: *d_ptr = g->invdeg_edge_d; *count = g->E; break;
     case TFGNN_G_SRC2DST_POS: *d_ptr = g->src2dst; *count = g->E; break;
     case TFGNN_G_TARGET_BY_DST: *d_ptr = g->tgt_d; *count = g->E; break;
+    case TFGNN_G_NZ_CPOS_BY_DST: case TFGNN_G_NZ_CPOS_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].cpos; *count = g->R; break;
+    case TFGNN_G_NZ_ROW_BY_DST: case TFGNN_G_NZ_ROW_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].nzrow; *count = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].num_nz; break;
+    case TFGNN_G_NZ_NODE_BY_DST: case TFGNN_G_NZ_NODE_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].nz_node; *count = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].num_nz; break;
+    case TFGNN_G_NZ_OFF_BY_DST: case TFGNN_G_NZ_OFF_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].nz_off; *count = g->L + 1; break;
+    case TFGNN_G_NZ_NODEPTR_BY_DST: case TFGNN_G_NZ_NODEPTR_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].nodeptr_nz; *count = g->V + 1; break;
+    case TFGNN_G_NZ_COL_BY_DST: case TFGNN_G_NZ_COL_BY_SRC:
+      *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].col_nz; *count = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].num_nz; break;
     default:
       tfgnn::set_error("unknown graph array id %d", array_id);
       return TFGNN_ERR_INVALID_ARGUMENT;

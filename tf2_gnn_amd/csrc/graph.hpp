@@ -23,6 +23,19 @@ struct CsrPlan {
   int32_t* multi_n = nullptr;     // [num_multi] number of items
 };
 
+// Non-empty buckets in type-major order (all non-empty (node, type 0) rows, then type 1, ...): lets the
+// dense per-relation multiply run only over buckets that received at least one edge.
+struct CompactBuckets {
+  int32_t num_nz = 0;
+  int32_t* cpos = nullptr;        // [R]   bucket row -> compact index, or -1
+  int32_t* nzrow = nullptr;       // [nz]  compact index -> bucket row (node * L + type)
+  int32_t* nz_node = nullptr;     // [nz]  compact index -> node
+  int32_t* nz_off = nullptr;      // [L+1] device: first compact index of every type
+  int32_t* nodeptr_nz = nullptr;  // [V+1] per node: range of its non-empty buckets in col_nz
+  int32_t* col_nz = nullptr;      // [nz]  compact indices grouped by node (type ascending)
+  int32_t h_nz_off[257] = {0};    // host copy (L <= 256), filled by tfgnn_graph_wait
+};
+
 struct GraphView {
   const int32_t* rowptr = nullptr;
   int64_t num_rows = 0;
@@ -41,6 +54,7 @@ struct tfgnn_graph {
   int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *tgt_d = nullptr;
   float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
   tfgnn::GraphView views[4];  // tfgnn_graph_view order
+  tfgnn::CompactBuckets compact[2];  // 0: by target, 1: by source
   // asynchronous build state (tfgnn_graph_create_async / tfgnn_graph_wait)
   size_t slab_bytes = 0;
   void* scratch = nullptr;

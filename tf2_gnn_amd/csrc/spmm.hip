@@ -100,6 +100,7 @@ struct GatherArgs {
   int ew_heads;    // K (MODE_HEADS)
   int head_width;  // floats per head (MODE_HEADS)
   int long_threshold;  // rows longer than this are left to the item kernels (0 = never)
+  const int32_t* out_row_map;  // nullable: output row of CSR row r is out_row_map[r]; < 0 = no output
   // item pass
   const int32_t* item_row;
   const int32_t* item_chunk;
@@ -190,6 +191,8 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   const int32_t beg = a.rowptr[row];
   const int32_t end = a.rowptr[row + 1];
   if (a.long_threshold > 0 && end - beg > a.long_threshold) return;  // handled by the item kernels
+  const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
+  if (orow < 0) return;  // compact output: empty buckets have no row
   const bool is_max = MODE == MODE_GENERAL && a.is_max;
 
   float acc[VPL][VEC];
@@ -203,7 +206,7 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
 
   const float rs = a.row_scale ? a.row_scale[row] : 1.f;
-  float* dst = a.out + row * a.ld_out + f0;
+  float* dst = a.out + orow * a.ld_out + f0;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     if (live[i]) {
@@ -263,7 +266,8 @@ __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
 #pragma unroll
     for (int g = 1; g < GROUPS; ++g) s = is_max ? fmaxf(s, red[g][f]) : s + red[g][f];
     if (slot < 0) {
-      a.out[row * a.ld_out + w0 + f] = act_apply(a.post_act, s * rs);
+      const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
+      a.out[orow * a.ld_out + w0 + f] = act_apply(a.post_act, s * rs);
     } else {
       a.partial[(int64_t)slot * a.width + w0 + f] = s;
     }
@@ -284,7 +288,8 @@ __global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
       s = a.is_max ? fmaxf(s, p) : s + p;
     }
     const float rs = a.row_scale ? a.row_scale[row] : 1.f;
-    a.out[row * a.ld_out + f] = act_apply(a.post_act, s * rs);
+    const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
+    a.out[orow * a.ld_out + f] = act_apply(a.post_act, s * rs);
   }
 }
 
@@ -379,7 +384,8 @@ extern "C" int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d
 }
 
 extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int view, int width) {
-  if (!g || view < 0 || view > 3 || width <= 0) return 0;
+  if (!g || view < 0 || view > 5 || width <= 0) return 0;
+  if (view >= 4) view = view == 4 ? 0 : 2;
   return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
 }
 
@@ -390,8 +396,14 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
                                          void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
-  TFGNN_REQUIRE(view >= 0 && view <= 3, "unknown graph view %d", view);
+  TFGNN_REQUIRE(view >= 0 && view <= 5, "unknown graph view %d", view);
   TFGNN_REQUIRE(width >= 0 && ew_heads >= 1, "bad sizes");
+  // views 4 / 5: the typed views 0 / 2 with compact output (one row per NON-EMPTY bucket, type-major)
+  const int32_t* out_map = nullptr;
+  if (view >= 4) {
+    out_map = g->compact[view - 4].cpos;
+    view = view == 4 ? 0 : 2;
+  }
   const GraphView& gv = g->views[view];
   if (gv.num_rows == 0 || width == 0) return TFGNN_OK;
   int rc = check_common(gv.num_rows, gv.rowptr, d_in, d_out, ld_in, ld_out, width, reduce_op);
@@ -405,6 +417,7 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   a.out = d_out; a.ld_out = ld_out; a.pre_act = pre_act; a.post_act = post_act;
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = LONG_ROW_THRESHOLD;
+  a.out_row_map = out_map;
   a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
   a.partial = (float*)d_workspace; a.item_chunk_edges = ITEM_CHUNK;
   a.multi_row = p.multi_row; a.multi_base = p.multi_base; a.multi_n = p.multi_n; a.num_multi = p.num_multi;

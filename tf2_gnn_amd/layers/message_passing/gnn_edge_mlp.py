@@ -181,7 +181,61 @@ class GNN_Edge_MLP(MessagePassing):
             return self._forward_B(X, g, fuse_act)
         return self._forward_C(X, g, fuse_act)
 
+    # Buckets (node, type) that received no edge contribute nothing: when enough of them are empty
+    # (45 % on an R-MAT batch) the dense multiply runs over the non-empty ones only.
+    SPARSE_BUCKET_THRESHOLD = 0.85
+
+    def _use_compact_buckets(self, g) -> bool:
+        if self._use_target_state_as_input or g.num_edge_types == 0 or g.num_edges == 0:
+            return False
+        nz = g.nonempty_offsets(False)[-1]
+        return nz < self.SPARSE_BUCKET_THRESHOLD * g.num_nodes * g.num_edge_types
+
+    def _forward_A_compact(self, X, g, fuse_act):
+        """path A over the non-empty buckets only (type-major compact rows):
+             A_c[c]  = scale * sum of source rows of bucket c          gather, compact output
+             Y_c     = A_c[rows of type l] @ W_l  for every l          grouped MFMA GEMM
+             out[v]  = act( sum over the non-empty buckets of v )       <= L rows per node"""
+        row_scale, _, _, _ = self._scales(g)
+        W = self._edge_type_mlps.kernels[0]  # [L, D, H]
+        off_h = g.nonempty_offsets(False)
+        Ac = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED_COMPACT, X, row_scale=row_scale)
+        Yc = ops.gemm_grouped_rows(Ac, g.array(ops.G_NZ_OFF_BY_DST), off_h, W)
+        gelu_split = fuse_act == "gelu"
+        pre = ops.gather_reduce(
+            g.array(ops.G_NZ_NODEPTR_BY_DST), g.array(ops.G_NZ_COL_BY_DST), Yc, post_act=None if gelu_split else fuse_act
+        )
+        ctx = {"path": "Ac", "fused_act": fuse_act}
+        if gelu_split:
+            ctx["pre"] = pre
+            return ops.activation_forward("gelu", pre), ctx
+        return pre, ctx
+
+    def _backward_A_compact(self, d_agg, ctx):
+        g, X = ctx["graph"], ctx["X"]
+        mlps = self._edge_type_mlps
+        W = mlps.kernels[0]  # [L, D, H]
+        L = g.num_edge_types
+        _, _, ew_s, _ = self._scales(g)
+        off_h = g.nonempty_offsets(True)
+        nz = off_h[-1]
+        off_d = g.array(ops.G_NZ_OFF_BY_SRC)
+        # G_c[c] = sum over the out-edges of bucket c = (u, l) of w_e * d_agg[target]
+        Gc = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, d_agg, edge_weight=ew_s)  # [nz, H]
+        Zc = ops.gemm_grouped_rows(Gc, off_d, off_h, W, trans_b=True)  # [nz, D] = G_c,l @ W_l^T
+        dX = ops.gather_reduce(g.array(ops.G_NZ_NODEPTR_BY_SRC), g.array(ops.G_NZ_COL_BY_SRC), Zc)
+        ident = g._cache.get(("ident_nz", nz))
+        if ident is None:
+            ident = torch.arange(nz + 1, dtype=torch.int32, device=X.device)
+            g._cache[("ident_nz", nz)] = ident
+        Xc = ops.gather_reduce(ident, g.array(ops.G_NZ_NODE_BY_SRC), X)  # source states of the compact rows
+        mlps.grads = [ops.gemm_grouped_k(Xc, Gc, off_d, off_h, L)]  # dW_l = X_c,l^T @ G_c,l
+        mlps.publish_grads()
+        return dX
+
     def _forward_A(self, X, g, fuse_act):
+        if self._use_compact_buckets(g):
+            return self._forward_A_compact(X, g, fuse_act)
         V, D = X.shape
         L, H = g.num_edge_types, self._hidden_dim
         T = self._use_target_state_as_input
@@ -397,6 +451,10 @@ class GNN_Edge_MLP(MessagePassing):
         """d(aggregated messages) [V, H] -> dX [V, D]; fills the edge-MLP kernel gradients."""
         if ctx["path"] == "C":
             return self._backward_C(d_agg, ctx)
+        if ctx["path"] == "Ac":
+            if self._aggregation_name == "max" or self._pre_activation():
+                raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
+            return self._backward_A_compact(d_agg, ctx)
         g = ctx["graph"]
         X = ctx["X"]
         V, D = X.shape

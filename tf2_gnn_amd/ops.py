@@ -85,7 +85,9 @@ class _DevArray:
 # graph array ids (include/tfgnn.h tfgnn_graph_array_id)
 (G_ROWPTR_BY_DST, G_COL_BY_DST, G_EID_BY_DST, G_COLL_BY_DST, G_ROWPTR_BY_SRC, G_COL_BY_SRC, G_EID_BY_SRC,
  G_COLL_BY_SRC, G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_NODEPTR_BY_DST, G_NODEPTR_BY_SRC,
- G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS, G_TARGET_BY_DST) = range(15)
+ G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS, G_TARGET_BY_DST, G_NZ_CPOS_BY_DST, G_NZ_ROW_BY_DST, G_NZ_NODE_BY_DST,
+ G_NZ_OFF_BY_DST, G_NZ_NODEPTR_BY_DST, G_NZ_COL_BY_DST, G_NZ_CPOS_BY_SRC, G_NZ_ROW_BY_SRC, G_NZ_NODE_BY_SRC,
+ G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC) = range(27)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
 
 
@@ -154,6 +156,18 @@ class Graph:
         self._cache[array_id] = t
         return t
 
+    def nonempty_offsets(self, by_src: bool):
+        """host list [L+1]: first compact index of each edge type among the non-empty buckets
+        (type-major); the last entry is the number of non-empty buckets."""
+        key = ("nz_off", bool(by_src))
+        off = self._cache.get(key)
+        if off is None:
+            buf = (ctypes.c_int32 * (self.num_edge_types + 1))()
+            _lib.check(_lib.load().tfgnn_graph_nonempty_offsets(self._h, int(by_src), buf))
+            off = list(buf)
+            self._cache[key] = off
+        return off
+
     def close(self):
         """Return the handle's memory to the library; work already enqueued on the current stream may
         still read it (the memory is only reused after that work)."""
@@ -216,7 +230,8 @@ def gather_reduce(
     return out
 
 
-VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE = range(4)
+(VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE, VIEW_BY_DST_TYPED_COMPACT,
+ VIEW_BY_SRC_TYPED_COMPACT) = range(6)
 
 
 def graph_gather(
@@ -236,7 +251,12 @@ def graph_gather(
     edge_weight: [E] or [E, K] (K heads of width/K floats each)."""
     lib = _lib.load()
     _require_dev(inp, torch.float32, "inp")
-    num_rows = graph.num_nodes * (graph.num_edge_types if view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED) else 1)
+    if view == VIEW_BY_DST_TYPED_COMPACT:
+        num_rows = graph.nonempty_offsets(False)[-1]
+    elif view == VIEW_BY_SRC_TYPED_COMPACT:
+        num_rows = graph.nonempty_offsets(True)[-1]
+    else:
+        num_rows = graph.num_nodes * (graph.num_edge_types if view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED) else 1)
     inp, ld_in = _rowmajor(inp, "inp")
     width = inp.shape[1]
     if out is None:
@@ -431,4 +451,46 @@ def permute_021(x: torch.Tensor) -> torch.Tensor:
     A, B, C = x.shape
     out = torch.empty((B, A, C), dtype=torch.float32, device=x.device)
     _lib.check(lib.tfgnn_permute_021(_ptr(x), A, B, C, _ptr(out), _stream()))
+    return out
+
+
+def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=False, act=ACT_NONE, out=None):
+    """out[rows g] = act(a[rows g] @ op(b_stack[g])) for row groups [off[g], off[g+1]).
+    b_stack: [G, K, N] (or [G, N, K] with trans_b)."""
+    lib = _lib.load()
+    a, lda = _rowmajor(a, "a")
+    G = b_stack.shape[0]
+    K = a.shape[1]
+    N = b_stack.shape[1] if trans_b else b_stack.shape[2]
+    b_stack = b_stack.contiguous()
+    if out is None:
+        out = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
+    out2, ldc = _rowmajor(out, "out")
+    max_rows = max((group_off_host[i + 1] - group_off_host[i] for i in range(G)), default=0)
+    _lib.check(
+        lib.tfgnn_gemm_grouped_rows(
+            int(trans_b), G, _ptr(group_off_dev), max_rows, N, K, _ptr(a), lda, _ptr(b_stack), b_stack.stride(1),
+            b_stack.stride(0), _ptr(out), ldc, act_id(act), _stream(),
+        )
+    )
+    return out
+
+
+def gemm_grouped_k(a, b, group_off_dev, group_off_host, num_groups, out=None):
+    """out[g] = a[rows g]^T @ b[rows g]  ->  [G, M, N]."""
+    lib = _lib.load()
+    a, lda = _rowmajor(a, "a")
+    b, ldb = _rowmajor(b, "b")
+    M, N = a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((num_groups, M, N), dtype=torch.float32, device=a.device)
+    max_rows = max((group_off_host[i + 1] - group_off_host[i] for i in range(num_groups)), default=0)
+    ws_bytes = lib.tfgnn_gemm_grouped_k_workspace_bytes(num_groups, max_rows, M, N)
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_gemm_grouped_k(
+            num_groups, _ptr(group_off_dev), max_rows, M, N, _ptr(a), lda, _ptr(b), ldb, _ptr(out), out.stride(1),
+            out.stride(0), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
     return out
