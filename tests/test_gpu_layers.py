@@ -56,6 +56,8 @@ CASES = [
     ("rgcn_max", "RGCN", {"aggregation_function": "max"}),
     ("rgcn_act_before", "RGCN", {"message_activation_before_aggregation": True, "message_activation_function": "elu"}),
     ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),
+    ("rgcn_compact_buckets", "RGCN", {"use_compact_buckets": True}),
+    ("ggnn_compact_buckets", "GGNN", {"use_compact_buckets": True}),
     ("edge_mlp_ppi", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 0, "message_activation_function": "gelu"}),
     ("edge_mlp_src_only", "GNN_Edge_MLP", {"use_target_state_as_input": False}),
     ("edge_mlp_default", "GNN_Edge_MLP", {}),  # target states + 1 hidden layer: per-edge MLP (path C)
@@ -144,6 +146,7 @@ def test_layers_on_empty_and_isolated_inputs(dev):
 
 BWD_CASES = [
     ("rgcn", "RGCN", {}),
+    ("rgcn_compact_buckets", "RGCN", {"use_compact_buckets": True}),
     ("rgcn_tanh_mean", "RGCN", {"message_activation_function": "tanh", "aggregation_function": "mean"}),
     ("rgcn_gelu_nonorm", "RGCN", {"message_activation_function": "gelu", "normalize_by_num_incoming": False}),
     ("rgcn_target", "RGCN", {"use_target_state_as_input": True}),

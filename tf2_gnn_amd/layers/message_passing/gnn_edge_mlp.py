@@ -97,6 +97,7 @@ class GNN_Edge_MLP(MessagePassing):
         self._use_target_state_as_input = params["use_target_state_as_input"]
         self._normalize_by_num_incoming = params["normalize_by_num_incoming"]
         self._num_edge_MLP_hidden_layers = params["num_edge_MLP_hidden_layers"]
+        self._compact_opt_in = bool(params.get("use_compact_buckets", False))  # not a reference hyper-parameter
         self._edge_type_mlps: Optional[StackedEdgeMLPs] = None
         self._in_dim = None
         self._num_edge_types = None
@@ -181,11 +182,19 @@ class GNN_Edge_MLP(MessagePassing):
             return self._forward_B(X, g, fuse_act)
         return self._forward_C(X, g, fuse_act)
 
-    # Buckets (node, type) that received no edge contribute nothing: when enough of them are empty
-    # (45 % on an R-MAT batch) the dense multiply runs over the non-empty ones only.
+    # Buckets (node, type) that received no edge contribute nothing: 45 % of them are empty on an R-MAT
+    # batch, and the dense multiply can run over the non-empty ones only (grouped GEMMs over compact
+    # rows).  Measured on MI355X (profiles/r01e_compact_kernel_stats.csv): 45 % fewer FLOPs buy only
+    # ~12 % on the forward GEMM because the per-relation groups have K = D (10 K-tiles) and the
+    # workgroup prologue / store-burst epilogue dominates; with the extra combine passes the step time
+    # is unchanged.  Kept opt-in (hyper-parameter "use_compact_buckets" or TFGNN_COMPACT_BUCKETS=1).
     SPARSE_BUCKET_THRESHOLD = 0.85
 
     def _use_compact_buckets(self, g) -> bool:
+        import os
+
+        if not (self._compact_opt_in or os.environ.get("TFGNN_COMPACT_BUCKETS") == "1"):
+            return False
         if self._use_target_state_as_input or g.num_edge_types == 0 or g.num_edges == 0:
             return False
         nz = g.nonempty_offsets(False)[-1]
