@@ -136,160 +136,106 @@ __device__ __forceinline__ int find_type(const int64_t* __restrict__ edge_off, i
   return lo;
 }
 
-__global__ void count_keys_kernel(EdgeLists el, int64_t E, int64_t V, int32_t* __restrict__ cnt_d,
-                                  int32_t* __restrict__ cnt_s, int32_t* __restrict__ err_flag) {
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E;
-       g += (int64_t)gridDim.x * blockDim.x) {
-    int l = find_type(el.edge_off, el.L, g);
+// ---- bucketing = one LSD radix sort per CSR (no global atomics, deterministic) -------------------
+// composite key of an edge: (row << sec_bits) | sec, row = node * L + type (the bucket), sec = the
+// node at the other end; payload = position of the edge in the concatenated adjacency lists.  Sorting
+// by the composite puts edges in bucket order with ascending columns inside a bucket (canonical).
+// Global memory atomics cost ~10 ns each on this chip (they execute at the memory side: the XCD L2s
+// are not coherent), which made a counting sort with 4 atomics per edge take ~1 ms per batch.
+constexpr int RS_THREADS = 256;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // 4096 keys per workgroup
+constexpr int RS_RADIX = 256;
+
+__global__ void fill_keys_kernel(EdgeLists el, int64_t E, int64_t V, int sec_bits, uint64_t* __restrict__ comp_d,
+                                 uint64_t* __restrict__ comp_s, uint32_t* __restrict__ pay,
+                                 int32_t* __restrict__ err_flag) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E; g += (int64_t)gridDim.x * blockDim.x) {
+    const int l = find_type(el.edge_off, el.L, g);
     const int32_t* a = el.adj[l] + 2 * (g - el.edge_off[l]);
-    int32_t src = a[0], dst = a[1];
+    int64_t src = a[0], dst = a[1];
     if (src < 0 || src >= V || dst < 0 || dst >= V) {
-      atomicOr(err_flag, 1);
-      continue;
+      atomicOr(err_flag, 1);  // rare path; the build is rejected in tfgnn_graph_wait
+      src = 0;
+      dst = 0;
     }
-    atomicAdd(&cnt_d[(int64_t)dst * el.L + l], 1);
-    atomicAdd(&cnt_s[(int64_t)src * el.L + l], 1);
+    comp_d[g] = ((uint64_t)(dst * el.L + l) << sec_bits) | (uint64_t)src;
+    comp_s[g] = ((uint64_t)(src * el.L + l) << sec_bits) | (uint64_t)dst;
+    pay[g] = (uint32_t)g;
   }
 }
 
-__global__ void scatter_kernel(EdgeLists el, int64_t E, int64_t V, const int32_t* __restrict__ rowptr_d,
-                               const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ cur_d,
-                               int32_t* __restrict__ cur_s, uint64_t* __restrict__ comp_d,
-                               uint64_t* __restrict__ comp_s, int32_t* __restrict__ rowid_d,
-                               int32_t* __restrict__ rowid_s) {
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E;
-       g += (int64_t)gridDim.x * blockDim.x) {
-    int l = find_type(el.edge_off, el.L, g);
-    const int32_t* a = el.adj[l] + 2 * (g - el.edge_off[l]);
-    int32_t src = a[0], dst = a[1];
-    if (src < 0 || src >= V || dst < 0 || dst >= V) continue;
-    int64_t kd = (int64_t)dst * el.L + l;
-    int64_t ks = (int64_t)src * el.L + l;
-    int32_t pd = rowptr_d[kd] + atomicAdd(&cur_d[kd], 1);
-    int32_t ps = rowptr_s[ks] + atomicAdd(&cur_s[ks], 1);
-    comp_d[pd] = ((uint64_t)(uint32_t)src << 32) | (uint32_t)g;
-    comp_s[ps] = ((uint64_t)(uint32_t)dst << 32) | (uint32_t)g;
-    rowid_d[pd] = (int32_t)kd;
-    rowid_s[ps] = (int32_t)ks;
-  }
-}
-
-// rows of length 2 are fixed in place; 3..64 -> list_a (wave sort); > 64 -> list_b (block sort)
-__global__ void classify_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R,
-                                     uint64_t* __restrict__ comp, int32_t* __restrict__ list_a,
-                                     int32_t* __restrict__ list_b, int32_t* __restrict__ counters) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R;
-       r += (int64_t)gridDim.x * blockDim.x) {
-    int32_t b = rowptr[r], e = rowptr[r + 1];
-    int32_t len = e - b;
-    if (len == 2) {
-      uint64_t x = comp[b], y = comp[b + 1];
-      if (y < x) {
-        comp[b] = y;
-        comp[b + 1] = x;
-      }
-    } else if (len > 2 && len <= 64) {
-      list_a[atomicAdd(&counters[0], 1)] = (int32_t)r;
-    } else if (len > 64) {
-      list_b[atomicAdd(&counters[1], 1)] = (int32_t)r;
-    }
-  }
-}
-
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl_xor(lo, mask, 64);
-  hi = __shfl_xor(hi, mask, 64);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-// one wave per listed row (len <= 64): normalized bitonic network over the 64 lanes
-__global__ void __launch_bounds__(256)
-sort_wave_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ list,
-                      const int32_t* __restrict__ count, uint64_t* __restrict__ comp) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int32_t n = *count;
-  for (int64_t i = wave; i < n; i += nwaves) {
-    int32_t r = list[i];
-    int32_t b = rowptr[r], len = rowptr[r + 1] - b;
-    uint64_t v = lane < len ? comp[b + lane] : ~0ull;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-      {
-        int m = k - 1;
-        uint64_t o = shfl_xor_u64(v, m);
-        const bool lower = (lane ^ m) > lane;
-        v = lower ? (o < v ? o : v) : (o > v ? o : v);
-      }
-#pragma unroll
-      for (int j = k >> 2; j > 0; j >>= 1) {
-        uint64_t o = shfl_xor_u64(v, j);
-        bool lower = (lane & j) == 0;
-        v = lower ? (o < v ? o : v) : (o > v ? o : v);
-      }
-    }
-    if (lane < len) comp[b + lane] = v;
-  }
-}
-
-constexpr int SORT_LDS_CAP = 4096;  // 32 KiB of composites
-
-// one block per listed row (len > 64): normalized bitonic network in LDS (or in place in global
-// memory for rows longer than SORT_LDS_CAP)
-__global__ void __launch_bounds__(256)
-sort_block_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ list,
-                       const int32_t* __restrict__ count, uint64_t* __restrict__ comp) {
-  __shared__ uint64_t lds[SORT_LDS_CAP];
+// hist[digit * nblocks + block] = number of keys of this workgroup's tile with that digit
+__global__ void __launch_bounds__(RS_THREADS)
+rs_hist_kernel(const uint64_t* __restrict__ comp, int64_t n, int shift, int32_t* __restrict__ hist, int nblocks) {
+  __shared__ int32_t h[RS_RADIX];
   const int tid = threadIdx.x;
-  const int32_t n_rows = *count;
-  for (int32_t li = blockIdx.x; li < n_rows; li += gridDim.x) {
-    int32_t r = list[li];
-    int32_t b = rowptr[r], n = rowptr[r + 1] - b;
-    uint64_t* g = comp + b;
-    const bool use_lds = n <= SORT_LDS_CAP;
-    uint64_t* a = use_lds ? lds : g;
-    if (use_lds) {
-      for (int i = tid; i < n; i += 256) lds[i] = g[i];
+  h[tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t idx = base + r * RS_THREADS + tid;
+    if (idx < n) atomicAdd(&h[(int)((comp[idx] >> shift) & (RS_RADIX - 1))], 1);  // LDS atomic
+  }
+  __syncthreads();
+  hist[(int64_t)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+// stable scatter: keys keep their input order inside a digit (tile order, then round, wave, lane)
+__global__ void __launch_bounds__(RS_THREADS)
+rs_scatter_kernel(const uint64_t* __restrict__ comp_in, const uint32_t* __restrict__ pay_in, int64_t n, int shift,
+                  const int32_t* __restrict__ offs, int nblocks, uint64_t* __restrict__ comp_out,
+                  uint32_t* __restrict__ pay_out) {
+  __shared__ int32_t base[RS_RADIX];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  base[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
+  __syncthreads();
+  const int64_t tile = (int64_t)blockIdx.x * RS_TILE;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t idx = tile + r * RS_THREADS + tid;
+    const bool valid = idx < n;
+    const uint64_t c = valid ? comp_in[idx] : 0;
+    const uint32_t pl = valid ? pay_in[idx] : 0;
+    const int d = (int)((c >> shift) & (RS_RADIX - 1));
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
     }
-    __syncthreads();
-    int N = 1;
-    while (N < n) N <<= 1;
-    for (int k = 2; k <= N; k <<= 1) {
-      // flip step
-      for (int idx = tid; idx < (N >> 1); idx += 256) {
-        int hb = k >> 1;
-        int blk = idx / hb, t = idx - blk * hb;
-        int i = blk * k + t, p = blk * k + (k - 1 - t);
-        if (p < n) {
-          uint64_t x = a[i], y = a[p];
-          if (y < x) {
-            a[i] = y;
-            a[p] = x;
-          }
-        }
+    const int rank = __popcll(peers & lt_mask);
+    const int cnt = __popcll(peers);
+    int mybase = 0;
+    for (int w = 0; w < RS_THREADS / 64; ++w) {  // waves take their turn: keeps the order stable
+      if (wave == w && valid && rank == 0) {
+        mybase = base[d];
+        base[d] = mybase + cnt;
       }
       __syncthreads();
-      for (int j = k >> 2; j > 0; j >>= 1) {
-        for (int idx = tid; idx < (N >> 1); idx += 256) {
-          int blk = idx / j, t = idx - blk * j;
-          int i = blk * 2 * j + t, p = i + j;
-          if (p < n) {
-            uint64_t x = a[i], y = a[p];
-            if (y < x) {
-              a[i] = y;
-              a[p] = x;
-            }
-          }
-        }
-        __syncthreads();
-      }
     }
-    if (use_lds) {
-      for (int i = tid; i < n; i += 256) g[i] = lds[i];
+    const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+    const int pos = __shfl(mybase, leader, 64) + rank;
+    if (valid) {
+      comp_out[pos] = c;
+      pay_out[pos] = pl;
     }
-    __syncthreads();
+  }
+}
+
+// rowptr[r] = first sorted position whose bucket is >= r
+__global__ void rowptr_from_sorted_kernel(const uint64_t* __restrict__ comp, int64_t E, int sec_bits, int64_t R,
+                                          int32_t* __restrict__ rowptr) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)(comp[mid] >> sec_bits) < r) lo = mid + 1; else hi = mid;
+    }
+    rowptr[r] = (int32_t)lo;
   }
 }
 
@@ -391,21 +337,22 @@ __global__ void invdeg_rows_kernel(const int32_t* __restrict__ rowptr_d, int64_t
   }
 }
 
-__global__ void unpack_kernel(const uint64_t* __restrict__ comp, const int32_t* __restrict__ rowid,
+__global__ void unpack_kernel(const uint64_t* __restrict__ comp, const uint32_t* __restrict__ pay, int sec_bits,
                               int64_t E, int L, int32_t* __restrict__ col, int32_t* __restrict__ eid,
                               int32_t* __restrict__ coll, const float* __restrict__ invdeg_d,
                               float* __restrict__ invdeg_edge, int by_src,
                               int32_t* __restrict__ eid_to_pos, int32_t* __restrict__ row_node) {
+  const uint64_t sec_mask = ((uint64_t)1 << sec_bits) - 1;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
        p += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t c = comp[p];
-    int32_t other = (int32_t)(c >> 32);
-    int32_t id = (int32_t)(c & 0xffffffffu);
-    int32_t row = rowid[p];
-    int l = row % L;
+    const uint64_t c = comp[p];
+    const int32_t other = (int32_t)(c & sec_mask);
+    const int32_t id = (int32_t)pay[p];
+    const int32_t row = (int32_t)(c >> sec_bits);
+    const int l = row % L;
     col[p] = other;
     eid[p] = id;
-    int64_t cl = (int64_t)other * L + l;
+    const int64_t cl = (int64_t)other * L + l;
     coll[p] = (int32_t)cl;
     if (row_node) row_node[p] = row / L;
     // the degree that normalises an edge is always the in-degree of its TARGET for its type
@@ -580,12 +527,14 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const size_t persistent = plan.total;
   // build-time scratch (freed with a second allocation)
   SlabPlan tmp;
-  const size_t t_cur_d = tmp.take((R + 1) * 4), t_cur_s = tmp.take((R + 1) * 4);
+  const int rs_blocks = (int)ceil_div(E > 0 ? E : 1, RS_TILE);
   const size_t t_comp_d = tmp.take(E * 8), t_comp_s = tmp.take(E * 8);
-  const size_t t_rowid_d = tmp.take(E * 4), t_rowid_s = tmp.take(E * 4);
-  const size_t t_list_a = tmp.take((E / 3 + 1) * 4), t_list_b = tmp.take((E / 65 + 1) * 4);
+  const size_t t_comp_alt_d = tmp.take(E * 8), t_comp_alt_s = tmp.take(E * 8);
+  const size_t t_pay_a = tmp.take(E * 4), t_pay_d0 = tmp.take(E * 4), t_pay_d1 = tmp.take(E * 4);
+  const size_t t_pay_s0 = tmp.take(E * 4), t_pay_s1 = tmp.take(E * 4);
+  const size_t t_hist = tmp.take((size_t)RS_RADIX * rs_blocks * 4 + 16);
   const size_t t_counters = tmp.take(64 * 4);
-  const size_t t_scan = tmp.take(scan_scratch_elems(R + 1) * 4 + 16);
+  const size_t t_scan = tmp.take((scan_scratch_elems(R + 1) + scan_scratch_elems((int64_t)RS_RADIX * rs_blocks)) * 4 + 16);
   const size_t t_eid2pos = tmp.take(E * 4);
   const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
   const size_t t_flags = tmp.take((R + 2) * 4);
@@ -639,14 +588,16 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     cb.col_nz = (int32_t*)(slab + o_cb[side][5]);
   }
 
-  int32_t* cur_d = (int32_t*)(scratch + t_cur_d);
-  int32_t* cur_s = (int32_t*)(scratch + t_cur_s);
   uint64_t* comp_d = (uint64_t*)(scratch + t_comp_d);
   uint64_t* comp_s = (uint64_t*)(scratch + t_comp_s);
-  int32_t* rowid_d = (int32_t*)(scratch + t_rowid_d);
-  int32_t* rowid_s = (int32_t*)(scratch + t_rowid_s);
-  int32_t* list_a = (int32_t*)(scratch + t_list_a);
-  int32_t* list_b = (int32_t*)(scratch + t_list_b);
+  uint64_t* comp_alt_d = (uint64_t*)(scratch + t_comp_alt_d);
+  uint64_t* comp_alt_s = (uint64_t*)(scratch + t_comp_alt_s);
+  uint32_t* pay_a = (uint32_t*)(scratch + t_pay_a);
+  uint32_t* pay_d0 = (uint32_t*)(scratch + t_pay_d0);
+  uint32_t* pay_d1 = (uint32_t*)(scratch + t_pay_d1);
+  uint32_t* pay_s0 = (uint32_t*)(scratch + t_pay_s0);
+  uint32_t* pay_s1 = (uint32_t*)(scratch + t_pay_s1);
+  int32_t* hist = (int32_t*)(scratch + t_hist);
   int32_t* counters = (int32_t*)(scratch + t_counters);
   int32_t* scan_tmp = (int32_t*)(scratch + t_scan);
   int32_t* eid2pos = (int32_t*)(scratch + t_eid2pos);
@@ -668,11 +619,6 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     }                                                                                          \
   } while (0)
 
-  // rowptr arrays double as the count arrays (shifted by one: count of row r at index r)
-  G_CHECK(hipMemsetAsync(g->rowptr_d, 0, (R + 1) * 4, s));
-  G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
-  G_CHECK(hipMemsetAsync(cur_d, 0, (R + 1) * 4, s));
-  G_CHECK(hipMemsetAsync(cur_s, 0, (R + 1) * 4, s));
   G_CHECK(hipMemsetAsync(counters, 0, 64 * 4, s));
   // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
   {
@@ -689,31 +635,52 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const int threads = 256;
   auto blocks_for = [&](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, threads), 8192)); };
 
+  // sort the edges into (bucket, column) order, once per bucketing
+  int sec_bits = 1;
+  while (((int64_t)1 << sec_bits) < V) ++sec_bits;
+  int row_bits = 1;
+  while (((int64_t)1 << row_bits) < (R > 0 ? R : 1)) ++row_bits;
+  const uint64_t* sorted_d = comp_d;
+  const uint64_t* sorted_s = comp_s;
+  const uint32_t* pay_d = pay_a;
+  const uint32_t* pay_s = pay_a;
   if (E > 0) {
-    hipLaunchKernelGGL(count_keys_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V,
-                       g->rowptr_d, g->rowptr_s, counters + 2);
-  }
-  rc = exclusive_scan_i32(g->rowptr_d, g->rowptr_d, R + 1, scan_tmp, s);
-  if (rc) return fail(rc);
-  rc = exclusive_scan_i32(g->rowptr_s, g->rowptr_s, R + 1, scan_tmp, s);
-  if (rc) return fail(rc);
-  if (E > 0) {
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V, g->rowptr_d,
-                       g->rowptr_s, cur_d, cur_s, comp_d, comp_s, rowid_d, rowid_s);
-    // canonicalise rows: by-dst
-    hipLaunchKernelGGL(classify_rows_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, g->rowptr_d, R,
-                       comp_d, list_a, list_b, counters + 0);
-    hipLaunchKernelGGL(sort_wave_rows_kernel, dim3(2048), dim3(256), 0, s, g->rowptr_d, list_a,
-                       counters + 0, comp_d);
-    hipLaunchKernelGGL(sort_block_rows_kernel, dim3(1024), dim3(256), 0, s, g->rowptr_d, list_b,
-                       counters + 1, comp_d);
-    // by-src (separate counters 4,5; the lists are reused after the by-dst sorts were enqueued)
-    hipLaunchKernelGGL(classify_rows_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, g->rowptr_s, R,
-                       comp_s, list_a, list_b, counters + 4);
-    hipLaunchKernelGGL(sort_wave_rows_kernel, dim3(2048), dim3(256), 0, s, g->rowptr_s, list_a,
-                       counters + 4, comp_s);
-    hipLaunchKernelGGL(sort_block_rows_kernel, dim3(1024), dim3(256), 0, s, g->rowptr_s, list_b,
-                       counters + 5, comp_s);
+    hipLaunchKernelGGL(fill_keys_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V, sec_bits, comp_d, comp_s,
+                       pay_a, counters + 2);
+    const int total_bits = sec_bits + row_bits;
+    for (int side = 0; side < 2; ++side) {
+      // private ping-pong buffers per side; both sorts start from the shared identity payload pay_a
+      uint64_t* cbuf[2] = {side == 0 ? comp_d : comp_s, side == 0 ? comp_alt_d : comp_alt_s};
+      uint32_t* pbuf[2] = {side == 0 ? pay_d0 : pay_s0, side == 0 ? pay_d1 : pay_s1};
+      const uint64_t* cin = cbuf[0];
+      const uint32_t* pin = pay_a;
+      int pass = 0;
+      for (int shift = 0; shift < total_bits; shift += 8, ++pass) {
+        uint64_t* cout = cbuf[(pass + 1) & 1];
+        uint32_t* pout = pbuf[pass & 1];
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(rs_blocks), dim3(RS_THREADS), 0, s, cin, E, shift, hist, rs_blocks);
+        rc = exclusive_scan_i32(hist, hist, (int64_t)RS_RADIX * rs_blocks, scan_tmp, s);
+        if (rc) return fail(rc);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(rs_blocks), dim3(RS_THREADS), 0, s, cin, pin, E, shift, hist,
+                           rs_blocks, cout, pout);
+        cin = cout;
+        pin = pout;
+      }
+      if (side == 0) {
+        sorted_d = cin;
+        pay_d = pin;
+      } else {
+        sorted_s = cin;
+        pay_s = pin;
+      }
+    }
+    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, sorted_d, E, sec_bits,
+                       R, g->rowptr_d);
+    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, sorted_s, E, sec_bits,
+                       R, g->rowptr_s);
+  } else {
+    G_CHECK(hipMemsetAsync(g->rowptr_d, 0, (R + 1) * 4, s));
+    G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
   }
   if (L > 0) {
     hipLaunchKernelGGL(invdeg_rows_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, g->rowptr_d, R, L,
@@ -723,9 +690,9 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     G_CHECK(hipMemsetAsync(g->nodeptr_s, 0, (V + 1) * 4, s));
   }
   if (E > 0) {
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_d, rowid_d, E, L,
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, sorted_d, pay_d, sec_bits, E, L,
                        g->col_d, g->eid_d, g->coll_d, g->invdeg_d, g->invdeg_edge_d, 0, eid2pos, g->tgt_d);
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, comp_s, rowid_s, E, L,
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, sorted_s, pay_s, sec_bits, E, L,
                        g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr,
                        (int32_t*)nullptr);
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
