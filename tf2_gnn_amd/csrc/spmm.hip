@@ -25,6 +25,7 @@
 //
 // blockIdx.y walks feature windows.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "graph.hpp"
@@ -96,11 +97,14 @@ struct GatherArgs {
   int64_t ld_out;
   int pre_act;
   int post_act;
+  int64_t num_src_rows;  // rows of `in` (0 = unknown): drives the L2-slicing heuristic
   int is_max;
   int ew_heads;    // K (MODE_HEADS)
   int head_width;  // floats per head (MODE_HEADS)
   int long_threshold;  // rows longer than this are left to the item kernels (0 = never)
   const int32_t* out_row_map;  // nullable: output row of CSR row r is out_row_map[r]; < 0 = no output
+  unsigned xcd_units_pad;      // != 0: 1-D XCD-aware grid over (window, unit); set by the launcher
+  unsigned total_units;
   // item pass
   const int32_t* item_row;
   const int32_t* item_chunk;
@@ -179,7 +183,7 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
 }
 
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
-__device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned row_block) {
+__device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned row_block, unsigned window) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;  // floats covered per pass
   const int tid = threadIdx.x;
@@ -187,7 +191,7 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   const int gl = tid % LPR;
   const int64_t row = (int64_t)row_block * GROUPS_PER_BLOCK + group;
   if (row >= a.num_rows) return;
-  const int f0 = blockIdx.y * WINDOW + gl * VEC;  // first float of this lane's chunk 0
+  const int f0 = window * WINDOW + gl * VEC;  // first float of this lane's chunk 0
   const int32_t beg = a.rowptr[row];
   const int32_t end = a.rowptr[row + 1];
   if (a.long_threshold > 0 && end - beg > a.long_threshold) return;  // handled by the item kernels
@@ -226,7 +230,7 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
 
 // one workgroup per item (a run of <= item_chunk_edges edges of a long row)
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
-__device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
+__device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item, unsigned window,
                                                   float (&red)[256 / LPR][LPR * VPL * VEC]) {
   constexpr int GROUPS = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
   const int per = (a.item_chunk_edges + GROUPS - 1) / GROUPS;
   const int32_t beg = min(iend, ibeg + group * per);
   const int32_t end = min(iend, beg + per);
-  const int w0 = blockIdx.y * WINDOW;
+  const int w0 = window * WINDOW;
   const int f0 = w0 + gl * VEC;
   const bool is_max = MODE == MODE_GENERAL && a.is_max;
 
@@ -298,21 +302,43 @@ __global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
 __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a, int num_items) {
   __shared__ float red[256 / LPR][LPR * VPL * VEC];
-  if ((int)blockIdx.x < num_items)
-    gather_item_block<LPR, VPL, VEC, UNROLL, MODE>(a, (int)blockIdx.x, red);
+  unsigned unit, window;
+  if (a.xcd_units_pad) {
+    // XCD-aware order (workgroup b runs on XCD b % 8): every XCD walks the feature windows one after the
+    // other over its share of the work units, so the source slice in[:, window] (V * window bytes)
+    // it is gathering from stays resident in that XCD's 4 MiB L2
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const unsigned per = a.xcd_units_pad >> 3;
+    window = j / per;
+    unit = (j % per) * 8u + xcd;
+    if (unit >= a.total_units) return;
+  } else {
+    unit = blockIdx.x;
+    window = blockIdx.y;
+  }
+  if ((int)unit < num_items)
+    gather_item_block<LPR, VPL, VEC, UNROLL, MODE>(a, (int)unit, window, red);
   else
-    gather_rows_block<LPR, VPL, VEC, UNROLL, MODE>(a, blockIdx.x - (unsigned)num_items);
+    gather_rows_block<LPR, VPL, VEC, UNROLL, MODE>(a, unit - (unsigned)num_items, window);
 }
 
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
-static int launch_mode(const GatherArgs& a, int num_items, hipStream_t s) {
+static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
   const unsigned windows = (unsigned)ceil_div(a.width, WINDOW);
+  const unsigned units = (unsigned)(num_items + ceil_div(a.num_rows, GROUPS_PER_BLOCK));
   dim3 block(256);
-  hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>),
-                     dim3((unsigned)(num_items + ceil_div(a.num_rows, GROUPS_PER_BLOCK)), windows), block, 0, s, a,
-                     num_items);
+  a.total_units = units;
+  if (a.xcd_units_pad && windows > 1) {
+    a.xcd_units_pad = (units + 7u) & ~7u;
+    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3(a.xcd_units_pad * windows), block, 0, s,
+                       a, num_items);
+  } else {
+    a.xcd_units_pad = 0;
+    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3(units, windows), block, 0, s, a,
+                       num_items);
+  }
   TFGNN_LAUNCH_CHECK();
   if (a.num_multi > 0) {
     const int64_t total = (int64_t)a.num_multi * a.width;
@@ -346,6 +372,17 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
     return launch_variant<16, 4, 1, 2>(a, mode, num_items, s);
   }
   const int chunks = a.width / 4;
+  // L2-resident slicing: gather 32-float (128 B) windows of the rows, XCD by XCD, when one window of
+  // ALL source rows fits an XCD's 4 MiB L2 but the full rows do not (cfg-2: 3.84 MB vs 38 MB).
+  static const int sliced_knob = [] { const char* e = getenv("TFGNN_GATHER_SLICED"); return e ? atoi(e) : -1; }();
+  const bool can_slice = a.num_src_rows > 0 && chunks > 16 && mode != MODE_HEADS;
+  // Measured at cfg-2 (tools/gather_probe.py): 322 us sliced vs 160 us whole-row - ten passes over the
+  // index arrays with 128-byte requests lose more than the L2 hits win.  Off unless TFGNN_GATHER_SLICED=1.
+  const bool want_slice = sliced_knob > 0;
+  if (can_slice && want_slice) {
+    a.xcd_units_pad = 1;
+    return launch_variant<8, 1, 4, 8>(a, mode, num_items, s);
+  }
   if (chunks <= 8) return launch_variant<8, 1, 4, 8>(a, mode, num_items, s);
   if (chunks <= 16) return launch_variant<16, 1, 4, 8>(a, mode, num_items, s);
   if (chunks <= 32) return launch_variant<16, 2, 4, 4>(a, mode, num_items, s);
@@ -418,6 +455,7 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = LONG_ROW_THRESHOLD;
   a.out_row_map = out_map;
+  a.num_src_rows = d_col_override ? 0 : ((view == 1 || view == 3) ? g->R : g->V);  // rows of `in`
   a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
   a.partial = (float*)d_workspace; a.item_chunk_edges = ITEM_CHUNK;
   a.multi_row = p.multi_row; a.multi_base = p.multi_base; a.multi_n = p.multi_n; a.num_multi = p.num_multi;
