@@ -10,6 +10,7 @@
 //   count keys (int atomics) -> exclusive scan -> scatter (col<<32 | edge_id) with an atomic cursor
 //   -> per-row sort of the 64-bit composites (canonical order) -> unpack + derived arrays.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -242,14 +243,15 @@ __global__ void rowptr_from_sorted_kernel(const uint64_t* __restrict__ comp, int
 // work items for rows longer than LONG_ROW_THRESHOLD (see graph.hpp / spmm.hip); counters = {items,
 // multi-item rows, partial slots}.  The order in which rows claim their slots is irrelevant: a row's
 // items are contiguous and are always combined in chunk order.
-__global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, int32_t* __restrict__ counters,
+__global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, int long_threshold, int chunk_edges,
+                                 int32_t* __restrict__ counters,
                                  int32_t* __restrict__ item_row, int32_t* __restrict__ item_chunk,
                                  int32_t* __restrict__ item_slot, int32_t* __restrict__ multi_row,
                                  int32_t* __restrict__ multi_base, int32_t* __restrict__ multi_n) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
     const int32_t len = rowptr[r + 1] - rowptr[r];
-    if (len <= LONG_ROW_THRESHOLD) continue;
-    const int32_t n = (len + ITEM_CHUNK - 1) / ITEM_CHUNK;
+    if (len <= long_threshold) continue;
+    const int32_t n = (len + chunk_edges - 1) / chunk_edges;
     const int32_t base = atomicAdd(&counters[0], n);
     int32_t pb = -1;
     if (n > 1) {
@@ -518,7 +520,21 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     o_cb[side][4] = plan.take((V + 1) * 4);            // nodeptr_nz
     o_cb[side][5] = plan.take((R + 1) * 4);            // col_nz
   }
-  const size_t max_items = (size_t)(E / LONG_ROW_THRESHOLD + 1), max_multi = (size_t)(E / ITEM_CHUNK + 1);
+  // long-row plan parameters per view (tools/gather_probe.py sweep at cfg-2: 133 us with (16, 128) on the
+  // typed views vs 160 us with (32, 256); the node views - all edge types of a node in one row - are best
+  // at (32, 256)); TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override all views for probing
+  static const int env_long = [] { const char* e = getenv("TFGNN_LONG_ROW"); return e ? atoi(e) : 0; }();
+  static const int env_chunk = [] { const char* e = getenv("TFGNN_ITEM_CHUNK"); return e ? atoi(e) : 0; }();
+  int view_long[4] = {16, LONG_ROW_THRESHOLD, 16, LONG_ROW_THRESHOLD};
+  int view_chunk[4] = {128, ITEM_CHUNK, 128, ITEM_CHUNK};
+  for (int v = 0; v < 4; ++v) {
+    if (env_long > 0) view_long[v] = env_long;
+    if (env_chunk > 0) view_chunk[v] = env_chunk;
+    if (view_chunk[v] < view_long[v]) view_chunk[v] = view_long[v];
+  }
+  const int min_long = std::min(std::min(view_long[0], view_long[1]), std::min(view_long[2], view_long[3]));
+  const int min_chunk = std::min(std::min(view_chunk[0], view_chunk[1]), std::min(view_chunk[2], view_chunk[3]));
+  const size_t max_items = (size_t)(E / min_long + 1), max_multi = (size_t)(E / min_chunk + 1);
   size_t o_item[4][3], o_multi[4][3];
   for (int v = 0; v < 4; ++v) {
     for (int k = 0; k < 3; ++k) o_item[v][k] = plan.take(max_items * 4);
@@ -739,9 +755,11 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     pl.multi_row = (int32_t*)(slab + o_multi[v][0]);
     pl.multi_base = (int32_t*)(slab + o_multi[v][1]);
     pl.multi_n = (int32_t*)(slab + o_multi[v][2]);
+    pl.long_threshold = view_long[v];
+    pl.item_chunk_edges = view_chunk[v];
     if (E > 0 && g->views[v].num_rows > 0) {
       hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks_for(g->views[v].num_rows)), dim3(threads), 0, s,
-                         g->views[v].rowptr, g->views[v].num_rows, counters + 16 + 4 * v, pl.item_row,
+                         g->views[v].rowptr, g->views[v].num_rows, view_long[v], view_chunk[v], counters + 16 + 4 * v, pl.item_row,
                          pl.item_chunk, pl.item_slot, pl.multi_row, pl.multi_base, pl.multi_n);
     }
   }

@@ -12,6 +12,8 @@ constexpr int LONG_ROW_THRESHOLD = 32;
 constexpr int ITEM_CHUNK = 256;
 
 struct CsrPlan {
+  int32_t long_threshold = LONG_ROW_THRESHOLD;  // values the plan was built with (env-tunable for probes)
+  int32_t item_chunk_edges = ITEM_CHUNK;
   int32_t num_items = 0;     // host copies of the device counters
   int32_t num_multi = 0;     // rows with more than one item
   int32_t num_partials = 0;  // items belonging to multi-item rows (scratch slots)

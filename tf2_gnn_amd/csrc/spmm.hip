@@ -387,7 +387,12 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
   if (chunks <= 16) return launch_variant<16, 1, 4, 8>(a, mode, num_items, s);
   if (chunks <= 32) return launch_variant<16, 2, 4, 4>(a, mode, num_items, s);
   if (chunks <= 64) return launch_variant<16, 4, 4, 2>(a, mode, num_items, s);
-  if (chunks % 80 == 0 || chunks <= 80) return launch_variant<16, 5, 4, 2>(a, mode, num_items, s);
+  static const int unroll_knob = [] { const char* e = getenv("TFGNN_GATHER_UNROLL"); return e ? atoi(e) : 0; }();
+  if (chunks % 80 == 0 || chunks <= 80) {
+    if (unroll_knob == 4) return launch_variant<16, 5, 4, 4>(a, mode, num_items, s);
+    if (unroll_knob == 1) return launch_variant<16, 5, 4, 1>(a, mode, num_items, s);
+    return launch_variant<16, 5, 4, 2>(a, mode, num_items, s);
+  }
   return launch_variant<32, 4, 4, 2>(a, mode, num_items, s);
 }
 
@@ -453,11 +458,11 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   a.row_scale = d_row_scale; a.num_rows = gv.num_rows; a.in = d_in; a.ld_in = ld_in; a.width = width;
   a.out = d_out; a.ld_out = ld_out; a.pre_act = pre_act; a.post_act = post_act;
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
-  a.long_threshold = LONG_ROW_THRESHOLD;
+  a.long_threshold = p.long_threshold;
   a.out_row_map = out_map;
   a.num_src_rows = d_col_override ? 0 : ((view == 1 || view == 3) ? g->R : g->V);  // rows of `in`
   a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
-  a.partial = (float*)d_workspace; a.item_chunk_edges = ITEM_CHUNK;
+  a.partial = (float*)d_workspace; a.item_chunk_edges = p.item_chunk_edges;
   a.multi_row = p.multi_row; a.multi_base = p.multi_base; a.multi_n = p.multi_n; a.num_multi = p.num_multi;
   return gather_dispatch(a, p.num_items, (hipStream_t)stream);
 }
