@@ -378,7 +378,10 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_byte
   p.k_chunk = ceil_div(K > 0 ? K : 1, BK) * BK;
   // split-K only when the output grid cannot fill the chip and K is long
   if (tiles < 192 && K >= 1024) {
-    int64_t want = ceil_div(512, tiles);
+    // one wave of workgroups on the 256 CUs: more splits only add rounds (12 output tiles x 43 splits ran
+    // as 3 rounds of 22 K-tiles; x 21 splits is one round of 45)
+    int64_t want = 256 / tiles;
+    if (want < 1) want = 1;
     int64_t max_by_k = K / (4 * BK);
     int64_t s = want < max_by_k ? want : max_by_k;
     if (s > 64) s = 64;
