@@ -1,0 +1,275 @@
+"""Parity at BASELINE.json's full sizes (configs[1..4]) through size-independent properties and
+sampled-subgraph oracles: the CPU oracle cannot run the whole batch in seconds, but
+
+  * a node's new state only depends on its incoming edges, so the oracle evaluated on the sub-batch
+    "all edges entering a random sample of target nodes" must reproduce exactly those rows;
+  * batches of small graphs (QM9 shape) are disjoint unions: the oracle on a sample of whole graphs
+    must reproduce those graphs' rows;
+  * sum aggregation is linear and conserves mass: sum_v out[v] = sum_u outdeg(u) * x[u];
+  * attention weights are a distribution per (target, head);
+  * the bucketing is a permutation of the edge list; results are bit-reproducible run to run.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf2gnn_oracle as orc
+from tests.helpers import assert_close, mp_weights_from_layer, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cls_name, params, D, L):
+    import tf2_gnn_amd.layers.message_passing as mp
+
+    cls = getattr(mp, cls_name)
+    p = cls.get_default_hyperparameters()
+    p.update(params)
+    layer = cls(p)
+    layer.build(mp.MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
+    return layer, p
+
+
+def _sub_batch_for_targets(adjs, targets):
+    """edges entering `targets`, with all nodes kept (ids unchanged): the oracle on it equals the full
+    oracle on the rows `targets` for every layer whose new state of v depends on v's in-edges only."""
+    mask = np.zeros(max(int(a.max()) + 1 if a.size else 1 for a in adjs) + 1, dtype=bool)
+    mask[targets] = True
+    return [a[mask[a[:, 1]]] if a.size else a for a in adjs]
+
+
+@pytest.fixture(scope="module")
+def cfg2(dev):
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+
+    V, E, L, H = 30000, 900000, 4, 320
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=0)  # parity seed 0
+    adj_dev = to_dev(adjs, dev)
+    g = ops.Graph(adj_dev, V)
+    return dict(V=V, E=E, L=L, H=H, feats=feats, adjs=adjs, adj_dev=adj_dev, graph=g, X=torch.from_numpy(feats).to(dev))
+
+
+def test_cfg2_bucketing_is_a_permutation_and_counts_match(cfg2, dev):
+    from tf2_gnn_amd import ops
+
+    g, adjs, V, L, E = cfg2["graph"], cfg2["adjs"], cfg2["V"], cfg2["L"], cfg2["E"]
+    for eid_id, rp_id, col_id, by in ((ops.G_EID_BY_DST, ops.G_ROWPTR_BY_DST, ops.G_COL_BY_DST, 1),
+                                      (ops.G_EID_BY_SRC, ops.G_ROWPTR_BY_SRC, ops.G_COL_BY_SRC, 0)):
+        eid = g.array(eid_id).cpu().numpy()
+        assert np.array_equal(np.sort(eid), np.arange(E))
+        rowptr = g.array(rp_id).cpu().numpy()
+        counts = np.zeros((V, L), dtype=np.int64)
+        for l, a in enumerate(adjs):
+            np.add.at(counts[:, l], a[:, by], 1)
+        assert np.array_equal(np.diff(rowptr), counts.reshape(-1))
+        # columns ascend inside every bucket (canonical order)
+        col = g.array(col_id).cpu().numpy().astype(np.int64)
+        row_of = np.repeat(np.arange(V * L), np.diff(rowptr))
+        assert np.all(np.diff(row_of * (V + 1) + col) >= 0)
+
+
+def test_cfg2_gather_linearity_conservation_determinism(cfg2, dev):
+    from tf2_gnn_amd import ops
+
+    g, V, L, H, adjs = cfg2["graph"], cfg2["V"], cfg2["L"], cfg2["H"], cfg2["adjs"]
+    gen = torch.Generator().manual_seed(1)
+    X = cfg2["X"]
+    Y = torch.randn((V, H), generator=gen).to(dev)
+    a1 = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X)
+    a2 = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X)
+    assert torch.equal(a1, a2), "gather is not bit-reproducible"
+    # linearity: S(2X - 3Y) = 2 S(X) - 3 S(Y)
+    Z = ops.add_scale(ops.add_scale(X, X, 1.0), ops.add_scale(Y, ops.add_scale(Y, Y, 1.0), -1.0), 1.0)  # 2X - 3Y
+    lhs = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Z)
+    rhs = 2.0 * a1 - 3.0 * ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Y)
+    scale = a1.abs().amax(dim=1, keepdim=True).clamp(min=1.0) * 8
+    assert float(((lhs - rhs).abs() / scale).max()) < 1e-5
+    # conservation: sum over buckets of the un-normalised sums = sum_u outdeg(u) x_u  (fp64 on the host)
+    outdeg = np.zeros(V)
+    for a in adjs:
+        np.add.at(outdeg, a[:, 0], 1)
+    expect = (torch.from_numpy(outdeg).unsqueeze(1) * X.cpu().double()).sum(0)
+    got = a1.double().sum(0).cpu()
+    l1 = (torch.from_numpy(outdeg).unsqueeze(1) * X.cpu().double().abs()).sum(0)
+    assert float(((got - expect).abs() / l1).max()) < 1e-6
+
+
+def test_cfg2_rgcn_layer_matches_oracle_on_sampled_targets(cfg2, dev):
+    """RGCN forward at V=30k, E=900k, 4 types, H=320 (BASELINE configs[1]) vs the oracle on 300 sampled
+    target nodes (incl. the highest in-degree hub and isolated nodes)."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, H, adjs = cfg2["V"], cfg2["L"], cfg2["H"], cfg2["adjs"]
+    layer, p = _build("RGCN", {"hidden_dim": H}, H, L)
+    out = layer(MessagePassingInput(cfg2["X"], cfg2["graph"]), training=False)
+    out2 = layer(MessagePassingInput(cfg2["X"], cfg2["graph"]), training=False)
+    assert torch.equal(out, out2)
+    indeg = np.zeros(V, dtype=np.int64)
+    for a in adjs:
+        np.add.at(indeg, a[:, 1], 1)
+    rng = np.random.default_rng(0)
+    targets = np.unique(np.concatenate([rng.integers(0, V, 290), np.argsort(indeg)[-5:], np.where(indeg == 0)[0][:5]]))
+    sub = _sub_batch_for_targets(adjs, targets)
+    ref = orc.message_passing_call("rgcn", p, mp_weights_from_layer(layer), torch.from_numpy(cfg2["feats"]),
+                                   [torch.from_numpy(a) for a in sub])
+    assert_close(out.cpu()[targets], ref[targets], tol=1e-5, what="cfg-2 RGCN sampled targets")
+    # nodes without incoming edges: relu(0) = 0
+    assert torch.all(out.cpu()[indeg == 0] == 0)
+
+
+def test_cfg2_rgcn_gnn_step_gradients_finite_and_reproducible(cfg2, dev):
+    """the benchmarked step (PPI_RGCN.json model, fwd + bwd) twice: identical gradients, all finite."""
+    from bench import ppi_rgcn_params
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    V, H = cfg2["V"], cfg2["H"]
+    params = ppi_rgcn_params(H, 4)
+    params["layer_input_dropout_rate"] = 0.0
+    set_seed(0)
+    gnn = GNN(params)
+    inp = GNNInput(cfg2["X"], cfg2["graph"], torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
+    grads = []
+    for _ in range(2):
+        gnn(inp, training=True)
+        gnn.backward(dOut)
+        grads.append([v.grad.clone() for v in gnn.trainable_variables])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+        assert bool(torch.isfinite(a).all())
+
+
+def test_cfg3_rgat_8_heads_h256(dev):
+    """BASELINE configs[2]: RGAT, 8 heads, H=256 on the cfg-2 graph: attention is a distribution per
+    (target, head); sampled targets match the oracle."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, E, L, H, K = 30000, 900000, 4, 256, 8
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=0)
+    g = ops.Graph(to_dev(adjs, dev), V)
+    layer, p = _build("RGAT", {"hidden_dim": H, "num_heads": K, "message_activation_function": "tanh"}, H, L)
+    X = torch.from_numpy(feats).to(dev)
+    out = layer(MessagePassingInput(X, g), training=True)
+    att = layer._ctx["att"]
+    nodeptr = g.array(ops.G_NODEPTR_BY_DST)
+    seg = torch.repeat_interleave(torch.arange(V, device=dev), (nodeptr[1:] - nodeptr[:-1]).long())
+    sums = torch.zeros((V, K), device=dev, dtype=torch.float64).index_add_(0, seg, att.double())
+    has_in = (nodeptr[1:] > nodeptr[:-1])
+    assert float((sums[has_in] - 1.0).abs().max()) < 1e-5
+    assert float(att.min()) >= 0.0
+    indeg = (nodeptr[1:] - nodeptr[:-1]).cpu().numpy()
+    rng = np.random.default_rng(1)
+    targets = np.unique(np.concatenate([rng.integers(0, V, 200), np.argsort(indeg)[-3:]]))
+    # RGAT's logits also use the TARGET's own state: keep all nodes, only drop edges into other targets
+    sub = _sub_batch_for_targets(adjs, targets)
+    ref = orc.message_passing_call("rgat", p, mp_weights_from_layer(layer), torch.from_numpy(feats),
+                                   [torch.from_numpy(a) for a in sub])
+    assert_close(out.cpu()[targets], ref[targets], tol=1e-5, what="cfg-3 RGAT sampled targets")
+    dX = layer.backward(torch.ones_like(out))
+    assert bool(torch.isfinite(dX).all())
+    g.close()
+
+
+def _qm9_shaped_batch(num_graphs, seed=0, D=128):
+    """QM9-shaped batch: graphs of 5..13 nodes, a random tree + ~0.8 extra bonds,
+    4 bond types tied fwd/bkwd + self-loop type 0 (tf2_gnn/data/qm9_dataset.py:54-77) -> 5 edge types."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(5, 14, size=num_graphs)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    V = int(offs[-1])
+    n2g = np.repeat(np.arange(num_graphs, dtype=np.int32), sizes)
+    # tree edges: node i>0 of a graph attaches to a random earlier node of the same graph
+    local = np.arange(V) - offs[n2g]
+    child = np.where(local > 0)[0]
+    parent = offs[n2g[child]] + (rng.random(child.shape[0]) * local[child]).astype(np.int64)
+    extra_g = np.where(rng.random(num_graphs) < 0.8)[0]
+    ea = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
+    eb = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
+    src = np.concatenate([child, ea])
+    dst = np.concatenate([parent, eb])
+    bond = rng.integers(1, 5, size=src.shape[0])
+    adjs = [np.stack([np.arange(V), np.arange(V)], axis=1).astype(np.int32)]  # type 0: self loops
+    for b in range(1, 5):
+        m = bond == b
+        fwd = np.stack([src[m], dst[m]], axis=1)
+        adjs.append(np.concatenate([fwd, fwd[:, ::-1]], axis=0).astype(np.int32))  # tied fwd/bkwd
+    feats = rng.standard_normal((V, D), dtype=np.float32)
+    return feats, adjs, n2g, offs
+
+
+@pytest.mark.parametrize("cls_name,over", [("GGNN", {"normalize_by_num_incoming": False}), ("GNN_Edge_MLP", {})])
+def test_cfg4_qm9_shaped_batch_sampled_graphs(dev, cls_name, over):
+    """BASELINE configs[3]: 128k small molecules (V ~ 1.15M, ~3.4M edges incl. self loops), H=128, GGNN and
+    GNN_Edge_MLP fwd+bwd + softmax pooling.  The batch is a disjoint union: the oracle on 150 sampled
+    graphs reproduces their rows and their pooled representations."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers import MessagePassingInput, NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
+
+    G, H = 128000, 128
+    feats, adjs, n2g, offs = _qm9_shaped_batch(G, seed=0, D=H)
+    V = feats.shape[0]
+    g = ops.Graph(to_dev(adjs, dev), V)
+    layer, p = _build(cls_name, dict(over, hidden_dim=H), H, len(adjs))
+    X = torch.from_numpy(feats).to(dev)
+    out = layer(MessagePassingInput(X, g), training=True)
+    pool = WeightedSumGraphRepresentation(32, 4, weighting_fun="softmax", scoring_mlp_layers=[64], transformation_mlp_layers=[64])
+    n2g_dev = torch.from_numpy(n2g).to(dev)
+    pooled = pool(NodesToGraphRepresentationInput(out, n2g_dev, G))
+    assert pooled.shape == (G, 32)
+    dOutNodes = pool.backward(torch.ones_like(pooled))
+    dX = layer.backward(dOutNodes)
+    assert bool(torch.isfinite(dX).all())
+    assert all(v.grad is not None and bool(torch.isfinite(v.grad).all()) for v in layer.trainable_variables)
+    # oracle on a sample of whole graphs
+    rng = np.random.default_rng(2)
+    sample = np.sort(rng.choice(G, 150, replace=False))
+    node_ids = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in sample])
+    new_id = np.full(V, -1, dtype=np.int64)
+    new_id[node_ids] = np.arange(node_ids.shape[0])
+    sub = []
+    for a in adjs:
+        keep = new_id[a[:, 1]] >= 0
+        aa = a[keep]
+        sub.append(np.stack([new_id[aa[:, 0]], new_id[aa[:, 1]]], axis=1).astype(np.int32))
+    ref = orc.message_passing_call(cls_name.lower(), p, mp_weights_from_layer(layer), torch.from_numpy(feats[node_ids]),
+                                   [torch.from_numpy(a) for a in sub])
+    assert_close(out.cpu()[node_ids], ref, tol=1e-5, what=f"cfg-4 {cls_name} sampled graphs")
+    sub_n2g = torch.from_numpy(np.repeat(np.arange(sample.shape[0], dtype=np.int32), np.diff(offs)[sample]))
+    cfg = {"graph_representation_size": 32, "num_heads": 4, "weighting_fun": "softmax",
+           "scoring_mlp_activation_fun": "ReLU", "transformation_mlp_activation_fun": "ReLU"}
+    w = {"scoring": ([k.value.cpu() for k in pool._scoring_mlp.kernels], None),
+         "transformation": ([k.value.cpu() for k in pool._transformation_mlp.kernels], None)}
+    ref_pool = orc.weighted_sum_graph_representation(cfg, w, ref, sub_n2g, sample.shape[0])
+    assert_close(pooled.cpu()[sample], ref_pool, tol=2e-5, what=f"cfg-4 {cls_name} pooled")
+    g.close()
+
+
+def test_cfg5_rgin_40_edge_types_h512(dev):
+    """BASELINE configs[4]: V=170k, E=1.2M, 40 edge types (Zipf), H=512, RGIN defaults (1 hidden layer per
+    edge-type MLP): sampled targets match the oracle; ragged / empty edge types are fine."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import rmat_edges
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, E, L, H = 170000, 1200000, 40, 512
+    rng = np.random.default_rng(0)
+    edges = rmat_edges(V, E, rng)
+    pz = 1.0 / np.arange(1, L + 1)
+    types = rng.choice(L, size=E, p=pz / pz.sum())
+    types[types == 17] = 16  # one empty edge type
+    adjs = [np.ascontiguousarray(edges[types == l]) for l in range(L)]
+    feats = rng.standard_normal((V, H), dtype=np.float32)
+    g = ops.Graph(to_dev(adjs, dev), V)
+    layer, p = _build("RGIN", {"hidden_dim": H}, H, L)
+    out = layer(MessagePassingInput(torch.from_numpy(feats).to(dev), g), training=False)
+    assert out.shape == (V, H)
+    targets = np.unique(rng.integers(0, V, 150))
+    sub = _sub_batch_for_targets(adjs, targets)
+    ref = orc.message_passing_call("rgin", p, mp_weights_from_layer(layer), torch.from_numpy(feats),
+                                   [torch.from_numpy(a) for a in sub])
+    assert_close(out.cpu()[targets], ref[targets], tol=1e-5, what="cfg-5 RGIN sampled targets")
+    g.close()
