@@ -253,7 +253,9 @@ int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const 
                              int64_t V, int H, void* stream);
 
 /* out[n] = sum_m in[m, n] (bias gradients of Dense / GRUCell). */
-int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* stream);
+size_t tfgnn_colsum_workspace_bytes(int64_t M, int N);
+int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* d_workspace,
+                 size_t workspace_bytes, void* stream);
 /* out = alpha * (x + y): residual averaging of the layer stack, gnn.py:291-296. */
 int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, float* d_out, int64_t n, void* stream);
 
@@ -262,27 +264,34 @@ int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, float* d_ou
  * tfgnn_rgat_node_scores: the two halves of the attention logit (rgat.py:111-121) per (node,type,head):
  *     s_src[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,:H/K]>   s_tgt[(v,l),k] = <Y[(v,l),k,:], alpha[l,k,H/K:]>
  *     d_alpha: [L, K, 2H/K] (the L "Edge_attention_parameters" stacked, rgat.py:82-86)
- * tfgnn_rgat_edge_attention: score_ek = leaky_relu(s_src[src,l,k] + s_tgt[tgt,l,k]); per head, softmax
- *     over all edges entering a node (dpu_utils unsorted_segment_log_softmax + exp, rgat.py:147-151);
- *     d_att [E,K] receives a_ek in by-dst edge order.  The weighted sum out[v,k,:] = sum_e a_ek
- *     Y[(src,l),k,:] (rgat.py:154-163) is tfgnn_graph_gather_reduce(view BY_DST_NODE, ew_heads = K).
+ * tfgnn_rgat_edge_scores: score_ek = leaky_relu(s_src[src,l,k] + s_tgt[tgt,l,k]) per bucketed edge (by-dst
+ *     order).  Per head, the softmax over all edges entering a node (dpu_utils unsorted_segment_log_softmax
+ *     + exp, rgat.py:147-151) is: m = segment max, p = exp(score - m[tgt]), den = segment sum of p,
+ *     a = p / den[tgt] - the two segment reductions are tfgnn_graph_gather_reduce over view BY_DST_NODE with
+ *     the identity as column array (so hub nodes use the long-row plan), the edge-parallel steps are
+ *     tfgnn_rgat_edge_node_op.  The weighted sum out[v,k,:] = sum_e a_ek Y[(src,l),k,:] (rgat.py:154-163) is
+ *     tfgnn_graph_gather_reduce(view BY_DST_NODE, ew_heads = K).
  * ------------------------------------------------------------------------------------------ */
 int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, int64_t num_nodes, int num_edge_types,
                            int num_heads, int hidden_dim, float* d_s_src, float* d_s_tgt, void* stream);
-int tfgnn_rgat_edge_attention(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
-                              const float* d_s_src, const float* d_s_tgt, int64_t num_nodes,
-                              int num_edge_types, int num_heads, float* d_att, void* stream);
+int tfgnn_rgat_edge_scores(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst, const float* d_s_src,
+                           const float* d_s_tgt, int64_t num_edges, int num_edge_types, int num_heads,
+                           float* d_scores, void* stream);
+/* mode 0: out[e,k] = exp(x[e,k] - node[tgt_e,k]);  mode 1: out[e,k] = x[e,k] / node[tgt_e,k] */
+int tfgnn_rgat_edge_node_op(const float* d_x, const int32_t* d_target_by_dst, const float* d_node,
+                            int64_t num_edges, int num_heads, int mode, float* d_out, void* stream);
 /* backward pieces (tf.GradientTape in the reference):
- *   tfgnn_rgat_edge_dot:           da[e,k] = < d_agg[tgt_e,k,:], Y[(src_e,l_e),k,:] >
- *   tfgnn_rgat_attention_backward: dz[e,k] = a_ek (da_ek - sum_e' a_e'k da_e'k) * leaky_relu'(z_ek)
- *   tfgnn_rgat_scores_backward:    dY[(v,l),k,:] += ds_src[(v,l),k] alpha[l,k,:H/K] + ds_tgt[(v,l),k] alpha[l,k,H/K:] */
+ *   tfgnn_rgat_edge_dot:              da[e,k] = < d_agg[tgt_e,k,:], Y[(src_e,l_e),k,:] >
+ *   tfgnn_rgat_edge_softmax_backward: dz[e,k] = a_ek (da_ek - t[tgt_e,k]) * leaky_relu'(z_ek),
+ *                                     t[v,k] = sum over in-edges of a*da (a generic gather)
+ *   tfgnn_rgat_scores_backward:       dY[(v,l),k,:] += ds_src[(v,l),k] alpha[l,k,:H/K] + ds_tgt[(v,l),k] alpha[l,k,H/K:] */
 int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst, const float* d_Y,
                         const float* d_dagg, int64_t num_edges, int num_heads, int hidden_dim, float* d_da,
                         void* stream);
-int tfgnn_rgat_attention_backward(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
-                                  const float* d_s_src, const float* d_s_tgt, const float* d_att,
-                                  const float* d_da, int64_t num_nodes, int num_edge_types, int num_heads,
-                                  float* d_dz, void* stream);
+int tfgnn_rgat_edge_softmax_backward(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst,
+                                     const float* d_s_src, const float* d_s_tgt, const float* d_att,
+                                     const float* d_da, const float* d_t, int64_t num_edges, int num_edge_types,
+                                     int num_heads, float* d_dz, void* stream);
 int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha,
                                int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
                                float* d_dY, void* stream);

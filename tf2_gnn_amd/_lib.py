@@ -77,15 +77,17 @@ _SIGNATURES = [
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     ),
-    ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_colsum_workspace_bytes", c_size_t, [c_int64, c_int]),
+    ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("tfgnn_add_scale", c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     ("tfgnn_rgat_node_scores", c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    ("tfgnn_rgat_edge_attention", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    ("tfgnn_rgat_edge_scores", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    ("tfgnn_rgat_edge_node_op", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     ("tfgnn_rgat_edge_dot", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     (
-        "tfgnn_rgat_attention_backward",
+        "tfgnn_rgat_edge_softmax_backward",
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
     ),
     ("tfgnn_rgat_scores_backward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     (

@@ -106,18 +106,30 @@ gru_gates_backward_kernel(const float* __restrict__ dh_new, const float* __restr
   }
 }
 
-// out[n] = sum_m in[m, n]   (bias gradients).  One block per 64 columns, deterministic tree.
+// out[n] = sum_m in[m, n]   (bias gradients).  Two deterministic stages: gridDim.y row slabs each
+// reduce to partial[slab, n] (4 waves x 64 columns per workgroup), then the slabs are summed in order.
 __global__ void __launch_bounds__(256)
-colsum_kernel(const float* __restrict__ in, int64_t M, int N, int64_t ld, float* __restrict__ out) {
+colsum_kernel(const float* __restrict__ in, int64_t M, int N, int64_t ld, float* __restrict__ out, int64_t rows_per_slab) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t m1 = m0 + rows_per_slab < M ? m0 + rows_per_slab : M;
   float s = 0.f;
   if (c < N)
-    for (int64_t m = w; m < M; m += 4) s += in[m * ld + c];
+    for (int64_t m = m0 + w; m < m1; m += 4) s += in[m * ld + c];
   red[w][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (w == 0 && c < N)
+    out[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int slabs, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < slabs; ++k) s += partial[(int64_t)k * N + c];
+  out[c] = s;
 }
 
 // y = a * x + b * y' style helpers used by the layer stack (gnn.py:291-296 residual averaging):
@@ -280,13 +292,30 @@ extern "C" int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_ga
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* stream) {
+extern "C" size_t tfgnn_colsum_workspace_bytes(int64_t M, int N) {
+  if (M <= 4096 || N <= 0) return 0;
+  const int64_t slabs = std::min<int64_t>(512, (M + 2047) / 2048);
+  return (size_t)slabs * N * 4;
+}
+
+extern "C" int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* d_workspace,
+                            size_t workspace_bytes, void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(M >= 0 && N >= 0, "negative size");
   if (N == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_out && (M == 0 || d_in) && ld >= N, "bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, d_in, M, N, ld, d_out);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t slabs = std::min<int64_t>(512, (M + 2047) / 2048);
+  if (M <= 4096 || !d_workspace || workspace_bytes < (size_t)slabs * N * 4) slabs = 1;
+  const int64_t rows_per_slab = slabs > 1 ? ceil_div(M, slabs) : (M > 0 ? M : 1);
+  float* stage1 = slabs > 1 ? (float*)d_workspace : d_out;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)slabs), dim3(256), 0, s, d_in, M, N, ld, stage1,
+                     rows_per_slab);
   TFGNN_LAUNCH_CHECK();
+  if (slabs > 1) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, stage1, (int)slabs, N, d_out);
+    TFGNN_LAUNCH_CHECK();
+  }
   return TFGNN_OK;
 }
 

@@ -10,11 +10,11 @@
 // gather instead of two [E,D]x[D,H] matmuls.
 //
 //   tfgnn_rgat_node_scores     s_src / s_tgt [V*L, K]
-//   tfgnn_rgat_edge_attention  a[e, k] for every bucketed edge (by-dst order); one wave per target
-//                              node, lanes over its incoming edges (hub nodes stay parallel)
+//   tfgnn_rgat_edge_scores / tfgnn_rgat_edge_node_op: edge-parallel pieces of the per-target softmax;
+//                              the segment max / sum in between are generic gathers (hub nodes stay parallel)
 //   the weighted sum of source rows is the generic gather kernel with per-head edge weights
 //   (tfgnn_graph_gather_reduce, ew_heads = K) - see spmm.hip.
-// Backward (stand-in for tf.GradientTape): tfgnn_rgat_edge_dot, tfgnn_rgat_attention_backward,
+// Backward (stand-in for tf.GradientTape): tfgnn_rgat_edge_dot, tfgnn_rgat_edge_softmax_backward,
 // tfgnn_rgat_scores_backward + generic gathers / GEMMs (layers/message_passing/rgat.py).
 #include <algorithm>
 
@@ -59,35 +59,37 @@ __device__ __forceinline__ float wave_add(float v) {
   return v;
 }
 
-// one wave per target node: per head, max and sum-exp over the incoming edges, then the
-// normalised attention of every edge.  log_softmax then exp (rgat.py:147-151):
-// exp(s - m - log(sum)) == exp(s - m) / sum.
+// Edge-parallel pieces of the per-target softmax (thread per (edge, head)).  The two segment
+// reductions in between (max and sum over all edges entering a node) are the generic gather kernel
+// over the node view with its long-row plan, so a hub with 15k incoming edges stays parallel:
+//   scores[e,k] = leaky_relu(s_src[(src,l),k] + s_tgt[(tgt,l),k])
+//   m[v,k]      = max over in-edges           (tfgnn_graph_gather_reduce, REDUCE_MAX, col = identity)
+//   p[e,k]      = exp(scores[e,k] - m[tgt,k])
+//   den[v,k]    = sum over in-edges of p      (tfgnn_graph_gather_reduce, REDUCE_SUM)
+//   a[e,k]      = p[e,k] / den[tgt,k]         == exp(log_softmax) of rgat.py:147-151
 __global__ void __launch_bounds__(256)
-rgat_edge_attention_kernel(const int32_t* __restrict__ nodeptr, const int32_t* __restrict__ coll,
-                           const float* __restrict__ s_src, const float* __restrict__ s_tgt, int64_t V, int L,
-                           int K, float* __restrict__ att) {
-  const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= V) return;
-  const int32_t beg = nodeptr[v], end = nodeptr[v + 1];
-  for (int k = 0; k < K; ++k) {
-    float m = kFloatLowest;
-    for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = coll[e];
-      m = fmaxf(m, leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]));
-    }
-    m = wave_max(m);
-    float s = 0.f;
-    for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = coll[e];
-      s += expf(leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]) - m);
-    }
-    s = wave_add(s);
-    const float inv = 1.f / s;
-    for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = coll[e];
-      att[(int64_t)e * K + k] = expf(leaky(s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k]) - m) * inv;
-    }
+rgat_edge_scores_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict__ tgt,
+                        const float* __restrict__ s_src, const float* __restrict__ s_tgt, int64_t E, int L, int K,
+                        float* __restrict__ scores) {
+  const int64_t total = E * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / K;
+    const int k = (int)(i - e * K);
+    const int32_t cl = coll[e];
+    scores[i] = leaky(s_src[(int64_t)cl * K + k] + s_tgt[((int64_t)tgt[e] * L + cl % L) * K + k]);
+  }
+}
+
+// mode 0: out = exp(x - node[tgt]) ; mode 1: out = x / node[tgt]
+__global__ void __launch_bounds__(256)
+rgat_edge_node_op_kernel(const float* __restrict__ x, const int32_t* __restrict__ tgt, const float* __restrict__ node,
+                         int64_t E, int K, int mode, float* __restrict__ out) {
+  const int64_t total = E * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / K;
+    const int k = (int)(i - e * K);
+    const float nv = node[(int64_t)tgt[e] * K + k];
+    out[i] = mode == 0 ? expf(x[i] - nv) : x[i] / nv;
   }
 }
 
@@ -108,26 +110,21 @@ rgat_edge_dot_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict
   }
 }
 
-// softmax + leaky_relu backward per target node: dz[e,k] = a (da - sum_e' a da) * lrelu'(z)
+// softmax + leaky_relu backward, edge-parallel: dz[e,k] = a (da - t[tgt,k]) * lrelu'(z), where
+// t[v,k] = sum over in-edges of a * da comes from the generic gather (node view, col = identity)
 __global__ void __launch_bounds__(256)
-rgat_attention_backward_kernel(const int32_t* __restrict__ nodeptr, const int32_t* __restrict__ coll,
-                               const float* __restrict__ s_src, const float* __restrict__ s_tgt,
-                               const float* __restrict__ att, const float* __restrict__ da, int64_t V, int L, int K,
-                               float* __restrict__ dz) {
-  const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= V) return;
-  const int32_t beg = nodeptr[v], end = nodeptr[v + 1];
-  for (int k = 0; k < K; ++k) {
-    float t = 0.f;
-    for (int32_t e = beg + lane; e < end; e += 64) t += att[(int64_t)e * K + k] * da[(int64_t)e * K + k];
-    t = wave_add(t);
-    for (int32_t e = beg + lane; e < end; e += 64) {
-      const int32_t cl = coll[e];
-      const float z = s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k];
-      const float ds = att[(int64_t)e * K + k] * (da[(int64_t)e * K + k] - t);
-      dz[(int64_t)e * K + k] = ds * (z > 0.f ? 1.f : 0.2f);
-    }
+rgat_edge_softmax_backward_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict__ tgt,
+                                  const float* __restrict__ s_src, const float* __restrict__ s_tgt,
+                                  const float* __restrict__ att, const float* __restrict__ da,
+                                  const float* __restrict__ t, int64_t E, int L, int K, float* __restrict__ dz) {
+  const int64_t total = E * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / K;
+    const int k = (int)(i - e * K);
+    const int32_t cl = coll[e];
+    const int64_t v = tgt[e];
+    const float z = s_src[(int64_t)cl * K + k] + s_tgt[(v * L + cl % L) * K + k];
+    dz[i] = att[i] * (da[i] - t[v * K + k]) * (z > 0.f ? 1.f : 0.2f);
   }
 }
 
@@ -174,16 +171,28 @@ extern "C" int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, in
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_rgat_edge_attention(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
-                                         const float* d_s_src, const float* d_s_tgt, int64_t num_nodes,
-                                         int num_edge_types, int num_heads, float* d_att, void* stream) {
+extern "C" int tfgnn_rgat_edge_scores(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst,
+                                      const float* d_s_src, const float* d_s_tgt, int64_t num_edges,
+                                      int num_edge_types, int num_heads, float* d_scores, void* stream) {
   using namespace tfgnn;
-  TFGNN_REQUIRE(num_nodes >= 0 && num_heads > 0 && num_heads <= MAX_HEADS, "bad sizes");
-  if (num_nodes == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_nodeptr_by_dst, "NULL pointer");
-  hipLaunchKernelGGL(rgat_edge_attention_kernel, dim3((unsigned)ceil_div(num_nodes, 4)), dim3(256), 0,
-                     (hipStream_t)stream, d_nodeptr_by_dst, d_coll_by_dst, d_s_src, d_s_tgt, num_nodes,
-                     num_edge_types > 0 ? num_edge_types : 1, num_heads, d_att);
+  TFGNN_REQUIRE(num_edges >= 0 && num_heads > 0, "bad sizes");
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_coll_by_dst && d_target_by_dst && d_s_src && d_s_tgt && d_scores, "NULL pointer");
+  hipLaunchKernelGGL(rgat_edge_scores_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                     d_coll_by_dst, d_target_by_dst, d_s_src, d_s_tgt, num_edges, num_edge_types > 0 ? num_edge_types : 1,
+                     num_heads, d_scores);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_edge_node_op(const float* d_x, const int32_t* d_target_by_dst, const float* d_node,
+                                       int64_t num_edges, int num_heads, int mode, float* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && num_heads > 0 && (mode == 0 || mode == 1), "bad arguments");
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_target_by_dst && d_node && d_out, "NULL pointer");
+  hipLaunchKernelGGL(rgat_edge_node_op_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                     d_x, d_target_by_dst, d_node, num_edges, num_heads, mode, d_out);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -203,16 +212,16 @@ extern "C" int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* 
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_rgat_attention_backward(const int32_t* d_nodeptr_by_dst, const int32_t* d_coll_by_dst,
-                                             const float* d_s_src, const float* d_s_tgt, const float* d_att,
-                                             const float* d_da, int64_t num_nodes, int num_edge_types,
-                                             int num_heads, float* d_dz, void* stream) {
+extern "C" int tfgnn_rgat_edge_softmax_backward(const int32_t* d_coll_by_dst, const int32_t* d_target_by_dst,
+                                                const float* d_s_src, const float* d_s_tgt, const float* d_att,
+                                                const float* d_da, const float* d_t, int64_t num_edges,
+                                                int num_edge_types, int num_heads, float* d_dz, void* stream) {
   using namespace tfgnn;
-  TFGNN_REQUIRE(num_nodes >= 0 && num_heads > 0 && num_heads <= MAX_HEADS, "bad sizes");
-  if (num_nodes == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_nodeptr_by_dst, "NULL pointer");
-  hipLaunchKernelGGL(rgat_attention_backward_kernel, dim3((unsigned)ceil_div(num_nodes, 4)), dim3(256), 0,
-                     (hipStream_t)stream, d_nodeptr_by_dst, d_coll_by_dst, d_s_src, d_s_tgt, d_att, d_da, num_nodes,
+  TFGNN_REQUIRE(num_edges >= 0 && num_heads > 0, "bad sizes");
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_coll_by_dst && d_target_by_dst && d_s_src && d_s_tgt && d_att && d_da && d_t && d_dz, "NULL pointer");
+  hipLaunchKernelGGL(rgat_edge_softmax_backward_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0,
+                     (hipStream_t)stream, d_coll_by_dst, d_target_by_dst, d_s_src, d_s_tgt, d_att, d_da, d_t, num_edges,
                      num_edge_types > 0 ? num_edge_types : 1, num_heads, d_dz);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;

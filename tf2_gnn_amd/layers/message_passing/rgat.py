@@ -94,13 +94,7 @@ class RGAT(MessagePassing):
                 ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
             )
         )
-        att = torch.empty((g.num_edges, K), dtype=torch.float32, device=dev)
-        _lib.check(
-            lib.tfgnn_rgat_edge_attention(
-                ops._ptr(g.array(ops.G_NODEPTR_BY_DST)), ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(s_src),
-                ops._ptr(s_tgt), V, L, K, ops._ptr(att), ops._stream(),
-            )
-        )
+        att = self._edge_attention(g, s_src, s_tgt, K)
         act = self._activation_name
         fused = None if act == "gelu" else act
         if L == 0 or g.num_edges == 0:
@@ -116,6 +110,36 @@ class RGAT(MessagePassing):
         ctx["out"] = out
         self._ctx = ctx
         return out
+
+    @staticmethod
+    def _ident(g, n):
+        ident = g._cache.get("ident_e")
+        if ident is None or ident.numel() < n + 1:
+            ident = torch.arange(n + 1, dtype=torch.int32, device=g.device)
+            g._cache["ident_e"] = ident
+        return ident
+
+    def _edge_attention(self, g, s_src, s_tgt, K):
+        """a[e,k]: per head, softmax over all edges entering the target (rgat.py:142-151).  Edge-parallel
+        kernels + two generic segment reductions over the node view (identity columns)."""
+        lib = _lib.load()
+        E, V, L = g.num_edges, g.num_nodes, g.num_edge_types
+        dev = s_src.device
+        att = torch.empty((E, K), dtype=torch.float32, device=dev)
+        if E == 0:
+            return att
+        coll, tgt = g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST)
+        ident = self._ident(g, E)[:E]
+        scores = torch.empty((E, K), dtype=torch.float32, device=dev)
+        _lib.check(lib.tfgnn_rgat_edge_scores(ops._ptr(coll), ops._ptr(tgt), ops._ptr(s_src), ops._ptr(s_tgt), E, L, K,
+                                              ops._ptr(scores), ops._stream()))
+        m = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, scores, col=ident, reduce=ops.REDUCE_MAX)  # [V, K]
+        _lib.check(lib.tfgnn_rgat_edge_node_op(ops._ptr(scores), ops._ptr(tgt), ops._ptr(m), E, K, 0, ops._ptr(scores),
+                                               ops._stream()))  # in place: p = exp(score - m[tgt])
+        den = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, scores, col=ident)  # [V, K]
+        _lib.check(lib.tfgnn_rgat_edge_node_op(ops._ptr(scores), ops._ptr(tgt), ops._ptr(den), E, K, 1, ops._ptr(att),
+                                               ops._stream()))
+        return att
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(out) -> d(loss)/d(node_embeddings); fills the kernel / attention gradients."""
@@ -139,12 +163,9 @@ class RGAT(MessagePassing):
                 v.grad = torch.zeros_like(v.value)
             return torch.zeros_like(X)
         s2d = g.array(ops.G_SRC2DST_POS)
-        ident_e = g._cache.get("ident_e")
-        if ident_e is None:
-            ident_e = torch.arange(E + 1, dtype=torch.int32, device=dev)
-            g._cache["ident_e"] = ident_e
+        ident_e = self._ident(g, E)
         # (1) dY[(u,l),k,:] = sum over out-edges e of (u,l): a_ek * d_agg[tgt_e, k, :]
-        att_s = ops.gather_reduce(ident_e, s2d, att)  # attention re-ordered to the by-src edge order
+        att_s = ops.gather_reduce(ident_e[: E + 1], s2d, att)  # attention re-ordered to the by-src edge order
         dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]
         # (2) gradient w.r.t. the attention values, softmax + leaky_relu backward
         da = torch.empty((E, K), dtype=torch.float32, device=dev)
@@ -154,11 +175,12 @@ class RGAT(MessagePassing):
                 ops._ptr(d_agg), E, K, H, ops._ptr(da), ops._stream(),
             )
         )
+        t = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, ops.mul(att, da), col=ident_e[:E])  # [V, K] sum of a * da
         dz = torch.empty((E, K), dtype=torch.float32, device=dev)
         _lib.check(
-            lib.tfgnn_rgat_attention_backward(
-                ops._ptr(g.array(ops.G_NODEPTR_BY_DST)), ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(s_src),
-                ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), V, L, K, ops._ptr(dz), ops._stream(),
+            lib.tfgnn_rgat_edge_softmax_backward(
+                ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(s_src),
+                ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), ops._ptr(t), E, L, K, ops._ptr(dz), ops._stream(),
             )
         )
         # (3) logits are s_src[(src,l)] + s_tgt[(tgt,l)]: segment sums of dz over both bucketings

@@ -381,7 +381,10 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x, ld = _rowmajor(x, "x")
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(lib.tfgnn_colsum(_ptr(x), x.shape[0], x.shape[1], ld, _ptr(out), _stream()))
+    ws_bytes = lib.tfgnn_colsum_workspace_bytes(x.shape[0], x.shape[1])
+    ws = _workspace(x.device, ws_bytes) if ws_bytes else None
+    _lib.check(lib.tfgnn_colsum(_ptr(x), x.shape[0], x.shape[1], ld, _ptr(out), _ptr(ws),
+                                ws.numel() if ws is not None else 0, _stream()))
     return out
 
 
