@@ -214,6 +214,19 @@ int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const 
                const float* d_bias, int act, int accumulate, void* d_workspace,
                size_t workspace_bytes, void* stream);
 
+/* How tfgnn_gemm evaluates the fp32 product (process-wide; initial value from the environment variable
+ * TFGNN_GEMM_MODE = fp32 | bf16x3 | bf16x3_9):
+ *   TFGNN_GEMM_FP32          v_mfma_f32_32x32x2_f32 on the fp32 operands (default)
+ *   TFGNN_GEMM_BF16X3        every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and
+ *                            the six largest piece products - each exact in fp32 - are accumulated in fp32 on
+ *                            v_mfma_f32_32x32x16_bf16; dropped terms are < 2^-23 |a b| (csrc/gemm_x3.hip)
+ *   TFGNN_GEMM_BF16X3_EXACT  all nine piece products: products exact, only the fp32 accumulation rounds
+ * Inputs, outputs and accumulators are fp32 in every mode.  The split modes cover the N % 320 == 0 shapes of
+ * the hot path (NN, NT, TN layouts); other shapes run the fp32 kernel whatever the mode. */
+enum { TFGNN_GEMM_FP32 = 0, TFGNN_GEMM_BF16X3 = 6, TFGNN_GEMM_BF16X3_EXACT = 9 };
+int tfgnn_gemm_set_mode(int mode);
+int tfgnn_gemm_get_mode(void);
+
 /* Grouped forms of the Dense layer for the per-relation multiply over NON-EMPTY buckets only (rows of
  * the stacked operand are grouped by edge type: group g owns rows [d_group_offsets[g],
  * d_group_offsets[g+1]), TFGNN_G_NZ_OFF_*; max_group_rows bounds the launch grid):

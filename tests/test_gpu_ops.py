@@ -34,6 +34,77 @@ def test_gemm_matches_fp64(dev, ta, tb, M, N, K):
     assert_close(out.cpu() / scale, (ref / scale).float(), tol=2e-6, what=f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
 
 
+@pytest.fixture
+def gemm_mode():
+    from tf2_gnn_amd import ops
+
+    prev = ops.get_gemm_mode()
+    yield ops.set_gemm_mode
+    ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_9"])
+@pytest.mark.parametrize(
+    "ta,tb,M,N,K",
+    [
+        (False, False, 1000, 320, 1280),  # forward: [V, L*D] @ [L*D, H]
+        (False, True, 1000, 320, 1280),   # dX:  G_cat @ Wh^T
+        (True, False, 320, 1280, 5000),   # dW:  X^T @ G_cat (split-K)
+        (False, False, 129, 640, 68),     # ragged M tile, K tail
+        (True, False, 324, 320, 100),     # ragged M with K-major A, K tail
+        (False, True, 7, 320, 64),
+    ],
+)
+def test_gemm_bf16x3_matches_fp64(dev, gemm_mode, mode, ta, tb, M, N, K):
+    """fp32 GEMM on the bf16 matrix cores via exact operand splitting (csrc/gemm_x3.hip): same 1e-5-class
+    bound against fp64 as the fp32-MFMA kernel, on operands that use all 24 significand bits."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    gemm_mode("fp32")
+    out32 = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    gemm_mode(mode)
+    out = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    out_b = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    assert torch.equal(out, out_b)
+    scale = max(1.0, float(K) ** 0.5)
+    assert_close(out.cpu() / scale, (ref / scale).float(), tol=2e-6, what=f"x3 gemm {M}x{N}x{K} ta={ta} tb={tb}")
+    e32 = (out32.cpu().double() - ref).abs().max().item()
+    e3 = (out.cpu().double() - ref).abs().max().item()
+    print(f"max|err| vs fp64: fp32-mfma {e32:.3e}  {mode} {e3:.3e}")
+    assert e3 <= 4.0 * e32 + 1e-6
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_9"])
+def test_gemm_bf16x3_epilogue_and_exactness(dev, gemm_mode, mode):
+    from tf2_gnn_amd import ops
+
+    gemm_mode(mode)
+    # integers: every piece product and every partial sum is exact -> bit-exact result, transposes detected
+    g = torch.Generator().manual_seed(11)
+    # (|a b| K < 2^24; 9-bit values exercise the h and m planes)
+    A = torch.randint(-400, 400, (200, 96), generator=g).float()
+    B = torch.randint(-400, 400, (96, 320), generator=g).float()
+    ref = (A.double() @ B.double())
+    out = ops.gemm(A.to(dev), B.to(dev))
+    assert torch.equal(out.cpu().double(), ref)
+    outT = ops.gemm(A.t().contiguous().to(dev), B.to(dev), trans_a=True)
+    outBT = ops.gemm(A.to(dev), B.t().contiguous().to(dev), trans_b=True)
+    assert torch.equal(out, outT) and torch.equal(out, outBT)
+    # bias + activation + accumulate into a strided output
+    bias = torch.randn(320, generator=g)
+    A = torch.randn((200, 96), generator=g)
+    B = torch.randn((96, 320), generator=g)
+    wide = torch.ones((200, 400), device=dev)
+    ops.gemm(A.to(dev), B.to(dev), bias=bias.to(dev), act="relu", out=wide[:, 40:360], accumulate=True)
+    ref = torch.relu(A.double() @ B.double() + bias.double()) + 1.0
+    assert_close(wide[:, 40:360].cpu(), ref.float(), tol=5e-6, what="x3 epilogue")
+    assert torch.all(wide[:, :40] == 1) and torch.all(wide[:, 360:] == 1)
+
+
 def test_gemm_asymmetric_identity(dev):
     """transpose-detecting check (A = I, asymmetric B)."""
     from tf2_gnn_amd import ops

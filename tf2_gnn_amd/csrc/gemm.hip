@@ -412,7 +412,24 @@ static bool operands_vectorisable(int trans_a, int trans_b, int64_t M, int64_t N
   return a16 && b16 && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0);
 }
 
+// gemm_x3.hip
+int gemm_x3_mode();
+int gemm_x3_set_mode(int mode);
+int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
+                void* workspace, size_t workspace_bytes, hipStream_t s, int* status);
+
 }  // namespace tfgnn
+
+extern "C" int tfgnn_gemm_set_mode(int mode) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(mode == TFGNN_GEMM_FP32 || mode == TFGNN_GEMM_BF16X3 || mode == TFGNN_GEMM_BF16X3_EXACT,
+                "unknown GEMM mode %d", mode);
+  gemm_x3_set_mode(mode);
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_gemm_get_mode(void) { return tfgnn::gemm_x3_mode(); }
 
 extern "C" size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   using namespace tfgnn;
@@ -435,6 +452,12 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   TFGNN_REQUIRE(K == 0 || (d_A && d_B), "A or B is NULL");
   TFGNN_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
   hipStream_t s = (hipStream_t)stream;
+  if (const int nprod = gemm_x3_mode()) {
+    int status = TFGNN_OK;
+    if (gemm_x3_try(nprod, trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, d_bias, act, accumulate,
+                    d_workspace, d_workspace ? workspace_bytes : 0, s, &status))
+      return status;
+  }
   const bool vec = K > 0 && operands_vectorisable(trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb);
   GemmPlan p = plan_gemm(M, N, K, d_workspace ? workspace_bytes : 0, vec);
   GemmArgs g;

@@ -280,6 +280,24 @@ def graph_gather(
     return out
 
 
+GEMM_FP32, GEMM_BF16X3, GEMM_BF16X3_EXACT = 0, 6, 9
+_GEMM_MODE_NAMES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "bf16x3_9": GEMM_BF16X3_EXACT}
+
+
+def set_gemm_mode(mode) -> int:
+    """Select how ``gemm`` evaluates the fp32 product (include/tfgnn.h, tfgnn_gemm_set_mode): "fp32" (fp32 MFMA),
+    "bf16x3" (exact 3-way bf16 split of both operands, 6 piece products) or "bf16x3_9" (all 9).  Returns the
+    previous mode id."""
+    lib = _lib.load()
+    prev = lib.tfgnn_gemm_get_mode()
+    _lib.check(lib.tfgnn_gemm_set_mode(_GEMM_MODE_NAMES.get(mode, mode)))
+    return prev
+
+
+def get_gemm_mode() -> int:
+    return _lib.load().tfgnn_gemm_get_mode()
+
+
 def gemm(
     a: torch.Tensor,
     b: torch.Tensor,
