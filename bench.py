@@ -29,6 +29,14 @@ import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_FP32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
+GEMM_MODE_NOTES = {
+    "fp32": "fp32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
+    "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 largest piece products (each exact in fp32), fp32 "
+    "accumulate on v_mfma_f32_32x32x16_bf16; fp32 in/out; max error vs fp64 measured equal to the fp32-MFMA kernel "
+    "(tests/test_gpu_ops.py::test_gemm_bf16x3_matches_fp64)",
+    "bf16x3_9": "bf16x3_9: as bf16x3 with all 9 piece products (products exact, only the fp32 accumulation rounds)",
+}
 
 WORKLOADS = {
     # BASELINE.json configs[1] shape + metric's model (RGCN H=320, 4 layers, PPI_RGCN.json hypers)
@@ -141,6 +149,10 @@ def main():
     ap.add_argument("--serial-bucketing", action="store_true", help="bucket each batch on the compute stream (no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-mode", default="bf16x3", choices=["fp32", "bf16x3", "bf16x3_9"],
+                    help="how the fp32 GEMMs run on the matrix cores (include/tfgnn.h, tfgnn_gemm_set_mode): fp32 MFMA, "
+                    "or exact bf16 operand splitting with 6 / 9 piece products (fp32 in, fp32 accumulate, fp32 out)")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timing in the other GEMM mode")
     args = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,19 +215,23 @@ def main():
     def barrier():
         parallel.barrier(dist)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for g_ in pending:  # the batch prepared for the step after the last one
-        g_.wait()
-        g_.close()
-    pending.clear()
-    elapsed = parallel.reduce_max(elapsed, dist, dev)
+    def timed(warmup, steps):
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        for g_ in pending:  # the batch prepared for the step after the last one
+            g_.wait()
+            g_.close()
+        pending.clear()
+        return parallel.reduce_max(dt, dist, dev)
+
+    ops.set_gemm_mode(args.gemm_mode)
+    elapsed = timed(args.warmup, args.steps)
     # final metric reduction: all-gather of the per-rank edge counts (north_star: the only collective)
     total_edges_per_step = float(parallel.all_gather_scalars([float(E)], dist, dev)[:, 0].sum())
     ms_per_step = 1000.0 * elapsed / args.steps
@@ -238,8 +254,20 @@ def main():
             "workload": f"{args.workload}: V={V} E={E} edge_types={L} D={D} H={H} layers={NL} RGCN (PPI_RGCN.json hypers), "
             f"step = edge bucketing{' (hoisted)' if args.reuse_graph else (' (on the compute stream)' if args.serial_bucketing else ' of the next batch (2nd stream, overlapped)')} + GNN fwd + full bwd, one batch per GPU",
             "per_layer_traversal_rate_edges_per_s": value * NL,
+            "gemm_mode": GEMM_MODE_NOTES[args.gemm_mode],
         },
     }
+    if not args.no_alt_mode:
+        # the same job with the GEMMs in the other evaluation mode, for reference (not the headline value)
+        alt = "fp32" if args.gemm_mode != "fp32" else "bf16x3"
+        ops.set_gemm_mode(alt)
+        alt_steps = max(3, args.steps // 2)
+        alt_elapsed = timed(2, alt_steps)
+        ops.set_gemm_mode(args.gemm_mode)
+        result["config"]["alt_gemm_mode"] = {
+            "gemm_mode": GEMM_MODE_NOTES[alt], "steps": alt_steps, "ms_per_step": 1000.0 * alt_elapsed / alt_steps,
+            "value": total_edges_per_step * alt_steps / alt_elapsed,
+        }
 
     if rank == 0 and not args.no_roofline:
         # ---- dominant kernels, measured live on the launch stream -------------------------------
@@ -250,7 +278,11 @@ def main():
         W = torch.randn((L * H, H), device=dev) * 0.05
         out = torch.empty((V, H), device=dev)
         ms_gather = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
-        ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
+        if args.gemm_mode == "fp32":
+            ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
+        else:  # the layers hand the split-operand kernel W^T (gnn_edge_mlp.py:_forward_A)
+            Wt = W.t().contiguous()
+            ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), Wt, trans_b=True, act="relu", out=out))
         ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
         # algorithmic bytes of one gather launch: one fp32 source row + one int32 col per
         # edge, the row pointer and scale once, one output row per (node, type) bucket
@@ -267,11 +299,21 @@ def main():
             "frac": gather_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_gather,
             "algorithmic_bytes_per_launch": gather_bytes, "share_of_step": share_gather,
         }
+        if args.gemm_mode == "fp32":
+            gemm_kernel = "gemm_mfma_kernel<4,2,1,5> 128x320 tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)"
+            gemm_peak, executed = MFMA_FP32_PEAK_TFLOPS, gemm_tflops
+        else:
+            # every fp32 product is evaluated as 6 (9) exact bf16 piece products: the matrix cores execute
+            # 6x (9x) the algorithmic flops, priced against the dense bf16 MFMA peak
+            nprod = 6 if args.gemm_mode == "bf16x3" else 9
+            gemm_kernel = (f"gemm_x3_kernel 128x320 tile ([V, L*H] x [H, L*H]^T + relu, {nprod} x v_mfma_f32_32x32x16_bf16 "
+                           "per fp32 k16 step on exactly split operands)")
+            gemm_peak, executed = MFMA_BF16_PEAK_TFLOPS, gemm_tflops * nprod
         roof_gemm = {
-            "kernel": "gemm_mfma_kernel<4,2,1,5> 128x320 tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)",
-            "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": gemm_tflops / MFMA_FP32_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_gemm,
-            "algorithmic_flops_per_launch": gemm_flops, "share_of_step": share_gemm,
+            "kernel": gemm_kernel,
+            "bound": "mfma", "achieved": executed, "peak": gemm_peak, "unit": "TFLOP/s",
+            "frac": executed / gemm_peak, "traffic": None, "ms_per_launch": ms_gemm,
+            "algorithmic_flops_per_launch": gemm_flops, "algorithmic_tflops": gemm_tflops, "share_of_step": share_gemm,
         }
         # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_probe.py, tools/parse_pmc.py;
         # FETCH_SIZE corrected x2 as calibrated on gfx950), committed under profiles/

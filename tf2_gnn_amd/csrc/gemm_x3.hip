@@ -51,6 +51,7 @@ struct X3Args {
   int splits;
   float* partial;
   unsigned n_tiles;
+  int debug;  // TFGNN_GEMM_DEBUG probe bits: 1 = no split/store/fetch in the loop, 2 = no multiply (results wrong)
 };
 
 // exact 3-way split of an fp32 value into bf16 pieces (upper halves of h, m, l)
@@ -270,12 +271,12 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3_kernel(X3Args g) {
       // sched_barrier: keep the splitting arithmetic (and the wait for its global loads) out of the multiply phase
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      multiply(cur);
+      if (!(g.debug & 2)) multiply(cur);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      stage_next(cur ^ 1 ^ grp, k_end - k0 - (2 + grp) * X3_BK);
+      if (!(g.debug & 1)) stage_next(cur ^ 1 ^ grp, k_end - k0 - (2 + grp) * X3_BK);
       __syncthreads();
     }
     if (grp == 0) __syncthreads();  // the second group ran one more phase
@@ -393,6 +394,10 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     }
   }
   g.partial = (float*)workspace;
+  {
+    static const int dbg = [] { const char* e = getenv("TFGNN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    g.debug = dbg;
+  }
   dim3 grid((unsigned)tiles, 1, (unsigned)g.splits);
   if (!trans_a && !trans_b) launch_x3<false, true>(g, grid, nprod, s);       // B stored [K, N]: K-major
   else if (!trans_a && trans_b) launch_x3<false, false>(g, grid, nprod, s);  // B stored [N, K]

@@ -261,7 +261,13 @@ class GNN_Edge_MLP(MessagePassing):
             k, ident_ptr, node_of_row = target_multiplier(g, row_scale)
             ops.gather_reduce(ident_ptr, node_of_row, X, edge_weight=k, out=Arows[:, D:])
         gelu_split = fuse_act == "gelu"
-        pre = ops.gemm(A, W.view(L * Din, H), act=None if gelu_split else fuse_act)
+        act = None if gelu_split else fuse_act
+        if ops.get_gemm_mode() != ops.GEMM_FP32:
+            # the split-operand kernel stages K-contiguous operands fastest: hand it W^T ([H, L*Din], 1.6 MB copy)
+            Wt = ops.permute_021(W.view(L * Din, H, 1)).view(H, L * Din)
+            pre = ops.gemm(A, Wt, trans_b=True, act=act)
+        else:
+            pre = ops.gemm(A, W.view(L * Din, H), act=act)
         ctx = {"path": "A", "A": A, "fused_act": fuse_act}
         if gelu_split:
             ctx["pre"] = pre
