@@ -306,7 +306,7 @@ def main():
             # every fp32 product is evaluated as 6 (9) exact bf16 piece products: the matrix cores execute
             # 6x (9x) the algorithmic flops, priced against the dense bf16 MFMA peak
             nprod = 6 if args.gemm_mode == "bf16x3" else 9
-            gemm_kernel = (f"gemm_x3_kernel 128x320 tile ([V, L*H] x [H, L*H]^T + relu, {nprod} x v_mfma_f32_32x32x16_bf16 "
+            gemm_kernel = (f"gemm_x3s_kernel 128x320 tile, 4 multiplying + 4 staging waves ([V, L*H] x [H, L*H]^T + relu, {nprod} x v_mfma_f32_32x32x16_bf16 "
                            "per fp32 k16 step on exactly split operands)")
             gemm_peak, executed = MFMA_BF16_PEAK_TFLOPS, gemm_tflops * nprod
         roof_gemm = {

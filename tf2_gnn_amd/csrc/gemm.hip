@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
       for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PS + li] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");  // LDS only: never wait for the previous tile's global stores
         __builtin_amdgcn_wave_barrier();
         const int64_t col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
 #pragma unroll

@@ -11,17 +11,17 @@
 // computation carried out on bf16 hardware, not a bf16 GEMM: inputs and outputs stay fp32 and the
 // parity bound (1e-5 vs the fp64 oracle) is tested for it like for the fp32-MFMA path.
 //
-// Structure: 8 waves (4 x 2) on a 128 x 320 tile like gemm.hip; BK = 16 (one MFMA k-step), two LDS
-// stages.  Operands are split while being staged into LDS: three bf16 planes per operand, rows of
-// 16 k + 8 pad = 48 bytes, so that a lane's 8 consecutive k - one MFMA operand - is one aligned,
-// conflict-free ds_read_b128.  Operands whose K index is contiguous in memory are staged row-wise;
-// operands stored K-major ([K, M] / [K, N]) are transposed in registers (a thread loads 4 k rows of a
-// 4-wide column strip and writes 4 LDS rows of 4 k).
-// The two waves that share a SIMD run in opposite phases ("ping-pong"): waves 0-3 multiply tile t while
-// waves 4-7 split/store tile t+1 and fetch tile t+2, then the roles swap - the matrix pipe always has one
-// wave feeding it and the splitting arithmetic runs in its shadow (two barriers per K tile).
+// Structure: a 128 x 320 output tile per 512-thread workgroup, BK = 16 (one MFMA k-step), a ring of three
+// LDS stages.  Operands are split while being staged into LDS: three bf16 planes per operand, unpadded
+// 32-byte rows (16 k) with the two 16-byte halves XOR-swizzled by bit 3 of the row, so that a lane's 8
+// consecutive k - one MFMA operand - is one aligned, conflict-free ds_read_b128.  Operands whose K index is
+// contiguous in memory are staged row-wise; operands stored K-major ([K, M] / [K, N]) are transposed in
+// registers (a thread loads 4 k rows of a 4-wide column strip and writes 4 LDS rows of 4 k).
+// Two kernels share this layout (launch_x3 picks): gemm_x3s_kernel (waves 0-3 multiply, waves 4-7 stage)
+// and gemm_x3p_kernel (all eight waves do both, software-pipelined).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -33,7 +33,6 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
 constexpr int X3_BK = 16;
-constexpr int X3_ROW = 24;  // bf16 elements per LDS row (16 + 8 pad): 48 bytes
 constexpr int X3_BM = 128, X3_BN = 320, X3_NT = 512;
 
 struct X3Args {
@@ -83,87 +82,6 @@ __device__ __forceinline__ void split_store4(float x0, float x1, float x2, float
   *reinterpret_cast<uint2v*>(d + 2 * plane_stride) = vl;
 }
 
-// ---- staging ------------------------------------------------------------------------------------
-// KC: operand stored [MN_total, K] (k contiguous).  item id = tid + NT p: row id >> 2, k quad id & 3.
-template <int MN>
-struct StageKC {
-  static constexpr int ITEMS = MN * 4;
-  static constexpr int NP = (ITEMS + X3_NT - 1) / X3_NT;
-  float4 r[NP];
-  const float* ptr[NP];
-  bool ok[NP];
-  __device__ __forceinline__ void init(const float* src, int64_t ld, int64_t mn0, int64_t mn_total, int64_t k_begin, int tid, int) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int id = tid + X3_NT * p;
-      const int64_t mn = mn0 + (id >> 2);
-      ok[p] = id < ITEMS && mn < mn_total;
-      ptr[p] = src + (ok[p] ? mn : 0) * ld + k_begin + (id & 3) * 4;
-    }
-  }
-  __device__ __forceinline__ void load(int64_t k_left, int64_t, int tid) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok[p] && ((tid + X3_NT * p) & 3) * 4 < k_left) v = *reinterpret_cast<const float4*>(ptr[p]);
-      r[p] = v;
-      ptr[p] += X3_BK;
-    }
-  }
-  __device__ __forceinline__ void store(unsigned short* planes, int tid) const {  // planes: [3][MN][X3_ROW]
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int id = tid + X3_NT * p;
-      if (id < ITEMS)
-        split_store4(r[p].x, r[p].y, r[p].z, r[p].w, planes + (id >> 2) * X3_ROW + (id & 3) * 4, MN * X3_ROW);
-    }
-  }
-};
-
-// KM: operand stored [K, MN_total] (mn contiguous).  item id = tid - first: k group id & 3 (4 k rows), column
-// strip id >> 2 (4 mn); a thread loads the 4 x 4 block and writes 4 LDS rows of 4 k each.
-template <int MN>
-struct StageKM {
-  static constexpr int ITEMS = MN;
-  float4 r[4];
-  const float* ptr;
-  bool ok, mine;
-  int id;
-  __device__ __forceinline__ void init(const float* src, int64_t ld, int64_t mn0, int64_t mn_total, int64_t k_begin, int tid, int first) {
-    id = tid - first;
-    mine = id >= 0 && id < ITEMS;
-    const int64_t mn = mn0 + (id >> 2) * 4;
-    ok = mine && mn < mn_total;  // mn_total % 4 == 0: a strip is fully in or out
-    ptr = src + (k_begin + (id & 3) * 4) * ld + (ok ? mn : 0);
-  }
-  __device__ __forceinline__ void load(int64_t k_left, int64_t ld, int) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok && (id & 3) * 4 + i < k_left) v = *reinterpret_cast<const float4*>(ptr + i * ld);
-      r[i] = v;
-    }
-    ptr += (int64_t)X3_BK * ld;
-  }
-  __device__ __forceinline__ void store(unsigned short* planes, int) const {
-    if (!mine) return;
-    unsigned short* d = planes + ((id >> 2) * 4) * X3_ROW + (id & 3) * 4;
-    split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, MN * X3_ROW);
-    split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d + X3_ROW, MN * X3_ROW);
-    split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d + 2 * X3_ROW, MN * X3_ROW);
-    split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d + 3 * X3_ROW, MN * X3_ROW);
-  }
-};
-
-template <int MN, bool KM>
-struct StageSel {
-  using type = StageKC<MN>;
-};
-template <int MN>
-struct StageSel<MN, true> {
-  using type = StageKM<MN>;
-};
-
 __device__ __forceinline__ bf16x8 frag8(const unsigned short* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(p));
 }
@@ -185,23 +103,193 @@ __device__ __forceinline__ floatx16 mfma_group(floatx16 c, bf16x8 ah, bf16x8 am,
   return c;
 }
 
-// A_KM: A stored [K, M] (trans_a) ; B_KM: B stored [K, N] (no trans_b)
+// =====================================================================================================
+// Pipelined variant: three LDS stages of unpadded, XOR-swizzled 32-byte rows, all 8 waves symmetric, one
+// barrier per K tile.  Iteration t multiplies tile t (stage t%3) while it splits/stores tile t+2 into
+// stage (t+2)%3 and fetches tile t+3 into registers; the first operands of tile t+1 (complete since the
+// previous barrier) are read before the barrier, so the matrix pipe restarts immediately after it.  The
+// staging code is branch-free (clamped addresses, a per-plane trash area for threads without an item) so
+// that the whole iteration is one scheduling region in which the splitting arithmetic is interleaved with
+// the MFMAs.
+// Plane layout (ushort units): [A rows 0..127 | B rows 128..447 | trash], row = 16 k; 16-byte half h of row
+// r is stored at half h ^ ((r >> 3) & 1).
+constexpr int X3_VALU_PER_MFMA = 5;
+constexpr int P_ROW = 16;
+constexpr int P_TRASH = 320;
+constexpr int P_PLANE = (X3_BM + X3_BN) * P_ROW + P_TRASH;  // 7488 ushorts
+constexpr int P_STAGE = 3 * P_PLANE;                        // 22464 ushorts = 44928 bytes
+constexpr int P_TRASH_OFF = (X3_BM + X3_BN) * P_ROW;
+
+__device__ __forceinline__ int swz_off(int row, int kq) {  // ushort offset of k quad kq (4 k) of plane row `row`
+  return row * P_ROW + ((((kq >> 1) ^ (row >> 3)) & 1) << 3) + ((kq & 1) << 2);
+}
+
+// K-contiguous operand: item = (row, k quad); one float4
+struct SlotKC {
+  const float* ptr;
+  const float* ptr0;
+  int lds_off;
+  int kofs;
+  float4 r;
+  __device__ __forceinline__ void init(const float* src, int64_t ld, int64_t mn0, int64_t mn_total, int64_t k_begin,
+                                       int id, int items, int row_base, int lane) {
+    const bool valid = id < items;
+    const int row = valid ? id >> 2 : 0, kq = valid ? id & 3 : 0;
+    int64_t mn = mn0 + row;
+    if (mn > mn_total - 1) mn = mn_total - 1;  // rows past the edge: any valid row (their outputs are never stored)
+    kofs = kq * 4;
+    ptr0 = ptr = src + mn * ld + k_begin + kofs;
+    lds_off = valid ? swz_off(row_base + row, kq) : P_TRASH_OFF + lane * 4;
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+    if (MASKED) {
+      const bool inb = kofs < k_left;
+      const float4 v = *reinterpret_cast<const float4*>(inb ? ptr : ptr0);
+      r.x = inb ? v.x : 0.f; r.y = inb ? v.y : 0.f; r.z = inb ? v.z : 0.f; r.w = inb ? v.w : 0.f;
+    } else {
+      r = *reinterpret_cast<const float4*>(ptr);
+    }
+    ptr += adv * X3_BK;
+  }
+  __device__ __forceinline__ void skip() { ptr += X3_BK; }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    split_store4(r.x, r.y, r.z, r.w, stage + lds_off, P_PLANE);
+  }
+};
+
+// K-major operand: item = (4-column strip, group of 4 k rows); four float4, transposed in registers
+struct SlotKM {
+  const float* ptr;
+  const float* ptr0;
+  int64_t ld;
+  int lds_off;
+  int kofs;
+  float4 r[4];
+  __device__ __forceinline__ void init(const float* src, int64_t ld_, int64_t mn0, int64_t mn_total, int64_t k_begin,
+                                       int id, int items, int row_base, int lane) {
+    const bool valid = id >= 0 && id < items;
+    const int kg = valid ? id & 3 : 0, strip = valid ? id >> 2 : 0;
+    int64_t mn = mn0 + strip * 4;
+    if (mn > mn_total - 4) mn = mn_total - 4;  // mn_total % 4 == 0
+    ld = ld_;
+    kofs = kg * 4;
+    ptr0 = ptr = src + (k_begin + kofs) * ld + mn;
+    lds_off = valid ? swz_off(row_base + strip * 4, kg) : P_TRASH_OFF + lane * 4;
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (MASKED) {
+        const bool inb = kofs + i < k_left;
+        const float4 v = *reinterpret_cast<const float4*>(inb ? ptr + i * ld : ptr0);
+        r[i].x = inb ? v.x : 0.f; r[i].y = inb ? v.y : 0.f; r[i].z = inb ? v.z : 0.f; r[i].w = inb ? v.w : 0.f;
+      } else {
+        r[i] = *reinterpret_cast<const float4*>(ptr + i * ld);
+      }
+    }
+    ptr += (int64_t)(adv * X3_BK) * ld;
+  }
+  __device__ __forceinline__ void skip() { ptr += (int64_t)X3_BK * ld; }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    unsigned short* d = stage + lds_off;  // rows strip*4 + j share (row >> 3) & 1: the swizzle term is the same
+    split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, P_PLANE);
+    split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d + P_ROW, P_PLANE);
+    split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d + 2 * P_ROW, P_PLANE);
+    split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d + 3 * P_ROW, P_PLANE);
+  }
+  template <int J>
+  __device__ __forceinline__ void store_row(unsigned short* stage) const {
+    unsigned short* d = stage + lds_off + J * P_ROW;
+    if (J == 0) split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, P_PLANE);
+    if (J == 1) split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d, P_PLANE);
+    if (J == 2) split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d, P_PLANE);
+    if (J == 3) split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d, P_PLANE);
+  }
+};
+
+// the staging work of one thread for one K tile, per operand layout pair
+template <bool A_KM, bool B_KM>
+struct Stager;
+template <>
+struct Stager<false, false> {  // NT: A 512 items (one per thread), B 1280 items (2.5 per thread)
+  SlotKC a, b0, b1, b2;
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
+    const int lane = tid & 63;
+    a.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM * 4, 0, lane);
+    b0.init(g.B, g.ldb, n0, g.N, k_begin, tid, X3_BN * 4, X3_BM, lane);
+    b1.init(g.B, g.ldb, n0, g.N, k_begin, tid + X3_NT, X3_BN * 4, X3_BM, lane);
+    b2.init(g.B, g.ldb, n0, g.N, k_begin, tid + 2 * X3_NT, X3_BN * 4, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+    a.load<MASKED>(k_left, adv); b0.load<MASKED>(k_left, adv); b1.load<MASKED>(k_left, adv); b2.load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() { a.skip(); b0.skip(); b1.skip(); b2.skip(); }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    a.store(stage); b0.store(stage); b1.store(stage); b2.store(stage);
+  }
+  template <int PIECE>
+  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
+    if (PIECE == 0) a.store(stage);
+    if (PIECE == 1) b0.store(stage);
+    if (PIECE == 2) b1.store(stage);
+    if (PIECE == 3) b2.store(stage);
+  }
+};
+template <>
+struct Stager<false, true> {  // NN: A 512 K-contiguous items, B 320 K-major items
+  SlotKC a;
+  SlotKM b;
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
+    const int lane = tid & 63;
+    a.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM * 4, 0, lane);
+    b.init(g.B, g.ldb, n0, g.N, k_begin, tid, X3_BN, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+    a.load<MASKED>(k_left, adv); b.load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() { a.skip(); b.skip(); }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    a.store(stage); b.store(stage);
+  }
+  template <int PIECE>
+  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
+    if (PIECE == 0) a.store(stage);
+    if (PIECE >= 1) b.template store_row<PIECE - 1>(stage);
+  }
+};
+template <>
+struct Stager<true, true> {  // TN: one K-major item per thread - A items on threads [0,128), B items on [128,448)
+  SlotKM s;
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
+    const int lane = tid & 63;
+    if (tid < X3_BM) s.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM, 0, lane);
+    else s.init(g.B, g.ldb, n0, g.N, k_begin, tid - X3_BM, X3_BN, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) { s.load<MASKED>(k_left, adv); }
+  __device__ __forceinline__ void skip() { s.skip(); }
+  __device__ __forceinline__ void store(unsigned short* stage) const { s.store(stage); }
+  template <int PIECE>
+  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
+    if (PIECE < 4) s.template store_row<PIECE>(stage);
+  }
+};
+
 template <bool A_KM, bool B_KM, int NPROD>
-__global__ void __launch_bounds__(X3_NT) gemm_x3_kernel(X3Args g) {
-  constexpr int WN_ = 2, TN = 5;
-  using SA = typename StageSel<X3_BM, A_KM>::type;
-  using SB = typename StageSel<X3_BN, B_KM>::type;
-  constexpr int PLANE_A = X3_BM * X3_ROW, PLANE_B = X3_BN * X3_ROW;
-  constexpr int STAGE = 3 * (PLANE_A + PLANE_B);  // ushorts
+__global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
+  constexpr int TN = 5;
   constexpr int PATCH_FLOATS = (X3_NT / 64) * 32 * 36;
-  static_assert(2 * STAGE * 2 >= PATCH_FLOATS * 4, "epilogue patch must fit in the stage buffers");
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
+  static_assert(3 * P_STAGE * 2 >= PATCH_FLOATS * 4, "epilogue patch must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * P_STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;  // waves 0-3 (one per SIMD) and 4-7 form the two phase groups
-  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  const int wm = wave & 3, wn = wave >> 2;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
   const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * X3_BN;
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
@@ -215,74 +303,69 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3_kernel(X3Args g) {
 
   const int li = lane & 31, lk = lane >> 5;
   if (k_begin < k_end) {
-    SA sa;
-    SB sb;
-    // K-major operands: one item per thread; A items on threads [0,128), B items on [128,448) when both are K-major
-    sa.init(g.A, g.lda, m0, g.M, k_begin, tid, 0);
-    sb.init(g.B, g.ldb, n0, g.N, k_begin, tid, A_KM ? X3_BM : 0);
-    const int a_frag = (wm * 32 + li) * X3_ROW + lk * 8;
-    const int b_frag = 3 * PLANE_A + (wn * TN * 32 + li) * X3_ROW + lk * 8;
+    Stager<A_KM, B_KM> st;
+    st.init(g, m0, n0, k_begin, tid);
+    const int half = (lk ^ (li >> 3)) & 1;
+    const int a_frag = (wm * 32 + li) * P_ROW + half * 8;
+    const int b_frag = (X3_BM + wn * TN * 32 + li) * P_ROW + half * 8;
+    const int64_t k_len = k_end - k_begin;
+    const int T = (int)((k_len + X3_BK - 1) / X3_BK);
 
-    auto multiply = [&](int stage) {
-      const unsigned short* base = lds + stage * STAGE;
-      const bf16x8 ah = frag8(base + a_frag);
-      const bf16x8 am = frag8(base + a_frag + PLANE_A);
-      const bf16x8 al = frag8(base + a_frag + 2 * PLANE_A);
-      bf16x8 bh = frag8(base + b_frag);
-      bf16x8 bm = frag8(base + b_frag + PLANE_B);
-      bf16x8 bl = frag8(base + b_frag + 2 * PLANE_B);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bf16x8 nh = bh, nm = bm, nl = bl;
-        if (j + 1 < TN) {  // next column tile's operands fly under this tile's MFMAs
-          const unsigned short* nb = base + b_frag + (j + 1) * 32 * X3_ROW;
-          nh = frag8(nb);
-          nm = frag8(nb + PLANE_B);
-          nl = frag8(nb + 2 * PLANE_B);
-        }
-        acc[j] = mfma_group<NPROD>(acc[j], ah, am, al, bh, bm, bl);
-        bh = nh; bm = nm; bl = nl;
-      }
-    };
-    auto stage_next = [&](int stage, int64_t k_next_left) {  // registers (tile t+1) -> LDS, then fetch tile t+2
-      unsigned short* base = lds + stage * STAGE;
-      sa.store(base, tid);
-      sb.store(base + 3 * PLANE_A, tid);
-      sa.load(k_next_left, g.lda, tid);
-      sb.load(k_next_left, g.ldb, tid);
-    };
-
-    // Phase schedule (one barrier between phases; M = multiply tile t, S = split/store a later tile + fetch):
-    //   waves 0-3:  M0 S  M1 S  M2 ...     S stores tile t+1 into stage (t+1)&1, fetches tile t+2
-    //   waves 4-7:  S' M0 S  M1 S  ...     S stores tile t+2 into stage t&1,     fetches tile t+3
-    // i.e. the second group runs the same loop one phase late and stages one tile further ahead; every
-    // stage is complete a full phase before anyone multiplies from it and is overwritten only after both
-    // groups have multiplied from it.
-    sa.load(k_end - k_begin, g.lda, tid);
-    sb.load(k_end - k_begin, g.ldb, tid);
-    stage_next(0, k_end - k_begin - X3_BK);  // tile 0 -> stage 0; registers <- tile 1
+    // prologue: tiles 0, 1 -> stages 0, 1; registers <- tile 2
+    st.template load<true>(k_len, 1);
+    st.store(lds);
+    st.template load<true>(k_len - X3_BK, 1);
+    st.store(lds + P_STAGE);
+    st.template load<true>(k_len - 2 * X3_BK, 1);
     __syncthreads();
-    if (grp == 1) {
-      stage_next(1, k_end - k_begin - 2 * X3_BK);  // S': tile 1 -> stage 1; registers <- tile 2
+    bf16x8 ah = frag8(lds + a_frag), am = frag8(lds + a_frag + P_PLANE), al = frag8(lds + a_frag + 2 * P_PLANE);
+    bf16x8 bh = frag8(lds + b_frag), bm = frag8(lds + b_frag + P_PLANE), bl = frag8(lds + b_frag + 2 * P_PLANE);
+
+    int s_cur = 0, s_nxt = P_STAGE, s_st = 2 * P_STAGE;  // stage of tile t, t+1, t+2
+    // One iteration = 5 chunks (one per 32-column tile of the wave): the split/store of one piece of tile
+    // t+2, the operand reads of the next column tile, 6 (9) MFMAs.  sched_barrier keeps the chunks apart so
+    // that the splitting arithmetic stays spread over the iteration; `from` holds tile t+2, the fetch of
+    // tile t+3 goes to the other register set `to` first and has the whole iteration to land.
+    auto iteration = [&](auto masked, int64_t left3, const Stager<A_KM, B_KM>& from, Stager<A_KM, B_KM>& to) {
+      constexpr bool MASKED = decltype(masked)::value;
+      to.template load<MASKED>(left3, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned short* dst = lds + s_st;
+      const unsigned short* cur = lds + s_cur;
+      const unsigned short* nxs = lds + s_nxt;
+      bf16x8 nh, nm, nl;
+#define X3P_CHUNK(J)                                                                        \
+      from.template store_piece<J>(dst);                                                    \
+      if (J + 1 < TN) {                                                                     \
+        const unsigned short* nb = cur + b_frag + (J + 1) * 32 * P_ROW;                     \
+        nh = frag8(nb); nm = frag8(nb + P_PLANE); nl = frag8(nb + 2 * P_PLANE);             \
+      } else { /* first operands of tile t+1 (complete since the previous barrier) */       \
+        nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + P_PLANE); nl = frag8(nxs + b_frag + 2 * P_PLANE); \
+      }                                                                                     \
+      acc[J] = mfma_group<NPROD>(acc[J], ah, am, al, bh, bm, bl);                           \
+      bh = nh; bm = nm; bl = nl;                                                            \
+      __builtin_amdgcn_sched_barrier(0);
+      X3P_CHUNK(0) X3P_CHUNK(1) X3P_CHUNK(2) X3P_CHUNK(3) X3P_CHUNK(4)
+#undef X3P_CHUNK
+      ah = frag8(nxs + a_frag); am = frag8(nxs + a_frag + P_PLANE); al = frag8(nxs + a_frag + 2 * P_PLANE);
       __syncthreads();
+      const int s = s_cur; s_cur = s_nxt; s_nxt = s_st; s_st = s;
+    };
+    Stager<A_KM, B_KM> st2 = st;  // two register sets, each fetching every second tile: st2 tiles 3, 5, ...;
+    st.skip();                    // st (holding tile 2) continues with 4, 6, ...
+    int t = 0;
+    const int t_fast = (int)(k_len / X3_BK) - 3;  // iterations whose fetched tile t+3 is a full tile
+    for (; t + 1 < t_fast; t += 2) {
+      iteration(std::false_type{}, 0, st, st2);
+      iteration(std::false_type{}, 0, st2, st);
     }
-    int cur = 0;
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += X3_BK, cur ^= 1) {
-      // sched_barrier: keep the splitting arithmetic (and the wait for its global loads) out of the multiply phase
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (!(g.debug & 2)) multiply(cur);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(g.debug & 1)) stage_next(cur ^ 1 ^ grp, k_end - k0 - (2 + grp) * X3_BK);
-      __syncthreads();
+    for (; t < T; t += 2) {
+      iteration(std::true_type{}, k_len - (int64_t)(t + 3) * X3_BK, st, st2);
+      if (t + 1 < T) iteration(std::true_type{}, k_len - (int64_t)(t + 4) * X3_BK, st2, st);
     }
-    if (grp == 0) __syncthreads();  // the second group ran one more phase
   }
 
-  // epilogue (same wide-store scheme as gemm.hip): C/D layout col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+  // epilogue: as above
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
@@ -292,7 +375,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3_kernel(X3Args g) {
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PS + li] = acc[j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     const int64_t col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
 #pragma unroll
@@ -321,6 +404,285 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3_kernel(X3Args g) {
   }
 }
 
+// =====================================================================================================
+// Specialised variant: waves 0-3 (one per SIMD) only multiply - each owns a 64 x 160 block of the
+// 128 x 320 tile (2 x 5 MFMA tiles, 160 accumulator registers) - and waves 4-7 (their SIMD partners)
+// only fetch, split and store.  Per fp32 MAC the splitting costs ~5.5 VALU issue slots per element
+// staged; an MFMA leaves room for about five other instructions of the same SIMD, so mixing the two in
+// one wave (the pipelined variant above) is issue-bound.  Here the multiplying wave issues one MFMA
+// per 32 cycles plus a ds_read every second MFMA, and its partner's VALU work runs beside it.
+// Same three-stage LDS ring and one barrier per K tile as the pipelined variant.
+constexpr int S_PT = 256;  // producer threads
+
+template <bool A_KM, bool B_KM>
+struct Producer;
+template <>
+struct Producer<false, false> {  // NT: A 512 items, B 1280 items of one float4 -> 2 + 5 per producer thread
+  SlotKC a[2], b[5];
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
+    const int lane = ptid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].init(g.A, g.lda, m0, g.M, k_begin, ptid + S_PT * i, X3_BM * 4, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, X3_BN * 4, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].load<MASKED>(k_left, adv);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i].load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].skip();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i].skip();
+  }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].store(stage);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i].store(stage);
+  }
+};
+template <>
+struct Producer<false, true> {  // NN: A 512 K-contiguous items (2 per thread), B 320 K-major items (2 slots, 64 real in the 2nd)
+  SlotKC a[2];
+  SlotKM b[2];
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
+    const int lane = ptid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].init(g.A, g.lda, m0, g.M, k_begin, ptid + S_PT * i, X3_BM * 4, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, X3_BN, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].load<MASKED>(k_left, adv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i].load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a[i].skip(); b[i].skip(); }
+  }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i].store(stage);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i].store(stage);
+  }
+};
+template <>
+struct Producer<true, true> {  // TN: 128 + 320 K-major items over 256 threads: items [0,128) are A strips, [128,448) B strips
+  SlotKM s[2];
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
+    const int lane = ptid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = ptid + S_PT * i;
+      if (id < X3_BM) s[i].init(g.A, g.lda, m0, g.M, k_begin, id, X3_BM, 0, lane);
+      else s[i].init(g.B, g.ldb, n0, g.N, k_begin, id - X3_BM, X3_BN, X3_BM, lane);
+    }
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s[i].load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s[i].skip();
+  }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s[i].store(stage);
+  }
+};
+
+template <bool A_KM, bool B_KM, int NPROD>
+__global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
+  constexpr int TM = 2, TN = 5;
+  constexpr int EP_LD = 164;  // floats per row of an epilogue block (160 + 4 pad)
+  static_assert(3 * P_STAGE * 2 >= 4 * 32 * EP_LD * 4, "epilogue blocks must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * P_STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool multiplier = wave < 4;
+  const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
+  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * X3_BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+  const int64_t k_len = k_end - k_begin;
+  const int T = k_len > 0 ? (int)((k_len + X3_BK - 1) / X3_BK) : 0;
+  const int wm = wave & 1, wn = (wave >> 1) & 1;
+  const int li = lane & 31, lk = lane >> 5;
+  long long probe_c0 = 0, probe_w0 = 0;
+  if (g.debug & 4) {
+    probe_c0 = clock64();
+    probe_w0 = wall_clock64();
+  }
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (!multiplier && T > 0) {
+    // ------------------------------- producer waves -------------------------------
+    Producer<A_KM, B_KM> p0;
+    p0.init(g, m0, n0, k_begin, tid - S_PT);
+    p0.template load<true>(k_len, 1);
+    p0.store(lds);
+    p0.template load<true>(k_len - X3_BK, 1);
+    p0.store(lds + P_STAGE);
+    // three register sets in rotation: the fetch of tile t+4 is issued at the top of iteration t and is split /
+    // stored two iterations later (tile u by set u % 3; each set's pointers advance three tiles per fetch)
+    Producer<A_KM, B_KM> p1 = p0;
+    p1.skip();
+    Producer<A_KM, B_KM> p2 = p1;
+    p2.skip();
+    p0.template load<true>(k_len - 2 * X3_BK, 3);
+    p1.template load<true>(k_len - 3 * X3_BK, 3);
+    __syncthreads();
+    int s_st = 2 * P_STAGE;  // stage of tile t+2
+    auto iteration = [&](auto masked, int64_t left4, const Producer<A_KM, B_KM>& from, Producer<A_KM, B_KM>& to) {
+      constexpr bool MASKED = decltype(masked)::value;
+      if (!(g.debug & 1)) to.template load<MASKED>(left4, 3);  // tile t+4
+      __builtin_amdgcn_sched_barrier(0);   // fetches first: two iterations to land
+      if (!(g.debug & 2)) from.store(lds + s_st);              // tile t+2
+      __syncthreads();
+      s_st = s_st == 2 * P_STAGE ? 0 : s_st + P_STAGE;
+    };
+    int t = 0;
+    const int t_fast = (int)(k_len / X3_BK) - 4;  // iterations whose fetched tile t+4 is a full tile
+    for (; t + 2 < t_fast; t += 3) {
+      iteration(std::false_type{}, 0, p0, p2);
+      iteration(std::false_type{}, 0, p1, p0);
+      iteration(std::false_type{}, 0, p2, p1);
+    }
+    for (; t < T; t += 3) {
+      iteration(std::true_type{}, k_len - (int64_t)(t + 4) * X3_BK, p0, p2);
+      if (t + 1 < T) iteration(std::true_type{}, k_len - (int64_t)(t + 5) * X3_BK, p1, p0);
+      if (t + 2 < T) iteration(std::true_type{}, k_len - (int64_t)(t + 6) * X3_BK, p2, p1);
+    }
+  } else if (multiplier && T > 0) {
+    // --------------------------------- multiplying waves ---------------------------------
+    const int half = (lk ^ (li >> 3)) & 1;
+    const int a_frag = (wm * 64 + li) * P_ROW + half * 8;
+    const int b_frag = (X3_BM + wn * TN * 32 + li) * P_ROW + half * 8;
+    __builtin_amdgcn_s_setprio(2);
+    __syncthreads();  // tiles 0 and 1 are in stages 0 and 1
+    if (g.debug & 8) {
+      probe_c0 = clock64();
+      probe_w0 = wall_clock64();
+    }
+    bf16x8 ah[TM], am[TM], al[TM], bh, bm, bl;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = frag8(lds + a_frag + i * 32 * P_ROW);
+      am[i] = frag8(lds + a_frag + i * 32 * P_ROW + P_PLANE);
+      al[i] = frag8(lds + a_frag + i * 32 * P_ROW + 2 * P_PLANE);
+    }
+    bh = frag8(lds + b_frag); bm = frag8(lds + b_frag + P_PLANE); bl = frag8(lds + b_frag + 2 * P_PLANE);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): enter the loop with no LDS read pending, as every back edge does
+    int s_cur = 0, s_nxt = P_STAGE;
+    for (int t = 0; t < T; ++t) {
+      const unsigned short* cur = lds + s_cur;
+      const unsigned short* nxs = lds + s_nxt;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8 nh, nm, nl;
+        if (j + 1 < TN) {
+          const unsigned short* nb = cur + b_frag + (j + 1) * 32 * P_ROW;
+          nh = frag8(nb); nm = frag8(nb + P_PLANE); nl = frag8(nb + 2 * P_PLANE);
+        } else {  // first operands of tile t+1 (complete since the previous barrier)
+          nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + P_PLANE); nl = frag8(nxs + b_frag + 2 * P_PLANE);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the reads above stay a full MFMA group (12 x 32 cycles) ahead of their use
+        // the two row tiles alternate: consecutive MFMAs never hit the same accumulator; smallest terms first
+#define X3S_PAIR(PA, PB)                                                                   \
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[0], PB, acc[0][j], 0, 0, 0); \
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[1], PB, acc[1][j], 0, 0, 0);
+        if (NPROD >= 9) { X3S_PAIR(al, bl) }
+        if (NPROD >= 8) { X3S_PAIR(am, bl) X3S_PAIR(al, bm) }
+        X3S_PAIR(al, bh) X3S_PAIR(ah, bl) X3S_PAIR(am, bm) X3S_PAIR(am, bh) X3S_PAIR(ah, bm) X3S_PAIR(ah, bh)
+#undef X3S_PAIR
+        bh = nh; bm = nm; bl = nl;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = frag8(nxs + a_frag + i * 32 * P_ROW);
+        am[i] = frag8(nxs + a_frag + i * 32 * P_ROW + P_PLANE);
+        al[i] = frag8(nxs + a_frag + i * 32 * P_ROW + 2 * P_PLANE);
+      }
+      __syncthreads();
+      s_cur = s_nxt;
+      s_nxt = s_nxt == 2 * P_STAGE ? 0 : s_nxt + P_STAGE;
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0) {
+    long long* pr = reinterpret_cast<long long*>(g.partial) + 4 * blockIdx.x;
+    pr[0] = clock64() - probe_c0;
+    pr[1] = probe_w0;
+    pr[2] = wall_clock64();
+  }
+
+  // Epilogue in two rounds of 32 rows per multiplying wave: the accumulators go to LDS as four 32 x 160
+  // blocks, then all eight waves stream them out with bias / activation / accumulate applied in a compact
+  // loop (row-contiguous 16-byte stores; no wait on earlier stores anywhere).
+  const bool split = g.splits > 1;
+  float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldo = split ? g.N : g.ldc;
+  float* ep = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (multiplier) {
+      float* blk = ep + wave * 32 * EP_LD;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) blk[((r & 3) + 8 * (r >> 2) + 4 * lk) * EP_LD + j * 32 + li] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int f = tid; f < 4 * 32 * 40; f += X3_NT) {
+      const int b = f / 1280, rem = f - b * 1280;
+      const int row = rem / 40, c4 = rem - row * 40;
+      const int64_t grow = m0 + (b & 1) * 64 + i * 32 + row;
+      const int64_t gcol = n0 + (b >> 1) * 160 + c4 * 4;
+      if (grow < g.M) {
+        float4 v = *reinterpret_cast<const float4*>(ep + (b * 32 + row) * EP_LD + c4 * 4);
+        float* dst = outp + grow * ldo + gcol;
+        if (!split) {
+          if (g.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(g.bias + gcol);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y);
+          v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+          if (g.accumulate) {
+            const float4 c4v = *reinterpret_cast<const float4*>(dst);
+            v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
+          }
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+    }
+    __syncthreads();
+  }
+  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0)
+    reinterpret_cast<long long*>(g.partial)[4 * blockIdx.x + 3] = wall_clock64();
+}
+
 __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
   const int64_t total = g.M * g.N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -335,10 +697,23 @@ __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
   }
 }
 
+// The specialised kernel wins where at least one operand is K-contiguous (NT 140 vs 160 us, NN 68 vs 72 us on the
+// hot-path shapes); with two K-major operands its four producer waves cannot keep up with the register transposes
+// and the pipelined kernel is faster (185 vs 207 us).  TFGNN_X3_KERNEL=spec|pipe overrides.
 template <bool A_KM, bool B_KM>
 static void launch_x3(const X3Args& g, dim3 grid, int nprod, hipStream_t s) {
-  if (nprod >= 9) hipLaunchKernelGGL((gemm_x3_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
-  else hipLaunchKernelGGL((gemm_x3_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
+  static const int which = [] {
+    const char* e = getenv("TFGNN_X3_KERNEL");
+    return !e ? 0 : (!strcmp(e, "spec") ? 1 : (!strcmp(e, "pipe") ? 2 : 0));
+  }();
+  const bool spec = which == 1 || (which == 0 && !(A_KM && B_KM));
+  if (spec) {
+    if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
+  } else {
+    if (nprod >= 9) hipLaunchKernelGGL((gemm_x3p_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3p_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
+  }
 }
 
 // 0 = off (fp32 MFMA), 6 / 9 = number of piece products.  Initialised from TFGNN_GEMM_MODE

@@ -48,8 +48,10 @@ if int(os.environ.get("TFGNN_GEMM_DEBUG", "0")) & 4:
     import ctypes
     lib = _lib.load()
     ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    Wt = W.t().contiguous()
     for name, (M, N, K, a, b, ta, tb) in {
         "fwd": (V, H, L * H, A, W, 0, 0),
+        "fwdT": (V, H, L * H, A, Wt, 0, 1),
     }.items():
         for _ in range(3):
             lib.tfgnn_gemm(ta, tb, M, N, K, ctypes.c_void_p(a.data_ptr()), a.stride(0), ctypes.c_void_p(b.data_ptr()), b.stride(0),
@@ -62,3 +64,4 @@ if int(os.environ.get("TFGNN_GEMM_DEBUG", "0")) & 4:
         mhz = c[:, 0] / (c[:, 2] - c[:, 1]) * 100.0
         print(f"{name}: {nb} workgroups; start skew max {start.max():.1f} us; main loop {float((loop_end-start).min()):.1f}/{float((loop_end-start).mean()):.1f}/{float((loop_end-start).max()):.1f} us (min/mean/max); "
               f"epilogue {float((end-loop_end).min()):.1f}/{float((end-loop_end).mean()):.1f}/{float((end-loop_end).max()):.1f} us; last end {end.max():.1f} us; clock {float(mhz.mean()):.0f} MHz")
+
