@@ -215,9 +215,25 @@ def main():
     def barrier():
         parallel.barrier(dist)
 
+    def settle(max_batches=40, batch=10, tol=0.03):
+        """Untimed extra warm-up: run short batches until two consecutive ones take the same time (clocks and
+        allocator pools settled); keeps a cold / ramping device out of the timed region."""
+        prev = None
+        for _ in range(max_batches):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(batch):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if prev is not None and abs(dt - prev) <= tol * prev:
+                return
+            prev = dt
+
     def timed(warmup, steps):
         for _ in range(warmup):
             step()
+        settle()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -351,6 +351,10 @@ int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, const float* d
  * (one bias-free kernel per edge type, gnn_edge_mlp.py:73-81) so that a layer's backward pass is two
  * large GEMMs. */
 int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float* d_dst, void* stream);
+/* [batch, rows, cols] -> [batch, cols, rows] (LDS-tiled).  Used to hand the GEMMs K-contiguous weights
+ * (W^T of gnn_edge_mlp.py:100 / rgcn.py:52-56 kernels) and to bring dW^T = G^T X back to the [L, D, H] layout. */
+int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_t rows, int64_t cols, float* d_dst,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,16 @@ def test_gemm_bf16x3_epilogue_and_exactness(dev, gemm_mode, mode):
     assert torch.all(wide[:, :40] == 1) and torch.all(wide[:, 360:] == 1)
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 64, 32), (4, 320, 320), (2, 33, 100), (1, 1280, 320)])
+def test_transpose_batched(dev, shape):
+    from tf2_gnn_amd import ops
+
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(sum(shape)))
+    out = ops.transpose_batched(x.to(dev))
+    assert torch.equal(out.cpu(), x.transpose(1, 2).contiguous())
+    assert torch.equal(ops.transpose_batched(x[0].to(dev)).cpu(), x[0].t().contiguous())
+
+
 def test_gemm_asymmetric_identity(dev):
     """transpose-detecting check (A = I, asymmetric B)."""
     from tf2_gnn_amd import ops

@@ -402,3 +402,40 @@ extern "C" int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
+
+// ---- batched 2-D transpose -----------------------------------------------------------------------
+namespace tfgnn {
+__global__ void __launch_bounds__(256)
+transpose_batched_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z;
+  const float* s = src + b * rows * cols;
+  float* d = dst + b * rows * cols;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * i][tx] = s[r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) d[c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_t rows, int64_t cols, float* d_dst,
+                                       void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(batch >= 0 && rows >= 0 && cols >= 0, "negative size");
+  if (batch * rows * cols == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_src && d_dst, "NULL pointer");
+  TFGNN_REQUIRE(batch < 65536 && ceil_div(rows, 32) < 65536, "transpose grid too large");
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, d_dst);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

@@ -264,7 +264,7 @@ class GNN_Edge_MLP(MessagePassing):
         act = None if gelu_split else fuse_act
         if ops.get_gemm_mode() != ops.GEMM_FP32:
             # the split-operand kernel stages K-contiguous operands fastest: hand it W^T ([H, L*Din], 1.6 MB copy)
-            Wt = ops.permute_021(W.view(L * Din, H, 1)).view(H, L * Din)
+            Wt = ops.transpose_batched(W.view(L * Din, H))
             pre = ops.gemm(A, Wt, trans_b=True, act=act)
         else:
             pre = ops.gemm(A, W.view(L * Din, H), act=act)
@@ -554,6 +554,12 @@ class GNN_Edge_MLP(MessagePassing):
             #   dX = [G_0|...|G_{L-1}] @ [W_0|...|W_{L-1}]^T      dW_h = X^T @ [G_0|...|G_{L-1}]
             Wh = ops.permute_021(W)  # [Din, L, H]
             G2 = G.view(V, L * H)
+            if L > 0 and not self._use_target_state_as_input:
+                # dW^T = G^T X [L*H, D]: ten full 128-row output tiles instead of the 2.5 x 4 ragged ones of X^T G
+                ops.gemm(G2, Wh.view(D, L * H), trans_b=True, out=dX)
+                mlps.grads = [ops.transpose_batched(ops.gemm(G2, X, trans_a=True).view(L, H, D))]
+                mlps.publish_grads()
+                return dX
             dWh = torch.empty((Din, L, H), dtype=torch.float32, device=X.device)
             if L == 0:
                 dX.zero_()

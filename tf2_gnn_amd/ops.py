@@ -475,6 +475,20 @@ def permute_021(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def transpose_batched(x: torch.Tensor) -> torch.Tensor:
+    """[B, R, C] -> [B, C, R] (contiguous copy); a 2-D input is one batch."""
+    lib = _lib.load()
+    _require_dev(x, torch.float32, "x")
+    x = x.contiguous()
+    squeeze = x.dim() == 2
+    if squeeze:
+        x = x.unsqueeze(0)
+    B, R, C = x.shape
+    out = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    _lib.check(lib.tfgnn_transpose_batched(_ptr(x), B, R, C, _ptr(out), _stream()))
+    return out[0] if squeeze else out
+
+
 def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=False, act=ACT_NONE, out=None):
     """out[rows g] = act(a[rows g] @ op(b_stack[g])) for row groups [off[g], off[g+1]).
     b_stack: [G, K, N] (or [G, N, K] with trans_b)."""
