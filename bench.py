@@ -337,7 +337,9 @@ def main():
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             roof_gather["traffic"] = pmc["gather"]["hbm_bytes_per_launch"]
-            roof_gemm["traffic"] = pmc["gemm"]["hbm_bytes_per_launch"]
+            key = "gemm" if args.gemm_mode == "fp32" else "gemm_bf16x3"
+            if key in pmc:
+                roof_gemm["traffic"] = pmc[key]["hbm_bytes_per_launch"]
             roof_gather["traffic_source"] = roof_gemm["traffic_source"] = os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))
         if share_gemm >= share_gather:
             result["roofline"], result["roofline_secondary"] = roof_gemm, roof_gather

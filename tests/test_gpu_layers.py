@@ -163,10 +163,13 @@ BWD_CASES = [
 @pytest.mark.parametrize("name,cls_name,over", BWD_CASES, ids=[c[0] for c in BWD_CASES])
 def test_layer_backward_parity(dev, name, cls_name, over):
     """explicit HIP backward == torch autograd through the fp64 oracle (stand-in for tf.GradientTape)."""
+    check_layer_backward(dev, name, cls_name, over, V=120, E=1500, L=3, H=32)
+
+
+def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     from tf2_gnn_amd.layers import MessagePassingInput
 
-    V, L, H = 120, 3, 32
-    adjs = random_graph(V, 1500, L, seed=4, hub=(2, 150))
+    adjs = random_graph(V, E, L, seed=4, hub=(2, min(150, V // 2)))
     layer, p = _build(cls_name, dict(over, hidden_dim=H), H, L)
     g = torch.Generator().manual_seed(11)
     X = torch.randn((V, H), generator=g)

@@ -36,7 +36,9 @@ cal_w = pick(write, "act_forward_kernel") * 1024.0
 kf, kw = known / cal_f, known / cal_w
 res = {"calibration": {"known_bytes_each_way": known, "fetch_raw_bytes": cal_f, "write_raw_bytes": cal_w,
                        "fetch_factor": kf, "write_factor": kw}}
-for name, needle in (("gather", "csr_gather_reduce_kernel"), ("gemm", "gemm_mfma_kernel")):
+for name, needle in (("gather", "csr_gather_reduce_kernel"), ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel")):
+    if pick(fetch, needle) is None:
+        continue
     f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0
     res[name] = {"fetch_raw_bytes": f, "write_raw_bytes": w, "hbm_bytes_per_launch": f * kf + w * kw}
 json.dump(res, open(sys.argv[3], "w"), indent=1)

@@ -22,9 +22,13 @@ out = torch.empty((V, H), device=dev)
 big = torch.randn(V * L * H, device=dev)  # 153.6 MB
 big2 = torch.empty_like(big)
 rs = g.array(ops.G_INVDEG_BY_DST)
+Wt = W.t().contiguous()
 for _ in range(5):
     ops.activation_forward("relu", big, out=big2)  # calibration: 153.6 MB read + 153.6 MB written
     ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, out=A)
+    ops.set_gemm_mode("fp32")
     ops.gemm(A.view(V, L * H), W, act="relu", out=out)
+    ops.set_gemm_mode("bf16x3")  # the same product on the split-operand kernel (W^T, as the layers call it)
+    ops.gemm(A.view(V, L * H), Wt, trans_b=True, act="relu", out=out)
 torch.cuda.synchronize()
 print("pmc probe done")
