@@ -195,6 +195,20 @@ int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t*
 int tfgnn_edge_pair_combine(const int32_t* d_index_a, const int32_t* d_index_b, const float* d_P,
                             const float* d_Q, int64_t num_edges, int width, int act, float* d_out,
                             void* stream);
+
+/* Backward through a general aggregation, i.e. the cases the sum-only algebra does not cover:
+ * aggregation_function "max" (utils/param_helpers.py:11) and message_activation_before_aggregation
+ * (message_passing.py:169-172).  Forward: agg[t,:] = node_scale[t] * REDUCE_{e->t} pre_act(w_e * msg[row_e,:])
+ * (tfgnn_graph_gather_reduce).  Per edge, in the order of d_target / d_msg_row / d_edge_weight:
+ *   phase 0 (max):  d_out[e,:] = 1 where the edge attains the maximum of its target, else 0
+ *                   (segment-sum it to get d_num_selected: TF splits the gradient evenly among ties [ext])
+ *   phase 1:        d_out[e,:] = d(loss)/d(msg[row_e,:]) through edge e
+ * d_msg_row NULL = identity (messages already per edge); d_agg_max / d_num_selected only for max. */
+int tfgnn_edge_aggregate_backward(int64_t num_edges, int64_t width, const float* d_msg, int64_t ld_msg,
+                                  const int32_t* d_msg_row, const int32_t* d_target, const float* d_edge_weight,
+                                  const float* d_node_scale, int pre_act, int reduce_op, const float* d_grad_agg,
+                                  const float* d_agg_max, const float* d_num_selected, int phase, float* d_out,
+                                  void* stream);
 int tfgnn_graph_original_order(const tfgnn_graph* graph, const float* d_weight_by_dst, int32_t* d_src_l,
                                int32_t* d_tgt_l, int32_t* d_tgt_node, float* d_weight, void* stream);
 

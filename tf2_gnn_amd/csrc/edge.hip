@@ -91,3 +91,80 @@ extern "C" int tfgnn_graph_original_order(const tfgnn_graph* g, const float* d_w
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
+
+// ---- backward through a general aggregation ---------------------------------------------------------
+// forward (spmm.hip, MODE_GENERAL):  agg[t, :] = node_scale[t] * REDUCE_{e -> t} pre_act( w_e * msg[row_e, :] )
+// phase 0 (max only): out[e, :] = 1 where the edge attains the maximum of its target, else 0
+// phase 1: out[e, :] = d(loss)/d(msg[row_e, :]) contributed by edge e
+//   sum: g = grad_agg[t] * node_scale[t];   max: g = selected ? grad_agg[t] / num_selected[t] : 0
+//        (the gradient of tf.math.unsorted_segment_max is split evenly among ties [ext])
+//   out = g * pre_act'(w_e * msg) * w_e
+namespace tfgnn {
+struct EdgeAggBwdArgs {
+  int64_t E;
+  int width;
+  const float* msg;
+  int64_t ld_msg;
+  const int32_t* msg_row;
+  const int32_t* target;
+  const float* edge_weight;
+  const float* node_scale;
+  int pre_act;
+  int is_max;
+  const float* grad_agg;
+  const float* agg_max;
+  const float* num_selected;
+  float* out;
+  int phase;
+};
+
+__global__ void __launch_bounds__(256) edge_aggregate_backward_kernel(EdgeAggBwdArgs a) {
+  const int64_t total = a.E * a.width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / a.width;
+    const int c = (int)(i - e * a.width);
+    const int64_t row = a.msg_row ? a.msg_row[e] : e;
+    const int64_t t = a.target[e];
+    const float w = a.edge_weight ? a.edge_weight[e] : 1.f;
+    const float u = w * a.msg[row * a.ld_msg + c];
+    const float z = act_apply(a.pre_act, u);
+    const bool selected = !a.is_max || z == a.agg_max[t * a.width + c];
+    float r;
+    if (a.phase == 0) {
+      r = selected ? 1.f : 0.f;
+    } else {
+      float gsel;
+      if (a.is_max) gsel = selected ? a.grad_agg[t * a.width + c] / a.num_selected[t * a.width + c] : 0.f;
+      else gsel = a.grad_agg[t * a.width + c] * (a.node_scale ? a.node_scale[t] : 1.f);
+      const float da = a.pre_act == TFGNN_ACT_NONE ? 1.f : act_grad(a.pre_act, a.pre_act == TFGNN_ACT_GELU ? u : z);
+      r = gsel * da * w;
+    }
+    a.out[i] = r;
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_edge_aggregate_backward(int64_t num_edges, int64_t width, const float* d_msg, int64_t ld_msg,
+                                             const int32_t* d_msg_row, const int32_t* d_target,
+                                             const float* d_edge_weight, const float* d_node_scale, int pre_act,
+                                             int reduce_op, const float* d_grad_agg, const float* d_agg_max,
+                                             const float* d_num_selected, int phase, float* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && width >= 0 && width < (1 << 30), "bad size");
+  TFGNN_REQUIRE(phase == 0 || phase == 1, "phase must be 0 or 1");
+  TFGNN_REQUIRE(reduce_op == TFGNN_REDUCE_SUM || reduce_op == TFGNN_REDUCE_MAX, "unknown reduce op");
+  if (num_edges == 0 || width == 0) return TFGNN_OK;
+  const bool is_max = reduce_op == TFGNN_REDUCE_MAX;
+  TFGNN_REQUIRE(d_msg && d_target && d_out && ld_msg >= width, "NULL pointer / bad leading dimension");
+  TFGNN_REQUIRE(phase == 0 ? is_max : d_grad_agg != nullptr, "phase 0 is for max aggregation; phase 1 needs grad_agg");
+  TFGNN_REQUIRE(!is_max || (d_agg_max && (phase == 0 || d_num_selected)), "max aggregation needs agg_max (+ num_selected)");
+  EdgeAggBwdArgs a;
+  a.E = num_edges; a.width = (int)width; a.msg = d_msg; a.ld_msg = ld_msg; a.msg_row = d_msg_row; a.target = d_target;
+  a.edge_weight = d_edge_weight; a.node_scale = d_node_scale; a.pre_act = pre_act; a.is_max = is_max ? 1 : 0;
+  a.grad_agg = d_grad_agg; a.agg_max = d_agg_max; a.num_selected = d_num_selected; a.out = d_out; a.phase = phase;
+  const int64_t total = num_edges * width;
+  hipLaunchKernelGGL(edge_aggregate_backward_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 8)),
+                     dim3(256), 0, (hipStream_t)stream, a);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

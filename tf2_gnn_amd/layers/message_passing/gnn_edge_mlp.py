@@ -182,6 +182,53 @@ class GNN_Edge_MLP(MessagePassing):
             return self._forward_B(X, g, fuse_act)
         return self._forward_C(X, g, fuse_act)
 
+    # ---- general aggregation (max / activation before aggregation) ----------------------------------
+    def _agg_general(self) -> bool:
+        return self._aggregation_name == "max" or self._pre_activation()
+
+    def _gather_messages(self, g, msgs, col, ew_d, node_scale, fuse_act, ctx):
+        """act?( node_scale * REDUCE_{e -> v} pre_act?( w_e * msgs[col_e] ) ) over the by-dst node view; keeps what
+        the backward pass of a max aggregation needs (the raw maxima)."""
+        is_max = self._aggregation_name == "max"
+        pre = self._activation_name if self._pre_activation() else None
+        gelu_split = fuse_act == "gelu"
+        separate_post = is_max and fuse_act is not None and not gelu_split
+        out = ops.graph_gather(
+            g, ops.VIEW_BY_DST_NODE, msgs, col=col, edge_weight=ew_d, row_scale=node_scale,
+            reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM, pre_act=pre,
+            post_act=None if (gelu_split or separate_post) else fuse_act,
+        )
+        if is_max:
+            ctx["agg_max"] = out
+        if gelu_split:
+            ctx["pre"] = out
+            return ops.activation_forward("gelu", out)
+        if separate_post:
+            return ops.activation_forward(fuse_act, out)
+        return out
+
+    def _message_grads(self, g, d_agg, ctx, msgs, msg_row, target, ew, node_scale, sel_col):
+        """d(loss)/d(message of every edge) [E, H], in the edge order of msg_row / target / ew
+        (csrc/edge.hip tfgnn_edge_aggregate_backward); sel_col maps by-dst positions to rows of that order."""
+        pre = self._activation_name if self._pre_activation() else None
+        d_agg = d_agg.contiguous()
+        if self._aggregation_name == "max":
+            sel = ops.edge_aggregate_backward(msgs, target, None, msg_row=msg_row, edge_weight=ew, pre_act=pre,
+                                              reduce=ops.REDUCE_MAX, agg_max=ctx["agg_max"], phase=0)
+            nsel = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, sel, col=sel_col)  # ties share the gradient evenly
+            return ops.edge_aggregate_backward(msgs, target, d_agg, msg_row=msg_row, edge_weight=ew, pre_act=pre,
+                                               reduce=ops.REDUCE_MAX, agg_max=ctx["agg_max"], num_selected=nsel)
+        return ops.edge_aggregate_backward(msgs, target, d_agg, msg_row=msg_row, edge_weight=ew, node_scale=node_scale,
+                                           pre_act=pre, reduce=ops.REDUCE_SUM)
+
+    @staticmethod
+    def _ident_e(g):
+        ident = g._cache.get("ident_e")
+        if ident is None or ident.numel() < g.num_edges + 1:
+            ident = torch.arange(g.num_edges + 1, dtype=torch.int32, device=g.device)
+            g._cache["ident_e"] = ident
+        return ident
+
     # Buckets (node, type) that received no edge contribute nothing: 45 % of them are empty on an R-MAT
     # batch, and the dense multiply can run over the non-empty ones only (grouped GEMMs over compact
     # rows).  Measured on MI355X (profiles/r01e_compact_kernel_stats.csv): 45 % fewer FLOPs buy only
@@ -319,18 +366,8 @@ class GNN_Edge_MLP(MessagePassing):
         if colc is None:
             colc = g.array(ops.G_NZ_CPOS_BY_SRC)[g.array(ops.G_COLL_BY_DST).long()].contiguous()
             g._cache["compact_src_col_by_dst"] = colc
-        is_max = self._aggregation_name == "max"
-        pre = self._activation_name if self._pre_activation() else None
-        gelu_split = fuse_act == "gelu"
-        out = ops.graph_gather(
-            g, ops.VIEW_BY_DST_NODE, cur, col=colc, edge_weight=ew_d, row_scale=node_scale,
-            reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM, pre_act=pre, post_act=None if gelu_split else fuse_act,
-        )
-        ctx = {"path": "Bc", "fused_act": fuse_act, "Xc": Xc, "mlp_acts": acts}
-        if gelu_split:
-            ctx["pre"] = out
-            return ops.activation_forward("gelu", out), ctx
-        return out, ctx
+        ctx = {"path": "Bc", "fused_act": fuse_act, "Xc": Xc, "mlp_acts": acts, "colc": colc}
+        return self._gather_messages(g, cur, colc, ew_d, node_scale, fuse_act, ctx), ctx
 
     def _backward_B_compact(self, d_agg, ctx):
         g = ctx["graph"]
@@ -340,7 +377,13 @@ class GNN_Edge_MLP(MessagePassing):
         off_h = g.nonempty_offsets(True)
         off_dev = g.array(ops.G_NZ_OFF_BY_SRC)
         acts = ctx["mlp_acts"]
-        dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, d_agg, edge_weight=ew_s)  # d(MLP outputs) [nz, H]
+        if self._agg_general():
+            _, ew_d, _, node_scale = self._scales(g)
+            dM = self._message_grads(g, d_agg, ctx, acts[-1], ctx["colc"], g.array(ops.G_TARGET_BY_DST), ew_d, node_scale,
+                                     self._ident_e(g)[: g.num_edges])
+            dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, dM, col=g.array(ops.G_SRC2DST_POS))
+        else:
+            dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, d_agg, edge_weight=ew_s)  # d(MLP outputs) [nz, H]
         grads = [None] * mlps.num_layers
         for j in range(mlps.num_layers - 1, -1, -1):
             inp = ctx["Xc"] if j == 0 else acts[j - 1]
@@ -360,19 +403,7 @@ class GNN_Edge_MLP(MessagePassing):
         _, ew_d, _, node_scale = self._scales(g)
         ctx = {"path": "B", "fused_act": fuse_act}
         Y = self._mlp_all_types(X, L, ctx)
-        is_max = self._aggregation_name == "max"
-        pre = self._activation_name if self._pre_activation() else None
-        gelu_split = fuse_act == "gelu"
-        out = ops.graph_gather(
-            g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H),
-            edge_weight=ew_d, row_scale=node_scale,
-            reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM,
-            pre_act=pre, post_act=None if gelu_split else fuse_act,
-        )
-        if gelu_split:
-            ctx["pre"] = out
-            return ops.activation_forward("gelu", out), ctx
-        return out, ctx
+        return self._gather_messages(g, Y.view(V * L, H), None, ew_d, node_scale, fuse_act, ctx), ctx
 
     def _original_order(self, g, ew_d):
         """index arrays in concatenated-adjacency-list order (type-contiguous), cached on the Graph."""
@@ -433,38 +464,31 @@ class GNN_Edge_MLP(MessagePassing):
             acts.append(nxt)
             cur = nxt
         is_max = self._aggregation_name == "max"
-        pre = self._activation_name if self._pre_activation() else None
         gelu_split = fuse_act == "gelu"
         ctx = {"path": "C", "fused_act": fuse_act, "edge_acts": acts, "P_shape": (V, L * H0)}
         if E == 0:
             out = torch.zeros((V, H), dtype=torch.float32, device=X.device)
             if is_max:
                 out.fill_(torch.finfo(torch.float32).min)
-            if fuse_act is not None and not gelu_split:
+            if gelu_split:
+                ctx["pre"] = out
+                return ops.activation_forward("gelu", out), ctx
+            if fuse_act is not None:
                 out = ops.activation_forward(fuse_act, out)
-        else:
-            out = ops.graph_gather(
-                g, ops.VIEW_BY_DST_NODE, cur, col=g.array(ops.G_EID_BY_DST), edge_weight=ew_d, row_scale=node_scale,
-                reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM, pre_act=pre,
-                post_act=None if gelu_split else fuse_act,
-            )
-        if gelu_split:
-            ctx["pre"] = out
-            return ops.activation_forward("gelu", out), ctx
-        return out, ctx
+            return out, ctx
+        return self._gather_messages(g, cur, g.array(ops.G_EID_BY_DST), ew_d, node_scale, fuse_act, ctx), ctx
 
     def _backward_C(self, d_agg, ctx):
         g, X = ctx["graph"], ctx["X"]
         V, D = X.shape
         L, E = g.num_edge_types, g.num_edges
         mlps = self._edge_type_mlps
-        if self._aggregation_name == "max" or self._pre_activation():
-            raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
         if E == 0:
             mlps.grads = [torch.zeros_like(W) for W in mlps.kernels]
             mlps.publish_grads()
             return torch.zeros_like(X)
         _, ew_d, _, node_scale = self._scales(g)
+        general = self._agg_general()
         # per-edge weight of the aggregation in by-dst order, including the mean / sqrt_n factor
         if node_scale is not None:
             tgt_d = g.array(ops.G_TARGET_BY_DST)
@@ -476,10 +500,15 @@ class GNN_Edge_MLP(MessagePassing):
             w_full = m_e if ew_d is None else ops.mul(m_e, ew_d)
         else:
             w_full = ew_d
-        src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, w_full)
         acts = ctx["edge_acts"]
-        # d messages, in edge-list order: dM[e] = w_e * d_agg[target_e]
-        dcur = ops.gather_reduce(ident, tgt_node, d_agg, edge_weight=w_orig)
+        if general:
+            # per-edge messages are acts[-1] in edge-list order; the normalisation weight in that order
+            src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, ew_d)
+            dcur = self._message_grads(g, d_agg, ctx, acts[-1], None, tgt_node, w_orig, node_scale, g.array(ops.G_EID_BY_DST))
+        else:
+            src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, w_full)
+            # d messages, in edge-list order: dM[e] = w_e * d_agg[target_e]
+            dcur = ops.gather_reduce(ident, tgt_node, d_agg, edge_weight=w_orig)
         grads = [None] * mlps.num_layers
         for j in range(mlps.num_layers - 1, 0, -1):
             W = mlps.kernels[j]
@@ -529,23 +558,24 @@ class GNN_Edge_MLP(MessagePassing):
         if ctx["path"] == "C":
             return self._backward_C(d_agg, ctx)
         if ctx["path"] == "Bc":
-            if self._aggregation_name == "max" or self._pre_activation():
-                raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
             return self._backward_B_compact(d_agg, ctx)
         if ctx["path"] == "Ac":
-            if self._aggregation_name == "max" or self._pre_activation():
-                raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
             return self._backward_A_compact(d_agg, ctx)
         g = ctx["graph"]
         X = ctx["X"]
         V, D = X.shape
         L, H = g.num_edge_types, self._hidden_dim
         mlps = self._edge_type_mlps
-        if self._aggregation_name == "max" or self._pre_activation():
-            raise NotImplementedError("backward through max aggregation / pre-aggregation activation")
-        row_scale, _, ew_s, _ = self._scales(g)
-        # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]
-        G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=ew_s).view(V, L, H)
+        row_scale, ew_d, ew_s, node_scale = self._scales(g)
+        if ctx["path"] == "B" and self._agg_general():
+            # max / activation before aggregation: per-edge gradients first, then the sum over every (source, type) bucket
+            Y = ctx["mlp_acts"][-1].view(V * L, H)
+            dM = self._message_grads(g, d_agg, ctx, Y, g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST), ew_d,
+                                     node_scale, self._ident_e(g)[: g.num_edges])
+            G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dM, col=g.array(ops.G_SRC2DST_POS)).view(V, L, H)
+        else:
+            # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]
+            G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=ew_s).view(V, L, H)
         dX = torch.empty_like(X)
         if ctx["path"] == "A":
             W = mlps.kernels[0]  # [L, Din, H]

@@ -475,6 +475,28 @@ def permute_021(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def edge_aggregate_backward(msg, target, grad_agg, *, msg_row=None, edge_weight=None, node_scale=None, pre_act=ACT_NONE,
+                            reduce=REDUCE_SUM, agg_max=None, num_selected=None, phase=1) -> torch.Tensor:
+    """Per-edge gradient through agg[t] = node_scale[t] * REDUCE_{e->t} pre_act(w_e * msg[row_e]) (phase 1), or the
+    0/1 indicator of the edges that attain a target's maximum (phase 0).  -> [E, width]"""
+    lib = _lib.load()
+    _require_dev(msg, torch.float32, "msg")
+    msg, ld = _rowmajor(msg, "msg")
+    E = target.numel()
+    width = msg.shape[1]
+    out = torch.empty((E, width), dtype=torch.float32, device=msg.device)
+    for t in (grad_agg, agg_max, num_selected):
+        if t is not None and (not t.is_contiguous() or t.shape[-1] != width):
+            raise ValueError("grad_agg / agg_max / num_selected must be contiguous [V, width]")
+    _lib.check(
+        lib.tfgnn_edge_aggregate_backward(
+            E, width, _ptr(msg), ld, _ptr(msg_row), _ptr(target), _ptr(edge_weight), _ptr(node_scale), act_id(pre_act),
+            int(reduce), _ptr(grad_agg), _ptr(agg_max), _ptr(num_selected), int(phase), _ptr(out), _stream(),
+        )
+    )
+    return out
+
+
 def transpose_batched(x: torch.Tensor) -> torch.Tensor:
     """[B, R, C] -> [B, C, R] (contiguous copy); a 2-D input is one batch."""
     lib = _lib.load()
