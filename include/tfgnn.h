@@ -209,6 +209,19 @@ int tfgnn_edge_aggregate_backward(int64_t num_edges, int64_t width, const float*
                                   const float* d_node_scale, int pre_act, int reduce_op, const float* d_grad_agg,
                                   const float* d_agg_max, const float* d_num_selected, int phase, float* d_out,
                                   void* stream);
+
+/* GNN_FiLM (gnn_film.py:84-108): every message is modulated by its target, m' = gamma[l,tgt] * m + beta[l,tgt],
+ * with (gamma | beta) = FiLM-MLP_l(h_tgt) [2H].  For sum / mean / sqrt_n aggregation this is a node-side epilogue
+ * over the per-bucket message sums Z [V, L, H] (bucket row r = node * L + type):
+ *   pre[v,:] = node_scale[v] * sum_l ( film[v,l,:H] * Z[v,l,:] + cnt[v,l] * film[v,l,H:] ),  out = act(pre)
+ * cnt[v,l] = d_rowptr_typed[r+1] - d_rowptr_typed[r] (TFGNN_G_ROWPTR_BY_DST).  d_pre may be NULL.
+ * Backward: d_grad_pre = d(loss)/d(pre)  ->  d_dZ [V,L,H], d_dfilm [V,L,2H]. */
+int tfgnn_film_combine_forward(const float* d_Z, const float* d_film, const int32_t* d_rowptr_typed,
+                               const float* d_node_scale, int64_t num_nodes, int num_edge_types, int64_t hidden,
+                               int act, float* d_pre, float* d_out, void* stream);
+int tfgnn_film_combine_backward(const float* d_grad_pre, const float* d_Z, const float* d_film,
+                                const int32_t* d_rowptr_typed, const float* d_node_scale, int64_t num_nodes,
+                                int num_edge_types, int64_t hidden, float* d_dZ, float* d_dfilm, void* stream);
 int tfgnn_graph_original_order(const tfgnn_graph* graph, const float* d_weight_by_dst, int32_t* d_src_l,
                                int32_t* d_tgt_l, int32_t* d_tgt_node, float* d_weight, void* stream);
 

@@ -215,11 +215,12 @@ def message_passing_call(
     adjacency_lists: Sequence[torch.Tensor],
 ):
     """MessagePassing.call (message_passing.py:95-133) for kind in
-    {rgcn, ggnn, rgin, gnn_edge_mlp, rgat, pass_source_states}; eval mode.
+    {rgcn, ggnn, rgin, gnn_edge_mlp, gnn_film, rgat, pass_source_states}; eval mode.
 
     weights:
       edge-MLP family: weights["edge_mlps"][l] = list of kernels ([in,out]) of MLP_l
       rgin:  + weights["aggr_mlp"] = list of kernels or None
+      gnn_film: + weights["film_mlps"][l] = list of kernels of the FiLM parameter MLP_l (out 2H; gnn_film.py:70-82)
       ggnn:  + weights["gru_kernel"] [D,3H], ["gru_recurrent_kernel"] [H,3H], ["gru_bias"] [2,3H]
       rgat:  weights["kernels"][l] [D,H], weights["attn"][l] [K, 2H/K]
     """
@@ -245,6 +246,10 @@ def message_passing_call(
             m = _rgat_message(params, weights["kernels"][l], weights["attn"][l], xs, xt)
         else:
             m = _edge_mlp_message(params, weights["edge_mlps"][l], xs, xt, c)
+            if kind == "gnn_film":  # gnn_film.py:84-108: the target state modulates the message feature-wise
+                film = mlp_forward(xt, weights["film_mlps"][l])  # [E, 2H]
+                H_ = params["hidden_dim"]
+                m = film[:, :H_] * m + film[:, H_:]
         messages_per_type.append(m)
     targets = [adj[:, 1] for adj in adjacency_lists]
     message_targets = torch.cat(targets, dim=0) if targets else torch.zeros(0, dtype=torch.int32)

@@ -12,7 +12,7 @@ What is extracted, and how:
         EXECUTING the reference's own tf2_gnn/data/utils.py (pure numpy, loaded as a stand-alone
         module), plus 6 seeded random cases run through the same reference function;
   * default_hyperparameters - the dict literals of get_default_hyperparameters of MessagePassing,
-        GNN_Edge_MLP, RGCN, RGIN, GGNN, RGAT and GNN (ast), for the API-compatibility tests;
+        GNN_Edge_MLP, RGCN, RGIN, GGNN, RGAT, GNN_FiLM and GNN (ast), for the API-compatibility tests;
   * rgcn_shape_cases / rgat_shape_cases - test/layers/test_RGCN.py:8-12, test_RGAT.py:9-28.
 """
 import ast
@@ -137,6 +137,7 @@ def default_hyperparameters():
         "RGIN": "tf2_gnn/layers/message_passing/rgin.py",
         "GGNN": "tf2_gnn/layers/message_passing/ggnn.py",
         "RGAT": "tf2_gnn/layers/message_passing/rgat.py",
+        "GNN_FiLM": "tf2_gnn/layers/message_passing/gnn_film.py",
         "GNN": "tf2_gnn/layers/gnn.py",
     }
     out = {}

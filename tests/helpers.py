@@ -36,6 +36,9 @@ def edge_mlp_weights_from_layer(layer):
         w["aggr_mlp"] = [k.detach().cpu().clone() for k in layer._aggregation_mlp]
     else:
         w["aggr_mlp"] = None
+    film = getattr(layer, "_film_mlps", None)
+    if film is not None:
+        w["film_mlps"] = [[k[l].detach().cpu().clone() for k in film.kernels] for l in range(film.L)]
     ru = getattr(layer, "_recurrent_unit", None)
     if ru is not None:
         w["gru_kernel"] = ru["kernel"].value.detach().cpu().clone()

@@ -520,3 +520,66 @@ def test_path_b_compact_sources_many_edge_types(dev, cls_name, over):
             i += 1
             r = torch.zeros_like(v.grad.cpu().double()) if r is None else r
             assert_close(v.grad.cpu(), r.float(), tol=2e-5, what=f"Bc d{v.name}")
+
+
+# ---- GNN_FiLM ("next" row f1) -------------------------------------------------------------------------
+FILM_CASES = [
+    ("film_default", {}),
+    ("film_norm_mean_tanh", {"normalize_by_num_incoming": True, "aggregation_function": "mean", "message_activation_function": "tanh"}),
+    ("film_hidden_edge_mlp_gelu", {"num_edge_MLP_hidden_layers": 1, "message_activation_function": "gelu"}),
+    ("film_hidden_film_mlp_sqrt_n", {"film_parameter_MLP_hidden_layers": [20], "aggregation_function": "sqrt_n",
+                                     "normalize_by_num_incoming": True}),
+]
+
+
+@pytest.mark.parametrize("name,over", FILM_CASES, ids=[c[0] for c in FILM_CASES])
+def test_gnn_film_forward_backward_parity(dev, name, over):
+    """gnn_film.py:84-108 against the per-edge oracle (fp64 autograd for the gradients)."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, H = 90, 3, 24
+    adjs = random_graph(V, 900, L, seed=8, empty_types=(), hub=(3, 70))
+    layer, p = _build("GNN_FiLM", dict(over, hidden_dim=H), H, L)
+    g = torch.Generator().manual_seed(13)
+    X = torch.randn((V, H), generator=g)
+    dOut = torch.randn((V, H), generator=g)
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
+    dX = layer.backward(dOut.to(dev))
+    w64 = _to64(mp_weights_from_layer(layer))
+    leaves = []
+    for key in ("film_mlps", "edge_mlps"):
+        for l in range(L):
+            w64[key][l] = [k.requires_grad_(True) for k in w64[key][l]]
+            leaves += w64[key][l]
+    X64 = X.double().requires_grad_(True)
+    ref = orc.message_passing_call("gnn_film", p, w64, X64, [torch.from_numpy(a) for a in adjs])
+    assert_close(out.cpu(), ref.detach().float(), tol=1e-5, what=name + " fwd")
+    ref32 = orc.message_passing_call("gnn_film", p, mp_weights_from_layer(layer), X, [torch.from_numpy(a) for a in adjs])
+    assert_close(out.cpu(), ref32, tol=2e-5, what=name + " fwd vs reference-order fp32")
+    grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
+    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=name + " dX")
+    # variable order of the reference: all FiLM MLPs first, then the edge MLPs (gnn_film.py:72-82)
+    hip_vars = [v for l in range(L) for v in layer._film_mlps.vars[l]] + [v for l in range(L) for v in layer._edge_type_mlps.vars[l]]
+    assert [v.name for v in layer.trainable_variables] == [v.name for v in hip_vars]
+    for v, r in zip(hip_vars, grads[1:]):
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=2e-5, what=f"{name} d{v.name}")
+
+
+def test_gnn_film_in_a_gnn_stack_and_unsupported_modes(dev):
+    from tf2_gnn_amd.layers import GNN, GNNInput, MessagePassingInput
+
+    V, L, Din, H = 60, 2, 7, 16
+    params = GNN.get_default_hyperparameters("gnn_film")
+    params.update({"hidden_dim": H, "num_layers": 2, "global_exchange_every_num_layers": 10000})
+    adjs = random_graph(V, 300, L, seed=3)
+    gnn = GNN(params)
+    X = torch.randn((V, Din), generator=torch.Generator().manual_seed(2))
+    inp = GNNInput(X.to(dev), to_dev(adjs, dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    out = gnn(inp, training=False)
+    assert out.shape == (V, H) and bool(torch.isfinite(out).all())
+    gnn.backward(torch.ones_like(out))
+    assert all(v.grad is not None and bool(torch.isfinite(v.grad).all()) for v in gnn.trainable_variables)
+    layer, _ = _build("GNN_FiLM", {"hidden_dim": H, "aggregation_function": "max"}, H, L)
+    with pytest.raises(NotImplementedError):
+        layer(MessagePassingInput(torch.zeros((V, H), device=dev), to_dev(adjs, dev)))

@@ -62,7 +62,7 @@ def test_registry_and_errors(kats):
 
     assert get_message_passing_class("RGCN").__name__ == "RGCN"
     assert get_message_passing_class("gnn_edge_mlp").__name__ == "GNN_Edge_MLP"
-    assert set(get_known_message_passing_classes()) >= {"RGCN", "RGAT", "RGIN", "GGNN", "GNN_Edge_MLP"}
+    assert set(get_known_message_passing_classes()) >= {"RGCN", "RGAT", "RGIN", "GGNN", "GNN_Edge_MLP", "GNN_FiLM"}
     with pytest.raises(ValueError, match="Unknown message passing type"):
         get_message_passing_class("nope")
     with pytest.raises(ValueError, match="Unknown aggregation function"):
@@ -75,7 +75,7 @@ def test_registry_and_errors(kats):
     assert get_activation_function("ReLU").tfgnn_name == "relu"
 
 
-@pytest.mark.parametrize("cls_name", ["MessagePassing", "GNN_Edge_MLP", "RGCN", "RGIN", "GGNN", "RGAT"])
+@pytest.mark.parametrize("cls_name", ["MessagePassing", "GNN_Edge_MLP", "RGCN", "RGIN", "GGNN", "RGAT", "GNN_FiLM"])
 def test_default_hyperparameters_match_reference(kats, cls_name):
     import tf2_gnn_amd.layers.message_passing as mp
 

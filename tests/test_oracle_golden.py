@@ -110,3 +110,32 @@ def test_gru_cell_gate_order_and_shapes():
     b[0, :H] = 50.0
     out = orc.gru_cell(z(2, H), h, z(H, 3 * H), z(H, 3 * H), b)
     np.testing.assert_allclose(out.numpy(), h.numpy(), rtol=1e-6)
+
+
+def test_gnn_film_oracle_doctest_shape_and_identity_modulation():
+    """gnn_film.py:35-47 doctest (5 nodes, 3 edge types, hidden 12 -> (5, 12)); with gamma = 1, beta = 0 the
+    FiLM layer is GNN_Edge_MLP without target input (gnn_film.py:84-108).  Parity unpinned: the reference holds
+    no numeric vector for FiLM."""
+    import torch
+
+    from oracle import tf2gnn_oracle as orc
+
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn((5, 3), generator=g, dtype=torch.float64)
+    adjs = [torch.tensor([[0, 1], [2, 4], [2, 4]], dtype=torch.int32), torch.tensor([[2, 3], [2, 4]], dtype=torch.int32),
+            torch.tensor([[3, 1]], dtype=torch.int32)]
+    H = 12
+    params = {"hidden_dim": H, "aggregation_function": "sum", "message_activation_function": "relu",
+              "message_activation_before_aggregation": False, "use_target_state_as_input": False,
+              "normalize_by_num_incoming": False, "num_edge_MLP_hidden_layers": 0, "film_parameter_MLP_hidden_layers": []}
+    edge = [[torch.randn((3, H), generator=g, dtype=torch.float64)] for _ in range(3)]
+    film = [[torch.randn((3, 2 * H), generator=g, dtype=torch.float64)] for _ in range(3)]
+    out = orc.message_passing_call("gnn_film", params, {"edge_mlps": edge, "film_mlps": film}, X, adjs)
+    assert tuple(out.shape) == (5, H)
+    # gamma = 1, beta = 0 through a bias-free Dense is impossible for general X; use constant features instead
+    Xc = torch.ones((5, 3), dtype=torch.float64)
+    ident = [[torch.cat([torch.full((3, H), 1.0 / 3.0, dtype=torch.float64), torch.zeros((3, H), dtype=torch.float64)], dim=1)]
+             for _ in range(3)]
+    a = orc.message_passing_call("gnn_film", params, {"edge_mlps": edge, "film_mlps": ident}, Xc, adjs)
+    b = orc.message_passing_call("gnn_edge_mlp", params, {"edge_mlps": edge}, Xc, adjs)
+    assert torch.allclose(a, b, atol=1e-12)

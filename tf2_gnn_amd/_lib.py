@@ -119,6 +119,16 @@ _SIGNATURES = [
         [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
          c_void_p, c_int, c_void_p, c_void_p],
     ),
+    (
+        "tfgnn_film_combine_forward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_film_combine_backward",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
     ("tfgnn_permute_021", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_mul", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 ]

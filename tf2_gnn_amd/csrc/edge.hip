@@ -168,3 +168,80 @@ extern "C" int tfgnn_edge_aggregate_backward(int64_t num_edges, int64_t width, c
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
+
+// ---- GNN_FiLM: feature-wise linear modulation of the aggregated messages ----------------------------
+// gnn_film.py:84-108 modulates every message by its TARGET: m'_e = gamma[l, tgt_e] * m_e + beta[l, tgt_e].
+// All edges of a (target, type) bucket share gamma / beta, so for the sum-like aggregations
+//   sum_e m'_e = gamma[v,l] * Z[v,l] + cnt[v,l] * beta[v,l],   Z[v,l] = sum of the bucket's messages,
+// and the modulation is a node-side epilogue:  out[v] = act( node_scale[v] * sum_l (...) ).
+namespace tfgnn {
+__global__ void __launch_bounds__(256)
+film_combine_forward_kernel(const float* __restrict__ Z, const float* __restrict__ film, const int32_t* __restrict__ rowptr,
+                            const float* __restrict__ node_scale, int64_t V, int L, int H, int act,
+                            float* __restrict__ pre, float* __restrict__ out) {
+  const int64_t total = V * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / H;
+    const int h = (int)(i - v * H);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int64_t r = v * L + l;
+      const float cnt = (float)(rowptr[r + 1] - rowptr[r]);
+      const float* f = film + r * 2 * H;
+      s += f[h] * Z[r * H + h] + cnt * f[H + h];
+    }
+    if (node_scale) s *= node_scale[v];
+    if (pre) pre[i] = s;
+    out[i] = act_apply(act, s);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+film_combine_backward_kernel(const float* __restrict__ d_pre, const float* __restrict__ Z, const float* __restrict__ film,
+                             const int32_t* __restrict__ rowptr, const float* __restrict__ node_scale, int64_t V, int L,
+                             int H, float* __restrict__ dZ, float* __restrict__ dfilm) {
+  const int64_t total = V * L * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H;
+    const int h = (int)(i - r * H);
+    const int64_t v = r / L;
+    float g = d_pre[v * H + h];
+    if (node_scale) g *= node_scale[v];
+    const float cnt = (float)(rowptr[r + 1] - rowptr[r]);
+    dZ[i] = film[r * 2 * H + h] * g;
+    dfilm[r * 2 * H + h] = Z[i] * g;
+    dfilm[r * 2 * H + H + h] = cnt * g;
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_film_combine_forward(const float* d_Z, const float* d_film, const int32_t* d_rowptr_typed,
+                                          const float* d_node_scale, int64_t num_nodes, int num_edge_types,
+                                          int64_t hidden, int act, float* d_pre, float* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0 && hidden >= 0 && hidden < (1 << 30), "bad size");
+  if (num_nodes == 0 || hidden == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_out && (num_edge_types == 0 || (d_Z && d_film && d_rowptr_typed)), "NULL pointer");
+  const int64_t total = num_nodes * hidden;
+  hipLaunchKernelGGL(film_combine_forward_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 8)),
+                     dim3(256), 0, (hipStream_t)stream, d_Z, d_film, d_rowptr_typed, d_node_scale, num_nodes,
+                     num_edge_types, (int)hidden, act, d_pre, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_film_combine_backward(const float* d_grad_pre, const float* d_Z, const float* d_film,
+                                           const int32_t* d_rowptr_typed, const float* d_node_scale, int64_t num_nodes,
+                                           int num_edge_types, int64_t hidden, float* d_dZ, float* d_dfilm,
+                                           void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0 && hidden >= 0 && hidden < (1 << 30), "bad size");
+  const int64_t total = num_nodes * num_edge_types * hidden;
+  if (total == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_grad_pre && d_Z && d_film && d_rowptr_typed && d_dZ && d_dfilm, "NULL pointer");
+  hipLaunchKernelGGL(film_combine_backward_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 8)),
+                     dim3(256), 0, (hipStream_t)stream, d_grad_pre, d_Z, d_film, d_rowptr_typed, d_node_scale, num_nodes,
+                     num_edge_types, (int)hidden, d_dZ, d_dfilm);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

@@ -2,6 +2,7 @@ from .gnn import GNN, GNNInput
 from .message_passing import (
     GGNN,
     GNN_Edge_MLP,
+    GNN_FiLM,
     MessagePassing,
     MessagePassingInput,
     RGAT,

@@ -15,6 +15,7 @@ from .rgcn import RGCN
 from .rgin import RGIN
 from .ggnn import GGNN
 from .gnn_edge_mlp import GNN_Edge_MLP
+from .gnn_film import GNN_FiLM
 
 
 def get_message_passing_class(message_calculation_class_name: str):

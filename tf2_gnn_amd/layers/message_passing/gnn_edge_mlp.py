@@ -46,7 +46,8 @@ class StackedEdgeMLPs:
     """L bias-free MLPs (one per edge type) stored layer-wise as [L, in, out] tensors so that the
     per-type kernels of one layer are contiguous ([L*in, out] is the vertical stack)."""
 
-    def __init__(self, owner: MessagePassing, num_types: int, in_size: int, out_size: int, hidden_layers, device):
+    def __init__(self, owner: MessagePassing, num_types: int, in_size: int, out_size: int, hidden_layers, device,
+                 scope: str = "edge_type_{l}"):
         sizes = mlp_hidden_sizes(out_size, hidden_layers) + [out_size]
         self.L = num_types
         self.kernels: List[torch.Tensor] = []  # per MLP layer j: [L, in_j, out_j]
@@ -62,7 +63,7 @@ class StackedEdgeMLPs:
             for j, w in enumerate(self.kernels):
                 w[l].copy_(glorot_uniform(w[l].shape, device=device))
                 tag = f"dense_{j}" if j < len(sizes) - 1 else "final_layer"
-                self.vars[l].append(owner.add_weight(f"edge_type_{l}/MLP_{tag}/kernel", w[l]))
+                self.vars[l].append(owner.add_weight(f"{scope.format(l=l)}/MLP_{tag}/kernel", w[l]))
         self.grads: List[Optional[torch.Tensor]] = [None] * len(self.kernels)
 
     @property
@@ -321,10 +322,10 @@ class GNN_Edge_MLP(MessagePassing):
             return ops.activation_forward("gelu", pre), ctx
         return pre, ctx
 
-    def _mlp_all_types(self, X, L, ctx):
-        """Y[:, l, :] = MLP_l(X) for all nodes -> [V, L, H]; hidden activations saved in ctx."""
+    def _mlp_all_types(self, X, L, ctx, mlps=None, key="mlp_acts"):
+        """Y[:, l, :] = MLP_l(X) for all nodes -> [V, L, H]; hidden activations saved in ctx[key]."""
         V = X.shape[0]
-        mlps = self._edge_type_mlps
+        mlps = self._edge_type_mlps if mlps is None else mlps
         acts = []
         cur = None
         for j, W in enumerate(mlps.kernels):
@@ -336,8 +337,33 @@ class GNN_Edge_MLP(MessagePassing):
                 ops.gemm(inp, W[l], act=None if last else "relu", out=Z[:, l, :])
             acts.append(Z)
             cur = Z
-        ctx["mlp_acts"] = acts
+        ctx[key] = acts
         return cur
+
+    @staticmethod
+    def _mlp_all_types_backward(mlps, X, acts, dY, dX, accumulate):
+        """Gradient of _mlp_all_types: dY [V, L, out] -> kernel gradients (mlps.grads) and dX (+= if accumulate)."""
+        L = mlps.L
+        grads = [torch.empty_like(W) for W in mlps.kernels]
+        dcur = dY
+        for j in range(mlps.num_layers - 1, -1, -1):
+            W = mlps.kernels[j]
+            inp_all = None if j == 0 else acts[j - 1]
+            if j > 0:
+                dprev = torch.empty_like(inp_all)
+            for l in range(L):
+                inp = X if j == 0 else inp_all[:, l, :]
+                ops.gemm(inp, dcur[:, l, :], trans_a=True, out=grads[j][l])
+                if j > 0:
+                    ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dprev[:, l, :])
+                else:
+                    ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dX, accumulate=accumulate or l > 0)
+            if j > 0:
+                # hidden layers use relu ([ext] dpu_utils MLP default activation)
+                dcur = ops.activation_backward("relu", dprev, inp_all)
+        mlps.grads = grads
+        if L == 0 and not accumulate:
+            dX.zero_()
 
     # Path B evaluates MLP_l(x_u) for every (node, type) pair that is the SOURCE of at least one edge.
     # When fewer than this fraction of the V*L pairs are (cfg-5: 40 edge types, ~13 %), the MLPs run as
@@ -609,24 +635,6 @@ class GNN_Edge_MLP(MessagePassing):
                 ops.gemm(kd, Wh[D:].view(D, L * H), trans_b=True, out=dX, accumulate=True)
             mlps.grads = [ops.permute_021(dWh)]
         else:
-            acts = ctx["mlp_acts"]
-            grads = [torch.empty_like(W) for W in mlps.kernels]
-            dcur = G  # gradient w.r.t. the MLP outputs Y [V, L, H]
-            for j in range(mlps.num_layers - 1, -1, -1):
-                W = mlps.kernels[j]
-                inp_all = None if j == 0 else acts[j - 1]
-                if j > 0:
-                    dprev = torch.empty_like(inp_all)
-                for l in range(L):
-                    inp = X if j == 0 else inp_all[:, l, :]
-                    ops.gemm(inp, dcur[:, l, :], trans_a=True, out=grads[j][l])
-                    if j > 0:
-                        ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dprev[:, l, :])
-                    else:
-                        ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dX, accumulate=l > 0)
-                if j > 0:
-                    # hidden layers use relu ([ext] dpu_utils MLP default activation)
-                    dcur = ops.activation_backward("relu", dprev, inp_all)
-            mlps.grads = grads
+            self._mlp_all_types_backward(mlps, X, ctx["mlp_acts"], G, dX, accumulate=False)
         mlps.publish_grads()
         return dX

@@ -1,0 +1,165 @@
+"""GNN layer with feature-wise linear modulation - mirror of tf2_gnn/layers/message_passing/gnn_film.py."""
+from typing import Any, Dict
+
+import torch
+
+from ... import _lib, ops
+from .gnn_edge_mlp import GNN_Edge_MLP, StackedEdgeMLPs
+from .message_passing import (
+    MessagePassingInput,
+    default_device,
+    get_graph,
+    register_message_passing_implementation,
+)
+
+
+@register_message_passing_implementation
+class GNN_FiLM(GNN_Edge_MLP):
+    """Compute new graph states by neural message passing modulated by the target state (gnn_film.py:12-108):
+        h^{t+1}_v := sigma( sum_l sum_{(u,v) in A_l} gamma_{l,v} * (1/c_{v,l} * W_l h^t_u) + beta_{l,v} )
+        (gamma_{l,v} | beta_{l,v}) := FiLM-MLP_l(h^t_v)
+    Weights (gnn_film.py:67-82): per edge type one FiLM parameter MLP (out 2H, created first) and one edge MLP.
+
+    On the device every edge of a (target, type) bucket shares gamma / beta, so the modulation is applied to the
+    bucket sums Z[v,l] (gather kernel + MFMA GEMMs as in GNN_Edge_MLP) by a node-side epilogue
+    (csrc/edge.hip tfgnn_film_combine_*):  out[v] = sigma( scale_v * sum_l (gamma_{l,v} * Z[v,l] + cnt[v,l] * beta_{l,v}) ).
+    Covered: sum / mean / sqrt_n aggregation with the activation after aggregation, source-only edge MLPs of any
+    depth (the class defaults).  Max aggregation, activation before aggregation and use_target_state_as_input need
+    the per-edge form and raise NotImplementedError."""
+
+    @classmethod
+    def get_default_hyperparameters(cls):
+        these_hypers = {
+            "use_target_state_as_input": False,
+            "normalize_by_num_incoming": False,
+            "num_edge_MLP_hidden_layers": 0,
+            "film_parameter_MLP_hidden_layers": [],
+        }
+        mp_hypers = super().get_default_hyperparameters()
+        mp_hypers.update(these_hypers)
+        return mp_hypers
+
+    def __init__(self, params: Dict[str, Any], **kwargs):
+        super().__init__(params, **kwargs)
+        self._film_parameter_MLP_hidden_layers = params["film_parameter_MLP_hidden_layers"]
+        self._film_mlps = None
+
+    def build(self, input_shapes: MessagePassingInput):
+        D = int(input_shapes.node_embeddings[-1])
+        L = len(input_shapes.adjacency_lists)
+        # the FiLM MLPs are created before the edge MLPs (gnn_film.py:72-82)
+        self._film_mlps = StackedEdgeMLPs(self, L, D, 2 * self._hidden_dim, self._film_parameter_MLP_hidden_layers,
+                                          default_device(), scope="edge_type_{l}-FiLM")
+        super().build(input_shapes)
+
+    def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message,
+                          edge_type_idx, training):
+        raise NotImplementedError(
+            "GNN_FiLM modulates the per-bucket message sums on the node side (see class docstring); "
+            "the per-edge form lives in oracle/tf2gnn_oracle.py:message_passing_call"
+        )
+
+    def _check_supported(self):
+        if self._aggregation_name == "max" or self._pre_activation() or self._use_target_state_as_input:
+            raise NotImplementedError(
+                "GNN_FiLM on the device covers sum/mean/sqrt_n aggregation, activation after aggregation and "
+                "source-only edge MLPs (the class defaults); max aggregation, message_activation_before_aggregation "
+                "and use_target_state_as_input need per-edge modulation"
+            )
+
+    def _film_scales(self, g):
+        """(per-bucket 1/(c+1e-7) | None, the same per edge in by-src order | None, mean / sqrt_n factor per node | None):
+        unlike the other layers the two factors cannot be merged - beta is added between them."""
+        from ..graph_scales import graph_scales
+
+        row_scale, _, ew_s, _ = graph_scales(g, bool(self._normalize_by_num_incoming), "sum")
+        node_scale = graph_scales(g, bool(self._normalize_by_num_incoming), self._aggregation_name)[3]
+        return row_scale, ew_s, node_scale
+
+    def call(self, inputs: MessagePassingInput, training: bool = False):
+        self._check_supported()
+        X = inputs.node_embeddings
+        V, D = X.shape
+        g = get_graph(inputs.adjacency_lists, V)
+        L, H = g.num_edge_types, self._hidden_dim
+        if L != self._num_edge_types:
+            raise ValueError(f"layer was built for {self._num_edge_types} edge types, got {L}")
+        row_scale, ew_s, node_scale = self._film_scales(g)
+        mlps = self._edge_type_mlps
+        ctx = {"graph": g, "X": X}
+        Z = torch.empty((V, L, H), dtype=torch.float32, device=X.device)
+        if mlps.num_layers == 1:
+            # Z[v,l] = (scale_{v,l} * sum_{(u,v) in A_l} x_u) @ W_l
+            A = torch.empty((V, L, D), dtype=torch.float32, device=X.device)
+            ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, out=A.view(V * L, D))
+            for l in range(L):
+                ops.gemm(A[:, l, :], mlps.kernels[0][l], out=Z[:, l, :])
+            ctx["A"] = A
+        else:
+            # Z[v,l] = scale_{v,l} * sum_{(u,v) in A_l} MLP_l(x_u)
+            Y = self._mlp_all_types(X, L, ctx)
+            if L > 0:
+                ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Y.view(V * L, H), col=g.array(ops.G_COLL_BY_DST),
+                                 row_scale=row_scale, out=Z.view(V * L, H))
+        film = self._mlp_all_types(X, L, ctx, mlps=self._film_mlps, key="film_acts")  # [V, L, 2H]
+        act = self._activation_name
+        out = torch.empty((V, H), dtype=torch.float32, device=X.device)
+        pre = torch.empty_like(out) if act == "gelu" else None
+        _lib.check(
+            _lib.load().tfgnn_film_combine_forward(
+                ops._ptr(Z), ops._ptr(film), ops._ptr(g.array(ops.G_ROWPTR_BY_DST)), ops._ptr(node_scale), V, L, H,
+                ops.act_id(act), ops._ptr(pre), ops._ptr(out), ops._stream(),
+            )
+        )
+        ctx.update({"Z": Z, "film": film, "out": out, "pre": pre, "node_scale": node_scale})
+        self._ctx = ctx
+        return out
+
+    def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        g, X, Z, film = ctx["graph"], ctx["X"], ctx["Z"], ctx["film"]
+        V, D = X.shape
+        L, H = g.num_edge_types, self._hidden_dim
+        act = self._activation_name
+        d_pre = grad_output
+        if act is not None:
+            d_pre = ops.activation_backward(act, grad_output, ctx["pre"] if act == "gelu" else ctx["out"])
+        d_pre = d_pre.contiguous()
+        dZ = torch.empty_like(Z)
+        dfilm = torch.empty_like(film)
+        _lib.check(
+            _lib.load().tfgnn_film_combine_backward(
+                ops._ptr(d_pre), ops._ptr(Z), ops._ptr(film), ops._ptr(g.array(ops.G_ROWPTR_BY_DST)),
+                ops._ptr(ctx["node_scale"]), V, L, H, ops._ptr(dZ), ops._ptr(dfilm), ops._stream(),
+            )
+        )
+        dX = torch.empty_like(X)
+        # the FiLM parameter MLPs read the node's own state
+        self._mlp_all_types_backward(self._film_mlps, X, ctx["film_acts"], dfilm, dX, accumulate=False)
+        self._film_mlps.publish_grads()
+        mlps = self._edge_type_mlps
+        _, ew_s, _ = self._film_scales(g)
+        if L == 0:
+            mlps.grads = [torch.zeros_like(W) for W in mlps.kernels]
+        elif mlps.num_layers == 1:
+            A = ctx["A"]
+            W = mlps.kernels[0]
+            gW = torch.empty_like(W)
+            dA = torch.empty_like(A)
+            for l in range(L):
+                ops.gemm(A[:, l, :], dZ[:, l, :], trans_a=True, out=gW[l])
+                ops.gemm(dZ[:, l, :], W[l], trans_b=True, out=dA[:, l, :])
+            mlps.grads = [gW]
+            # dX[u] += sum over edges (u -> v) of type l of scale_{v,l} * dA[v,l]
+            dXe = ops.graph_gather(g, ops.VIEW_BY_SRC_NODE, dA.view(V * L, D), col=g.array(ops.G_COLL_BY_SRC),
+                                   edge_weight=ew_s)
+            dX = ops.add_scale(dX, dXe, 1.0)
+        else:
+            # dY[u,l] = sum over edges (u -> v) of type l of scale_{v,l} * dZ[v,l]
+            G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dZ.view(V * L, H), col=g.array(ops.G_COLL_BY_SRC),
+                                 edge_weight=ew_s).view(V, L, H)
+            self._mlp_all_types_backward(mlps, X, ctx["mlp_acts"], G, dX, accumulate=True)
+        mlps.publish_grads()
+        return dX
