@@ -269,6 +269,68 @@ __global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, 
   }
 }
 
+// ---- short rows ordered by length (CsrPlan::short_rows) ------------------------------------------
+__global__ void __launch_bounds__(256)
+short_hist_kernel(const int32_t* __restrict__ rowptr, int64_t R, int thr, int32_t* __restrict__ bin_count,
+                  int32_t* __restrict__ num_short) {
+  __shared__ int h[SHORT_BINS];
+  __shared__ int n_short;
+  for (int i = threadIdx.x; i <= thr; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) n_short = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t len = rowptr[r + 1] - rowptr[r];
+    if (len <= thr) {
+      atomicAdd(&h[len], 1);
+      ++mine;
+    }
+  }
+  if (mine) atomicAdd(&n_short, mine);
+  __syncthreads();
+  for (int i = threadIdx.x; i <= thr; i += 256)
+    if (h[i]) atomicAdd(&bin_count[i], h[i]);
+  if (threadIdx.x == 0 && n_short) atomicAdd(num_short, n_short);
+}
+
+// short_rows = rows with len <= thr in order of descending length (the order inside one length is arbitrary and
+// has no effect on any result: every row is reduced on its own)
+constexpr int SHORT_TILE_ROWS = 8;  // rows per thread and tile: one global atomic per (tile, length) pair
+__global__ void __launch_bounds__(256)
+short_scatter_kernel(const int32_t* __restrict__ rowptr, int64_t R, int thr, const int32_t* __restrict__ bin_count,
+                     int32_t* __restrict__ bin_cursor, int32_t* __restrict__ short_rows) {
+  __shared__ int h[SHORT_BINS], base[SHORT_BINS], start[SHORT_BINS];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = thr; i >= 0; --i) {
+      start[i] = acc;
+      acc += bin_count[i];
+    }
+  }
+  constexpr int TILE = 256 * SHORT_TILE_ROWS;
+  for (int64_t tile = blockIdx.x; tile * TILE < R; tile += gridDim.x) {
+    for (int i = threadIdx.x; i <= thr; i += 256) h[i] = 0;
+    __syncthreads();
+    int32_t len[SHORT_TILE_ROWS];
+    int rank[SHORT_TILE_ROWS];
+#pragma unroll
+    for (int k = 0; k < SHORT_TILE_ROWS; ++k) {
+      const int64_t r = tile * TILE + k * 256 + threadIdx.x;
+      len[k] = r < R ? rowptr[r + 1] - rowptr[r] : -1;
+      rank[k] = (len[k] >= 0 && len[k] <= thr) ? atomicAdd(&h[len[k]], 1) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= thr; i += 256)
+      if (h[i]) base[i] = atomicAdd(&bin_cursor[i], h[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SHORT_TILE_ROWS; ++k)
+      if (len[k] >= 0 && len[k] <= thr)
+        short_rows[start[len[k]] + base[len[k]] + rank[k]] = (int32_t)(tile * TILE + k * 256 + threadIdx.x);
+    __syncthreads();
+  }
+}
+
 // ---- non-empty buckets, type-major (CompactBuckets) ---------------------------------------------
 // flags in type-major layout: i = l * V + v ; flags[R] = 0 ; node_cnt[v] = non-empty buckets of v
 __global__ void nz_flags_kernel(const int32_t* __restrict__ rowptr, int64_t V, int L, int32_t* __restrict__ flags,
@@ -520,16 +582,21 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     o_cb[side][4] = plan.take((V + 1) * 4);            // nodeptr_nz
     o_cb[side][5] = plan.take((R + 1) * 4);            // col_nz
   }
-  // long-row plan parameters per view (tools/gather_probe.py sweep at cfg-2: 133 us with (16, 128) on the
-  // typed views vs 160 us with (32, 256); the node views - all edge types of a node in one row - are best
-  // at (32, 256)); TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override all views for probing
+  // long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
+  // views 95 us at (48, 192) vs 114 us at (16, 128) (134 us in natural row order); the node views - all edge
+  // types of a node in one row - 125 us at (64, 512) vs 131 us at (32, 256) (138 us in natural order).  TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override the typed views, TFGNN_LONG_ROW_NODE /
+  // TFGNN_ITEM_CHUNK_NODE the node views, for probing.
   static const int env_long = [] { const char* e = getenv("TFGNN_LONG_ROW"); return e ? atoi(e) : 0; }();
   static const int env_chunk = [] { const char* e = getenv("TFGNN_ITEM_CHUNK"); return e ? atoi(e) : 0; }();
-  int view_long[4] = {16, LONG_ROW_THRESHOLD, 16, LONG_ROW_THRESHOLD};
-  int view_chunk[4] = {128, ITEM_CHUNK, 128, ITEM_CHUNK};
+  static const int env_long_n = [] { const char* e = getenv("TFGNN_LONG_ROW_NODE"); return e ? atoi(e) : 0; }();
+  static const int env_chunk_n = [] { const char* e = getenv("TFGNN_ITEM_CHUNK_NODE"); return e ? atoi(e) : 0; }();
+  int view_long[4] = {LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD, LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD};
+  int view_chunk[4] = {ITEM_CHUNK_TYPED, ITEM_CHUNK, ITEM_CHUNK_TYPED, ITEM_CHUNK};
   for (int v = 0; v < 4; ++v) {
-    if (env_long > 0) view_long[v] = env_long;
-    if (env_chunk > 0) view_chunk[v] = env_chunk;
+    const bool node_view = v & 1;
+    if ((node_view ? env_long_n : env_long) > 0) view_long[v] = node_view ? env_long_n : env_long;
+    if ((node_view ? env_chunk_n : env_chunk) > 0) view_chunk[v] = node_view ? env_chunk_n : env_chunk;
+    if (view_long[v] > SHORT_BINS - 1) view_long[v] = SHORT_BINS - 1;
     if (view_chunk[v] < view_long[v]) view_chunk[v] = view_long[v];
   }
   const int min_long = std::min(std::min(view_long[0], view_long[1]), std::min(view_long[2], view_long[3]));
@@ -540,6 +607,8 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     for (int k = 0; k < 3; ++k) o_item[v][k] = plan.take(max_items * 4);
     for (int k = 0; k < 3; ++k) o_multi[v][k] = plan.take(max_multi * 4);
   }
+  size_t o_short[4];
+  for (int v = 0; v < 4; ++v) o_short[v] = plan.take((size_t)((v & 1) ? V : R) * 4 + 4);
   const size_t persistent = plan.total;
   // build-time scratch (freed with a second allocation)
   SlabPlan tmp;
@@ -550,6 +619,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const size_t t_pay_s0 = tmp.take(E * 4), t_pay_s1 = tmp.take(E * 4);
   const size_t t_hist = tmp.take((size_t)RS_RADIX * rs_blocks * 4 + 16);
   const size_t t_counters = tmp.take(64 * 4);
+  const size_t t_bins = tmp.take((size_t)4 * 2 * SHORT_BINS * 4);
   const size_t t_scan = tmp.take((scan_scratch_elems(R + 1) + scan_scratch_elems((int64_t)RS_RADIX * rs_blocks)) * 4 + 16);
   const size_t t_eid2pos = tmp.take(E * 4);
   const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
@@ -636,6 +706,8 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   } while (0)
 
   G_CHECK(hipMemsetAsync(counters, 0, 64 * 4, s));
+  int32_t* bins = (int32_t*)(scratch + t_bins);
+  G_CHECK(hipMemsetAsync(bins, 0, (size_t)4 * 2 * SHORT_BINS * 4, s));
   // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
   {
     char* hp = (char*)g->pinned + 256;
@@ -757,6 +829,17 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     pl.multi_n = (int32_t*)(slab + o_multi[v][2]);
     pl.long_threshold = view_long[v];
     pl.item_chunk_edges = view_chunk[v];
+    pl.short_rows = (int32_t*)(slab + o_short[v]);
+    if (g->views[v].num_rows > 0) {
+      int32_t* bc = bins + (size_t)v * 2 * SHORT_BINS;
+      const int64_t nr = g->views[v].num_rows;
+      const unsigned hist_blocks = (unsigned)std::min<int64_t>(ceil_div(nr, 256), 1024);
+      const unsigned scat_blocks = (unsigned)std::min<int64_t>(ceil_div(nr, 256 * SHORT_TILE_ROWS), 4096);
+      hipLaunchKernelGGL(short_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, g->views[v].rowptr, nr, view_long[v], bc,
+                         counters + 16 + 4 * v + 3);
+      hipLaunchKernelGGL(short_scatter_kernel, dim3(scat_blocks), dim3(256), 0, s, g->views[v].rowptr, nr, view_long[v],
+                         bc, bc + SHORT_BINS, pl.short_rows);
+    }
     if (E > 0 && g->views[v].num_rows > 0) {
       hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks_for(g->views[v].num_rows)), dim3(threads), 0, s,
                          g->views[v].rowptr, g->views[v].num_rows, view_long[v], view_chunk[v], counters + 16 + 4 * v, pl.item_row,
@@ -789,6 +872,7 @@ extern "C" int tfgnn_graph_wait(tfgnn_graph* g) {
     g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
     g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
     g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
+    g->views[v].plan.num_short = h_counters[16 + 4 * v + 3];
   }
   for (int side = 0; side < 2; ++side) {
     const int32_t* h = (const int32_t*)((const char*)g->pinned + 256 + (size_t)(g->L + 1) * 16 + (size_t)side * (g->L + 1) * 4);

@@ -8,8 +8,10 @@ namespace tfgnn {
 // Rows longer than LONG_ROW_THRESHOLD edges are not walked by a single lane group: they are cut
 // into items of ITEM_CHUNK consecutive edges, one workgroup per item (deterministic partial sums,
 // combined in item order).  Keeps the tail of the gather kernel bounded on skewed (R-MAT) graphs.
-constexpr int LONG_ROW_THRESHOLD = 32;
-constexpr int ITEM_CHUNK = 256;
+constexpr int LONG_ROW_THRESHOLD = 64;        // node views (all edge types of a node in one row)
+constexpr int ITEM_CHUNK = 512;
+constexpr int LONG_ROW_THRESHOLD_TYPED = 48;  // typed views (one row per (node, type) bucket)
+constexpr int ITEM_CHUNK_TYPED = 192;
 
 struct CsrPlan {
   int32_t long_threshold = LONG_ROW_THRESHOLD;  // values the plan was built with (env-tunable for probes)
@@ -23,7 +25,12 @@ struct CsrPlan {
   int32_t* multi_row = nullptr;   // [num_multi]
   int32_t* multi_base = nullptr;  // [num_multi] first scratch slot
   int32_t* multi_n = nullptr;     // [num_multi] number of items
+  // rows of at most long_threshold edges, longest first: the lane groups of a wave get rows of (almost) equal
+  // length, so a wave is not held up by its longest row (65 % -> ~100 % lane use on an R-MAT batch)
+  int32_t* short_rows = nullptr;  // [num_short]
+  int32_t num_short = 0;
 };
+constexpr int SHORT_BINS = 257;  // long_threshold <= 256
 
 // Non-empty buckets in type-major order (all non-empty (node, type 0) rows, then type 1, ...): lets the
 // dense per-relation multiply run only over buckets that received at least one edge.

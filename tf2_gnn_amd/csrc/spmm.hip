@@ -87,6 +87,8 @@ enum { MODE_SUM = 0, MODE_HEADS = 1, MODE_GENERAL = 2 };
 struct GatherArgs {
   const int32_t* rowptr;
   const int32_t* col;
+  const int32_t* short_rows;  // nullable: the rows the row workgroups handle, longest first (CsrPlan)
+  int64_t num_short;
   const float* ew;         // nullable; [E] or [E, ew_heads]
   const float* row_scale;  // nullable
   int64_t num_rows;
@@ -189,8 +191,9 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   const int tid = threadIdx.x;
   const int group = tid / LPR;
   const int gl = tid % LPR;
-  const int64_t row = (int64_t)row_block * GROUPS_PER_BLOCK + group;
-  if (row >= a.num_rows) return;
+  const int64_t slot = (int64_t)row_block * GROUPS_PER_BLOCK + group;
+  if (slot >= (a.short_rows ? a.num_short : a.num_rows)) return;
+  const int64_t row = a.short_rows ? a.short_rows[slot] : slot;
   const int f0 = window * WINDOW + gl * VEC;  // first float of this lane's chunk 0
   const int32_t beg = a.rowptr[row];
   const int32_t end = a.rowptr[row + 1];
@@ -241,7 +244,10 @@ __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
   const int32_t rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
   const int32_t ibeg = rbeg + a.item_chunk[item] * a.item_chunk_edges;
   const int32_t iend = min(rend, ibeg + a.item_chunk_edges);
-  const int per = (a.item_chunk_edges + GROUPS - 1) / GROUPS;
+  // the item's edges are dealt evenly to the lane groups (in pairs: the walk is unrolled by UNROLL), so a
+  // 60-edge row keeps all 16 groups busy instead of the first five
+  int per = (iend - ibeg + GROUPS - 1) / GROUPS;
+  per = (per + UNROLL - 1) / UNROLL * UNROLL;
   const int32_t beg = min(iend, ibeg + group * per);
   const int32_t end = min(iend, beg + per);
   const int w0 = window * WINDOW;
@@ -327,7 +333,7 @@ static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
   const unsigned windows = (unsigned)ceil_div(a.width, WINDOW);
-  const unsigned units = (unsigned)(num_items + ceil_div(a.num_rows, GROUPS_PER_BLOCK));
+  const unsigned units = (unsigned)(num_items + ceil_div(a.short_rows ? a.num_short : a.num_rows, GROUPS_PER_BLOCK));
   dim3 block(256);
   a.total_units = units;
   if (a.xcd_units_pad && windows > 1) {
@@ -464,5 +470,11 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
   a.partial = (float*)d_workspace; a.item_chunk_edges = p.item_chunk_edges;
   a.multi_row = p.multi_row; a.multi_base = p.multi_base; a.multi_n = p.multi_n; a.num_multi = p.num_multi;
+  // bit 0: typed views, bit 1: node views keep the natural row order (probing)
+  static const int natural_order = [] { const char* e = getenv("TFGNN_GATHER_NATURAL_ORDER"); return e ? atoi(e) : 0; }();
+  if (!(natural_order & ((view & 1) ? 2 : 1))) {
+    a.short_rows = p.short_rows;
+    a.num_short = p.num_short;
+  }
   return gather_dispatch(a, p.num_items, (hipStream_t)stream);
 }
