@@ -583,8 +583,8 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     o_cb[side][5] = plan.take((R + 1) * 4);            // col_nz
   }
   // long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
-  // views 95 us at (48, 192) vs 114 us at (16, 128) (134 us in natural row order); the node views - all edge
-  // types of a node in one row - 125 us at (64, 512) vs 131 us at (32, 256) (138 us in natural order).  TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override the typed views, TFGNN_LONG_ROW_NODE /
+  // views 91 us at (48, 512) vs 104 us at (16, 192) (134 us in natural row order at (16, 128)); the node views -
+  // all edge types of a node in one row - 121 us at (32, 512) vs 128 us at (64, 512) (138 us in natural order).  TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override the typed views, TFGNN_LONG_ROW_NODE /
   // TFGNN_ITEM_CHUNK_NODE the node views, for probing.
   static const int env_long = [] { const char* e = getenv("TFGNN_LONG_ROW"); return e ? atoi(e) : 0; }();
   static const int env_chunk = [] { const char* e = getenv("TFGNN_ITEM_CHUNK"); return e ? atoi(e) : 0; }();

@@ -8,10 +8,10 @@ namespace tfgnn {
 // Rows longer than LONG_ROW_THRESHOLD edges are not walked by a single lane group: they are cut
 // into items of ITEM_CHUNK consecutive edges, one workgroup per item (deterministic partial sums,
 // combined in item order).  Keeps the tail of the gather kernel bounded on skewed (R-MAT) graphs.
-constexpr int LONG_ROW_THRESHOLD = 64;        // node views (all edge types of a node in one row)
+constexpr int LONG_ROW_THRESHOLD = 32;        // node views (all edge types of a node in one row)
 constexpr int ITEM_CHUNK = 512;
 constexpr int LONG_ROW_THRESHOLD_TYPED = 48;  // typed views (one row per (node, type) bucket)
-constexpr int ITEM_CHUNK_TYPED = 192;
+constexpr int ITEM_CHUNK_TYPED = 512;
 
 struct CsrPlan {
   int32_t long_threshold = LONG_ROW_THRESHOLD;  // values the plan was built with (env-tunable for probes)
