@@ -319,9 +319,13 @@ def gnn_internal_call(
     node_features: torch.Tensor,
     adjacency_lists: Sequence[torch.Tensor],
     dropout_masks: Optional[Sequence[Optional[torch.Tensor]]] = None,
+    node_to_graph_map: Optional[torch.Tensor] = None,
+    num_graphs: Optional[int] = None,
+    exchange_dropout_masks: Optional[Dict[int, torch.Tensor]] = None,
 ):
     """weights: {"initial_projection": [Din,H], "mp": [per-layer weights dict],
-                 "dense": {layer_idx: [H,H]}, "layernorm": [(gamma, beta)] }.
+                 "dense": {layer_idx: [H,H]}, "layernorm": [(gamma, beta)],
+                 "global_exchange": {layer_idx: weights of graph_global_exchange} }.
     ``dropout_masks[i]`` (already scaled by 1/(1-rate), or None) multiplies the input of layer i:
     lets tests inject the exact mask the HIP path drew ([ext] tf.nn.dropout scales kept units by
     1/(1-rate))."""
@@ -345,7 +349,11 @@ def gnn_internal_call(
         cur = message_passing_call(kind, params, weights["mp"][i], cur, adjacency_lists)
         all_reprs.append(cur)
         if i and i % params["global_exchange_every_num_layers"] == 0:
-            raise NotImplementedError("graph global exchange is out of scope (SURVEY.md 8f rank 3)")
+            ex = weights["global_exchange"][i]
+            cur = graph_global_exchange(
+                params["global_exchange_mode"], params, ex, cur, node_to_graph_map, num_graphs,
+                None if exchange_dropout_masks is None else exchange_dropout_masks.get(i),
+            )
         if params["use_inter_layer_layernorm"]:
             g, b = weights["layernorm"][i]
             cur = layer_norm(cur, g, b)
@@ -354,6 +362,33 @@ def gnn_internal_call(
             if act_dense is not None:
                 cur = act_dense(cur)
     return cur, tuple(all_reprs)
+
+
+# --------------------------------------------------------------------------------------------
+# graph-global exchange: tf2_gnn/layers/graph_global_exchange.py
+# --------------------------------------------------------------------------------------------
+def graph_global_exchange(mode, params, weights, node_embeddings, node_to_graph_map, num_graphs, dropout_mask=None):
+    """GraphGlobal{Mean,GRU,MLP}Exchange.call (graph_global_exchange.py:83-183).
+    weights: {"pool": weights of the WeightedSumGraphRepresentation(graph_representation_size=H, weighting_fun,
+              num_heads, scoring_mlp_layers=[H]) of :46-58,
+              gru:  "gru_kernel" [H,3H], "gru_recurrent_kernel" [H,3H], "gru_bias" [2,3H]   (:140-153)
+              mlp:  "mlp" = list of kernels of MLP(out_size=H) on [graph repr | node state]  (:168-182)}
+    dropout_mask: the (already 1/(1-rate)-scaled) mask of :104-107, or None (eval)."""
+    H = params["hidden_dim"]
+    cfg = {"graph_representation_size": H, "num_heads": params["global_exchange_num_heads"],
+           "weighting_fun": params["global_exchange_weighting_fun"]}
+    graph_reprs = weighted_sum_graph_representation(cfg, weights["pool"], node_embeddings, node_to_graph_map, num_graphs)
+    per_node = graph_reprs[node_to_graph_map.long()]  # gather_dense_gradient, :99-101
+    if dropout_mask is not None:
+        per_node = per_node * dropout_mask
+    mode = mode.lower()
+    if mode == "mean":
+        return (node_embeddings + per_node) / 2
+    if mode == "gru":
+        return gru_cell(per_node, node_embeddings, weights["gru_kernel"], weights["gru_recurrent_kernel"], weights["gru_bias"])
+    if mode == "mlp":
+        return mlp_forward(torch.cat([per_node, node_embeddings], dim=-1), weights["mlp"])
+    raise ValueError(f"Unknown global_exchange_mode mode {mode}")
 
 
 # --------------------------------------------------------------------------------------------

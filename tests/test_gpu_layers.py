@@ -108,6 +108,8 @@ def _to64(w):
         return {k: _to64(v) for k, v in w.items()}
     if isinstance(w, list):
         return [_to64(v) for v in w]
+    if isinstance(w, tuple):
+        return tuple(_to64(v) for v in w)
     if isinstance(w, torch.Tensor):
         return w.double()
     return w
@@ -583,3 +585,102 @@ def test_gnn_film_in_a_gnn_stack_and_unsupported_modes(dev):
     layer, _ = _build("GNN_FiLM", {"hidden_dim": H, "aggregation_function": "max"}, H, L)
     with pytest.raises(NotImplementedError):
         layer(MessagePassingInput(torch.zeros((V, H), device=dev), to_dev(adjs, dev)))
+
+
+# ---- graph global exchange ("next" row f3) --------------------------------------------------------------
+def _exchange_weights(ex):
+    w = {"pool": _pool_weights(ex._node_to_graph_representation_layer)}
+    if hasattr(ex, "_gru"):
+        w["gru_kernel"] = ex._gru["kernel"].value.cpu().clone()
+        w["gru_recurrent_kernel"] = ex._gru["recurrent_kernel"].value.cpu().clone()
+        w["gru_bias"] = ex._gru["bias"].value.cpu().clone()
+    if hasattr(ex, "_mlp"):
+        w["mlp"] = [k.value.cpu().clone() for k in ex._mlp.kernels]
+    return w
+
+
+@pytest.mark.parametrize("mode,wf", [("gru", "softmax"), ("mean", "sigmoid"), ("mlp", "softmax")])
+def test_gnn_with_graph_global_exchange_parity(dev, mode, wf):
+    """gnn.py:307-315 + graph_global_exchange.py: a 3-layer RGCN stack with an exchange after layer 2 on a batch of
+    5 graphs; forward and every weight gradient against fp64 autograd through the oracle."""
+    from tf2_gnn_amd.layers import GNN, GNNInput
+
+    sizes = [13, 1, 22, 9, 15]
+    V, L, Din, H = sum(sizes), 2, 6, 16
+    rng = np.random.default_rng(3)
+    adjs = []
+    for _ in range(L):
+        parts, base = [], 0
+        for n in sizes:
+            parts.append(rng.integers(0, n, size=(3 * n, 2)) + base)
+            base += n
+        adjs.append(np.concatenate(parts).astype(np.int32))
+    n2g = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
+    params = GNN.get_default_hyperparameters("rgcn")
+    params.update({"hidden_dim": H, "num_layers": 3, "global_exchange_every_num_layers": 2, "global_exchange_mode": mode,
+                   "global_exchange_weighting_fun": wf, "global_exchange_num_heads": 4,
+                   "dense_every_num_layers": 10000, "residual_every_num_layers": 10000})
+    gnn = GNN(params)
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn((V, Din), generator=g)
+    dOut = torch.randn((V, H), generator=g)
+    inp = GNNInput(X.to(dev), to_dev(adjs, dev), torch.from_numpy(n2g).to(dev), len(sizes))
+    out = gnn(inp, training=False)
+    assert sorted(gnn._global_exchange_layers) == ["2"]
+    w = _gnn_oracle_weights(gnn)
+    w["global_exchange"] = {2: _exchange_weights(gnn._global_exchange_layers["2"])}
+    tadjs = [torch.from_numpy(a) for a in adjs]
+    ref, _ = orc.gnn_internal_call(params, w, X, tadjs, node_to_graph_map=torch.from_numpy(n2g), num_graphs=len(sizes))
+    assert_close(out.cpu(), ref, tol=2e-5, what=f"gnn + {mode} exchange")
+
+    w64 = _to64(w)
+    leaves = []
+
+    def visit(obj):
+        if isinstance(obj, torch.Tensor):
+            obj.requires_grad_(True)
+            leaves.append(obj)
+        elif isinstance(obj, dict):
+            for k in obj:
+                visit(obj[k])
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                if v is not None:
+                    visit(v)
+
+    visit(w64)
+    ref64, _ = orc.gnn_internal_call(params, w64, X.double(), tadjs, node_to_graph_map=torch.from_numpy(n2g),
+                                     num_graphs=len(sizes))
+    grads = torch.autograd.grad((ref64 * dOut.double()).sum(), leaves, allow_unused=True)
+    by_id = {id(t): gr for t, gr in zip(leaves, grads)}
+    gnn.backward(dOut.to(dev))
+
+    def check(var, ref_t, what):
+        r = by_id[id(ref_t)]
+        assert var.grad is not None, what
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(var.grad.cpu() / scale, (r / scale).float(), tol=5e-5, what=what)
+
+    check(gnn._initial_projection_layer, w64["initial_projection"], "d initial projection")
+    for i, mp in enumerate(gnn._mp_layers):
+        for l in range(L):
+            for j, v in enumerate(mp._edge_type_mlps.vars[l]):
+                check(v, w64["mp"][i]["edge_mlps"][l][j], f"layer {i} {v.name}")
+    ex = gnn._global_exchange_layers["2"]
+    ew = w64["global_exchange"][2]
+    pool = ex._node_to_graph_representation_layer
+    for k, t in zip(pool._scoring_mlp.kernels, ew["pool"]["scoring"][0]):
+        check(k, t, "exchange scoring " + k.name)
+    for k, t in zip(pool._transformation_mlp.kernels, ew["pool"]["transformation"][0]):
+        check(k, t, "exchange transformation " + k.name)
+    if mode == "gru":
+        check(ex._gru["kernel"], ew["gru_kernel"], "exchange gru kernel")
+        check(ex._gru["recurrent_kernel"], ew["gru_recurrent_kernel"], "exchange gru recurrent kernel")
+        check(ex._gru["bias"], ew["gru_bias"], "exchange gru bias")
+    if mode == "mlp":
+        for k, t in zip(ex._mlp.kernels, ew["mlp"]):
+            check(k, t, "exchange mlp " + k.name)
+    # training mode: dropout on the broadcast graph representations is drawn and finite
+    out_t = gnn(inp, training=True)
+    gnn.backward(dOut.to(dev))
+    assert bool(torch.isfinite(out_t).all())

@@ -153,7 +153,9 @@ def test_gnn_build_creates_reference_layer_set():
     assert sum("Dense/kernel" in n for n in names) == 1
     assert sum("MessagePassing" in n for n in names) == 4 * 3
     assert tuple(gnn.trainable_variables[0].shape) == (5, 8)
-    # default GNN params enable global exchange at layer 2: explicitly out of scope
-    with pytest.raises(NotImplementedError, match="global exchange"):
-        g2 = GNN(GNN.get_default_hyperparameters())
-        g2.build(GNNInput((None, 5), ((None, 2),), (None,), ()))
+    # default GNN params (gnn.py:53-79) enable a GRU global exchange every 2 layers: layer 2 of 4 gets one
+    g2 = GNN(GNN.get_default_hyperparameters())
+    g2.build(GNNInput((None, 5), ((None, 2),), (None,), ()))
+    assert sorted(g2._global_exchange_layers) == ["2"]
+    ex_names = [v.name for v in g2.trainable_variables if "Global_Exchange" in v.name]
+    assert sum("gru_cell" in n for n in ex_names) == 3 and any("ScoringMLP" in n for n in ex_names)

@@ -1,4 +1,11 @@
 from .gnn import GNN, GNNInput
+from .graph_global_exchange import (
+    GraphGlobalExchange,
+    GraphGlobalExchangeInput,
+    GraphGlobalGRUExchange,
+    GraphGlobalMeanExchange,
+    GraphGlobalMLPExchange,
+)
 from .message_passing import (
     GGNN,
     GNN_Edge_MLP,

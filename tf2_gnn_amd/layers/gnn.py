@@ -6,7 +6,7 @@ residual averaging, LayerNorm) runs on the same HIP library so that a whole forw
 stays on the device without a second framework in the loop.  The batch's edges are bucketed once
 (ops.Graph) and shared by all message passing layers and both passes.
 
-Out of scope (raises): graph global exchange (layers/graph_global_exchange.py) - disabled in every
+Graph global exchange (layers/graph_global_exchange.py) is built from the same kernels - disabled in every
 PPI / QM9 default_hypers file; see DESIGN.md.
 """
 from __future__ import annotations
@@ -17,6 +17,13 @@ import torch
 
 from .. import ops
 from ..utils.param_helpers import get_activation_function
+from .graph_global_exchange import (
+    GraphGlobalExchange,
+    GraphGlobalExchangeInput,
+    GraphGlobalGRUExchange,
+    GraphGlobalMeanExchange,
+    GraphGlobalMLPExchange,
+)
 from .message_passing import MessagePassing, MessagePassingInput, get_message_passing_class
 from .message_passing.message_passing import Variable, _num_edge_types, default_device, get_graph, glorot_uniform
 
@@ -87,6 +94,7 @@ class GNN:
         self._mp_layers: List[MessagePassing] = []
         self._inter_layer_layernorms: List[Tuple[Variable, Variable]] = []
         self._dense_layers: Dict[str, Variable] = {}
+        self._global_exchange_layers: Dict[str, GraphGlobalExchange] = {}
         self.built = False
         self._ctx = None
         self._dropout_calls = 0
@@ -98,6 +106,8 @@ class GNN:
         out = [self._initial_projection_layer]
         for i, mp in enumerate(self._mp_layers):
             out.extend(mp.trainable_variables)
+            if str(i) in self._global_exchange_layers:
+                out.extend(self._global_exchange_layers[str(i)].trainable_variables)
             if self._use_inter_layer_layernorm:
                 out.extend(self._inter_layer_layernorms[i])
             if str(i) in self._dense_layers:
@@ -139,10 +149,18 @@ class GNN:
                     f"{name}/Layer_{layer_idx}/Dense/kernel", glorot_uniform((H, H), device=dev)
                 )
             if layer_idx and layer_idx % self._global_exchange_every_num_layers == 0:
-                raise NotImplementedError(
-                    "graph global exchange (layers/graph_global_exchange.py) is out of scope of the MI355X hot "
-                    "path; set global_exchange_every_num_layers > num_layers (as all PPI/QM9 default_hypers do)"
+                mode = self._params["global_exchange_mode"].lower()
+                cls = {"mean": GraphGlobalMeanExchange, "gru": GraphGlobalGRUExchange, "mlp": GraphGlobalMLPExchange}[mode]
+                ex = cls(
+                    hidden_dim=H,
+                    weighting_fun=self._params["global_exchange_weighting_fun"],
+                    num_heads=self._params["global_exchange_num_heads"],
+                    dropout_rate=self._params["global_exchange_dropout_rate"],
                 )
+                ex.build(GraphGlobalExchangeInput(embedded_shape, (None,), ()))
+                for v in ex.trainable_variables:
+                    v.name = f"{name}/Layer_{layer_idx}/Global_Exchange/{v.name}"
+                self._global_exchange_layers[str(layer_idx)] = ex
         self.built = True
 
     def __call__(self, inputs: GNNInput, training: bool = False, return_all_representations: bool = False):
@@ -194,6 +212,11 @@ class GNN:
                 last = tmp
             cur = mp_layer(MessagePassingInput(node_embeddings=cur, adjacency_lists=graph), training=training)
             all_reprs.append(cur)
+            if str(layer_idx) in self._global_exchange_layers:  # gnn.py:307-315
+                ex = self._global_exchange_layers[str(layer_idx)]
+                self._dropout_calls += 1
+                ex.dropout_seed = self.dropout_seed * 1000003 + self._dropout_calls
+                cur = ex(GraphGlobalExchangeInput(cur, inputs.node_to_graph_map, inputs.num_graphs), training=training)
             if self._use_inter_layer_layernorm:
                 g_, b_ = self._inter_layer_layernorms[layer_idx]
                 st["ln_in"] = cur
@@ -230,6 +253,8 @@ class GNN:
             if self._use_inter_layer_layernorm:
                 gam, bet = self._inter_layer_layernorms[layer_idx]
                 g, gam.grad, bet.grad = ops.layernorm_backward(g, st["ln_in"], gam.value, st["ln_mean"], st["ln_rstd"])
+            if str(layer_idx) in self._global_exchange_layers:
+                g = self._global_exchange_layers[str(layer_idx)].backward(g)
             g = self._mp_layers[layer_idx].backward(g)
             if layer_idx % self._residual_every_num_layers == 0:
                 if layer_idx > 0:
