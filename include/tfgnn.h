@@ -222,6 +222,20 @@ int tfgnn_film_combine_forward(const float* d_Z, const float* d_film, const int3
 int tfgnn_film_combine_backward(const float* d_grad_pre, const float* d_Z, const float* d_film,
                                 const int32_t* d_rowptr_typed, const float* d_node_scale, int64_t num_nodes,
                                 int num_edge_types, int64_t hidden, float* d_dZ, float* d_dfilm, void* stream);
+
+/* Batch finalisation of the adjacency lists on the device (tf2_gnn/data/utils.py:9-124, called per batch from
+ * data/graph_dataset.py:161-246): the building blocks of process_adjacency_lists.
+ *   tfgnn_adjacency_append      d_out[i] = flip ? (dst, src) : (src, dst) of edge i   (_add_backward_edges, :99-113;
+ *                               the caller points d_out at the tail of the tied type's list or at a new type's list)
+ *   tfgnn_adjacency_self_loops  d_out[i] = (i, i)                                       (_add_self_loop_edges, :88-96)
+ *   tfgnn_adjacency_in_degrees  d_counts[v] = number of edges of the list entering v, as float like the reference
+ *                               (_compute_type_to_num_inedges, :116-124); targets outside [0, V) are skipped here and
+ *                               reported by tfgnn_graph_create
+ * Edge lists are int32 [n, 2], 8-byte aligned. */
+int tfgnn_adjacency_append(const int32_t* d_edges, int64_t num_edges, int flip, int32_t* d_out, void* stream);
+int tfgnn_adjacency_self_loops(int64_t num_nodes, int32_t* d_out, void* stream);
+int tfgnn_adjacency_in_degrees(const int32_t* d_edges, int64_t num_edges, int64_t num_nodes, float* d_counts,
+                               void* stream);
 int tfgnn_graph_original_order(const tfgnn_graph* graph, const float* d_weight_by_dst, int32_t* d_src_l,
                                int32_t* d_tgt_l, int32_t* d_tgt_node, float* d_weight, void* stream);
 

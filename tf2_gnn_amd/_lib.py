@@ -129,6 +129,9 @@ _SIGNATURES = [
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    ("tfgnn_adjacency_append", c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    ("tfgnn_adjacency_self_loops", c_int, [c_int64, c_void_p, c_void_p]),
+    ("tfgnn_adjacency_in_degrees", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_permute_021", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_mul", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 ]

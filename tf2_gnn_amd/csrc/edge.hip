@@ -245,3 +245,70 @@ extern "C" int tfgnn_film_combine_backward(const float* d_grad_pre, const float*
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
+
+// ---- batch finalisation of the adjacency lists (tf2_gnn/data/utils.py:9-124) ------------------------
+// The reference adds backward edges, self loops and per-type in-degree counts with Python loops over every
+// edge while batching (data/graph_dataset.py:161-246); here they are three streaming kernels on the device.
+namespace tfgnn {
+__global__ void __launch_bounds__(256)
+adjacency_append_kernel(const int32_t* __restrict__ in, int64_t n, int flip, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int2 e = reinterpret_cast<const int2*>(in)[i];
+    reinterpret_cast<int2*>(out)[i] = flip ? make_int2(e.y, e.x) : e;
+  }
+}
+__global__ void __launch_bounds__(256) adjacency_self_loops_kernel(int64_t V, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<int2*>(out)[i] = make_int2((int)i, (int)i);
+}
+__global__ void __launch_bounds__(256)
+adjacency_in_degrees_kernel(const int32_t* __restrict__ edges, int64_t n, int64_t V, float* __restrict__ counts,
+                            int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = edges[2 * i + 1];
+    if (d < 0 || d >= V) {
+      if (bad) *bad = 1;
+      continue;
+    }
+    atomicAdd(&counts[d], 1.0f);  // integer-valued: exact and order-independent below 2^24 edges per node
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_adjacency_append(const int32_t* d_edges, int64_t num_edges, int flip, int32_t* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0, "negative size");
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_edges && d_out, "NULL pointer");
+  TFGNN_REQUIRE(((uintptr_t)d_edges | (uintptr_t)d_out) % 8 == 0, "edge lists must be 8-byte aligned");
+  hipLaunchKernelGGL(adjacency_append_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_edges, 256), 65535)), dim3(256),
+                     0, (hipStream_t)stream, d_edges, num_edges, flip, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_adjacency_self_loops(int64_t num_nodes, int32_t* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_nodes < ((int64_t)1 << 31), "bad node count");
+  if (num_nodes == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_out && (uintptr_t)d_out % 8 == 0, "NULL / unaligned pointer");
+  hipLaunchKernelGGL(adjacency_self_loops_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_nodes, 256), 65535)),
+                     dim3(256), 0, (hipStream_t)stream, num_nodes, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_adjacency_in_degrees(const int32_t* d_edges, int64_t num_edges, int64_t num_nodes, float* d_counts,
+                                          void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && num_nodes >= 0, "negative size");
+  if (num_nodes == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_counts != nullptr, "NULL pointer");
+  TFGNN_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)num_nodes * 4, (hipStream_t)stream));
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_edges != nullptr, "NULL pointer");
+  hipLaunchKernelGGL(adjacency_in_degrees_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_edges, 256), 65535)),
+                     dim3(256), 0, (hipStream_t)stream, d_edges, num_edges, num_nodes, d_counts, (int*)nullptr);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}

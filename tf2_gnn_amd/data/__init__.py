@@ -1,1 +1,2 @@
 from .synthetic import make_synthetic_batch, rmat_edges
+from .utils import compute_number_of_edge_types, get_tied_edge_types, process_adjacency_lists
