@@ -268,6 +268,19 @@ enum { TFGNN_GEMM_FP32 = 0, TFGNN_GEMM_BF16X3 = 6, TFGNN_GEMM_BF16X3_EXACT = 9 }
 int tfgnn_gemm_set_mode(int mode);
 int tfgnn_gemm_get_mode(void);
 
+/* The input-gradient product with the element-wise factors of the NEXT backward step applied on the way out:
+ *   C[M,N] = (op(A) @ op(B)) * mul * act'(saved)
+ * mul    = the dropout mask of tf.nn.dropout on the layer input (gnn.py:285-288), NULL = absent;
+ * saved  = what tfgnn_activation_backward takes for `act_of_saved` (the activation's output, or its input for
+ *          gelu) of the layer below (message_passing.py:176-177 / Dense activation gnn.py:324-327), NULL = absent.
+ * Saves two passes over [V, H] per layer boundary.  Returns TFGNN_ERR_UNSUPPORTED when the active GEMM mode / shape
+ * has no fused epilogue (only the split-operand NN / NT kernel has one): the caller then runs tfgnn_gemm, tfgnn_mul
+ * and tfgnn_activation_backward. */
+int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
+                             int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                             const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved,
+                             int64_t ld_saved, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Grouped forms of the Dense layer for the per-relation multiply over NON-EMPTY buckets only (rows of
  * the stacked operand are grouped by edge type: group g owns rows [d_group_offsets[g],
  * d_group_offsets[g+1]), TFGNN_G_NZ_OFF_*; max_group_rows bounds the launch grid):

@@ -49,6 +49,12 @@ _SIGNATURES = [
     ("tfgnn_edge_pair_combine", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     ("tfgnn_graph_original_order", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("tfgnn_gemm_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64]),
+    (
+        "tfgnn_gemm_grad_epilogue",
+        c_int,
+        [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+         c_int, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
+    ),
     ("tfgnn_gemm_set_mode", c_int, [c_int]),
     ("tfgnn_gemm_get_mode", c_int, []),
     (

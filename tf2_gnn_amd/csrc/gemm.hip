@@ -417,7 +417,8 @@ int gemm_x3_mode();
 int gemm_x3_set_mode(int mode);
 int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
-                void* workspace, size_t workspace_bytes, hipStream_t s, int* status);
+                void* workspace, size_t workspace_bytes, hipStream_t s, int* status, const float* mul = nullptr,
+                int64_t ld_mul = 0, const float* saved = nullptr, int64_t ld_saved = 0, int dact = 0);
 
 }  // namespace tfgnn
 
@@ -430,6 +431,26 @@ extern "C" int tfgnn_gemm_set_mode(int mode) {
 }
 
 extern "C" int tfgnn_gemm_get_mode(void) { return tfgnn::gemm_x3_mode(); }
+
+extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
+                                        int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                                        const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved,
+                                        int64_t ld_saved, void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative GEMM size");
+  if (M == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_C && d_A && d_B, "NULL operand");
+  TFGNN_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
+  TFGNN_REQUIRE((!d_mul || ld_mul >= N) && (!d_saved || ld_saved >= N), "bad leading dimension of an epilogue operand");
+  const int nprod = gemm_x3_mode();
+  if (!nprod) return TFGNN_ERR_UNSUPPORTED;
+  int status = TFGNN_OK;
+  if (gemm_x3_try(nprod, trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, nullptr, TFGNN_ACT_NONE, 0, d_workspace,
+                  d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status, d_mul, ld_mul, d_saved, ld_saved,
+                  act_of_saved))
+    return status;
+  return TFGNN_ERR_UNSUPPORTED;
+}
 
 extern "C" size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   using namespace tfgnn;

@@ -51,7 +51,26 @@ struct X3Args {
   float* partial;
   unsigned n_tiles;
   int debug;  // TFGNN_GEMM_DEBUG probe bits: 1 = no split/store/fetch in the loop, 2 = no multiply (results wrong)
+  // gradient epilogue (tfgnn_gemm_grad_epilogue): C = (A B) * mul * act'(saved); NULL = factor absent
+  const float* mul;
+  int64_t ld_mul;
+  const float* saved;
+  int64_t ld_saved;
+  int dact;
 };
+
+__device__ __forceinline__ float4 grad_epilogue(const X3Args& g, float4 v, int64_t row, int64_t col) {
+  if (g.mul) {
+    const float4 m = *reinterpret_cast<const float4*>(g.mul + row * g.ld_mul + col);
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+  }
+  if (g.saved) {
+    const float4 sv = *reinterpret_cast<const float4*>(g.saved + row * g.ld_saved + col);
+    v.x *= act_grad(g.dact, sv.x); v.y *= act_grad(g.dact, sv.y);
+    v.z *= act_grad(g.dact, sv.z); v.w *= act_grad(g.dact, sv.w);
+  }
+  return v;
+}
 
 // exact 3-way split of an fp32 value into bf16 pieces (upper halves of h, m, l)
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -669,6 +688,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
           }
           v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y);
           v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+          v = grad_epilogue(g, v, grow, gcol);
           if (g.accumulate) {
             const float4 c4v = *reinterpret_cast<const float4*>(dst);
             v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
@@ -691,6 +711,8 @@ __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
     const int64_t row = i / g.N, col = i - row * g.N;
     if (g.bias) s += g.bias[col];
     s = act_apply(g.act, s);
+    if (g.mul) s *= g.mul[row * g.ld_mul + col];
+    if (g.saved) s *= act_grad(g.dact, g.saved[row * g.ld_saved + col]);
     float* c = g.C + row * g.ldc + col;
     if (g.accumulate) s += *c;
     *c = s;
@@ -706,7 +728,7 @@ static void launch_x3(const X3Args& g, dim3 grid, int nprod, hipStream_t s) {
     const char* e = getenv("TFGNN_X3_KERNEL");
     return !e ? 0 : (!strcmp(e, "spec") ? 1 : (!strcmp(e, "pipe") ? 2 : 0));
   }();
-  const bool spec = which == 1 || (which == 0 && !(A_KM && B_KM));
+  const bool spec = which == 1 || (which == 0 && !(A_KM && B_KM)) || g.mul || g.saved;
   if (spec) {
     if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
     else hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
@@ -739,8 +761,13 @@ int gemm_x3_set_mode(int mode) {
 // returns 1 if it took the call, 0 if the shape / layout is not covered (caller falls back to gemm.hip)
 int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
-                void* workspace, size_t workspace_bytes, hipStream_t s, int* status) {
+                void* workspace, size_t workspace_bytes, hipStream_t s, int* status, const float* mul, int64_t ld_mul,
+                const float* saved, int64_t ld_saved, int dact) {
   *status = TFGNN_OK;
+  if (mul || saved) {  // the gradient epilogue lives in the specialised kernel (NN / NT) only
+    if (trans_a) return 0;
+    if ((mul && (((uintptr_t)mul % 16) || ld_mul % 4)) || (saved && (((uintptr_t)saved % 16) || ld_saved % 4))) return 0;
+  }
   // the 128 x 320 tile only (N = 320 family), 16-byte aligned operands, supported layout pairs:
   //   NN (A [M,K], B [K,N]), NT (A [M,K], B [N,K]), TN (A [K,M], B [K,N])
   if (trans_a && trans_b) return 0;
@@ -752,6 +779,7 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   X3Args g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.act = act; g.accumulate = accumulate;
+  g.mul = mul; g.ld_mul = ld_mul; g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
   g.n_tiles = (unsigned)ceil_div(N, 320);
   const int64_t tiles = ceil_div(M, 128) * (int64_t)g.n_tiles;
   g.splits = 1;

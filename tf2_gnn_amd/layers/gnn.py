@@ -230,44 +230,82 @@ class GNN:
         return cur, tuple(all_reprs)
 
     # ---- backward (stands in for tf.GradientTape, models/graph_task_model.py:347-357) ---------
-    def _dense_backward(self, grad, x_in, w: Variable, act_name, out, pre):
-        if act_name is not None:
-            grad = ops.activation_backward(act_name, grad, pre if act_name == "gelu" else out)
-        w.grad = ops.gemm(x_in, grad, trans_a=True)
-        return grad
+    def _tail_first_backward_op(self, layer_idx: int, ctx):
+        """What the backward pass meets first below layer ``layer_idx``'s input gradient (after its dropout mask): the
+        activation of the last forward op of layer ``layer_idx - 1`` (Dense, else the message passing layer itself), or
+        of the initial projection for layer 0.  -> (activation name, saved tensor) or None if that op is not a plain
+        activation (LayerNorm / global exchange in between, no activation)."""
+        if layer_idx == 0:
+            if self._init_act is None:
+                return None
+            return self._init_act, (ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
+        prev = layer_idx - 1
+        st = ctx["steps"][prev]
+        if prev % self._dense_every_num_layers == 0:
+            if self._dense_act is None:
+                return None
+            return self._dense_act, (st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"])
+        if self._use_inter_layer_layernorm or str(prev) in self._global_exchange_layers:
+            return None
+        return self._mp_layers[prev].activation_backward_spec()
 
     def backward(self, grad_output: torch.Tensor, need_input_grad: bool = False):
         """Back-propagate d(loss)/d(final node representations) through the stack; fills ``.grad``
-        of every trainable variable; returns d(loss)/d(node_features) if requested."""
+        of every trainable variable; returns d(loss)/d(node_features) if requested.
+
+        Between two layers the gradient only meets element-wise factors - the dropout mask of the upper layer's
+        input and the activation derivative of the lower layer's last op; where no residual / LayerNorm / exchange
+        intervenes they are handed to the upper layer's input-gradient GEMM (backward_with_epilogue) instead of
+        running as two more passes over [V, H]."""
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
         g = grad_output
+        g_is_pre = False  # g already carries the activation derivative of the op differentiated next
         g_last = None
         for layer_idx in range(self._num_layers - 1, -1, -1):
             st = ctx["steps"][layer_idx]
+            mp = self._mp_layers[layer_idx]
+            has_ln = self._use_inter_layer_layernorm
+            has_ex = str(layer_idx) in self._global_exchange_layers
             if layer_idx % self._dense_every_num_layers == 0:
                 w = self._dense_layers[str(layer_idx)]
-                gpre = self._dense_backward(g, st["dense_in"], w, self._dense_act, st["dense_out"], st["dense_pre"])
-                g = ops.gemm(gpre, w.value, trans_b=True)
-            if self._use_inter_layer_layernorm:
+                gpre = g
+                if self._dense_act is not None and not g_is_pre:
+                    gpre = ops.activation_backward(
+                        self._dense_act, g, st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"]
+                    )
+                w.grad = ops.gemm(st["dense_in"], gpre, trans_a=True)
+                nxt = None if (has_ln or has_ex) else mp.activation_backward_spec()
+                g = ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=nxt)
+                g_is_pre = nxt is not None
+            if has_ln:
                 gam, bet = self._inter_layer_layernorms[layer_idx]
                 g, gam.grad, bet.grad = ops.layernorm_backward(g, st["ln_in"], gam.value, st["ln_mean"], st["ln_rstd"])
-            if str(layer_idx) in self._global_exchange_layers:
+            if has_ex:
                 g = self._global_exchange_layers[str(layer_idx)].backward(g)
-            g = self._mp_layers[layer_idx].backward(g)
-            if layer_idx % self._residual_every_num_layers == 0:
+            residual_here = layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and g_last is None)
+            mask = st.get("mask")
+            if not residual_here:
+                nxt = self._tail_first_backward_op(layer_idx, ctx)
+                g = mp.backward_with_epilogue(g, grad_is_pre_activation=g_is_pre, out_mul=mask, out_act_grad=nxt)
+                g_is_pre = nxt is not None
+            else:
+                g = mp.backward_with_epilogue(g, grad_is_pre_activation=g_is_pre)
+                g_is_pre = False
                 if layer_idx > 0:
                     half = ops.add_scale(g, g, 0.25)  # 0.5 * g
                     g = half if g_last is None else ops.add_scale(half, g_last, 1.0)
                     g_last = half
                 else:
-                    if g_last is not None:
-                        g = ops.add_scale(g, g_last, 1.0)
+                    g = ops.add_scale(g, g_last, 1.0)
                     g_last = None
-            if "mask" in st:
-                g = ops.mul(g, st["mask"])
-        gpre = self._dense_backward(g, ctx["X"], self._initial_projection_layer, self._init_act, ctx["h0"], ctx["pre0"])
+                if mask is not None:
+                    g = ops.mul(g, mask)
+        gpre = g
+        if self._init_act is not None and not g_is_pre:
+            gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
+        self._initial_projection_layer.grad = ops.gemm(ctx["X"], gpre, trans_a=True)
         if need_input_grad:
             return ops.gemm(gpre, self._initial_projection_layer.value, trans_b=True)
         return None

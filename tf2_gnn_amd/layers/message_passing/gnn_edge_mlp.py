@@ -25,6 +25,7 @@ import torch
 
 from ... import ops
 from .message_passing import (
+    apply_gradient_epilogue,
     MessagePassing,
     MessagePassingInput,
     Variable,
@@ -571,6 +572,33 @@ class GNN_Edge_MLP(MessagePassing):
         d_agg = self._backward_finish(grad_output, ctx)
         return self._backward_messages(d_agg, ctx)
 
+    def _plain_base_backward(self) -> bool:
+        cls = type(self)
+        return cls.backward is GNN_Edge_MLP.backward and cls._backward_finish is GNN_Edge_MLP._backward_finish
+
+    def activation_backward_spec(self):
+        ctx = self._ctx
+        if ctx is None or not self._plain_base_backward() or ctx.get("fused_act") is None:
+            return None
+        act = ctx["fused_act"]
+        return act, (ctx["pre"] if act == "gelu" else ctx["out"])
+
+    def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
+        if not self._plain_base_backward():
+            return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward called before a forward pass")
+        d_agg = grad_output if grad_is_pre_activation else self._backward_finish(grad_output, ctx)
+        self._out_epilogue = (out_mul, out_act_grad)
+        try:
+            dX = self._backward_messages(d_agg, ctx)
+            if self._out_epilogue is not None:  # the path taken had no GEMM to fold the factors into
+                dX = apply_gradient_epilogue(dX, out_mul, out_act_grad)
+        finally:
+            self._out_epilogue = None
+        return dX
+
     def _backward_finish(self, grad_output, ctx):
         """base class: undo the fused activation."""
         act = ctx["fused_act"]
@@ -612,7 +640,12 @@ class GNN_Edge_MLP(MessagePassing):
             G2 = G.view(V, L * H)
             if L > 0 and not self._use_target_state_as_input:
                 # dW^T = G^T X [L*H, D]: ten full 128-row output tiles instead of the 2.5 x 4 ragged ones of X^T G
-                ops.gemm(G2, Wh.view(D, L * H), trans_b=True, out=dX)
+                epi = getattr(self, "_out_epilogue", None)
+                if epi is not None:
+                    dX = ops.gemm_grad(G2, Wh.view(D, L * H), trans_b=True, out=dX, out_mul=epi[0], act_grad=epi[1])
+                    self._out_epilogue = None  # consumed
+                else:
+                    ops.gemm(G2, Wh.view(D, L * H), trans_b=True, out=dX)
                 mlps.grads = [ops.transpose_batched(ops.gemm(G2, X, trans_a=True).view(L, H, D))]
                 mlps.publish_grads()
                 return dX

@@ -253,6 +253,28 @@ class MessagePassing:
             "the built-in layers (RGCN, RGAT, RGIN, GGNN, GNN_Edge_MLP) implement it"
         )
 
+    # ---- hooks that let the layer stack fold element-wise backward steps into this layer's last GEMM ----------
+    def activation_backward_spec(self):
+        """(activation name, saved tensor) if backward() starts with activation_backward(name, grad, saved) and can
+        skip it when handed the already multiplied gradient (grad_is_pre_activation); None otherwise."""
+        return None
+
+    def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
+        """backward(), then d(node_embeddings) * out_mul * act'(saved) - the element-wise factors the caller would
+        apply next (dropout mask of this layer's input, activation derivative of the layer below).  Generic form:
+        separate kernels; GNN_Edge_MLP folds them into its input-gradient GEMM."""
+        if grad_is_pre_activation:
+            raise ValueError(f"{type(self).__name__} does not accept an already activation-multiplied gradient")
+        return apply_gradient_epilogue(self.backward(grad_output), out_mul, out_act_grad)
+
+
+def apply_gradient_epilogue(g, out_mul, out_act_grad):
+    if out_mul is not None:
+        g = ops.mul(g, out_mul)
+    if out_act_grad is not None:
+        g = ops.activation_backward(out_act_grad[0], g, out_act_grad[1])
+    return g
+
 
 def _num_edge_types(adjacency_lists) -> int:
     if isinstance(adjacency_lists, ops.Graph):

@@ -280,6 +280,44 @@ def graph_gather(
     return out
 
 
+def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> torch.Tensor:
+    """out = (a @ op(b)) * out_mul * act'(saved): an input-gradient product with the element-wise factors of the next
+    backward step (dropout mask ``out_mul``, ``act_grad = (activation name, saved tensor)``) applied in the GEMM
+    epilogue when the active kernel has one (tfgnn_gemm_grad_epilogue), by separate kernels otherwise."""
+    if out_mul is None and act_grad is None:
+        return gemm(a, b, trans_b=trans_b, out=out)
+    lib = _lib.load()
+    a2, lda = _rowmajor(a, "a")
+    b2, ldb = _rowmajor(b, "b")
+    M, K = a2.shape
+    N = b2.shape[0] if trans_b else b2.shape[1]
+    res = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    res2, ldc = _rowmajor(res, "out")
+    act_name, saved = act_grad if act_grad is not None else (None, None)
+
+    def plain(t):
+        return t is None or (t.dim() == 2 and t.stride(1) == 1 and tuple(t.shape) == (M, N))
+
+    if plain(out_mul) and plain(saved) and res2 is res:
+        ws_bytes = lib.tfgnn_gemm_workspace_bytes(M, N, K)
+        ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+        rc = lib.tfgnn_gemm_grad_epilogue(
+            0, int(trans_b), M, N, K, _ptr(a2), lda, _ptr(b2), ldb, _ptr(res), ldc, _ptr(out_mul),
+            out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
+            saved.stride(0) if saved is not None else 0, _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+        )
+        if rc == 0:
+            return res
+        if rc != -4:  # TFGNN_ERR_UNSUPPORTED: no fused epilogue for this mode / shape
+            _lib.check(rc)
+    res = gemm(a, b, trans_b=trans_b, out=out)
+    if out_mul is not None:
+        res = mul(res, out_mul)
+    if act_grad is not None:
+        res = activation_backward(act_name, res, saved)
+    return res
+
+
 GEMM_FP32, GEMM_BF16X3, GEMM_BF16X3_EXACT = 0, 6, 9
 _GEMM_MODE_NAMES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "bf16x3_9": GEMM_BF16X3_EXACT}
 
