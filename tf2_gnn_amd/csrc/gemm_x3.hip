@@ -132,7 +132,6 @@ __device__ __forceinline__ floatx16 mfma_group(floatx16 c, bf16x8 ah, bf16x8 am,
 // the MFMAs.
 // Plane layout (ushort units): [A rows 0..127 | B rows 128..447 | trash], row = 16 k; 16-byte half h of row
 // r is stored at half h ^ ((r >> 3) & 1).
-constexpr int X3_VALU_PER_MFMA = 5;
 constexpr int P_ROW = 16;
 constexpr int P_TRASH = 320;
 constexpr int P_PLANE = (X3_BM + X3_BN) * P_ROW + P_TRASH;  // 7488 ushorts

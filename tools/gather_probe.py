@@ -42,3 +42,13 @@ ms = t(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y, out=out))
 print(f"node gather from [V*L,H] (154 MB source)   {ms*1000:7.1f} us")
 ref = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=rs)
 print("checksum", float(ref.double().sum()), float(ref.double().abs().sum()))
+
+# what bounds the gather?  same edges, but every source row index folded into the first 1024 rows (4 x 1.3 MB:
+# L2-resident on every XCD): the difference to the real run is what the cache misses cost
+col = g.array(ops.G_COL_BY_DST)
+small = (col % 1024).contiguous()
+ms = t(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, col=small, row_scale=rs, out=A))
+print(f"fwd  aggregate, sources folded into 1024 rows (L2 hits) {ms*1000:7.1f} us")
+onecol = torch.zeros_like(col)
+ms = t(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, col=onecol, row_scale=rs, out=A))
+print(f"fwd  aggregate, every edge reads row 0                  {ms*1000:7.1f} us")
