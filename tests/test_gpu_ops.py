@@ -115,6 +115,44 @@ def test_transpose_batched(dev, shape):
     assert torch.equal(ops.transpose_batched(x[0].to(dev)).cpu(), x[0].t().contiguous())
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("act", ["relu", "tanh", "gelu", None])
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_gemm_grad_epilogue(dev, gemm_mode, mode, act, with_mask):
+    """C = (A @ B^T) * mask * act'(saved): fused into the split-operand kernel's epilogue in bf16x3 mode
+    (tfgnn_gemm_grad_epilogue), separate kernels otherwise - same result either way."""
+    from tf2_gnn_amd import ops
+
+    if act is None and not with_mask:
+        pytest.skip("nothing to fuse")
+    gemm_mode(mode)
+    M, N, K = 1000, 320, 640
+    g = torch.Generator().manual_seed(M + (7 if with_mask else 0))
+    A = torch.randn((M, K), generator=g)
+    B = torch.randn((N, K), generator=g) * 0.1
+    mask = ((torch.rand((M, N), generator=g) > 0.1).float() / 0.9) if with_mask else None
+    pre = torch.randn((M, N), generator=g)
+    saved = None
+    ref = A.double() @ B.double().t()
+    if with_mask:
+        ref = ref * mask.double()
+    if act is not None:
+        p64 = pre.double().requires_grad_(True)
+        y = _ref_act(act)(p64)
+        (dact,) = torch.autograd.grad(y.sum(), p64)
+        ref = ref * dact
+        saved = pre if act == "gelu" else y.detach().float()
+    out = ops.gemm_grad(A.to(dev), B.to(dev), trans_b=True, out_mul=None if mask is None else mask.to(dev),
+                        act_grad=None if act is None else (act, saved.to(dev)))
+    scale = float(K) ** 0.5
+    assert_close(out.cpu() / scale, (ref / scale).float(), tol=2e-6, what=f"gemm_grad {mode} {act} mask={with_mask}")
+    # in-place form
+    buf = torch.empty((M, N), device=dev)
+    out2 = ops.gemm_grad(A.to(dev), B.to(dev), trans_b=True, out=buf, out_mul=None if mask is None else mask.to(dev),
+                         act_grad=None if act is None else (act, saved.to(dev)))
+    assert torch.equal(out2, out)
+
+
 def test_gemm_asymmetric_identity(dev):
     """transpose-detecting check (A = I, asymmetric B)."""
     from tf2_gnn_amd import ops
