@@ -262,8 +262,9 @@ int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const 
  *                            the six largest piece products - each exact in fp32 - are accumulated in fp32 on
  *                            v_mfma_f32_32x32x16_bf16; dropped terms are < 2^-23 |a b| (csrc/gemm_x3.hip)
  *   TFGNN_GEMM_BF16X3_EXACT  all nine piece products: products exact, only the fp32 accumulation rounds
- * Inputs, outputs and accumulators are fp32 in every mode.  The split modes cover the N % 320 == 0 shapes of
- * the hot path (NN, NT, TN layouts); other shapes run the fp32 kernel whatever the mode. */
+ * Inputs, outputs and accumulators are fp32 in every mode.  The split modes cover N % 128 == 0 (tiles of 320, 256
+ * or 128 columns; NN, NT, TN layouts, K >= 64, 16-byte aligned operands); other shapes run the fp32 kernel
+ * whatever the mode. */
 enum { TFGNN_GEMM_FP32 = 0, TFGNN_GEMM_BF16X3 = 6, TFGNN_GEMM_BF16X3_EXACT = 9 };
 int tfgnn_gemm_set_mode(int mode);
 int tfgnn_gemm_get_mode(void);

@@ -53,6 +53,14 @@ def gemm_mode():
         (False, False, 129, 640, 68),     # ragged M tile, K tail
         (True, False, 324, 320, 100),     # ragged M with K-major A, K tail
         (False, True, 7, 320, 64),
+        # 128 x 256 and 128 x 128 tiles (hidden sizes 128 / 256 / 512, GRU 3H = 384)
+        (False, False, 900, 256, 640),
+        (False, True, 515, 512, 256),
+        (True, False, 256, 1024, 3000),
+        (False, False, 777, 128, 640),
+        (False, True, 300, 384, 128),
+        (True, False, 128, 384, 2100),
+        (True, False, 132, 128, 70),
     ],
 )
 def test_gemm_bf16x3_matches_fp64(dev, gemm_mode, mode, ta, tb, M, N, K):
@@ -70,12 +78,14 @@ def test_gemm_bf16x3_matches_fp64(dev, gemm_mode, mode, ta, tb, M, N, K):
     out = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
     out_b = ops.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
     assert torch.equal(out, out_b)
+    # fp32 accumulation of K N(0,1) products: rounding noise ~ eps * sqrt(K) * sqrt(K) / sqrt(3) per output (1 sigma),
+    # the maximum over 1e5 outputs sits at ~4.5 sigma -> 4e-6 * sqrt(K) absolute; and never worse than the fp32 kernel
     scale = max(1.0, float(K) ** 0.5)
-    assert_close(out.cpu() / scale, (ref / scale).float(), tol=2e-6, what=f"x3 gemm {M}x{N}x{K} ta={ta} tb={tb}")
+    assert_close(out.cpu() / scale, (ref / scale).float(), tol=4e-6, what=f"x3 gemm {M}x{N}x{K} ta={ta} tb={tb}")
     e32 = (out32.cpu().double() - ref).abs().max().item()
     e3 = (out.cpu().double() - ref).abs().max().item()
     print(f"max|err| vs fp64: fp32-mfma {e32:.3e}  {mode} {e3:.3e}")
-    assert e3 <= 4.0 * e32 + 1e-6
+    assert e3 <= 1.5 * e32 + 1e-6
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_9"])

@@ -33,7 +33,7 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
 constexpr int X3_BK = 16;
-constexpr int X3_BM = 128, X3_BN = 320, X3_NT = 512;
+constexpr int X3_BM = 128, X3_NT = 512;
 
 struct X3Args {
   int64_t M, N, K;
@@ -123,26 +123,27 @@ __device__ __forceinline__ floatx16 mfma_group(floatx16 c, bf16x8 ah, bf16x8 am,
 }
 
 // =====================================================================================================
-// Pipelined variant: three LDS stages of unpadded, XOR-swizzled 32-byte rows, all 8 waves symmetric, one
-// barrier per K tile.  Iteration t multiplies tile t (stage t%3) while it splits/stores tile t+2 into
-// stage (t+2)%3 and fetches tile t+3 into registers; the first operands of tile t+1 (complete since the
-// previous barrier) are read before the barrier, so the matrix pipe restarts immediately after it.  The
-// staging code is branch-free (clamped addresses, a per-plane trash area for threads without an item) so
-// that the whole iteration is one scheduling region in which the splitting arithmetic is interleaved with
-// the MFMAs.
-// Plane layout (ushort units): [A rows 0..127 | B rows 128..447 | trash], row = 16 k; 16-byte half h of row
-// r is stored at half h ^ ((r >> 3) & 1).
+// Shared geometry.  The output tile is 128 x BN, BN = 64 * TN (TN = 5, 4, 2 -> 320, 256, 128 columns: the hidden
+// sizes the layers come with), BK = 16, three LDS stages of unpadded, XOR-swizzled 32-byte rows.
+// Plane layout (ushort units): [A rows 0..127 | B rows 128..128+BN-1 | trash], row = 16 k; 16-byte half h of row
+// r is stored at half h ^ ((r >> 3) & 1).  The staging code is branch-free (clamped addresses, a per-plane trash
+// area for threads without an item).
 constexpr int P_ROW = 16;
 constexpr int P_TRASH = 320;
-constexpr int P_PLANE = (X3_BM + X3_BN) * P_ROW + P_TRASH;  // 7488 ushorts
-constexpr int P_STAGE = 3 * P_PLANE;                        // 22464 ushorts = 44928 bytes
-constexpr int P_TRASH_OFF = (X3_BM + X3_BN) * P_ROW;
+template <int TN>
+struct Geo {
+  static constexpr int BN = 64 * TN;
+  static constexpr int TRASH_OFF = (X3_BM + BN) * P_ROW;
+  static constexpr int PLANE = TRASH_OFF + P_TRASH;  // TN = 5: 7488 ushorts
+  static constexpr int STAGE = 3 * PLANE;            // TN = 5: 44928 bytes
+};
 
 __device__ __forceinline__ int swz_off(int row, int kq) {  // ushort offset of k quad kq (4 k) of plane row `row`
   return row * P_ROW + ((((kq >> 1) ^ (row >> 3)) & 1) << 3) + ((kq & 1) << 2);
 }
 
 // K-contiguous operand: item = (row, k quad); one float4
+template <int TN>
 struct SlotKC {
   const float* ptr;
   const float* ptr0;
@@ -157,7 +158,7 @@ struct SlotKC {
     if (mn > mn_total - 1) mn = mn_total - 1;  // rows past the edge: any valid row (their outputs are never stored)
     kofs = kq * 4;
     ptr0 = ptr = src + mn * ld + k_begin + kofs;
-    lds_off = valid ? swz_off(row_base + row, kq) : P_TRASH_OFF + lane * 4;
+    lds_off = valid ? swz_off(row_base + row, kq) : Geo<TN>::TRASH_OFF + lane * 4;
   }
   template <bool MASKED>
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
@@ -172,11 +173,12 @@ struct SlotKC {
   }
   __device__ __forceinline__ void skip() { ptr += X3_BK; }
   __device__ __forceinline__ void store(unsigned short* stage) const {
-    split_store4(r.x, r.y, r.z, r.w, stage + lds_off, P_PLANE);
+    split_store4(r.x, r.y, r.z, r.w, stage + lds_off, Geo<TN>::PLANE);
   }
 };
 
 // K-major operand: item = (4-column strip, group of 4 k rows); four float4, transposed in registers
+template <int TN>
 struct SlotKM {
   const float* ptr;
   const float* ptr0;
@@ -193,7 +195,7 @@ struct SlotKM {
     ld = ld_;
     kofs = kg * 4;
     ptr0 = ptr = src + (k_begin + kofs) * ld + mn;
-    lds_off = valid ? swz_off(row_base + strip * 4, kg) : P_TRASH_OFF + lane * 4;
+    lds_off = valid ? swz_off(row_base + strip * 4, kg) : Geo<TN>::TRASH_OFF + lane * 4;
   }
   template <bool MASKED>
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
@@ -210,106 +212,64 @@ struct SlotKM {
     ptr += (int64_t)(adv * X3_BK) * ld;
   }
   __device__ __forceinline__ void skip() { ptr += (int64_t)X3_BK * ld; }
-  __device__ __forceinline__ void store(unsigned short* stage) const {
-    unsigned short* d = stage + lds_off;  // rows strip*4 + j share (row >> 3) & 1: the swizzle term is the same
-    split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, P_PLANE);
-    split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d + P_ROW, P_PLANE);
-    split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d + 2 * P_ROW, P_PLANE);
-    split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d + 3 * P_ROW, P_PLANE);
-  }
   template <int J>
   __device__ __forceinline__ void store_row(unsigned short* stage) const {
+    // rows strip*4 + j share (row >> 3) & 1: the swizzle term is the same for the four rows
     unsigned short* d = stage + lds_off + J * P_ROW;
-    if (J == 0) split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, P_PLANE);
-    if (J == 1) split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d, P_PLANE);
-    if (J == 2) split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d, P_PLANE);
-    if (J == 3) split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d, P_PLANE);
+    if (J == 0) split_store4(r[0].x, r[1].x, r[2].x, r[3].x, d, Geo<TN>::PLANE);
+    if (J == 1) split_store4(r[0].y, r[1].y, r[2].y, r[3].y, d, Geo<TN>::PLANE);
+    if (J == 2) split_store4(r[0].z, r[1].z, r[2].z, r[3].z, d, Geo<TN>::PLANE);
+    if (J == 3) split_store4(r[0].w, r[1].w, r[2].w, r[3].w, d, Geo<TN>::PLANE);
+  }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    store_row<0>(stage); store_row<1>(stage); store_row<2>(stage); store_row<3>(stage);
   }
 };
 
-// the staging work of one thread for one K tile, per operand layout pair
-template <bool A_KM, bool B_KM>
-struct Stager;
-template <>
-struct Stager<false, false> {  // NT: A 512 items (one per thread), B 1280 items (2.5 per thread)
-  SlotKC a, b0, b1, b2;
-  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
-    const int lane = tid & 63;
-    a.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM * 4, 0, lane);
-    b0.init(g.B, g.ldb, n0, g.N, k_begin, tid, X3_BN * 4, X3_BM, lane);
-    b1.init(g.B, g.ldb, n0, g.N, k_begin, tid + X3_NT, X3_BN * 4, X3_BM, lane);
-    b2.init(g.B, g.ldb, n0, g.N, k_begin, tid + 2 * X3_NT, X3_BN * 4, X3_BM, lane);
-  }
-  template <bool MASKED>
-  __device__ __forceinline__ void load(int64_t k_left, int adv) {
-    a.load<MASKED>(k_left, adv); b0.load<MASKED>(k_left, adv); b1.load<MASKED>(k_left, adv); b2.load<MASKED>(k_left, adv);
-  }
-  __device__ __forceinline__ void skip() { a.skip(); b0.skip(); b1.skip(); b2.skip(); }
-  __device__ __forceinline__ void store(unsigned short* stage) const {
-    a.store(stage); b0.store(stage); b1.store(stage); b2.store(stage);
-  }
-  template <int PIECE>
-  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
-    if (PIECE == 0) a.store(stage);
-    if (PIECE == 1) b0.store(stage);
-    if (PIECE == 2) b1.store(stage);
-    if (PIECE == 3) b2.store(stage);
-  }
-};
-template <>
-struct Stager<false, true> {  // NN: A 512 K-contiguous items, B 320 K-major items
-  SlotKC a;
-  SlotKM b;
-  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
-    const int lane = tid & 63;
-    a.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM * 4, 0, lane);
-    b.init(g.B, g.ldb, n0, g.N, k_begin, tid, X3_BN, X3_BM, lane);
-  }
-  template <bool MASKED>
-  __device__ __forceinline__ void load(int64_t k_left, int adv) {
-    a.load<MASKED>(k_left, adv); b.load<MASKED>(k_left, adv);
-  }
-  __device__ __forceinline__ void skip() { a.skip(); b.skip(); }
-  __device__ __forceinline__ void store(unsigned short* stage) const {
-    a.store(stage); b.store(stage);
-  }
-  template <int PIECE>
-  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
-    if (PIECE == 0) a.store(stage);
-    if (PIECE >= 1) b.template store_row<PIECE - 1>(stage);
-  }
-};
-template <>
-struct Stager<true, true> {  // TN: one K-major item per thread - A items on threads [0,128), B items on [128,448)
-  SlotKM s;
+// =====================================================================================================
+// Pipelined kernel (both operands K-major: the weight-gradient products): all 8 waves (4 x 2, wave tile
+// 32 x 32 TN) split / store and multiply, software-pipelined, one barrier per K tile.  Iteration t multiplies
+// tile t (stage t%3) while it splits/stores tile t+2 into stage (t+2)%3 and fetches tile t+3 into registers; the
+// first operands of tile t+1 (complete since the previous barrier) are read before the barrier, so the matrix
+// pipe restarts immediately after it.  One K-major item per thread: A strips on threads [0,128), B strips on
+// [128, 128+BN).
+template <int TN>
+struct StagerKM {
+  SlotKM<TN> s;
   __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
     const int lane = tid & 63;
     if (tid < X3_BM) s.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM, 0, lane);
-    else s.init(g.B, g.ldb, n0, g.N, k_begin, tid - X3_BM, X3_BN, X3_BM, lane);
+    else s.init(g.B, g.ldb, n0, g.N, k_begin, tid - X3_BM, Geo<TN>::BN, X3_BM, lane);
   }
   template <bool MASKED>
-  __device__ __forceinline__ void load(int64_t k_left, int adv) { s.load<MASKED>(k_left, adv); }
+  __device__ __forceinline__ void load(int64_t k_left, int adv) { s.template load<MASKED>(k_left, adv); }
   __device__ __forceinline__ void skip() { s.skip(); }
   __device__ __forceinline__ void store(unsigned short* stage) const { s.store(stage); }
-  template <int PIECE>
+  // piece J of the split/store work; the last MFMA chunk (LAST) takes whatever pieces are left
+  template <int J, bool LAST>
   __device__ __forceinline__ void store_piece(unsigned short* stage) const {
-    if (PIECE < 4) s.template store_row<PIECE>(stage);
+    if (J < 4) s.template store_row<(J < 4 ? J : 0)>(stage);
+    if (LAST) {
+      if (J + 1 < 4) s.template store_row<(J + 1 < 4 ? J + 1 : 0)>(stage);
+      if (J + 2 < 4) s.template store_row<(J + 2 < 4 ? J + 2 : 0)>(stage);
+      if (J + 3 < 4) s.template store_row<(J + 3 < 4 ? J + 3 : 0)>(stage);
+    }
   }
 };
 
-template <bool A_KM, bool B_KM, int NPROD>
+template <int NPROD, int TN>
 __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
-  constexpr int TN = 5;
+  constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
   constexpr int PATCH_FLOATS = (X3_NT / 64) * 32 * 36;
-  static_assert(3 * P_STAGE * 2 >= PATCH_FLOATS * 4, "epilogue patch must fit in the stage buffers");
-  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * P_STAGE];
+  static_assert(3 * STAGE * 2 >= PATCH_FLOATS * 4, "epilogue patch must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * X3_BN;
+  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
 
@@ -321,7 +281,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 
   const int li = lane & 31, lk = lane >> 5;
   if (k_begin < k_end) {
-    Stager<A_KM, B_KM> st;
+    StagerKM<TN> st;
     st.init(g, m0, n0, k_begin, tid);
     const int half = (lk ^ (li >> 3)) & 1;
     const int a_frag = (wm * 32 + li) * P_ROW + half * 8;
@@ -333,44 +293,51 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
     st.template load<true>(k_len, 1);
     st.store(lds);
     st.template load<true>(k_len - X3_BK, 1);
-    st.store(lds + P_STAGE);
+    st.store(lds + STAGE);
     st.template load<true>(k_len - 2 * X3_BK, 1);
     __syncthreads();
-    bf16x8 ah = frag8(lds + a_frag), am = frag8(lds + a_frag + P_PLANE), al = frag8(lds + a_frag + 2 * P_PLANE);
-    bf16x8 bh = frag8(lds + b_frag), bm = frag8(lds + b_frag + P_PLANE), bl = frag8(lds + b_frag + 2 * P_PLANE);
+    bf16x8 ah = frag8(lds + a_frag), am = frag8(lds + a_frag + PLANE), al = frag8(lds + a_frag + 2 * PLANE);
+    bf16x8 bh = frag8(lds + b_frag), bm = frag8(lds + b_frag + PLANE), bl = frag8(lds + b_frag + 2 * PLANE);
 
-    int s_cur = 0, s_nxt = P_STAGE, s_st = 2 * P_STAGE;  // stage of tile t, t+1, t+2
-    // One iteration = 5 chunks (one per 32-column tile of the wave): the split/store of one piece of tile
+    int s_cur = 0, s_nxt = STAGE, s_st = 2 * STAGE;  // stage of tile t, t+1, t+2
+    // One iteration = TN chunks (one per 32-column tile of the wave): the split/store of one piece of tile
     // t+2, the operand reads of the next column tile, 6 (9) MFMAs.  sched_barrier keeps the chunks apart so
     // that the splitting arithmetic stays spread over the iteration; `from` holds tile t+2, the fetch of
     // tile t+3 goes to the other register set `to` first and has the whole iteration to land.
-    auto iteration = [&](auto masked, int64_t left3, const Stager<A_KM, B_KM>& from, Stager<A_KM, B_KM>& to) {
+    auto iteration = [&](auto masked, int64_t left3, const StagerKM<TN>& from, StagerKM<TN>& to) {
       constexpr bool MASKED = decltype(masked)::value;
       to.template load<MASKED>(left3, 2);
       __builtin_amdgcn_sched_barrier(0);
       unsigned short* dst = lds + s_st;
       const unsigned short* cur = lds + s_cur;
       const unsigned short* nxs = lds + s_nxt;
-      bf16x8 nh, nm, nl;
-#define X3P_CHUNK(J)                                                                        \
-      from.template store_piece<J>(dst);                                                    \
-      if (J + 1 < TN) {                                                                     \
-        const unsigned short* nb = cur + b_frag + (J + 1) * 32 * P_ROW;                     \
-        nh = frag8(nb); nm = frag8(nb + P_PLANE); nl = frag8(nb + 2 * P_PLANE);             \
-      } else { /* first operands of tile t+1 (complete since the previous barrier) */       \
-        nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + P_PLANE); nl = frag8(nxs + b_frag + 2 * P_PLANE); \
-      }                                                                                     \
-      acc[J] = mfma_group<NPROD>(acc[J], ah, am, al, bh, bm, bl);                           \
-      bh = nh; bm = nm; bl = nl;                                                            \
-      __builtin_amdgcn_sched_barrier(0);
-      X3P_CHUNK(0) X3P_CHUNK(1) X3P_CHUNK(2) X3P_CHUNK(3) X3P_CHUNK(4)
-#undef X3P_CHUNK
-      ah = frag8(nxs + a_frag); am = frag8(nxs + a_frag + P_PLANE); al = frag8(nxs + a_frag + 2 * P_PLANE);
+      auto chunk = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if constexpr (J < TN) {
+          from.template store_piece<J, J == TN - 1>(dst);
+          bf16x8 nh, nm, nl;
+          if (J + 1 < TN) {
+            const unsigned short* nb = cur + b_frag + (J + 1) * 32 * P_ROW;
+            nh = frag8(nb); nm = frag8(nb + PLANE); nl = frag8(nb + 2 * PLANE);
+          } else {  // first operands of tile t+1 (complete since the previous barrier)
+            nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + PLANE); nl = frag8(nxs + b_frag + 2 * PLANE);
+          }
+          acc[J] = mfma_group<NPROD>(acc[J], ah, am, al, bh, bm, bl);
+          bh = nh; bm = nm; bl = nl;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      chunk(std::integral_constant<int, 0>{});
+      chunk(std::integral_constant<int, 1>{});
+      chunk(std::integral_constant<int, 2>{});
+      chunk(std::integral_constant<int, 3>{});
+      chunk(std::integral_constant<int, 4>{});
+      ah = frag8(nxs + a_frag); am = frag8(nxs + a_frag + PLANE); al = frag8(nxs + a_frag + 2 * PLANE);
       __syncthreads();
       const int s = s_cur; s_cur = s_nxt; s_nxt = s_st; s_st = s;
     };
-    Stager<A_KM, B_KM> st2 = st;  // two register sets, each fetching every second tile: st2 tiles 3, 5, ...;
-    st.skip();                    // st (holding tile 2) continues with 4, 6, ...
+    StagerKM<TN> st2 = st;  // two register sets, each fetching every second tile: st2 tiles 3, 5, ...;
+    st.skip();              // st (holding tile 2) continues with 4, 6, ...
     int t = 0;
     const int t_fast = (int)(k_len / X3_BK) - 3;  // iterations whose fetched tile t+3 is a full tile
     for (; t + 1 < t_fast; t += 2) {
@@ -383,7 +350,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
     }
   }
 
-  // epilogue: as above
+  // epilogue: wave-private LDS patch per 32 x 32 tile, 16-byte stores
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
@@ -423,116 +390,95 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 }
 
 // =====================================================================================================
-// Specialised variant: waves 0-3 (one per SIMD) only multiply - each owns a 64 x 160 block of the
-// 128 x 320 tile (2 x 5 MFMA tiles, 160 accumulator registers) - and waves 4-7 (their SIMD partners)
-// only fetch, split and store.  Per fp32 MAC the splitting costs ~5.5 VALU issue slots per element
-// staged; an MFMA leaves room for about five other instructions of the same SIMD, so mixing the two in
-// one wave (the pipelined variant above) is issue-bound.  Here the multiplying wave issues one MFMA
-// per 32 cycles plus a ds_read every second MFMA, and its partner's VALU work runs beside it.
-// Same three-stage LDS ring and one barrier per K tile as the pipelined variant.
+// Specialised kernel (A K-contiguous): waves 0-3 (one per SIMD) only multiply - each owns a 64 x 32 TN block of
+// the 128 x 64 TN tile (2 x TN MFMA tiles, 160 accumulator registers at TN = 5) - and waves 4-7 (their SIMD
+// partners) only fetch, split and store.  Per fp32 MAC the splitting costs ~5.5 VALU issue slots per element
+// staged; an MFMA leaves room for about five other instructions of the same SIMD, so mixing the two in one wave
+// (the pipelined kernel above) is issue-bound.  Here the multiplying wave issues one MFMA per 32 cycles plus a
+// ds_read every third MFMA, and its partner's VALU work runs beside it.  Same three-stage LDS ring and one
+// barrier per K tile.
 constexpr int S_PT = 256;  // producer threads
 
-template <bool A_KM, bool B_KM>
+template <bool B_KM, int TN>
 struct Producer;
-template <>
-struct Producer<false, false> {  // NT: A 512 items, B 1280 items of one float4 -> 2 + 5 per producer thread
-  SlotKC a[2], b[5];
+template <int TN>
+struct Producer<false, TN> {  // NT: A 512 items, B 256 TN items of one float4 -> 2 + TN per producer thread
+  SlotKC<TN> a[2], b[TN];
   __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
     const int lane = ptid & 63;
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].init(g.A, g.lda, m0, g.M, k_begin, ptid + S_PT * i, X3_BM * 4, 0, lane);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, X3_BN * 4, X3_BM, lane);
+    for (int i = 0; i < TN; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, Geo<TN>::BN * 4, X3_BM, lane);
   }
   template <bool MASKED>
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i].load<MASKED>(k_left, adv);
+    for (int i = 0; i < 2; ++i) a[i].template load<MASKED>(k_left, adv);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) b[i].load<MASKED>(k_left, adv);
+    for (int i = 0; i < TN; ++i) b[i].template load<MASKED>(k_left, adv);
   }
   __device__ __forceinline__ void skip() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].skip();
 #pragma unroll
-    for (int i = 0; i < 5; ++i) b[i].skip();
+    for (int i = 0; i < TN; ++i) b[i].skip();
   }
   __device__ __forceinline__ void store(unsigned short* stage) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].store(stage);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) b[i].store(stage);
+    for (int i = 0; i < TN; ++i) b[i].store(stage);
   }
 };
-template <>
-struct Producer<false, true> {  // NN: A 512 K-contiguous items (2 per thread), B 320 K-major items (2 slots, 64 real in the 2nd)
-  SlotKC a[2];
-  SlotKM b[2];
+template <int TN>
+struct Producer<true, TN> {  // NN: A 512 K-contiguous items (2 per thread), B 64 TN K-major items (NB slots per thread)
+  static constexpr int NB = (Geo<TN>::BN + S_PT - 1) / S_PT;
+  SlotKC<TN> a[2];
+  SlotKM<TN> b[NB];
   __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
     const int lane = ptid & 63;
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].init(g.A, g.lda, m0, g.M, k_begin, ptid + S_PT * i, X3_BM * 4, 0, lane);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, X3_BN, X3_BM, lane);
+    for (int i = 0; i < NB; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, ptid + S_PT * i, Geo<TN>::BN, X3_BM, lane);
   }
   template <bool MASKED>
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i].load<MASKED>(k_left, adv);
+    for (int i = 0; i < 2; ++i) a[i].template load<MASKED>(k_left, adv);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b[i].load<MASKED>(k_left, adv);
+    for (int i = 0; i < NB; ++i) b[i].template load<MASKED>(k_left, adv);
   }
   __device__ __forceinline__ void skip() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { a[i].skip(); b[i].skip(); }
+    for (int i = 0; i < 2; ++i) a[i].skip();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[i].skip();
   }
   __device__ __forceinline__ void store(unsigned short* stage) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].store(stage);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b[i].store(stage);
-  }
-};
-template <>
-struct Producer<true, true> {  // TN: 128 + 320 K-major items over 256 threads: items [0,128) are A strips, [128,448) B strips
-  SlotKM s[2];
-  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int ptid) {
-    const int lane = ptid & 63;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = ptid + S_PT * i;
-      if (id < X3_BM) s[i].init(g.A, g.lda, m0, g.M, k_begin, id, X3_BM, 0, lane);
-      else s[i].init(g.B, g.ldb, n0, g.N, k_begin, id - X3_BM, X3_BN, X3_BM, lane);
-    }
-  }
-  template <bool MASKED>
-  __device__ __forceinline__ void load(int64_t k_left, int adv) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) s[i].load<MASKED>(k_left, adv);
-  }
-  __device__ __forceinline__ void skip() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) s[i].skip();
-  }
-  __device__ __forceinline__ void store(unsigned short* stage) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) s[i].store(stage);
+    for (int i = 0; i < NB; ++i) b[i].store(stage);
   }
 };
 
-template <bool A_KM, bool B_KM, int NPROD>
+template <bool B_KM, int NPROD, int TN>
 __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
-  constexpr int TM = 2, TN = 5;
-  constexpr int EP_LD = 164;  // floats per row of an epilogue block (160 + 4 pad)
-  static_assert(3 * P_STAGE * 2 >= 4 * 32 * EP_LD * 4, "epilogue blocks must fit in the stage buffers");
-  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * P_STAGE];
+  constexpr int TM = 2;
+  constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
+  constexpr int EP_COLS = BN / 2;      // columns of a multiplying wave's block
+  constexpr int EP_LD = EP_COLS + 4;   // floats per row of an epilogue block
+  static_assert(3 * STAGE * 2 >= 4 * 32 * EP_LD * 4, "epilogue blocks must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool multiplier = wave < 4;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * X3_BN;
+  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
   const int64_t k_len = k_end - k_begin;
@@ -554,29 +500,29 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
 
   if (!multiplier && T > 0) {
     // ------------------------------- producer waves -------------------------------
-    Producer<A_KM, B_KM> p0;
+    Producer<B_KM, TN> p0;
     p0.init(g, m0, n0, k_begin, tid - S_PT);
     p0.template load<true>(k_len, 1);
     p0.store(lds);
     p0.template load<true>(k_len - X3_BK, 1);
-    p0.store(lds + P_STAGE);
+    p0.store(lds + STAGE);
     // three register sets in rotation: the fetch of tile t+4 is issued at the top of iteration t and is split /
     // stored two iterations later (tile u by set u % 3; each set's pointers advance three tiles per fetch)
-    Producer<A_KM, B_KM> p1 = p0;
+    Producer<B_KM, TN> p1 = p0;
     p1.skip();
-    Producer<A_KM, B_KM> p2 = p1;
+    Producer<B_KM, TN> p2 = p1;
     p2.skip();
     p0.template load<true>(k_len - 2 * X3_BK, 3);
     p1.template load<true>(k_len - 3 * X3_BK, 3);
     __syncthreads();
-    int s_st = 2 * P_STAGE;  // stage of tile t+2
-    auto iteration = [&](auto masked, int64_t left4, const Producer<A_KM, B_KM>& from, Producer<A_KM, B_KM>& to) {
+    int s_st = 2 * STAGE;  // stage of tile t+2
+    auto iteration = [&](auto masked, int64_t left4, const Producer<B_KM, TN>& from, Producer<B_KM, TN>& to) {
       constexpr bool MASKED = decltype(masked)::value;
       if (!(g.debug & 1)) to.template load<MASKED>(left4, 3);  // tile t+4
       __builtin_amdgcn_sched_barrier(0);   // fetches first: two iterations to land
       if (!(g.debug & 2)) from.store(lds + s_st);              // tile t+2
       __syncthreads();
-      s_st = s_st == 2 * P_STAGE ? 0 : s_st + P_STAGE;
+      s_st = s_st == 2 * STAGE ? 0 : s_st + STAGE;
     };
     int t = 0;
     const int t_fast = (int)(k_len / X3_BK) - 4;  // iterations whose fetched tile t+4 is a full tile
@@ -605,12 +551,12 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       ah[i] = frag8(lds + a_frag + i * 32 * P_ROW);
-      am[i] = frag8(lds + a_frag + i * 32 * P_ROW + P_PLANE);
-      al[i] = frag8(lds + a_frag + i * 32 * P_ROW + 2 * P_PLANE);
+      am[i] = frag8(lds + a_frag + i * 32 * P_ROW + PLANE);
+      al[i] = frag8(lds + a_frag + i * 32 * P_ROW + 2 * PLANE);
     }
-    bh = frag8(lds + b_frag); bm = frag8(lds + b_frag + P_PLANE); bl = frag8(lds + b_frag + 2 * P_PLANE);
+    bh = frag8(lds + b_frag); bm = frag8(lds + b_frag + PLANE); bl = frag8(lds + b_frag + 2 * PLANE);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): enter the loop with no LDS read pending, as every back edge does
-    int s_cur = 0, s_nxt = P_STAGE;
+    int s_cur = 0, s_nxt = STAGE;
     for (int t = 0; t < T; ++t) {
       const unsigned short* cur = lds + s_cur;
       const unsigned short* nxs = lds + s_nxt;
@@ -619,9 +565,9 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
         bf16x8 nh, nm, nl;
         if (j + 1 < TN) {
           const unsigned short* nb = cur + b_frag + (j + 1) * 32 * P_ROW;
-          nh = frag8(nb); nm = frag8(nb + P_PLANE); nl = frag8(nb + 2 * P_PLANE);
+          nh = frag8(nb); nm = frag8(nb + PLANE); nl = frag8(nb + 2 * PLANE);
         } else {  // first operands of tile t+1 (complete since the previous barrier)
-          nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + P_PLANE); nl = frag8(nxs + b_frag + 2 * P_PLANE);
+          nh = frag8(nxs + b_frag); nm = frag8(nxs + b_frag + PLANE); nl = frag8(nxs + b_frag + 2 * PLANE);
         }
         __builtin_amdgcn_sched_barrier(0);  // the reads above stay a full MFMA group (12 x 32 cycles) ahead of their use
         // the two row tiles alternate: consecutive MFMAs never hit the same accumulator; smallest terms first
@@ -638,12 +584,12 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = frag8(nxs + a_frag + i * 32 * P_ROW);
-        am[i] = frag8(nxs + a_frag + i * 32 * P_ROW + P_PLANE);
-        al[i] = frag8(nxs + a_frag + i * 32 * P_ROW + 2 * P_PLANE);
+        am[i] = frag8(nxs + a_frag + i * 32 * P_ROW + PLANE);
+        al[i] = frag8(nxs + a_frag + i * 32 * P_ROW + 2 * PLANE);
       }
       __syncthreads();
       s_cur = s_nxt;
-      s_nxt = s_nxt == 2 * P_STAGE ? 0 : s_nxt + P_STAGE;
+      s_nxt = s_nxt == 2 * STAGE ? 0 : s_nxt + STAGE;
     }
     __builtin_amdgcn_s_setprio(0);
   }
@@ -654,13 +600,14 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
     pr[2] = wall_clock64();
   }
 
-  // Epilogue in two rounds of 32 rows per multiplying wave: the accumulators go to LDS as four 32 x 160
-  // blocks, then all eight waves stream them out with bias / activation / accumulate applied in a compact
-  // loop (row-contiguous 16-byte stores; no wait on earlier stores anywhere).
+  // Epilogue in two rounds of 32 rows per multiplying wave: the accumulators go to LDS as four 32 x 32 TN
+  // blocks, then all eight waves stream them out with bias / activation / accumulate (and the gradient factors)
+  // applied in a compact loop (row-contiguous 16-byte stores; no wait on earlier stores anywhere).
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   float* ep = reinterpret_cast<float*>(lds);
+  constexpr int ROW4 = EP_COLS / 4;  // float4 per block row
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (multiplier) {
@@ -672,11 +619,11 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
     }
     __syncthreads();
 #pragma unroll 1
-    for (int f = tid; f < 4 * 32 * 40; f += X3_NT) {
-      const int b = f / 1280, rem = f - b * 1280;
-      const int row = rem / 40, c4 = rem - row * 40;
+    for (int f = tid; f < 4 * 32 * ROW4; f += X3_NT) {
+      const int b = f / (32 * ROW4), rem = f - b * (32 * ROW4);
+      const int row = rem / ROW4, c4 = rem - row * ROW4;
       const int64_t grow = m0 + (b & 1) * 64 + i * 32 + row;
-      const int64_t gcol = n0 + (b >> 1) * 160 + c4 * 4;
+      const int64_t gcol = n0 + (b >> 1) * EP_COLS + c4 * 4;
       if (grow < g.M) {
         float4 v = *reinterpret_cast<const float4*>(ep + (b * 32 + row) * EP_LD + c4 * 4);
         float* dst = outp + grow * ldo + gcol;
@@ -718,22 +665,21 @@ __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
   }
 }
 
-// The specialised kernel wins where at least one operand is K-contiguous (NT 140 vs 160 us, NN 68 vs 72 us on the
-// hot-path shapes); with two K-major operands its four producer waves cannot keep up with the register transposes
-// and the pipelined kernel is faster (185 vs 207 us).  TFGNN_X3_KERNEL=spec|pipe overrides.
-template <bool A_KM, bool B_KM>
-static void launch_x3(const X3Args& g, dim3 grid, int nprod, hipStream_t s) {
-  static const int which = [] {
-    const char* e = getenv("TFGNN_X3_KERNEL");
-    return !e ? 0 : (!strcmp(e, "spec") ? 1 : (!strcmp(e, "pipe") ? 2 : 0));
-  }();
-  const bool spec = which == 1 || (which == 0 && !(A_KM && B_KM)) || g.mul || g.saved;
-  if (spec) {
-    if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
-    else hipLaunchKernelGGL((gemm_x3s_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
+// Layouts: NN / NT (A K-contiguous) -> specialised kernel (NT 140 vs 160 us, NN 68 vs 72 us for the pipelined one
+// on the hot-path shapes); TN (both K-major: weight gradients) -> pipelined kernel (with two K-major operands four
+// producer waves cannot keep up with the register transposes: 185 vs 207 us).
+template <int TN>
+static void launch_x3(const X3Args& g, dim3 grid, int nprod, int trans_a, int trans_b, hipStream_t s) {
+  const bool nine = nprod >= 9;
+  if (trans_a) {
+    if (nine) hipLaunchKernelGGL((gemm_x3p_kernel<9, TN>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3p_kernel<6, TN>), grid, dim3(X3_NT), 0, s, g);
+  } else if (trans_b) {
+    if (nine) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, TN>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, TN>), grid, dim3(X3_NT), 0, s, g);
   } else {
-    if (nprod >= 9) hipLaunchKernelGGL((gemm_x3p_kernel<A_KM, B_KM, 9>), grid, dim3(X3_NT), 0, s, g);
-    else hipLaunchKernelGGL((gemm_x3p_kernel<A_KM, B_KM, 6>), grid, dim3(X3_NT), 0, s, g);
+    if (nine) hipLaunchKernelGGL((gemm_x3s_kernel<true, 9, TN>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3s_kernel<true, 6, TN>), grid, dim3(X3_NT), 0, s, g);
   }
 }
 
@@ -767,10 +713,11 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     if (trans_a) return 0;
     if ((mul && (((uintptr_t)mul % 16) || ld_mul % 4)) || (saved && (((uintptr_t)saved % 16) || ld_saved % 4))) return 0;
   }
-  // the 128 x 320 tile only (N = 320 family), 16-byte aligned operands, supported layout pairs:
+  // 128 x {320, 256, 128} tiles (N a multiple of one of them), 16-byte aligned operands, supported layout pairs:
   //   NN (A [M,K], B [K,N]), NT (A [M,K], B [N,K]), TN (A [K,M], B [K,N])
   if (trans_a && trans_b) return 0;
-  if (!(N % 320 == 0) || K < 64 || M < 1) return 0;
+  const int bn = N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0));
+  if (!bn || K < 64 || M < 1) return 0;
   const bool a16 = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool b16 = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   if (!a16 || !b16 || K % 4 != 0 || (trans_a && M % 4 != 0) || (ldc % 4 != 0) || ((uintptr_t)C % 16 != 0)) return 0;
@@ -779,7 +726,7 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.act = act; g.accumulate = accumulate;
   g.mul = mul; g.ld_mul = ld_mul; g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
-  g.n_tiles = (unsigned)ceil_div(N, 320);
+  g.n_tiles = (unsigned)(N / bn);
   const int64_t tiles = ceil_div(M, 128) * (int64_t)g.n_tiles;
   g.splits = 1;
   g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
@@ -801,9 +748,9 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     g.debug = dbg;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)g.splits);
-  if (!trans_a && !trans_b) launch_x3<false, true>(g, grid, nprod, s);       // B stored [K, N]: K-major
-  else if (!trans_a && trans_b) launch_x3<false, false>(g, grid, nprod, s);  // B stored [N, K]
-  else launch_x3<true, true>(g, grid, nprod, s);                             // A stored [K, M], B [K, N]
+  if (bn == 320) launch_x3<5>(g, grid, nprod, trans_a, trans_b, s);
+  else if (bn == 256) launch_x3<4>(g, grid, nprod, trans_a, trans_b, s);
+  else launch_x3<2>(g, grid, nprod, trans_a, trans_b, s);
   if (hipGetLastError() != hipSuccess) {
     set_error("bf16x3 GEMM launch failed");
     *status = TFGNN_ERR_HIP;
