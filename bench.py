@@ -72,6 +72,15 @@ def ppi_rgcn_params(hidden_dim, num_layers):
     return p
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file travels with the repo)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "edges/sec (fwd+bwd) RGCN H=320 L=4, PPI-shaped batch, 1/2/4/8 MI355X"
+
+
 def time_kernel(fn, iters=20, warmup=3):
     """average launch duration in ms, HIP events on the current (= launch) stream"""
     for _ in range(warmup):
@@ -262,7 +271,7 @@ def main():
     value = total_edges_per_step * args.steps / elapsed
 
     result = {
-        "metric": "edges/sec (fwd+bwd) RGCN H=320 L=4, PPI-shaped batch",
+        "metric": baseline_metric(),
         "value": value,
         "unit": "edges/s",
         "n_gpus": world,
