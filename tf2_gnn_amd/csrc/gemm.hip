@@ -148,6 +148,15 @@ struct Stage {
   static constexpr int LDS_FLOATS = KCONTIG ? MN * (BK + 1) : BK * MN;
 };
 
+// the activation switch of the epilogue as out-of-line functions: inlined into every unrolled store of every
+// instantiation it made this translation unit take 160 s to compile (and the kernels 25 000 lines of ISA)
+__device__ __noinline__ float4 act_apply4(int act, float4 v) {
+  v.x = act_apply(act, v.x); v.y = act_apply(act, v.y);
+  v.z = act_apply(act, v.z); v.w = act_apply(act, v.w);
+  return v;
+}
+__device__ __noinline__ float act_apply1(int act, float v) { return act_apply(act, v); }
+
 template <int WM_, int WN_, int TM, int TN, bool TA, bool TB, bool VEC>
 __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
   constexpr int NT = 64 * WM_ * WN_;
@@ -293,8 +302,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
                 const float4 b4 = *reinterpret_cast<const float4*>(g.bias + col);
                 v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
               }
-              v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y);
-              v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+              v = act_apply4(g.act, v);
               if (g.accumulate) {
                 const float4 c4 = *reinterpret_cast<const float4*>(dst);
                 v.x += c4.x; v.y += c4.y; v.z += c4.z; v.w += c4.w;
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
             if (row < Mloc) {
               float v = acc[i][j][r];
               if (!split) {
-                v = act_apply(g.act, v + bv);
+                v = act_apply1(g.act, v + bv);
                 if (g.accumulate) v += outp[row * ldo + col];
               }
               outp[row * ldo + col] = v;
