@@ -46,6 +46,34 @@ rgat_node_scores_kernel(const float* __restrict__ Y, const float* __restrict__ a
   }
 }
 
+// The same with H/4 lanes per row (one float4 each, coalesced) and a shuffle reduction inside each head's lane group:
+// the thread-per-(row, head) form above walks Hk floats at a 4 Hk-byte lane stride (32x over-fetch at Hk = 32).
+// Needs H % 4 == 0, Hk % 4 == 0, Hk / 4 a power of two and H / 4 a divisor of 64.
+__global__ void __launch_bounds__(256)
+rgat_node_scores_vec_kernel(const float* __restrict__ Y, const float* __restrict__ alpha, int64_t rows, int L, int K,
+                            int Hk, float* __restrict__ s_src, float* __restrict__ s_tgt) {
+  const int H = K * Hk, lpe = H >> 2, lph = Hk >> 2;
+  const int per_block = 256 / lpe;
+  const int l = threadIdx.x % lpe;
+  for (int64_t row = (int64_t)blockIdx.x * per_block + threadIdx.x / lpe; row < rows; row += (int64_t)gridDim.x * per_block) {
+    const int k = l / lph;
+    const float4 y = *reinterpret_cast<const float4*>(Y + row * H + 4 * l);
+    const float* a = alpha + ((int64_t)(row % L) * K + k) * 2 * Hk + 4 * (l - k * lph);
+    const float4 as = *reinterpret_cast<const float4*>(a);
+    const float4 at = *reinterpret_cast<const float4*>(a + Hk);
+    float ss = y.x * as.x + y.y * as.y + y.z * as.z + y.w * as.w;
+    float st = y.x * at.x + y.y * at.y + y.z * at.z + y.w * at.w;
+    for (int d = lph >> 1; d > 0; d >>= 1) {
+      ss += __shfl_xor(ss, d, 64);
+      st += __shfl_xor(st, d, 64);
+    }
+    if (l % lph == 0) {
+      s_src[row * K + k] = ss;
+      s_tgt[row * K + k] = st;
+    }
+  }
+}
+
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : 0.2f * z; }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -110,6 +138,22 @@ rgat_edge_dot_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict
   }
 }
 
+// H/4 lanes per edge, coalesced float4 reads of both rows, shuffle reduction per head (see rgat_node_scores_vec_kernel)
+__global__ void __launch_bounds__(256)
+rgat_edge_dot_vec_kernel(const int32_t* __restrict__ coll, const int32_t* __restrict__ tgt, const float* __restrict__ Y,
+                         const float* __restrict__ d_agg, int64_t E, int K, int Hk, float* __restrict__ da) {
+  const int H = K * Hk, lpe = H >> 2, lph = Hk >> 2;
+  const int per_block = 256 / lpe;
+  const int l = threadIdx.x % lpe;
+  for (int64_t e = (int64_t)blockIdx.x * per_block + threadIdx.x / lpe; e < E; e += (int64_t)gridDim.x * per_block) {
+    const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)coll[e] * H + 4 * l);
+    const float4 g = *reinterpret_cast<const float4*>(d_agg + (int64_t)tgt[e] * H + 4 * l);
+    float sum = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
+    for (int d = lph >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (l % lph == 0) da[e * K + l / lph] = sum;
+  }
+}
+
 // softmax + leaky_relu backward, edge-parallel: dz[e,k] = a (da - t[tgt,k]) * lrelu'(z), where
 // t[v,k] = sum over in-edges of a * da comes from the generic gather (node view, col = identity)
 __global__ void __launch_bounds__(256)
@@ -147,6 +191,15 @@ rgat_scores_backward_kernel(const float* __restrict__ ds_src, const float* __res
 
 static unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 16384)); }
 
+// shapes the lane-group kernels take: H / 4 lanes per row inside one wave, Hk / 4 lanes per head, both powers of two
+static bool rgat_vec_shape(int num_heads, int hidden_dim) {
+  if (num_heads <= 0 || hidden_dim % num_heads) return false;
+  const int hk = hidden_dim / num_heads;
+  if (hk % 4 || hidden_dim % 4) return false;
+  const int lph = hk / 4, lpe = hidden_dim / 4;
+  return (lph & (lph - 1)) == 0 && (lpe & (lpe - 1)) == 0 && lpe <= 64;
+}
+
 static int check_heads(int num_heads, int hidden_dim) {
   TFGNN_REQUIRE(num_heads > 0 && num_heads <= MAX_HEADS && hidden_dim > 0, "bad sizes");
   TFGNN_REQUIRE(hidden_dim % num_heads == 0, "hidden_dim %d is not divisible by num_heads %d", hidden_dim, num_heads);
@@ -165,8 +218,15 @@ extern "C" int tfgnn_rgat_node_scores(const float* d_Y, const float* d_alpha, in
   const int64_t rows = num_nodes * num_edge_types;
   if (rows == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_Y && d_alpha && d_s_src && d_s_tgt, "NULL pointer");
-  hipLaunchKernelGGL(rgat_node_scores_kernel, dim3(grid_for(rows * num_heads)), dim3(256), 0, (hipStream_t)stream,
-                     d_Y, d_alpha, rows, num_edge_types, num_heads, hidden_dim / num_heads, d_s_src, d_s_tgt);
+  if (rgat_vec_shape(num_heads, hidden_dim) && ((uintptr_t)d_Y | (uintptr_t)d_alpha) % 16 == 0) {
+    const int per_block = 256 / (hidden_dim / 4);
+    hipLaunchKernelGGL(rgat_node_scores_vec_kernel, dim3(grid_for(ceil_div(rows, per_block) * 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_Y, d_alpha, rows, num_edge_types, num_heads, hidden_dim / num_heads, d_s_src,
+                       d_s_tgt);
+  } else {
+    hipLaunchKernelGGL(rgat_node_scores_kernel, dim3(grid_for(rows * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                       d_Y, d_alpha, rows, num_edge_types, num_heads, hidden_dim / num_heads, d_s_src, d_s_tgt);
+  }
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -206,8 +266,15 @@ extern "C" int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* 
   if (rc) return rc;
   if (num_edges == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_coll_by_dst && d_target_by_dst && d_Y && d_dagg && d_da, "NULL pointer");
-  hipLaunchKernelGGL(rgat_edge_dot_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0, (hipStream_t)stream,
-                     d_coll_by_dst, d_target_by_dst, d_Y, d_dagg, num_edges, num_heads, hidden_dim / num_heads, d_da);
+  if (rgat_vec_shape(num_heads, hidden_dim) && ((uintptr_t)d_Y | (uintptr_t)d_dagg) % 16 == 0) {
+    const int per_block = 256 / (hidden_dim / 4);
+    hipLaunchKernelGGL(rgat_edge_dot_vec_kernel, dim3(grid_for(ceil_div(num_edges, per_block) * 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_coll_by_dst, d_target_by_dst, d_Y, d_dagg, num_edges, num_heads,
+                       hidden_dim / num_heads, d_da);
+  } else {
+    hipLaunchKernelGGL(rgat_edge_dot_kernel, dim3(grid_for(num_edges * num_heads)), dim3(256), 0, (hipStream_t)stream,
+                       d_coll_by_dst, d_target_by_dst, d_Y, d_dagg, num_edges, num_heads, hidden_dim / num_heads, d_da);
+  }
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
