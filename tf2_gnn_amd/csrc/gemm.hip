@@ -428,6 +428,13 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
                 void* workspace, size_t workspace_bytes, hipStream_t s, int* status, const float* mul = nullptr,
                 int64_t ld_mul = 0, const float* saved = nullptr, int64_t ld_saved = 0, int dact = 0);
 
+int gemm_x3_try_grouped_rows(int nprod, int trans_b, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t N,
+                             int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t stride_b,
+                             float* C, int64_t ldc, int act, hipStream_t s, int* status);
+int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t M, int64_t N,
+                          const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t stride_c, void* workspace, size_t workspace_bytes, hipStream_t s, int* status);
+
 }  // namespace tfgnn
 
 extern "C" int tfgnn_gemm_set_mode(int mode) {
@@ -546,6 +553,12 @@ extern "C" int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_
   TFGNN_REQUIRE(d_group_offsets && d_A && d_B && d_C, "NULL pointer");
   TFGNN_REQUIRE(lda >= K && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
   TFGNN_REQUIRE(num_groups <= 65535, "too many groups");
+  if (const int nprod = gemm_x3_mode()) {
+    int status = TFGNN_OK;
+    if (gemm_x3_try_grouped_rows(nprod, trans_b, num_groups, d_group_offsets, max_group_rows, N, K, d_A, lda, d_B, ldb,
+                                 stride_b, d_C, ldc, act, (hipStream_t)stream, &status))
+      return status;
+  }
   const bool vec = K > 0 && operands_vectorisable(0, trans_b, 4, N, K, d_A, lda, d_B, ldb) && (stride_b % 4 == 0);
   GemmPlan p = plan_gemm(max_group_rows, N, K, 0, vec);
   GemmArgs g;
@@ -587,6 +600,12 @@ extern "C" int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offse
   TFGNN_REQUIRE(d_group_offsets && d_C && (max_group_rows == 0 || (d_A && d_B)), "NULL pointer");
   TFGNN_REQUIRE(lda >= M && ldb >= N && ldc >= N, "bad leading dimension");
   TFGNN_REQUIRE(num_groups <= 65535, "too many groups");
+  if (const int nprod = gemm_x3_mode()) {
+    int status = TFGNN_OK;
+    if (gemm_x3_try_grouped_k(nprod, num_groups, d_group_offsets, max_group_rows, M, N, d_A, lda, d_B, ldb, d_C, ldc,
+                              stride_c, d_workspace, d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status))
+      return status;
+  }
   const bool vec = operands_vectorisable(1, 0, M, N, 4, d_A, lda, d_B, ldb);
   GemmPlan p = plan_gemm(M, N, 0, 0, vec);
   int splits = grouped_splits(num_groups, max_group_rows, M, N, p.bm, p.bn);

@@ -57,6 +57,10 @@ struct X3Args {
   const float* saved;
   int64_t ld_saved;
   int dact;
+  // grouped forms (tfgnn_gemm_grouped_rows / _k): blockIdx.y = group
+  int group_mode;  // 0 plain, 1 rows of A / C grouped (own B per group), 2 K range grouped (own C per group)
+  const int32_t* group_off;
+  int64_t strideB, strideC;
 };
 
 __device__ __forceinline__ float4 grad_epilogue(const X3Args& g, float4 v, int64_t row, int64_t col) {
@@ -270,8 +274,19 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
   const int wm = wave & 3, wn = wave >> 2;
   const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
   const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
-  const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
-  const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+  int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+  float* Cp = g.C;
+  int64_t partial_slab = blockIdx.z;
+  if (g.group_mode == 2) {  // the K range is the group's rows; every group has its own output
+    const int64_t gb = g.group_off[blockIdx.y], ge = g.group_off[blockIdx.y + 1];
+    const int64_t per = (ge - gb + g.splits - 1) / g.splits;
+    const int64_t chunk = (per + X3_BK - 1) / X3_BK * X3_BK;
+    k_begin = gb + (int64_t)blockIdx.z * chunk;
+    k_end = k_begin + chunk < ge ? k_begin + chunk : ge;
+    Cp += (int64_t)blockIdx.y * g.strideC;
+    partial_slab = (int64_t)blockIdx.y * g.splits + blockIdx.z;
+  }
 
   floatx16 acc[TN];
 #pragma unroll
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 
   // epilogue: wave-private LDS patch per 32 x 32 tile, 16-byte stores
   const bool split = g.splits > 1;
-  float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  float* outp = split ? g.partial + partial_slab * g.M * g.N : Cp;
   const int64_t ldo = split ? g.N : g.ldc;
   constexpr int PS = 36;
   float* patch = reinterpret_cast<float*>(lds) + wave * 32 * PS;
@@ -465,7 +480,7 @@ struct Producer<true, TN> {  // NN: A 512 K-contiguous items (2 per thread), B 6
 };
 
 template <bool B_KM, int NPROD, int TN>
-__global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
+__global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g_in) {
   constexpr int TM = 2;
   constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
   constexpr int EP_COLS = BN / 2;      // columns of a multiplying wave's block
@@ -477,8 +492,20 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool multiplier = wave < 4;
-  const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
+  const int64_t m0 = (int64_t)(blockIdx.x / g_in.n_tiles) * X3_BM;
+  const int64_t n0 = (int64_t)(blockIdx.x % g_in.n_tiles) * BN;
+  if (g_in.group_mode == 1) {  // rows [off[y], off[y+1]) of A and C with the group's own B
+    const int64_t gb = g_in.group_off[blockIdx.y], ge = g_in.group_off[blockIdx.y + 1];
+    if (m0 >= ge - gb) return;  // uniform for the whole workgroup
+  }
+  X3Args g = g_in;
+  if (g.group_mode == 1) {
+    const int64_t gb = g.group_off[blockIdx.y];
+    g.M = g.group_off[blockIdx.y + 1] - gb;
+    g.A += gb * g.lda;
+    g.C += gb * g.ldc;
+    g.B += (int64_t)blockIdx.y * g.strideB;
+  }
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
   const int64_t k_len = k_end - k_begin;
@@ -651,9 +678,11 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g) {
 
 __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
   const int64_t total = g.M * g.N;
+  const float* part = g.partial + (int64_t)blockIdx.y * g.splits * total;  // blockIdx.y = group (0 if ungrouped)
+  g.C += (int64_t)blockIdx.y * g.strideC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int z = 0; z < g.splits; ++z) s += g.partial[(int64_t)z * total + i];
+    for (int z = 0; z < g.splits; ++z) s += part[(int64_t)z * total + i];
     const int64_t row = i / g.N, col = i - row * g.N;
     if (g.bias) s += g.bias[col];
     s = act_apply(g.act, s);
@@ -726,6 +755,7 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.act = act; g.accumulate = accumulate;
   g.mul = mul; g.ld_mul = ld_mul; g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
+  g.group_mode = 0; g.group_off = nullptr; g.strideB = 0; g.strideC = 0;
   g.n_tiles = (unsigned)(N / bn);
   const int64_t tiles = ceil_div(M, 128) * (int64_t)g.n_tiles;
   g.splits = 1;
@@ -759,6 +789,70 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   if (g.splits > 1) {
     const int64_t total = M * N;
     hipLaunchKernelGGL(x3_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0, s, g);
+  }
+  return 1;
+}
+
+static int x3_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
+
+static void launch_bn(const X3Args& g, dim3 grid, int bn, int nprod, int trans_a, int trans_b, hipStream_t s) {
+  if (bn == 320) launch_x3<5>(g, grid, nprod, trans_a, trans_b, s);
+  else if (bn == 256) launch_x3<4>(g, grid, nprod, trans_a, trans_b, s);
+  else launch_x3<2>(g, grid, nprod, trans_a, trans_b, s);
+}
+
+// C[rows g] = act(A[rows g] @ op(B + g stride_b)) on the specialised kernel; 1 = taken
+int gemm_x3_try_grouped_rows(int nprod, int trans_b, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t N,
+                             int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t stride_b,
+                             float* C, int64_t ldc, int act, hipStream_t s, int* status) {
+  *status = TFGNN_OK;
+  const int bn = x3_tile_width(N);
+  if (!bn || K < 64 || K % 4 || lda % 4 || ldb % 4 || ldc % 4 || stride_b % 4) return 0;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16) return 0;
+  X3Args g{};
+  g.M = max_rows; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.act = act; g.splits = 1; g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
+  g.group_mode = 1; g.group_off = group_off; g.strideB = stride_b;
+  g.n_tiles = (unsigned)(N / bn);
+  dim3 grid((unsigned)(ceil_div(max_rows, X3_BM) * g.n_tiles), (unsigned)num_groups, 1);
+  launch_bn(g, grid, bn, nprod, 0, trans_b, s);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("bf16x3 grouped GEMM launch failed");
+    *status = TFGNN_ERR_HIP;
+  }
+  return 1;
+}
+
+// C + g stride_c = A[rows g]^T @ B[rows g] on the pipelined kernel (+ deterministic split-K over the group's rows)
+int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t M, int64_t N,
+                          const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t stride_c, void* workspace, size_t workspace_bytes, hipStream_t s, int* status) {
+  *status = TFGNN_OK;
+  const int bn = x3_tile_width(N);
+  if (!bn || M % 4 || lda % 4 || ldb % 4 || ldc % 4 || stride_c % 4 || max_rows < 64) return 0;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16) return 0;
+  X3Args g{};
+  g.M = M; g.N = N; g.K = max_rows; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.n_tiles = (unsigned)(N / bn);
+  const int64_t tiles = ceil_div(M, X3_BM) * (int64_t)g.n_tiles * num_groups;
+  int64_t splits = ceil_div(512, tiles > 0 ? tiles : 1);
+  splits = std::min<int64_t>(splits, std::min<int64_t>(max_rows / 128, 64));
+  const size_t per_split = (size_t)num_groups * (size_t)M * (size_t)N * 4;
+  if (splits > 1 && (!workspace || (uintptr_t)workspace % 16 || workspace_bytes < 2 * per_split)) splits = 1;
+  if (splits > 1) splits = std::min<int64_t>(splits, (int64_t)(workspace_bytes / per_split));
+  if (splits < 1) splits = 1;
+  g.splits = (int)splits; g.k_chunk = 0; g.partial = (float*)workspace;
+  g.group_mode = 2; g.group_off = group_off; g.strideC = stride_c;
+  dim3 grid((unsigned)(ceil_div(M, X3_BM) * g.n_tiles), (unsigned)num_groups, (unsigned)splits);
+  launch_bn(g, grid, bn, nprod, 1, 0, s);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("bf16x3 grouped GEMM launch failed");
+    *status = TFGNN_ERR_HIP;
+    return 1;
+  }
+  if (splits > 1) {
+    dim3 rgrid((unsigned)std::min<int64_t>(ceil_div(M * N, 256), 1024), (unsigned)num_groups);
+    hipLaunchKernelGGL(x3_splitk_reduce_kernel, rgrid, dim3(256), 0, s, g);
   }
   return 1;
 }
