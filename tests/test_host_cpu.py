@@ -159,3 +159,14 @@ def test_gnn_build_creates_reference_layer_set():
     assert sorted(g2._global_exchange_layers) == ["2"]
     ex_names = [v.name for v in g2.trainable_variables if "Global_Exchange" in v.name]
     assert sum("gru_cell" in n for n in ex_names) == 3 and any("ScoringMLP" in n for n in ex_names)
+
+
+def test_data_utils_helpers_match_reference_semantics():
+    """tf2_gnn/data/utils.py:61-85 (pure-Python helpers of the batch finalisation)."""
+    from tf2_gnn_amd.data import compute_number_of_edge_types, get_tied_edge_types
+
+    assert get_tied_edge_types(True, 3) == {0, 1, 2}
+    assert get_tied_edge_types(False, 3) == set()
+    assert get_tied_edge_types([0, 2], 3) == {0, 2}
+    assert compute_number_of_edge_types({0, 2}, 3, True) == 2 * 3 - 2 + 1
+    assert compute_number_of_edge_types(set(), 4, False) == 8
