@@ -283,7 +283,9 @@ def graph_gather(
 def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> torch.Tensor:
     """out = (a @ op(b)) * out_mul * act'(saved): an input-gradient product with the element-wise factors of the next
     backward step (dropout mask ``out_mul``, ``act_grad = (activation name, saved tensor)``) applied in the GEMM
-    epilogue when the active kernel has one (tfgnn_gemm_grad_epilogue), by separate kernels otherwise."""
+    epilogue when the active kernel has one (tfgnn_gemm_grad_epilogue), by separate kernels otherwise.
+    Use the RETURN value: on the unfused route the factors are applied out of place and ``out`` only holds the raw
+    product."""
     if out_mul is None and act_grad is None:
         return gemm(a, b, trans_b=trans_b, out=out)
     lib = _lib.load()
