@@ -1,3 +1,6 @@
+"""Message passing layers on the HIP path.  The registry keys are the lower-cased class names, as in the
+reference (tf2_gnn/layers/message_passing/message_passing.py:221-227), so ``params["message_calculation_class"]``
+resolves to the same layer types."""
 from .message_passing import (
     MESSAGE_PASSING_IMPLEMENTATIONS,
     MessagePassing,
@@ -10,22 +13,25 @@ from .message_passing import (
     set_default_device,
     set_seed,
 )
-from .rgat import RGAT
-from .rgcn import RGCN
-from .rgin import RGIN
-from .ggnn import GGNN
-from .gnn_edge_mlp import GNN_Edge_MLP
-from .gnn_film import GNN_FiLM
+
+# importing a module registers its class
+from .gnn_edge_mlp import GNN_Edge_MLP  # isort: skip
+from .gnn_film import GNN_FiLM  # isort: skip
+from .ggnn import GGNN  # isort: skip
+from .rgat import RGAT  # isort: skip
+from .rgcn import RGCN  # isort: skip
+from .rgin import RGIN  # isort: skip
 
 
 def get_message_passing_class(message_calculation_class_name: str):
-    """tf2_gnn/layers/message_passing/__init__.py:9-13"""
-    calculation_class = MESSAGE_PASSING_IMPLEMENTATIONS.get(message_calculation_class_name.lower())
-    if calculation_class is None:
-        raise ValueError(f"Unknown message passing type: {message_calculation_class_name}")
-    return calculation_class
+    """Registry lookup by (case-insensitive) class name; unknown names raise ValueError with the reference's
+    message (tf2_gnn/layers/message_passing/__init__.py:9-13)."""
+    try:
+        return MESSAGE_PASSING_IMPLEMENTATIONS[message_calculation_class_name.lower()]
+    except KeyError:
+        raise ValueError(f"Unknown message passing type: {message_calculation_class_name}") from None
 
 
 def get_known_message_passing_classes():
-    for message_passing_implementation in MESSAGE_PASSING_IMPLEMENTATIONS.values():
-        yield message_passing_implementation.__name__
+    """Names of the registered layer classes."""
+    return (cls.__name__ for cls in MESSAGE_PASSING_IMPLEMENTATIONS.values())
