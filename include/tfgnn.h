@@ -411,6 +411,27 @@ int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float
 int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_t rows, int64_t cols, float* d_dst,
                             void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Task metrics behind the path: the losses the reference differentiates
+ * and the per-batch numbers its epoch loop aggregates.  One streaming pass + a fixed-order two-stage
+ * reduction (reproducible run to run); d_workspace: tfgnn_task_metrics_workspace_bytes() bytes.
+ *   tfgnn_sigmoid_ce_metrics: NodeMulticlassTask._fast_task_metrics and micro_f1
+ *       (models/node_multiclass_task.py:10-23,62-70).  logits / labels [V, C] fp32 (labels 0 / 1);
+ *       d_metrics[0] = mean over nodes of the per-node sum of [ext] tf.nn.sigmoid_cross_entropy_with_logits,
+ *       d_metrics[1] = micro-F1 of round(sigmoid(logits)) against int32(labels) (nan when undefined, as
+ *       there); d_counts (optional) = {true pos, false pos, false neg}; d_dlogits (optional, [V, C]
+ *       contiguous) = d loss / d logits = (sigmoid(x) - z) / V.
+ *   tfgnn_regression_metrics: tf.losses.mean_squared_error / mean_absolute_error of per-graph outputs
+ *       (models/graph_regression_task.py:157-158, models/qm9_regression.py:122-123): d_metrics = {mse, mae};
+ *       d_dpred (optional) = d mse / d pred = 2 (pred - target) / G.
+ * ------------------------------------------------------------------------------------------ */
+size_t tfgnn_task_metrics_workspace_bytes(void);
+int tfgnn_sigmoid_ce_metrics(const float* d_logits, int64_t ld_logits, const float* d_labels, int64_t ld_labels,
+                             int64_t V, int64_t C, float* d_metrics, int64_t* d_counts, float* d_dlogits,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+int tfgnn_regression_metrics(const float* d_pred, const float* d_target, int64_t G, float* d_metrics,
+                             float* d_dpred, void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

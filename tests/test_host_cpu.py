@@ -170,3 +170,19 @@ def test_data_utils_helpers_match_reference_semantics():
     assert get_tied_edge_types([0, 2], 3) == {0, 2}
     assert compute_number_of_edge_types({0, 2}, 3, True) == 2 * 3 - 2 + 1
     assert compute_number_of_edge_types(set(), 4, False) == 8
+
+
+def test_task_model_requires_edge_type_count_and_labels():
+    from tf2_gnn_amd.tasks import GraphTaskModel, NodeMulticlassTask, QM9RegressionTask
+
+    with pytest.raises(ValueError):
+        GraphTaskModel(GraphTaskModel.get_default_hyperparameters("rgcn"))
+
+    class DS:
+        num_edge_types = 3
+
+    with pytest.raises(ValueError, match="num_node_target_labels"):
+        NodeMulticlassTask(NodeMulticlassTask.get_default_hyperparameters("rgcn"), dataset=DS())
+    p = QM9RegressionTask.get_default_hyperparameters("ggnn")
+    assert p["gnn_message_calculation_class"] == "ggnn" and p["out_layer_dropout_keep_prob"] == 1.0
+    assert p["use_intermediate_gnn_results"] is False and "optimizer" in p

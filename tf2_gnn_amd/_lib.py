@@ -140,6 +140,13 @@ _SIGNATURES = [
     ("tfgnn_adjacency_in_degrees", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_permute_021", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     ("tfgnn_mul", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_task_metrics_workspace_bytes", c_size_t, []),
+    (
+        "tfgnn_sigmoid_ce_metrics",
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    ("tfgnn_regression_metrics", c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]

@@ -11,7 +11,7 @@ PPI / QM9 default_hypers file; see DESIGN.md.
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, NamedTuple, Optional, Tuple
+from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -249,9 +249,13 @@ class GNN:
             return None
         return self._mp_layers[prev].activation_backward_spec()
 
-    def backward(self, grad_output: torch.Tensor, need_input_grad: bool = False):
+    def backward(self, grad_output: Optional[torch.Tensor], need_input_grad: bool = False,
+                 grad_all_representations: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """Back-propagate d(loss)/d(final node representations) through the stack; fills ``.grad``
         of every trainable variable; returns d(loss)/d(node_features) if requested.
+        ``grad_all_representations`` (num_layers + 1 entries, None = no gradient): d(loss)/d(the tuple returned with
+        ``return_all_representations=True``), for task heads that read the intermediate results
+        (tf2_gnn/models/graph_regression_task.py:112-121); entry i + 1 is the output of message passing layer i.
 
         Between two layers the gradient only meets element-wise factors - the dropout mask of the upper layer's
         input and the activation derivative of the lower layer's last op; where no residual / LayerNorm / exchange
@@ -260,7 +264,12 @@ class GNN:
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
+        extras = list(grad_all_representations) if grad_all_representations is not None else [None] * (self._num_layers + 1)
+        if len(extras) != self._num_layers + 1:
+            raise ValueError(f"grad_all_representations needs {self._num_layers + 1} entries, got {len(extras)}")
         g = grad_output
+        if g is None:  # only intermediate results were read: the last op's output gets no gradient of its own
+            g = torch.zeros_like(ctx["steps"][-1].get("dense_out", ctx["h0"])) if self._num_layers else None
         g_is_pre = False  # g already carries the activation derivative of the op differentiated next
         g_last = None
         for layer_idx in range(self._num_layers - 1, -1, -1):
@@ -276,7 +285,7 @@ class GNN:
                         self._dense_act, g, st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"]
                     )
                 w.grad = ops.gemm(st["dense_in"], gpre, trans_a=True)
-                nxt = None if (has_ln or has_ex) else mp.activation_backward_spec()
+                nxt = None if (has_ln or has_ex or extras[layer_idx + 1] is not None) else mp.activation_backward_spec()
                 g = ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=nxt)
                 g_is_pre = nxt is not None
             if has_ln:
@@ -284,10 +293,12 @@ class GNN:
                 g, gam.grad, bet.grad = ops.layernorm_backward(g, st["ln_in"], gam.value, st["ln_mean"], st["ln_rstd"])
             if has_ex:
                 g = self._global_exchange_layers[str(layer_idx)].backward(g)
+            if extras[layer_idx + 1] is not None:  # g is the plain gradient here (the fusions above were switched off)
+                g = ops.add_scale(g, extras[layer_idx + 1], 1.0)
             residual_here = layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and g_last is None)
             mask = st.get("mask")
             if not residual_here:
-                nxt = self._tail_first_backward_op(layer_idx, ctx)
+                nxt = None if extras[layer_idx] is not None else self._tail_first_backward_op(layer_idx, ctx)
                 g = mp.backward_with_epilogue(g, grad_is_pre_activation=g_is_pre, out_mul=mask, out_act_grad=nxt)
                 g_is_pre = nxt is not None
             else:
@@ -302,6 +313,8 @@ class GNN:
                     g_last = None
                 if mask is not None:
                     g = ops.mul(g, mask)
+        if extras[0] is not None:
+            g = ops.add_scale(g, extras[0], 1.0)
         gpre = g
         if self._init_act is not None and not g_is_pre:
             gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])

@@ -591,3 +591,43 @@ def gemm_grouped_k(a, b, group_off_dev, group_off_host, num_groups, out=None):
         )
     )
     return out
+
+
+def sigmoid_ce_metrics(logits: torch.Tensor, labels: torch.Tensor, need_grad: bool = True):
+    """NodeMulticlassTask._fast_task_metrics (tf2_gnn/models/node_multiclass_task.py:62-70) ->
+    (metrics [2] = (loss, micro-F1) on the device, counts [3] int64 = (tp, fp, fn), d loss / d logits or None)."""
+    lib = _lib.load()
+    _require_dev(logits, torch.float32, "logits")
+    _require_dev(labels, torch.float32, "labels")
+    logits, ldx = _rowmajor(logits, "logits")
+    labels, ldz = _rowmajor(labels, "labels")
+    if logits.shape != labels.shape:
+        raise ValueError(f"logits {tuple(logits.shape)} and labels {tuple(labels.shape)} differ in shape")
+    V, C = logits.shape
+    metrics = torch.empty(2, dtype=torch.float32, device=logits.device)
+    counts = torch.empty(3, dtype=torch.int64, device=logits.device)
+    grad = torch.empty((V, C), dtype=torch.float32, device=logits.device) if need_grad else None
+    nbytes = lib.tfgnn_task_metrics_workspace_bytes()
+    ws = _workspace(logits.device, nbytes)
+    _lib.check(lib.tfgnn_sigmoid_ce_metrics(_ptr(logits), ldx, _ptr(labels), ldz, V, C, _ptr(metrics), _ptr(counts), _ptr(grad),
+                                            _ptr(ws), ws.numel(), _stream()))
+    return metrics, counts, grad
+
+
+def regression_metrics(pred: torch.Tensor, target: torch.Tensor, need_grad: bool = True):
+    """tf.losses.mean_squared_error / mean_absolute_error of per-graph outputs
+    (tf2_gnn/models/graph_regression_task.py:157-158) -> (metrics [2] = (mse, mae), d mse / d pred or None)."""
+    lib = _lib.load()
+    _require_dev(pred, torch.float32, "pred")
+    _require_dev(target, torch.float32, "target")
+    pred = pred.contiguous().view(-1)
+    target = target.contiguous().view(-1)
+    if pred.shape != target.shape:
+        raise ValueError(f"pred {tuple(pred.shape)} and target {tuple(target.shape)} differ in shape")
+    metrics = torch.empty(2, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if need_grad else None
+    nbytes = lib.tfgnn_task_metrics_workspace_bytes()
+    ws = _workspace(pred.device, nbytes)
+    _lib.check(lib.tfgnn_regression_metrics(_ptr(pred), _ptr(target), pred.numel(), _ptr(metrics), _ptr(grad), _ptr(ws),
+                                            ws.numel(), _stream()))
+    return metrics, grad
