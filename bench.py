@@ -165,6 +165,9 @@ def main():
                     help="how the fp32 GEMMs run on the matrix cores (include/tfgnn.h, tfgnn_gemm_set_mode): fp32 MFMA, "
                     "or exact bf16 operand splitting with 6 / 9 piece products (fp32 in, fp32 accumulate, fp32 out)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timing in the other GEMM mode")
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="N > 1: add the training-step exchange (one bucketed RCCL all-reduce of the weight gradients) to every "
+                         "step; off by default - the fwd+bwd metric itself has no collective")
     args = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,6 +224,8 @@ def main():
             pending.append(enqueue_bucketing())  # next batch, overlapped with this step
         gnn(GNNInput(X, g, n2g, 1), training=True)
         gnn.backward(dOut)
+        if args.allreduce_grads:
+            parallel.allreduce_gradients(gnn.trainable_variables, dist)
         if graph is None:
             g.close()
 
@@ -288,6 +293,8 @@ def main():
             f"step = edge bucketing{' (hoisted)' if args.reuse_graph else (' (on the compute stream)' if args.serial_bucketing else ' of the next batch (2nd stream, overlapped)')} + GNN fwd + full bwd, one batch per GPU",
             "per_layer_traversal_rate_edges_per_s": value * NL,
             "gemm_mode": GEMM_MODE_NOTES[args.gemm_mode],
+            "collectives_per_step": ("1 bucketed all-reduce of the weight gradients (--allreduce-grads)"
+                                     if (args.allreduce_grads and world > 1) else "none (graph-sharded batches)"),
         },
     }
     if not args.no_alt_mode:

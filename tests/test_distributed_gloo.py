@@ -76,6 +76,19 @@ def _worker(rank, world, port, tmpdir):
     # forward outputs concatenate (by global node id) to the unsharded result - no halo, no collective
     full = _oracle_rgcn(feats, adjs, W)
     np.testing.assert_allclose(local_out.numpy(), full.numpy()[node_ids], rtol=1e-6, atol=1e-6)
+    # training-step exchange: bucketed gradient all-reduce (mean over ranks), untouched variables count as zeros
+    class Var:
+        def __init__(self, value, grad):
+            self.value, self.grad = value, grad
+
+    vs = [Var(torch.zeros(3, 4), torch.full((3, 4), float(rank + 1))), Var(torch.zeros(5), None if rank == 0 else torch.ones(5)),
+          Var(torch.zeros(2, 2), torch.arange(4.0).view(2, 2) * (rank + 1))]
+    assert parallel.allreduce_gradients(vs, dist, average=True, bucket_bytes=64) == 2  # 48 B | 20 B + 16 B
+    mean_scale = sum(range(1, world + 1)) / world
+    assert torch.allclose(vs[0].grad, torch.full((3, 4), mean_scale))
+    assert torch.allclose(vs[1].grad, torch.full((5,), (world - 1) / world))
+    assert torch.allclose(vs[2].grad, torch.arange(4.0).view(2, 2) * mean_scale)
+    assert parallel.allreduce_gradients(vs, None) == 0
     torch.save({"node_ids": node_ids, "edges": local_edges}, os.path.join(tmpdir, f"rank{rank}.pt"))
     parallel.barrier(dist)
     dist.destroy_process_group()
