@@ -412,6 +412,9 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 // (the pipelined kernel above) is issue-bound.  Here the multiplying wave issues one MFMA per 32 cycles plus a
 // ds_read every third MFMA, and its partner's VALU work runs beside it.  Same three-stage LDS ring and one
 // barrier per K tile.
+#ifndef X3_PROBE
+#define X3_PROBE 0
+#endif
 constexpr int S_PT = 256;  // producer threads
 
 template <bool B_KM, int TN>
@@ -430,6 +433,9 @@ struct Producer<false, TN> {  // NT: A 512 items, B 256 TN items of one float4 -
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].template load<MASKED>(k_left, adv);
+#if X3_PROBE == 1  // probe: no global reads of B in the steady state (results wrong)
+    if (MASKED)
+#endif
 #pragma unroll
     for (int i = 0; i < TN; ++i) b[i].template load<MASKED>(k_left, adv);
   }
@@ -442,8 +448,20 @@ struct Producer<false, TN> {  // NT: A 512 items, B 256 TN items of one float4 -
   __device__ __forceinline__ void store(unsigned short* stage) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].store(stage);
+#if X3_PROBE == 2  // probe: B is fetched but neither split nor stored (results wrong)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(b[i].r.x), "v"(b[i].r.y), "v"(b[i].r.z), "v"(b[i].r.w));
+#elif X3_PROBE == 3  // probe: B is fetched and split, not stored
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      unsigned h, m, l;
+      split3(b[i].r.x + b[i].r.y + b[i].r.z + b[i].r.w, h, m, l);
+      asm volatile("" ::"v"(h), "v"(m), "v"(l));
+    }
+#else
 #pragma unroll
     for (int i = 0; i < TN; ++i) b[i].store(stage);
+#endif
   }
 };
 template <int TN>
