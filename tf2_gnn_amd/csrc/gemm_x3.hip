@@ -497,8 +497,10 @@ struct Producer<true, TN> {  // NN: A 512 K-contiguous items (2 per thread), B 6
   }
 };
 
+// Narrow tile (TN = 2, 80 KB of LDS): capped at 128 registers so that two workgroups share a CU - one's prologue /
+// epilogue overlaps the other's main loop (GRU products of the QM9-sized configs, K = 128: 2.05 -> 1.53 ms).
 template <bool B_KM, int NPROD, int TN>
-__global__ void __launch_bounds__(X3_NT) gemm_x3s_kernel(X3Args g_in) {
+__global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args g_in) {
   constexpr int TM = 2;
   constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
   constexpr int EP_COLS = BN / 2;      // columns of a multiplying wave's block
