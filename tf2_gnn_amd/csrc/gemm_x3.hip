@@ -50,7 +50,7 @@ struct X3Args {
   int splits;
   float* partial;
   unsigned n_tiles;
-  int debug;  // TFGNN_GEMM_DEBUG probe bits: 1 = no split/store/fetch in the loop, 2 = no multiply (results wrong)
+  int debug;  // TFGNN_GEMM_DEBUG probe bits (pipelined kernel: 1 = no split/store/fetch in the loop, 2 = no multiply; 4 / 8: clocks)
   // gradient epilogue (tfgnn_gemm_grad_epilogue): C = (A B) * mul * act'(saved); NULL = factor absent
   const float* mul;
   int64_t ld_mul;
@@ -565,9 +565,10 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
     int s_st = 2 * STAGE;  // stage of tile t+2
     auto iteration = [&](auto masked, int64_t left4, const Producer<B_KM, TN>& from, Producer<B_KM, TN>& to) {
       constexpr bool MASKED = decltype(masked)::value;
-      if (!(g.debug & 1)) to.template load<MASKED>(left4, 3);  // tile t+4
+      to.template load<MASKED>(left4, 3);                      // tile t+4 (no branch around the fetch / the stores:
+                                                               // with one the compiler waits for vmcnt(6..0) here)
       __builtin_amdgcn_sched_barrier(0);   // fetches first: two iterations to land
-      if (!(g.debug & 2)) from.store(lds + s_st);              // tile t+2
+      from.store(lds + s_st);                                  // tile t+2
       __syncthreads();
       s_st = s_st == 2 * STAGE ? 0 : s_st + STAGE;
     };
