@@ -79,7 +79,7 @@ for name in which:
     except NotImplementedError as e:
         ms_fb = float("nan")
     print(f"{name:14s} {type(layer).__name__:13s} V={V} E={E} L={L} H={H}: bucketing {ms_graph:7.3f} ms | layer fwd {ms_fwd:8.3f} ms "
-          f"({E/ms_fwd/1e6:7.1f} M edges/s) | fwd+bwd {ms_fb:8.3f} ms ({E/ms_fb/1e6:7.1f} M edges/s)", flush=True)
+          f"({E/ms_fwd/1e6:7.2f} G edges/s) | fwd+bwd {ms_fb:8.3f} ms ({E/ms_fb/1e6:7.2f} G edges/s)", flush=True)
     g.close()
     del layer, X, out, dOut, g
     torch.cuda.empty_cache()
