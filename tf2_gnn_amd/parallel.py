@@ -33,8 +33,13 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
     if not dist.is_initialized():
         kwargs = {}
         if backend == "nccl" and device is not None:
-            kwargs["device_id"] = device
-        dist.init_process_group(backend=backend, **kwargs)
+            kwargs["device_id"] = device  # binds the communicator to this rank's GPU at once (no lazy device guess)
+        try:
+            dist.init_process_group(backend=backend, **kwargs)
+        except (TypeError, ValueError, RuntimeError):
+            if not kwargs or dist.is_initialized():
+                raise
+            dist.init_process_group(backend=backend)  # a torch / RCCL build without eager init: lazy binding
     return rank, world, dist
 
 
