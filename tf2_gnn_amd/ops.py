@@ -565,6 +565,10 @@ def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=Fals
     K = a.shape[1]
     N = b_stack.shape[1] if trans_b else b_stack.shape[2]
     b_stack = b_stack.contiguous()
+    if (not trans_b and a.shape[0] >= 4096 * max(G, 1) // 8 and K >= 64 and K % 4 == 0
+            and (N % 320 == 0 or N % 128 == 0) and get_gemm_mode() != GEMM_FP32):
+        # as in gemm(): the split-operand kernel stages K-contiguous weights fastest; [G, K, N] -> [G, N, K] once
+        b_stack, trans_b = transpose_batched(b_stack), True
     if out is None:
         out = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
     out2, ldc = _rowmajor(out, "out")
