@@ -766,7 +766,11 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   // 128 x {320, 256, 128} tiles (N a multiple of one of them), 16-byte aligned operands, supported layout pairs:
   //   NN (A [M,K], B [K,N]), NT (A [M,K], B [N,K]), TN (A [K,M], B [K,N])
   if (trans_a && trans_b) return 0;
-  const int bn = N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0));
+  int bn = N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0));
+  // short K, many row blocks (QM9-sized batches): the 128-wide tile runs two workgroups per CU, which overlaps one's
+  // prologue / output burst with the other's few K tiles
+  static const int narrow_k = [] { const char* e = getenv("TFGNN_X3_NARROW_K"); return e ? atoi(e) : 256; }();
+  if (!trans_a && K <= narrow_k && N % 128 == 0 && M >= 128 * 1024) bn = 128;
   if (!bn || K < 64 || M < 1) return 0;
   const bool a16 = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool b16 = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
