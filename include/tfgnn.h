@@ -314,6 +314,15 @@ int tfgnn_activation_backward(int act, const float* d_dy, const float* d_saved, 
  *           d_gates (nullable) [V,3H] receives z|r|c for the backward pass.
  * backward: d_dmx, d_dmh [V,3H] and d_dh_direct [V,H] = dh' * z.
  * ------------------------------------------------------------------------------------------ */
+/* tfgnn_gemm_gru (bf16x3 GEMM modes, H a multiple of 64): the first matmul and the gate math in one kernel -
+ *   h' = GRU(mx = x @ kernel + bias[0], mh, h) with mx kept in registers / LDS (never written to HBM).
+ * d_kernel_t: the kernel transposed to [3H, K] (K contiguous) with its rows regrouped per block of 192 rows as
+ * [z | r | h] of the same 64 units (row t*192 + g*64 + c = column g*H + t*64 + c of the Keras kernel); d_bias
+ * (nullable) regrouped likewise.  d_mh as above; d_gates nullable.  TFGNN_ERR_UNSUPPORTED otherwise: callers then
+ * use tfgnn_gemm + tfgnn_gru_gates_forward. */
+int tfgnn_gemm_gru(int64_t V, int H, int64_t K, const float* d_x, int64_t ld_x, const float* d_kernel_t,
+                   const float* d_bias, const float* d_mh, const float* d_h, float* d_h_new, float* d_gates,
+                   void* stream);
 int tfgnn_gru_gates_forward(const float* d_mx, const float* d_mh, const float* d_h, float* d_h_new,
                             float* d_gates, int64_t V, int H, void* stream);
 int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const float* d_mh,

@@ -79,6 +79,11 @@ _SIGNATURES = [
     ("tfgnn_graph_nonempty_offsets", c_int, [c_void_p, c_int, POINTER(c_int32)]),
     ("tfgnn_activation_forward", c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     ("tfgnn_activation_backward", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    (
+        "tfgnn_gemm_gru",
+        c_int,
+        [c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     ("tfgnn_gru_gates_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     (
         "tfgnn_gru_gates_backward",

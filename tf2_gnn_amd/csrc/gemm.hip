@@ -428,6 +428,9 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
                 void* workspace, size_t workspace_bytes, hipStream_t s, int* status, const float* mul = nullptr,
                 int64_t ld_mul = 0, const float* saved = nullptr, int64_t ld_saved = 0, int dact = 0);
 
+int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t lda, const float* Bt, const float* bias,
+                const float* mh, const float* h, float* h_new, float* gates, hipStream_t s);
+
 int gemm_x3_try_grouped_rows(int nprod, int trans_b, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t N,
                              int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t stride_b,
                              float* C, int64_t ldc, int act, hipStream_t s, int* status);
@@ -464,6 +467,22 @@ extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int
                   d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status, d_mul, ld_mul, d_saved, ld_saved,
                   act_of_saved))
     return status;
+  return TFGNN_ERR_UNSUPPORTED;
+}
+
+extern "C" int tfgnn_gemm_gru(int64_t V, int H, int64_t K, const float* d_x, int64_t ld_x, const float* d_kernel_t,
+                              const float* d_bias, const float* d_mh, const float* d_h, float* d_h_new, float* d_gates,
+                              void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && H >= 0 && K >= 0, "negative size");
+  if (V == 0 || H == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_kernel_t && d_mh && d_h && d_h_new, "NULL pointer");
+  TFGNN_REQUIRE(ld_x >= K, "bad leading dimension");
+  const int nprod = gemm_x3_mode();
+  if (nprod && gemm_x3_gru(nprod, V, H, K, d_x, ld_x, d_kernel_t, d_bias, d_mh, d_h, d_h_new, d_gates, (hipStream_t)stream)) {
+    TFGNN_LAUNCH_CHECK();
+    return TFGNN_OK;
+  }
   return TFGNN_ERR_UNSUPPORTED;
 }
 

@@ -61,6 +61,12 @@ struct X3Args {
   int group_mode;  // 0 plain, 1 rows of A / C grouped (own B per group), 2 K range grouped (own C per group)
   const int32_t* group_off;
   int64_t strideB, strideC;
+  // GRU epilogue (tfgnn_gemm_gru, kernel variant EPI = 1): the product is mx of a GRUCell with the columns of B
+  // regrouped per 192-wide tile as [z | r | h] of the same 64 units; C receives h' [M, H]
+  const float* gru_mh;   // [M, 3H]: h @ recurrent_kernel + recurrent bias
+  const float* gru_h;    // [M, H]: previous state
+  float* gru_gates;      // [M, 3H] z | r | c for the backward pass, or NULL
+  int gru_H;
 };
 
 __device__ __forceinline__ float4 grad_epilogue(const X3Args& g, float4 v, int64_t row, int64_t col) {
@@ -499,7 +505,7 @@ struct Producer<true, TN> {  // NN: A 512 K-contiguous items (2 per thread), B 6
 
 // Narrow tile (TN = 2, 80 KB of LDS): capped at 128 registers so that two workgroups share a CU - one's prologue /
 // epilogue overlaps the other's main loop (GRU products of the QM9-sized configs, K = 128: 2.05 -> 1.53 ms).
-template <bool B_KM, int NPROD, int TN>
+template <bool B_KM, int NPROD, int TN, int EPI = 0>
 __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args g_in) {
   constexpr int TM = 2;
   constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
@@ -666,6 +672,55 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
         for (int r = 0; r < 16; ++r) blk[((r & 3) + 8 * (r >> 2) + 4 * lk) * EP_LD + j * 32 + li] = acc[i][j][r];
     }
     __syncthreads();
+    if constexpr (EPI == 1) {
+      // GRU epilogue ([ext] GRUCell, reset_after: ggnn.py:84-87): tile column j = gate * 64 + c holds mx_gate of unit
+      // c of this tile's 64 units; z and the first half of r are in the wn = 0 blocks, the rest in the wn = 1 blocks.
+      static_assert(EPI != 1 || TN == 3, "the GRU epilogue is written for the 192-wide tile");
+      const int H = g.gru_H;
+      const int64_t unit0 = (n0 / BN) * 64;
+#pragma unroll 1
+      for (int f = tid; f < 2 * 32 * 16; f += X3_NT) {
+        const int wmb = f >> 9, rem = f & 511;
+        const int row = rem >> 4, cl = (rem & 15) * 4;
+        const int64_t grow = m0 + wmb * 64 + i * 32 + row;
+        if (grow < g.M) {
+          const float* blk0 = ep + (wmb * 32 + row) * EP_LD;
+          const float* blk1 = ep + ((wmb + 2) * 32 + row) * EP_LD;
+          float4 xz = *reinterpret_cast<const float4*>(blk0 + cl);
+          float4 xr = cl < 32 ? *reinterpret_cast<const float4*>(blk0 + 64 + cl) : *reinterpret_cast<const float4*>(blk1 + cl - 32);
+          float4 xh = *reinterpret_cast<const float4*>(blk1 + 32 + cl);
+          if (g.bias) {
+            const float4 bz = *reinterpret_cast<const float4*>(g.bias + n0 + cl);
+            const float4 br = *reinterpret_cast<const float4*>(g.bias + n0 + 64 + cl);
+            const float4 bh = *reinterpret_cast<const float4*>(g.bias + n0 + 128 + cl);
+            xz.x += bz.x; xz.y += bz.y; xz.z += bz.z; xz.w += bz.w;
+            xr.x += br.x; xr.y += br.y; xr.z += br.z; xr.w += br.w;
+            xh.x += bh.x; xh.y += bh.y; xh.z += bh.z; xh.w += bh.w;
+          }
+          const int64_t unit = unit0 + cl;
+          const float* pm = g.gru_mh + grow * 3 * H + unit;
+          const float4 hz = *reinterpret_cast<const float4*>(pm);
+          const float4 hr = *reinterpret_cast<const float4*>(pm + H);
+          const float4 hc = *reinterpret_cast<const float4*>(pm + 2 * H);
+          const float4 hv = *reinterpret_cast<const float4*>(g.gru_h + grow * H + unit);
+          float4 z, r, c, o;
+#define X3_GRU1(q)                                          \
+          z.q = 1.f / (1.f + expf(-(xz.q + hz.q)));         \
+          r.q = 1.f / (1.f + expf(-(xr.q + hr.q)));         \
+          c.q = tanhf(xh.q + r.q * hc.q);                   \
+          o.q = z.q * hv.q + (1.f - z.q) * c.q;
+          X3_GRU1(x) X3_GRU1(y) X3_GRU1(z) X3_GRU1(w)
+#undef X3_GRU1
+          *reinterpret_cast<float4*>(g.C + grow * g.ldc + unit) = o;
+          if (g.gru_gates) {
+            float* pg = g.gru_gates + grow * 3 * H + unit;
+            *reinterpret_cast<float4*>(pg) = z;
+            *reinterpret_cast<float4*>(pg + H) = r;
+            *reinterpret_cast<float4*>(pg + 2 * H) = c;
+          }
+        }
+      }
+    } else
 #pragma unroll 1
     for (int f = tid; f < 4 * 32 * ROW4; f += X3_NT) {
       const int b = f / (32 * ROW4), rem = f - b * (32 * ROW4);
@@ -815,6 +870,27 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     const int64_t total = M * N;
     hipLaunchKernelGGL(x3_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0, s, g);
   }
+  return 1;
+}
+
+// h' = GRU(mx = A Bt^T + bias, mh, h) with the gate math in the epilogue (mx is never written).  Bt: [3H, K]
+// K-contiguous with its rows regrouped per 192-row tile as [z | r | h] of 64 units (bias likewise).  1 = taken.
+int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t lda, const float* Bt, const float* bias,
+                const float* mh, const float* h, float* h_new, float* gates, hipStream_t s) {
+  if (H % 64 != 0 || K < 64 || K % 4 != 0 || M < 1 || lda % 4 != 0) return 0;
+  for (const void* ptr : {(const void*)A, (const void*)Bt, (const void*)mh, (const void*)h, (const void*)h_new})
+    if ((uintptr_t)ptr % 16) return 0;
+  if ((bias && (uintptr_t)bias % 16) || (gates && (uintptr_t)gates % 16)) return 0;
+  X3Args g{};
+  g.M = M; g.N = 3 * (int64_t)H; g.K = K; g.A = A; g.lda = lda; g.B = Bt; g.ldb = K; g.C = h_new; g.ldc = H;
+  g.bias = bias; g.act = TFGNN_ACT_NONE; g.splits = 1; g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
+  g.n_tiles = (unsigned)(3 * H / 192);
+  g.gru_mh = mh; g.gru_h = h; g.gru_gates = gates; g.gru_H = H;
+  const int64_t tiles = ceil_div(M, X3_BM) * g.n_tiles;
+  if (tiles > 0x7fffffff) return 0;
+  dim3 grid((unsigned)tiles, 1, 1);
+  if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, 3, 1>), grid, dim3(X3_NT), 0, s, g);
+  else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   return 1;
 }
 

@@ -63,9 +63,13 @@ class GGNN(GNN_Edge_MLP):
     def _finish(self, agg, X, ctx, training):
         ru = self._recurrent_unit
         b = ru["bias"].value
-        mx = ops.gemm(agg, ru["kernel"].value, bias=b[0])
         mh = ops.gemm(X, ru["recurrent_kernel"].value, bias=b[1])
-        h_new, gates = ops.gru_gates_forward(mx, mh, X)
+        fused = ops.gemm_gru(agg, ru["kernel"].value, b[0], mh, X)  # mx stays on chip (bf16x3 modes, H % 64 == 0)
+        if fused is not None:
+            h_new, gates = fused
+        else:
+            mx = ops.gemm(agg, ru["kernel"].value, bias=b[0])
+            h_new, gates = ops.gru_gates_forward(mx, mh, X)
         ctx.update({"agg": agg, "mh": mh, "gates": gates, "out": h_new})
         return h_new
 

@@ -424,6 +424,39 @@ def gru_gates_forward(mx, mh, h, save_gates: bool = True):
     return h_new, gates
 
 
+def gru_kernel_regrouped(kernel: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Keras GRUCell kernel [K, 3H] (+ bias [3H]) -> the operand form of tfgnn_gemm_gru: [3H, K], K contiguous, rows
+    regrouped per 192-row block as [z | r | h] of the same 64 units (an index gather on a small weight matrix)."""
+    K, H3 = kernel.shape
+    H = H3 // 3
+    t = torch.arange(H // 64, device=kernel.device).view(-1, 1, 1)
+    g = torch.arange(3, device=kernel.device).view(1, -1, 1)
+    c = torch.arange(64, device=kernel.device).view(1, 1, -1)
+    perm = (g * H + t * 64 + c).reshape(-1)
+    return transpose_batched(kernel.index_select(1, perm)), (None if bias is None else bias.index_select(0, perm).contiguous())
+
+
+def gemm_gru(x, kernel, bias, mh, h, save_gates: bool = True):
+    """h' = GRUCell gate math on (x @ kernel + bias, mh, h) with the matmul and the gates in one kernel
+    (tfgnn_gemm_gru) -> (h', gates or None), or None when the library has no such kernel for this mode / shape."""
+    H = h.shape[1]
+    if get_gemm_mode() == GEMM_FP32 or H % 64 != 0 or kernel.shape[0] < 64 or kernel.shape[0] % 4 != 0:
+        return None
+    lib = _lib.load()
+    x, ldx = _rowmajor(x, "x")
+    mh = mh.contiguous()
+    h = h.contiguous()
+    kt, bp = gru_kernel_regrouped(kernel, bias)
+    V, K = x.shape
+    h_new = torch.empty_like(h)
+    gates = torch.empty_like(mh) if save_gates else None
+    rc = lib.tfgnn_gemm_gru(V, H, K, _ptr(x), ldx, _ptr(kt), _ptr(bp), _ptr(mh), _ptr(h), _ptr(h_new), _ptr(gates), _stream())
+    if rc == -4:
+        return None
+    _lib.check(rc)
+    return h_new, gates
+
+
 def gru_gates_backward(dh_new, gates, mh, h):
     lib = _lib.load()
     V, H = h.shape
