@@ -124,9 +124,13 @@ class GraphGlobalGRUExchange(GraphGlobalExchange):
         X = inputs.node_embeddings
         per_node = self._compute_per_node_graph_representations(inputs, training)
         b = self._gru["bias"].value
-        mx = ops.gemm(per_node, self._gru["kernel"].value, bias=b[0])
         mh = ops.gemm(X, self._gru["recurrent_kernel"].value, bias=b[1])
-        h_new, gates = ops.gru_gates_forward(mx, mh, X)
+        fused = ops.gemm_gru(per_node, self._gru["kernel"].value, b[0], mh, X)  # as in GGNN: mx stays on chip
+        if fused is not None:
+            h_new, gates = fused
+        else:
+            mx = ops.gemm(per_node, self._gru["kernel"].value, bias=b[0])
+            h_new, gates = ops.gru_gates_forward(mx, mh, X)
         self._ctx = {"X": X, "per_node": per_node, "mh": mh, "gates": gates}
         return h_new
 
