@@ -124,12 +124,63 @@ colsum_kernel(const float* __restrict__ in, int64_t M, int N, int64_t ld, float*
     out[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// the same for 16-byte aligned rows: a lane owns four columns (a wave reads 1 KB of a row), eight rows in flight per lane
+__global__ void __launch_bounds__(256)
+colsum4_kernel(const float* __restrict__ in, int64_t M, int N, int64_t ld, float* __restrict__ out, int64_t rows_per_slab) {
+  __shared__ float4 red[4][64];
+  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int w = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t m1 = m0 + rows_per_slab < M ? m0 + rows_per_slab : M;
+  float4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {
+    int64_t m = m0 + w;
+    for (; m + 28 < m1; m += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(in + (m + 4 * u) * ld + c);
+        s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+      }
+    }
+    for (; m < m1; m += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(in + m * ld + c);
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+  }
+  float4 t;
+  t.x = ((s[0].x + s[1].x) + (s[2].x + s[3].x)) + ((s[4].x + s[5].x) + (s[6].x + s[7].x));
+  t.y = ((s[0].y + s[1].y) + (s[2].y + s[3].y)) + ((s[4].y + s[5].y) + (s[6].y + s[7].y));
+  t.z = ((s[0].z + s[1].z) + (s[2].z + s[3].z)) + ((s[4].z + s[5].z) + (s[6].z + s[7].z));
+  t.w = ((s[0].w + s[1].w) + (s[2].w + s[3].w)) + ((s[4].w + s[5].w) + (s[6].w + s[7].w));
+  red[w][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (w == 0 && c < N) {
+    const float4 a = red[0][threadIdx.x], b = red[1][threadIdx.x], e = red[2][threadIdx.x], f = red[3][threadIdx.x];
+    float* o = out + (int64_t)blockIdx.y * N + c;
+    o[0] = (a.x + b.x) + (e.x + f.x); o[1] = (a.y + b.y) + (e.y + f.y);
+    o[2] = (a.z + b.z) + (e.z + f.z); o[3] = (a.w + b.w) + (e.w + f.w);
+  }
+}
+
+// stage 2: 64 columns per workgroup; wave w adds slabs w, w+4, ... (eight loads in flight), then the four waves in order
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int slabs, int N, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int k = 0; k < slabs; ++k) s += partial[(int64_t)k * N + c];
-  out[c] = s;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    int k = w;
+    for (; k + 28 < slabs; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += partial[(int64_t)(k + 4 * u) * N + c];
+    }
+    for (; k < slabs; k += 4) s[0] += partial[(int64_t)k * N + c];
+  }
+  red[w][threadIdx.x & 63] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (w == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // y = a * x + b * y' style helpers used by the layer stack (gnn.py:291-296 residual averaging):
@@ -294,7 +345,7 @@ extern "C" int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_ga
 
 extern "C" size_t tfgnn_colsum_workspace_bytes(int64_t M, int N) {
   if (M <= 4096 || N <= 0) return 0;
-  const int64_t slabs = std::min<int64_t>(512, (M + 2047) / 2048);
+  const int64_t slabs = std::min<int64_t>(2048, (M + 511) / 512);
   return (size_t)slabs * N * 4;
 }
 
@@ -305,15 +356,19 @@ extern "C" int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, flo
   if (N == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_out && (M == 0 || d_in) && ld >= N, "bad argument");
   hipStream_t s = (hipStream_t)stream;
-  int64_t slabs = std::min<int64_t>(512, (M + 2047) / 2048);
+  int64_t slabs = std::min<int64_t>(2048, (M + 511) / 512);
   if (M <= 4096 || !d_workspace || workspace_bytes < (size_t)slabs * N * 4) slabs = 1;
   const int64_t rows_per_slab = slabs > 1 ? ceil_div(M, slabs) : (M > 0 ? M : 1);
   float* stage1 = slabs > 1 ? (float*)d_workspace : d_out;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)slabs), dim3(256), 0, s, d_in, M, N, ld, stage1,
-                     rows_per_slab);
+  if (N % 4 == 0 && ld % 4 == 0 && (uintptr_t)d_in % 16 == 0)
+    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)slabs), dim3(256), 0, s, d_in, M, N, ld,
+                       stage1, rows_per_slab);
+  else
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)slabs), dim3(256), 0, s, d_in, M, N, ld, stage1,
+                       rows_per_slab);
   TFGNN_LAUNCH_CHECK();
   if (slabs > 1) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, stage1, (int)slabs, N, d_out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, s, stage1, (int)slabs, N, d_out);
     TFGNN_LAUNCH_CHECK();
   }
   return TFGNN_OK;
