@@ -60,3 +60,22 @@ def test_gemm_fuzz(dev, mode, case):
             assert torch.equal(Cd[:, N:].cpu(), C_full[:, N:])
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 1001), (320, 1280, 67), (128, 320, 30001)])
+def test_gemm_k_major_operands_with_odd_k(dev, M, N, K):
+    """Weight-gradient layout (both operands K-major, K = number of edges / nodes: any value): the split kernels mask
+    whole k rows, so K need not be a multiple of 4."""
+    from tf2_gnn_amd import ops
+
+    prev = ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(K)
+        A = torch.randn((K, M), generator=g)
+        B = torch.randn((K, N), generator=g) * 0.2
+        out = ops.gemm(A.to(dev), B.to(dev), trans_a=True)
+        ref = A.double().t() @ B.double()
+        scale = max(1.0, 0.2 * float(K) ** 0.5)
+        assert_close(out.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"TN odd K {M}x{N}x{K}")
+    finally:
+        ops.set_gemm_mode(prev)

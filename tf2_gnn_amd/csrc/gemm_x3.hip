@@ -829,7 +829,9 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   if (!bn || K < 64 || M < 1) return 0;
   const bool a16 = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool b16 = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
-  if (!a16 || !b16 || K % 4 != 0 || (trans_a && M % 4 != 0) || (ldc % 4 != 0) || ((uintptr_t)C % 16 != 0)) return 0;
+  // K % 4: only where an operand is K-contiguous (16-byte fetches along K); K-major operands mask whole k rows
+  const bool k_aligned = K % 4 == 0 || (trans_a && !trans_b);
+  if (!a16 || !b16 || !k_aligned || (trans_a && M % 4 != 0) || (ldc % 4 != 0) || ((uintptr_t)C % 16 != 0)) return 0;
   if (bias && (uintptr_t)bias % 16 != 0) return 0;
   X3Args g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
