@@ -1,3 +1,4 @@
+"""Column sums (bias gradients) of tall matrices: error against fp64 and time per call.  Run on the GPU box."""
 import torch, sys
 sys.path.insert(0,'.')
 from tf2_gnn_amd import ops

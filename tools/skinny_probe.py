@@ -34,5 +34,5 @@ for name, K, N, tb in shapes:
         ops.set_gemm_mode(mode)
         res.append(t(lambda: ops.gemm(A, B, trans_b=tb, out=out)))
     gb = (M * K + M * N) * 4 / 1e9
-    print(f"{name:30s} fp32 {res[0]:8.1f} us  bf16x3 {res[1]:8.1f} us   ({gb:.2f} GB in+out -> {gb / 6e-6 / 1e6 * 1e0:.0f} us at 6 TB/s)", flush=True)
+    print(f"{name:30s} fp32 {res[0]:8.1f} us  bf16x3 {res[1]:8.1f} us   ({gb:.2f} GB in+out -> {gb / 6e3 * 1e6:.0f} us at 6 TB/s)", flush=True)
     del A, B, out
