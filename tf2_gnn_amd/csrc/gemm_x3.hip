@@ -267,7 +267,52 @@ struct StagerKM {
   }
 };
 
-template <int NPROD, int TN>
+// K-contiguous operand pair (NT) for the pipelined kernel: 512 A items + 4 BN B items of one float4 over the 512
+// threads - one A slot and NB B slots per thread, each slot one piece of the split / store work.
+template <int TN>
+struct StagerKC {
+  static constexpr int NB = (Geo<TN>::BN * 4 + X3_NT - 1) / X3_NT;
+  static constexpr int P = 1 + NB;
+  SlotKC<TN> a, b[NB];
+  __device__ __forceinline__ void init(const X3Args& g, int64_t m0, int64_t n0, int64_t k_begin, int tid) {
+    const int lane = tid & 63;
+    a.init(g.A, g.lda, m0, g.M, k_begin, tid, X3_BM * 4, 0, lane);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[i].init(g.B, g.ldb, n0, g.N, k_begin, tid + X3_NT * i, Geo<TN>::BN * 4, X3_BM, lane);
+  }
+  template <bool MASKED>
+  __device__ __forceinline__ void load(int64_t k_left, int adv) {
+    a.template load<MASKED>(k_left, adv);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[i].template load<MASKED>(k_left, adv);
+  }
+  __device__ __forceinline__ void skip() {
+    a.skip();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[i].skip();
+  }
+  __device__ __forceinline__ void store(unsigned short* stage) const {
+    a.store(stage);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[i].store(stage);
+  }
+  template <int Q>
+  __device__ __forceinline__ void piece(unsigned short* stage) const {
+    if constexpr (Q == 0) a.store(stage);
+    else if constexpr (Q < P) b[Q - 1].store(stage);
+  }
+  template <int J, bool LAST>
+  __device__ __forceinline__ void store_piece(unsigned short* stage) const {
+    piece<J>(stage);
+    if (LAST) {
+      piece<J + 1>(stage);
+      piece<J + 2>(stage);
+      piece<J + 3>(stage);
+    }
+  }
+};
+
+template <int NPROD, int TN, bool NT = false>
 __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
   constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
   constexpr int PATCH_FLOATS = (X3_NT / 64) * 32 * 36;
@@ -302,7 +347,8 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 
   const int li = lane & 31, lk = lane >> 5;
   if (k_begin < k_end) {
-    StagerKM<TN> st;
+    using Stager = typename std::conditional<NT, StagerKC<TN>, StagerKM<TN>>::type;
+    Stager st;
     st.init(g, m0, n0, k_begin, tid);
     const int half = (lk ^ (li >> 3)) & 1;
     const int a_frag = (wm * 32 + li) * P_ROW + half * 8;
@@ -325,7 +371,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
     // t+2, the operand reads of the next column tile, 6 (9) MFMAs.  sched_barrier keeps the chunks apart so
     // that the splitting arithmetic stays spread over the iteration; `from` holds tile t+2, the fetch of
     // tile t+3 goes to the other register set `to` first and has the whole iteration to land.
-    auto iteration = [&](auto masked, int64_t left3, const StagerKM<TN>& from, StagerKM<TN>& to) {
+    auto iteration = [&](auto masked, int64_t left3, const Stager& from, Stager& to) {
       constexpr bool MASKED = decltype(masked)::value;
       to.template load<MASKED>(left3, 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +403,7 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
       __syncthreads();
       const int s = s_cur; s_cur = s_nxt; s_nxt = s_st; s_st = s;
     };
-    StagerKM<TN> st2 = st;  // two register sets, each fetching every second tile: st2 tiles 3, 5, ...;
+    Stager st2 = st;  // two register sets, each fetching every second tile: st2 tiles 3, 5, ...;
     st.skip();              // st (holding tile 2) continues with 4, 6, ...
     int t = 0;
     const int t_fast = (int)(k_len / X3_BK) - 3;  // iterations whose fetched tile t+3 is a full tile
@@ -371,10 +417,55 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
     }
   }
 
-  // epilogue: wave-private LDS patch per 32 x 32 tile, 16-byte stores
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + partial_slab * g.M * g.N : Cp;
   const int64_t ldo = split ? g.N : g.ldc;
+  if constexpr (NT) {
+    // compact epilogue (as in the specialised kernel): the four waves of one column half put their 32 x 32 TN blocks
+    // into LDS, all eight waves stream them out with bias / activation / gradient factors / accumulate; two rounds
+    constexpr int EP_COLS = 32 * TN, EP_LD = EP_COLS + 4, ROW4 = EP_COLS / 4;
+    static_assert(3 * STAGE * 2 >= 4 * 32 * EP_LD * 4, "epilogue blocks must fit in the stage buffers");
+    float* ep = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (wn == r) {
+        float* blk = ep + wm * 32 * EP_LD;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) blk[((q & 3) + 8 * (q >> 2) + 4 * lk) * EP_LD + j * 32 + li] = acc[j][q];
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int f = tid; f < 4 * 32 * ROW4; f += X3_NT) {
+        const int b = f / (32 * ROW4), rem = f - b * (32 * ROW4);
+        const int row = rem / ROW4, c4 = rem - row * ROW4;
+        const int64_t grow = m0 + b * 32 + row;
+        const int64_t gcol = n0 + r * EP_COLS + c4 * 4;
+        if (grow < g.M) {
+          float4 v = *reinterpret_cast<const float4*>(ep + (b * 32 + row) * EP_LD + c4 * 4);
+          float* dst = outp + grow * ldo + gcol;
+          if (!split) {
+            if (g.bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(g.bias + gcol);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y);
+            v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+            v = grad_epilogue(g, v, grow, gcol);
+            if (g.accumulate) {
+              const float4 c4v = *reinterpret_cast<const float4*>(dst);
+              v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
+            }
+          }
+          *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // epilogue: wave-private LDS patch per 32 x 32 tile, 16-byte stores
   constexpr int PS = 36;
   float* patch = reinterpret_cast<float*>(lds) + wave * 32 * PS;
 #pragma unroll
@@ -628,9 +719,15 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
 #define X3S_PAIR(PA, PB)                                                                   \
         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[0], PB, acc[0][j], 0, 0, 0); \
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[1], PB, acc[1][j], 0, 0, 0);
+#if X3_PROBE == 4  // probe: half the MFMAs (results wrong)
+        X3S_PAIR(al, bl) X3S_PAIR(am, bm) X3S_PAIR(ah, bh)
+#elif X3_PROBE == 5  // probe: the staging side alone - fragment reads kept alive, no MFMA at all (results wrong)
+        asm volatile("" ::"v"(al[0]), "v"(am[0]), "v"(ah[0]), "v"(al[1]), "v"(am[1]), "v"(ah[1]), "v"(bl), "v"(bm), "v"(bh));
+#else
         if (NPROD >= 9) { X3S_PAIR(al, bl) }
         if (NPROD >= 8) { X3S_PAIR(am, bl) X3S_PAIR(al, bm) }
         X3S_PAIR(al, bh) X3S_PAIR(ah, bl) X3S_PAIR(am, bm) X3S_PAIR(am, bh) X3S_PAIR(ah, bm) X3S_PAIR(ah, bh)
+#endif
 #undef X3S_PAIR
         bh = nh; bm = nm; bl = nl;
         __builtin_amdgcn_sched_barrier(0);
@@ -773,12 +870,24 @@ __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
 // Layouts: NN / NT (A K-contiguous) -> specialised kernel (NT 140 vs 160 us, NN 68 vs 72 us for the pipelined one
 // on the hot-path shapes); TN (both K-major: weight gradients) -> pipelined kernel (with two K-major operands four
 // producer waves cannot keep up with the register transposes: 185 vs 207 us).
+// NT products on the pipelined kernel: the narrow tile only (106 registers there: two workgroups per CU and all eight
+// waves of each multiplying - the QM9-sized shapes run ~10 % faster than on the specialised kernel; on the wide tiles the
+// two kernels take the same time).  TFGNN_X3_NT_PIPELINED = 0 / 1 forces never / always.
+template <int TN>
+static bool pipelined_nt() {
+  static const int knob = [] { const char* e = getenv("TFGNN_X3_NT_PIPELINED"); return e ? atoi(e) : -1; }();
+  return knob < 0 ? TN == 2 : knob != 0;
+}
+
 template <int TN>
 static void launch_x3(const X3Args& g, dim3 grid, int nprod, int trans_a, int trans_b, hipStream_t s) {
   const bool nine = nprod >= 9;
   if (trans_a) {
     if (nine) hipLaunchKernelGGL((gemm_x3p_kernel<9, TN>), grid, dim3(X3_NT), 0, s, g);
     else hipLaunchKernelGGL((gemm_x3p_kernel<6, TN>), grid, dim3(X3_NT), 0, s, g);
+  } else if (trans_b && g.group_mode == 0 && pipelined_nt<TN>()) {
+    if (nine) hipLaunchKernelGGL((gemm_x3p_kernel<9, TN, true>), grid, dim3(X3_NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_x3p_kernel<6, TN, true>), grid, dim3(X3_NT), 0, s, g);
   } else if (trans_b) {
     if (nine) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, TN>), grid, dim3(X3_NT), 0, s, g);
     else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, TN>), grid, dim3(X3_NT), 0, s, g);
