@@ -355,6 +355,11 @@ def main():
             "frac": executed / gemm_peak, "traffic": None, "ms_per_launch": ms_gemm,
             "algorithmic_flops_per_launch": gemm_flops, "algorithmic_tflops": gemm_tflops, "share_of_step": share_gemm,
         }
+        if args.gemm_mode != "fp32":
+            # tools/mfma_dep_probe.hip on this part: back-to-back v_mfma_f32_32x32x16_bf16 sustains 2.47 PFLOP/s on smooth
+            # operands and 1.87 PFLOP/s on operands with random significands (the clock drops to 1.78 GHz)
+            roof_gemm["peak_measured_random_operands"] = 1870.0
+            roof_gemm["frac_of_measured_random_operand_peak"] = executed / 1870.0
         # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_probe.py, tools/parse_pmc.py;
         # FETCH_SIZE corrected x2 as calibrated on gfx950), committed under profiles/
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_{args.workload}.json")
