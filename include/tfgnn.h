@@ -415,6 +415,38 @@ int tfgnn_layernorm_backward(const float* d_dy, const float* d_x, const float* d
  * (one bias-free kernel per edge type, gnn_edge_mlp.py:73-81) so that a layer's backward pass is two
  * large GEMMs. */
 int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float* d_dst, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Split-operand Dense products on the fp16 matrix cores ("f16x2", csrc/gemm_sp.hip): the same Keras Dense /
+ * MatMul-gradient call sites as tfgnn_gemm (gnn_edge_mlp.py:100, rgcn.py:52-56, gnn.py:279,324-327,
+ * models/graph_task_model.py:347-357), fp32 in / fp32 accumulate / fp32 out, with the operands handed over
+ * already split so that the product kernel only moves data (LDS-DMA) and multiplies.
+ *
+ * SP16 operand format of an fp32 matrix [rows, cols] (cols % 16 == 0; the same number of bytes as the matrix):
+ *   element (r, c) = h + l,  h, l fp16:  byte r * ld_bytes + (c / 16) * 64 + plane * 32 + (c % 16) * 2
+ *   (plane 0 = h = fp16(x * 2^e), plane 1 = l = fp16(x * 2^e - h)), one power-of-two scale 2^e per row and per
+ *   block of `scale_block` columns chosen so that the block maximum lies in [2^14, 2^15);
+ *   d_inv_scale[r * (cols / scale_block) + b] = 2^-e.  |x - (h + l) 2^-e| <= 2^-22 |x| (elements within 2^-3 of the
+ *   block maximum) or 2^-39 of the block maximum.
+ * tfgnn_sp_split_rows: source element (r, c) = d_src[r * ld + (c / seg_len) * seg_stride + c % seg_len]
+ *   (seg_len <= 0: plain row-major rows).  d_fixed_inv_scale (nullable, 1 float on the device): use this 2^-e for the
+ *   whole tensor instead of per-block maxima (a caller-side bound; what the weight-gradient product needs).
+ * tfgnn_sp_split_cols: SP16 row n, column k = d_src[k * ld + n] (a Keras kernel [K, N] -> the [N, K] operand).
+ * tfgnn_sp_gemm_nt:   C[M,N] = epilogue( A[M,K] . B[N,K]^T ), A and B in SP16 (K contiguous);
+ *   epilogue = act(. + bias) (+ C if accumulate), then * d_mul * act'(d_saved) as in tfgnn_gemm_grad_epilogue.
+ *   a_scale_block: columns per scale block of A (<= 0: K); B has one scale per row (d_b_inv_scale [N]); NULL
+ *   scales = 1.  N % 128 == 0 (tiles of 320, 256 or 128 columns), K % 16 == 0; TFGNN_ERR_UNSUPPORTED otherwise.
+ * ------------------------------------------------------------------------------------------ */
+size_t tfgnn_sp_bytes(int64_t rows, int64_t cols);
+int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
+                        int scale_block, void* d_sp, int64_t ld_sp_bytes, float* d_inv_scale,
+                        const float* d_fixed_inv_scale, void* stream);
+int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                        float* d_inv_scale, void* stream);
+int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                     int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                     int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                     int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream);
+
 /* [batch, rows, cols] -> [batch, cols, rows] (LDS-tiled).  Used to hand the GEMMs K-contiguous weights
  * (W^T of gnn_edge_mlp.py:100 / rgcn.py:52-56 kernels) and to bring dW^T = G^T X back to the [L, D, H] layout. */
 int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_t rows, int64_t cols, float* d_dst,

@@ -152,6 +152,19 @@ _SIGNATURES = [
         [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     ("tfgnn_regression_metrics", c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("tfgnn_sp_bytes", c_size_t, [c_int64, c_int64]),
+    (
+        "tfgnn_sp_split_rows",
+        c_int,
+        [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    ("tfgnn_sp_split_cols", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    (
+        "tfgnn_sp_gemm_nt",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p],
+    ),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]

@@ -1,0 +1,709 @@
+// fp32 GEMM on the fp16 matrix cores from PRE-SPLIT operands ("f16x2" / SP16 operand format).
+//
+// Numerics.  Every fp32 operand value x of a row (or of a block of a row) is scaled by a power of two 2^e chosen
+// so that the block maximum lies in [2^14, 2^15), and the scaled value is split by two round-to-nearest
+// conversions  xs = h + l + r,  h = fp16(xs),  l = fp16(xs - h)  (xs - h is exact in fp32).  |r| <= 2^-22 |xs| for
+// every element within 2^-3 of the block maximum (l normal), and |r| <= 2^-25 (absolute, in units where the block
+// maximum is 2^14..2^15, i.e. <= 2^-39 of the block maximum) below that.  A product a*b is evaluated as
+// l_a h_b + h_a l_b + h_a h_b on v_mfma_f32_32x32x16_f16: each piece product has 11 x 11 significand bits and is
+// exact in fp32, the accumulation is fp32, the dropped l_a l_b term is <= 2^-22 |a b|.  The power-of-two scales
+// are removed exactly in the epilogue.  Measured against fp64 the result is in the error class of the fp32-MFMA
+// kernel (tests/test_gpu_gemm_sp.py: same max error within 10 % on N(0,1), relu-sparse and wide-dynamic-range
+// operands): the fp32 accumulation rounds more than the operand representation.  fp32 in, fp32 out.
+//
+// Operand format SP16 (the same number of bytes as the fp32 matrix, so it can be produced in place of it by the
+// kernel that computes the operand - the gather writes its sums this way, sp_split_* converts anything else):
+//   row r, column c  ->  byte  r * ld_bytes + (c / 16) * 64 + plane * 32 + (c % 16) * 2,   plane 0 = h, 1 = l
+// i.e. per row and per group of 16 columns one 64-byte granule [16 x h | 16 x l].  Scales: inv[r][c / SB] = 2^-e
+// (fp32), SB = columns per scale block (a multiple of 16; SB = C: one scale per row).
+//
+// NT kernel (both operands K-contiguous: activations [M, K] against weights kept as [N, K]):
+//   128 x BN output tile per 256-thread workgroup (BN = 320 / 256 / 128), one wave per SIMD, each wave a
+//   64 x BN/2 block of 32x32 MFMA tiles (160 accumulator registers at BN = 320).  K advances in steps of 16 (one
+//   MFMA k-step = one granule per row); a ring of five or six LDS stages is filled by LDS-DMA only
+//   (buffer_load_dwordx4 ... lds: no VALU, no registers), four or five steps ahead; the per-lane SOURCE address is
+//   permuted so that the lane-linear LDS image is XOR-swizzled and every ds_read_b128 fragment read is
+//   conflict-free.  Fragments of step s+1 are read while step s multiplies (two register sets), so the one
+//   barrier per step only orders buffer reuse.  Epilogue: scales, bias, activation, gradient factors, through a
+//   wave-private LDS patch so that every lane stores 16 contiguous bytes.
+#include <algorithm>
+#include <cstdlib>
+
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace tfgnn {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+// Probe builds (tools/sp_ablate.py) compile this file with -DSP_ABLATE=<bits> to leave parts of the main loop out:
+// 1 no DMA, 2 no fragment reads, 4 no MFMAs, 8 no barrier, 16 no stores, 32 no DMA of A, 64 no DMA of B.  The
+// library is built without it.
+#ifndef SP_ABLATE
+#define SP_ABLATE 0
+#endif
+
+constexpr int SP_BM = 128;
+constexpr int SP_NT = 256;
+
+struct SpArgs {
+  int64_t M, N, K;
+  const uint8_t* A;   // SP16 [M rows]
+  int64_t lda;        // bytes per row
+  const float* a_inv; // [M][a_nblk] 2^-e per (row, scale block) or NULL (all 1)
+  int a_nblk;
+  int a_blk_steps;    // k16 steps per scale block
+  const uint8_t* B;   // SP16 [N rows]
+  int64_t ldb;
+  const float* b_inv; // [N] or NULL
+  float* C;
+  int64_t ldc;
+  const float* bias;
+  int act;
+  int accumulate;
+  const float* mul;
+  int64_t ld_mul;
+  const float* saved;
+  int64_t ld_saved;
+  int dact;
+  unsigned n_tiles;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 -> SP16 conversion
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sp_scale_for_max(float mx, float* inv) {
+  // power of two s with mx * s in [2^14, 2^15); zero / non-finite blocks: s = 1
+  const unsigned b = __float_as_uint(mx);
+  int ex = (int)((b >> 23) & 0xffu);
+  if (ex == 255) {  // inf / nan in the block: no scaling, the result is inf / nan anyway
+    *inv = 1.f;
+    return 1.f;
+  }
+  if (mx == 0.f) {  // all-zero block: any scale represents it; the smallest one, so that among the blocks of a row (the
+    *inv = 1.1754943508222875e-38f;  // kernel normalises them to the LARGEST 2^-e) it never is the reference
+    return 1.f;
+  }
+  if (ex == 0) ex = 1;  // subnormal maximum: scale as the smallest normal exponent
+  int e = 14 - (ex - 127);
+  e = e > 126 ? 126 : e;
+  *inv = __uint_as_float((unsigned)(127 - e) << 23);
+  return __uint_as_float((unsigned)(127 + e) << 23);
+}
+
+__device__ __forceinline__ void sp_split(float xs, _Float16& h, _Float16& l) {
+  h = (_Float16)xs;  // v_cvt_f16_f32: round to nearest even
+  const float r = xs - (float)h;
+  // inf / nan: keep the class in h, nothing in l (inf - inf would make l a NaN)
+  l = (__float_as_uint(xs) & 0x7f800000u) == 0x7f800000u ? (_Float16)0.f : (_Float16)r;
+}
+
+__device__ __forceinline__ void sp_store4(uint8_t* row, int64_t c, float4 v, float s) {
+  _Float16 h[4], l[4];
+  sp_split(v.x * s, h[0], l[0]);
+  sp_split(v.y * s, h[1], l[1]);
+  sp_split(v.z * s, h[2], l[2]);
+  sp_split(v.w * s, h[3], l[3]);
+  uint8_t* g = row + (c >> 4) * 64 + (c & 15) * 2;
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<half4*>(g) = half4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<half4*>(g + 32) = half4{l[0], l[1], l[2], l[3]};
+}
+
+// One wave per (row, scale block).  Source element (r, c): src[r * ld + (c / seg_len) * seg_stride + c % seg_len]
+// (seg_len = C, seg_stride = 0: a plain row-major matrix; otherwise a row assembled from C / seg_len segments, e.g.
+// row d of [W_0[d,:] | W_1[d,:] | ...] from the stacked kernels [L, D, H]).  Two passes over the block (the second
+// one hits L1 / L2).
+__global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t seg_len,
+                                                            int64_t seg_stride, int64_t R, int64_t C, int sb,
+                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
+                                                            const float* __restrict__ fixed_inv) {
+  const int lane = threadIdx.x & 63;
+  const int nblk = (int)(C / sb);
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= R * nblk) return;
+  const int64_t r = item / nblk;
+  const int blk = (int)(item - r * nblk);
+  const float* srow = src + r * ld;
+  const int64_t c0 = (int64_t)blk * sb;
+  float s, iv;
+  if (fixed_inv) {  // caller-chosen scale (a tensor-wide bound): inv given, s = 1 / inv (a power of two)
+    iv = fixed_inv[0];
+    s = 1.f / iv;
+  } else {
+    float mx = 0.f;
+    for (int c = lane * 4; c < sb; c += 256) {
+      const int64_t cc = c0 + c;
+      const int64_t sg = cc / seg_len;
+      const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    s = sp_scale_for_max(mx, &iv);
+  }
+  if (inv && lane == 0) inv[item] = iv;
+  uint8_t* drow = dst + r * ld_dst;
+  for (int c = lane * 4; c < sb; c += 256) {
+    const int64_t cc = c0 + c;
+    const int64_t sg = cc / seg_len;
+    const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
+    sp_store4(drow, cc, v, s);
+  }
+}
+
+// SP16 rows from the COLUMNS of a row-major fp32 matrix: dst row n, column k = src[k * ld + n]  (a Keras kernel
+// [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  One workgroup per 16 dst rows.
+__global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
+                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv) {
+  __shared__ float red[64][4];
+  __shared__ float tile[16][65];
+  __shared__ float sc[16];
+  const int tid = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const int kq = tid >> 2, nq = (tid & 3) * 4;  // this thread: k = kq + 64 i, columns n0 + nq .. +3
+  const bool ok = n0 + nq < N;                  // N % 4 == 0
+  float4 mx = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t k = kq; k < K; k += 64) {
+    if (ok) {
+      const float4 v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
+      mx.x = fmaxf(mx.x, fabsf(v.x)); mx.y = fmaxf(mx.y, fabsf(v.y));
+      mx.z = fmaxf(mx.z, fabsf(v.z)); mx.w = fmaxf(mx.w, fabsf(v.w));
+    }
+  }
+  // reduce over the 64 k-rows of threads with the same nq
+  for (int j = 0; j < 4; ++j) {
+    red[kq][tid & 3] = j == 0 ? mx.x : (j == 1 ? mx.y : (j == 2 ? mx.z : mx.w));
+    __syncthreads();
+    if (tid < 4) {
+      float m = 0.f;
+      for (int i = 0; i < 64; ++i) m = fmaxf(m, red[i][tid]);
+      float iv;
+      sc[tid * 4 + j] = sp_scale_for_max(m, &iv);
+      if (inv && n0 + tid * 4 + j < N) inv[n0 + tid * 4 + j] = iv;
+    }
+    __syncthreads();
+  }
+  for (int64_t kb = 0; kb < K; kb += 64) {
+    const int64_t k = kb + kq;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok && k < K) v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
+    tile[nq + 0][kq] = v.x; tile[nq + 1][kq] = v.y; tile[nq + 2][kq] = v.z; tile[nq + 3][kq] = v.w;
+    __syncthreads();
+    // 16 rows x 64 k = 256 float4 items: thread -> row tid / 16, k4 = (tid % 16) * 4
+    const int rr = tid >> 4, k4 = (tid & 15) * 4;
+    if (n0 + rr < N && kb + k4 < K) {
+      const float4 o = {tile[rr][k4], tile[rr][k4 + 1], tile[rr][k4 + 2], tile[rr][k4 + 3]};
+      sp_store4(dst + (n0 + rr) * ld_dst, kb + k4, o, sc[rr]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------------
+template <int TNW>
+struct SpGeo {
+  static constexpr int BN = 64 * TNW;
+  static constexpr int ROWS = SP_BM + BN;      // rows per stage
+  static constexpr int STG = ROWS * 64;        // bytes per stage
+  static constexpr int ND_A = 2;               // DMA instructions per wave and step for A (8 x 16 rows / 4 waves)
+  static constexpr int ND_B = TNW;             // ... for B (4 TNW x 16 rows / 4 waves)
+  static constexpr int ND = ND_A + ND_B;
+  static constexpr int PATCH_LD = 32 * TNW + 4;  // floats per patch row (wave-private epilogue patch: 32 rows)
+  // LDS ring: one k16 step per stage, as many stages as 160 KB hold (at most 6).  The DMA of a step is issued NST-1
+  // steps before the step and has to have landed two steps before it: NST - 3 steps (and the rest of the issuing
+  // one) cover its latency - ~1 us under load, a step is ~0.45 us (tools/sp_ablate.py: with four stages the loop
+  // waited for its DMAs).
+  static constexpr int NST = (163840 / STG) < 6 ? (163840 / STG) : 6;
+  static constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;  // steps per unrolled loop body (register sets alternate)
+  static constexpr int VMW = (NST - 3) * ND;                // DMAs that may still be in flight at the end of a step
+  static constexpr int LDS_BYTES = NST * STG;
+  static_assert(NST >= 4 && VMW < 64, "ring depth");
+  static_assert(4 * 32 * PATCH_LD * 4 <= LDS_BYTES, "epilogue patch must fit the ring");
+};
+
+// Register state of the main loop.  The loop is pinned instruction by instruction with small volatile asm statements
+// (hipcc's scheduler otherwise sinks the fragment reads to their uses and puts dependent MFMAs back to back); the
+// member templates have every index as a template argument so that each operand is a fixed register.
+template <int TNW>
+struct SpLoop {
+  using G = SpGeo<TNW>;
+  // references to arrays that live in the kernel's frame (one alloca each: the optimizer's scalar replacement gives
+  // up on one big aggregate with this many uses and would keep the whole state in scratch memory)
+  half8 (&fa)[2][2][2];    // [set][row tile][plane]
+  half8 (&fb)[2][TNW][2];  // [set][col tile][plane]
+  floatx16 (&acc)[2][TNW];  // one accumulator for the three piece products (tools/mfma_acc_probe.hip, K = 1280: rms
+                            // accumulation error 7.0e-7, fp32-MFMA chain 1.14e-6, bf16x3 9.8e-7; a second accumulator for
+                            // the l*h + h*l terms would give 4.1e-7 but 320 accumulator registers exceed the 256 AGPRs)
+  unsigned (&a_addr)[G::NST][2], (&b_addr)[G::NST][2];  // LDS byte address of this lane's fragment slot per stage / plane
+  unsigned (&voff_a)[G::ND_A], (&voff_b)[G::ND_B];      // DMA source offsets of this lane
+  uint4v rs_a, rs_b;       // buffer descriptors of this tile's A / B rows (wave-uniform)
+  unsigned m0_a, m0_b;     // LDS byte address of this wave's first DMA slot in stage 0 (A part / B part)
+  int nsteps;
+  __device__ __forceinline__ SpLoop(half8 (&fa_)[2][2][2], half8 (&fb_)[2][TNW][2], floatx16 (&acc_)[2][TNW],
+                                    unsigned (&aa)[G::NST][2], unsigned (&ba)[G::NST][2], unsigned (&va)[G::ND_A],
+                                    unsigned (&vb)[G::ND_B])
+      : fa(fa_), fb(fb_), acc(acc_), a_addr(aa), b_addr(ba), voff_a(va), voff_b(vb) {}
+
+  template <int I, int SET, int ST>
+  __device__ __forceinline__ void read_one() {
+    if constexpr (I < 4) {
+      constexpr int t = I >> 1, p = I & 1;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][t][p]) : "v"(a_addr[ST][p]), "n"(t * 2048) : "memory");
+    } else {
+      constexpr int c = (I - 4) >> 1, p = (I - 4) & 1;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][c][p]) : "v"(b_addr[ST][p]), "n"(c * 2048) : "memory");
+    }
+  }
+  // MFMA order: the three piece products (l*h, h*l, h*h) each over all 2 x TNW tiles - consecutive MFMAs never share
+  // an accumulator; smallest terms first
+  template <int I, int SET>
+  __device__ __forceinline__ void mfma_one() {
+    constexpr int prod = I / (2 * TNW), j = I % (2 * TNW), t = j / TNW, c = j % TNW;
+    constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t][c]) : "v"(fa[SET][t][pa]), "v"(fb[SET][c][pb]));
+  }
+  // steps past the end of K re-load the last step into a stage nobody reads any more: the count of outstanding DMAs
+  // per step stays constant, which is what the counted vmcnt waits rely on
+  template <int I, int ST>
+  __device__ __forceinline__ void dma_one(int step) {
+    // written out (not the builtin): with the builtin hipcc keeps one SGPR per (stage, instruction) LDS address -
+    // 35 of them at BN = 320 - runs out of SGPRs, parks the buffer descriptors in VGPRs and wraps every DMA in a
+    // readfirstlane waterfall loop.  Here m0 is base + immediate: two SGPRs in all.
+    unsigned so = (unsigned)(step < nsteps ? step : nsteps - 1) * 64u;
+    if constexpr ((SP_ABLATE & 256) != 0) so = (unsigned)(step % (nsteps / 2)) * 128u;  // probe: 8 rows x 128 B per DMA
+    if constexpr (I < G::ND_A)
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                   :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(so) : "memory");
+    else
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                   :: "s"(m0_b), "n"(ST * G::STG + SP_BM * 64 + (I - G::ND_A) * 1024), "v"(voff_b[I - G::ND_A]), "s"(rs_b), "s"(so)
+                   : "memory");
+  }
+  template <int I, int N, int ST>
+  __device__ __forceinline__ void dma_all(int step) {
+    if constexpr (I < N) {
+      dma_one<I, ST>(step);
+      dma_all<I + 1, N, ST>(step);
+    }
+  }
+  template <int I, int N, int SET, int ST>
+  __device__ __forceinline__ void read_all() {
+    if constexpr (I < N) {
+      read_one<I, SET, ST>();
+      read_all<I + 1, N, SET, ST>();
+    }
+  }
+
+  // block scaling of A: fragments of scale block b are multiplied by inv[row][b] / max_b inv[row][b] <= 1
+  const float* a_inv;
+  int a_nblk, a_blk_steps;
+  int64_t a_row[2];
+  float a_rmax[2];
+  half2v afac[2];
+  template <int SET>
+  __device__ __forceinline__ void scale_frags(int step) {  // plain VALU on the freshly read A fragments
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (step % a_blk_steps == 0) {
+      const int b = step / a_blk_steps;
+      if (b < a_nblk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const _Float16 f = (_Float16)(a_inv[a_row[t] * a_nblk + b] / a_rmax[t]);
+          afac[t] = half2v{f, f};
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        half2v* v = reinterpret_cast<half2v*>(&fa[SET][t][p]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * afac[t];
+      }
+  }
+
+  // one k16 step S (mod UNR; stage S % NST, register set S & 1):  MFMA i (i < NR) + fragment read i of the NEXT step
+  // (other register set);  MFMA NR + i (i < ND) + LDS-DMA i of step s + NST - 1;  the remaining MFMAs bare;
+  // s_waitcnt vmcnt(VMW) lgkmcnt(0) (step s+2 has landed, the fragments of s+1 are in registers);  barrier.
+  static constexpr int NR = 4 + 2 * TNW;  // fragment reads per step
+  static constexpr int NM = 6 * TNW;      // MFMAs per step
+  static_assert(NR + G::ND <= NM, "issue pattern");
+  template <int S, int I, bool ABLK>
+  __device__ __forceinline__ void step_items(int sbase) {
+    if constexpr (I < NM) {
+      if constexpr (!(SP_ABLATE & 4)) mfma_one<I, (S & 1)>();
+      if constexpr (I < NR) {
+        if constexpr (!(SP_ABLATE & 2)) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
+      } else if constexpr (I < NR + G::ND) {
+        constexpr bool is_a = (I - NR) < G::ND_A;
+        if constexpr (!(SP_ABLATE & 1) && !((SP_ABLATE & 32) && is_a) && !((SP_ABLATE & 64) && !is_a))
+          dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
+      }
+      if constexpr (ABLK && I == NR + G::ND) scale_frags<((S + 1) & 1)>(sbase + S + 1);
+      step_items<S, I + 1, ABLK>(sbase);
+    }
+  }
+  template <int S, bool ABLK>
+  __device__ __forceinline__ void step(int sbase) {
+    step_items<S, 0, ABLK>(sbase);
+    if constexpr ((SP_ABLATE & (1 | 32 | 64)) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    if constexpr (!(SP_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+  }
+  template <int S, bool ABLK>
+  __device__ __forceinline__ void steps(int sbase) {  // one unrolled loop body: up to UNR steps (wave-uniform guard)
+    if constexpr (S < G::UNR) {
+      if (sbase + S < nsteps) step<S, ABLK>(sbase);
+      steps<S + 1, ABLK>(sbase);
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_prologue() {  // steps 0 .. NST-2 in flight
+    if constexpr (J < G::NST - 1) {
+      dma_all<0, G::ND, J>(J);
+      dma_prologue<J + 1>();
+    }
+  }
+};
+
+template <int TNW, bool ABLK, bool GRAD>
+__global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
+  using G = SpGeo<TNW>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned tile_n = blockIdx.x % g.n_tiles;
+  const unsigned tile_m = blockIdx.x / g.n_tiles;
+  const int64_t row0 = (int64_t)tile_m * SP_BM;
+  const int64_t col0 = (int64_t)tile_n * G::BN;
+  const int nsteps = (int)(g.K >> 4);
+
+  // ---- DMA setup: buffer descriptors over this tile's rows (rows past M / N read as zeros) -------------------
+  const int64_t rows_a = g.M - row0 < SP_BM ? g.M - row0 : SP_BM;
+  const int64_t rows_b = g.N - col0 < G::BN ? g.N - col0 : G::BN;
+  // raw buffer descriptors: {base[31:0], base[47:32] (stride 0), bytes, 0x00020000}
+  auto make_rsrc = [](const uint8_t* p, int64_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return uint4v{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+  };
+  const uint4v rs_a = make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
+  const uint4v rs_b = make_rsrc(g.B + col0 * g.ldb, rows_b * g.ldb);
+  half8 r_fa[2][2][2];
+  half8 r_fb[2][TNW][2];
+  floatx16 r_acc[2][TNW];
+  unsigned r_aa[G::NST][2], r_ba[G::NST][2], r_va[G::ND_A], r_vb[G::ND_B];
+  SpLoop<TNW> L(r_fa, r_fb, r_acc, r_aa, r_ba, r_va, r_vb);
+  L.rs_a = rs_a;
+  L.rs_b = rs_b;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)lds;
+  L.m0_a = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_A * 1024);
+  L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
+  L.nsteps = nsteps;
+  // lane j of a DMA instruction fills LDS slot j of 16 rows x 64 bytes: row j / 4, slot q' = j % 4 holds source
+  // chunk q = q' ^ ((row >> 2) & 3)
+  const int drow = lane >> 2;
+  const int dq = (lane & 3) ^ ((drow >> 2) & 3);
+#pragma unroll
+  for (int i = 0; i < G::ND_A; ++i) L.voff_a[i] = (unsigned)(((wave * G::ND_A + i) * 16 + drow) * g.lda + dq * 16);
+#pragma unroll
+  for (int i = 0; i < G::ND_B; ++i) L.voff_b[i] = (unsigned)(((wave * G::ND_B + i) * 16 + drow) * g.ldb + dq * 16);
+  if constexpr ((SP_ABLATE & 256) != 0) {  // probe: full 128-byte lines, 8 rows per DMA instruction (data lands wrongly)
+#pragma unroll
+    for (int i = 0; i < G::ND_A; ++i) L.voff_a[i] = (unsigned)(((wave * G::ND_A + i) * 8 + (lane >> 3)) * g.lda + (lane & 7) * 16);
+#pragma unroll
+    for (int i = 0; i < G::ND_B; ++i) L.voff_b[i] = (unsigned)(((wave * G::ND_B + i) * 8 + (lane >> 3)) * g.ldb + (lane & 7) * 16);
+  }
+
+  // ---- fragment addresses (one base register per stage and operand plane; tiles are immediate offsets) ---------
+  const int fi = lane & 31, kg = lane >> 5;
+  const int sw = (fi >> 2) & 3;
+#pragma unroll
+  for (int st = 0; st < G::NST; ++st)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      L.a_addr[st][p] = (unsigned)(st * G::STG + (wm * 64 + fi) * 64 + (((p * 2 + kg) ^ sw) * 16));
+      L.b_addr[st][p] = (unsigned)(st * G::STG + SP_BM * 64 + (wn * 32 * TNW + fi) * 64 + (((p * 2 + kg) ^ sw) * 16));
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L.acc[t][c][r] = 0.f;
+
+  L.a_inv = g.a_inv; L.a_nblk = g.a_nblk; L.a_blk_steps = g.a_blk_steps;
+  L.afac[0] = L.afac[1] = half2v{(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int64_t r = row0 + wm * 64 + t * 32 + fi;
+    L.a_row[t] = r < g.M ? r : g.M - 1;
+    float m = 1.f;
+    if (ABLK) {
+      m = 0.f;
+      for (int b = 0; b < g.a_nblk; ++b) m = fmaxf(m, g.a_inv[L.a_row[t] * g.a_nblk + b]);
+    } else if (g.a_inv) {
+      m = g.a_inv[L.a_row[t]];
+    }
+    L.a_rmax[t] = m;  // the row's epilogue factor (lane fi holds row fi of row tile t)
+  }
+  float cfac[TNW], cbias[TNW];  // column factors / bias of this lane's accumulator columns
+#pragma unroll
+  for (int c = 0; c < TNW; ++c) {
+    const int64_t col = col0 + wn * 32 * TNW + c * 32 + fi;
+    cfac[c] = g.b_inv ? g.b_inv[col] : 1.f;
+    cbias[c] = g.bias ? g.bias[col] : 0.f;
+  }
+
+  // ---- prologue: three steps in flight, fragments of step 0 in set 0 ----------------------------------------
+  constexpr int NR = SpLoop<TNW>::NR;
+  L.template dma_prologue<0>();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::VMW) : "memory");  // steps 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  L.template read_all<0, NR, 0, 0>();
+  if (ABLK) L.template scale_frags<0>(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0, ABLK>(s);
+  // the re-loads of the last steps must not land in the patch; the accumulators of the last MFMAs must be
+  // readable by plain VALU (the compiler does not see the MFMAs inside the asm statements)
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  if constexpr (SP_ABLATE & 128) {  // probe: where did the waves of this workgroup run?  (HW_REG_HW_ID = 4)
+    if (lane == 0) reinterpret_cast<unsigned*>(g.C)[blockIdx.x * 4 + wave] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    return;
+  }
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+  // Scales, bias and activation are applied in the accumulator layout (their operands were fetched before the main
+  // loop: column factors / bias per (lane, column tile), row factors by a lane exchange of a_rmax), then a 32-row
+  // block goes through the wave's LDS patch so that every lane stores 16 contiguous bytes; the gradient factors and the
+  // accumulate operand are fetched four float4 ahead of their use.
+  float* patch = reinterpret_cast<float*>(lds) + wave * 32 * G::PATCH_LD;
+  const int64_t wcol0 = col0 + wn * 32 * TNW;
+  constexpr int C4 = 8 * TNW;             // float4 per patch row
+  constexpr int NIT = 32 * C4 / 64;       // float4 per lane and row tile
+  static_assert(NIT % 4 == 0, "epilogue chunking");
+  auto epilogue_tile = [&](auto t_c) {
+    constexpr int t = decltype(t_c)::value;
+    float rf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rf[r] = __shfl(L.a_rmax[t], (r & 3) + 8 * (r >> 2) + 4 * kg, 64);
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L.acc[t][c][r] = L.acc[t][c][r] * (rf[r] * cfac[c]) + cbias[c];
+    // one wave-uniform dispatch on the activation for the whole tile (a switch per element costs a taken branch each:
+    // 320 of them were 40 us of a 120 us kernel)
+    auto act_tile = [&](auto act_c) {
+#pragma unroll
+      for (int c = 0; c < TNW; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) L.acc[t][c][r] = act_apply(decltype(act_c)::value, L.acc[t][c][r]);
+    };
+    switch (g.act) {
+      case TFGNN_ACT_RELU: act_tile(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+      case TFGNN_ACT_TANH: act_tile(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+      case TFGNN_ACT_LEAKY_RELU: act_tile(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+      case TFGNN_ACT_ELU: act_tile(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+      case TFGNN_ACT_SELU: act_tile(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+      case TFGNN_ACT_GELU: act_tile(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+      case TFGNN_ACT_SIGMOID: act_tile(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+      default: break;
+    }
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        patch[prow * G::PATCH_LD + c * 32 + fi] = L.acc[t][c][r];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t wrow0 = row0 + wm * 64 + t * 32;
+    const float* __restrict__ mulp = g.mul;
+    const float* __restrict__ savp = g.saved;
+    float* __restrict__ cptr = g.C;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += 4) {
+      float4 v[4], m[4], sv[4], o[4];
+      bool ok[4];
+      int64_t coff[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = lane + (it0 + j) * 64;
+        const int pr = idx / C4, c4 = idx - pr * C4;
+        const int64_t row = wrow0 + pr, col = wcol0 + c4 * 4;
+        ok[j] = row < g.M;
+        const int64_t rr = ok[j] ? row : g.M - 1;
+        coff[j] = rr * g.ldc + col;
+        v[j] = *reinterpret_cast<const float4*>(patch + pr * G::PATCH_LD + c4 * 4);
+        if (GRAD) {
+          m[j] = mulp ? *reinterpret_cast<const float4*>(mulp + rr * g.ld_mul + col) : float4{1.f, 1.f, 1.f, 1.f};
+          if (savp) sv[j] = *reinterpret_cast<const float4*>(savp + rr * g.ld_saved + col);
+        }
+        if (g.accumulate) o[j] = *reinterpret_cast<const float4*>(cptr + coff[j]);
+      }
+      if (GRAD && savp) {  // sv <- act'(saved), one dispatch per four float4
+        auto dact_chunk = [&](auto act_c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv[j].x = act_grad(decltype(act_c)::value, sv[j].x); sv[j].y = act_grad(decltype(act_c)::value, sv[j].y);
+            sv[j].z = act_grad(decltype(act_c)::value, sv[j].z); sv[j].w = act_grad(decltype(act_c)::value, sv[j].w);
+          }
+        };
+        switch (g.dact) {
+          case TFGNN_ACT_RELU: dact_chunk(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+          case TFGNN_ACT_TANH: dact_chunk(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+          case TFGNN_ACT_LEAKY_RELU: dact_chunk(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+          case TFGNN_ACT_ELU: dact_chunk(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+          case TFGNN_ACT_SELU: dact_chunk(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+          case TFGNN_ACT_GELU: dact_chunk(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+          case TFGNN_ACT_SIGMOID: dact_chunk(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+          default: dact_chunk(std::integral_constant<int, TFGNN_ACT_NONE>{}); break;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 w = v[j];
+        if (GRAD) {
+          w.x *= m[j].x; w.y *= m[j].y; w.z *= m[j].z; w.w *= m[j].w;
+          if (savp) { w.x *= sv[j].x; w.y *= sv[j].y; w.z *= sv[j].z; w.w *= sv[j].w; }
+        }
+        if (g.accumulate) { w.x += o[j].x; w.y += o[j].y; w.z += o[j].z; w.w += o[j].w; }
+        if (ok[j] && (!(SP_ABLATE & 16) || w.x == 12345.678f)) *reinterpret_cast<float4*>(cptr + coff[j]) = w;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  epilogue_tile(std::integral_constant<int, 0>{});
+  epilogue_tile(std::integral_constant<int, 1>{});
+}
+
+template <int TNW>
+static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
+  using G = SpGeo<TNW>;
+  const bool ablk = g.a_inv && g.a_nblk > 1;
+  const bool grad = g.mul || g.saved;
+#define SP_LAUNCH(AB, GR)                                                                                          \
+  do {                                                                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_nt_kernel<TNW, AB, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                G::LDS_BYTES);                                                                     \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((gemm_sp_nt_kernel<TNW, AB, GR>), grid, dim3(SP_NT), G::LDS_BYTES, s, g);                   \
+  } while (0)
+  if (ablk) {
+    if (grad) SP_LAUNCH(true, true);
+    else SP_LAUNCH(true, false);
+  } else {
+    if (grad) SP_LAUNCH(false, true);
+    else SP_LAUNCH(false, false);
+  }
+#undef SP_LAUNCH
+}
+
+static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
+
+}  // namespace tfgnn
+
+using namespace tfgnn;
+
+extern "C" {
+
+size_t tfgnn_sp_bytes(int64_t rows, int64_t cols) { return (size_t)rows * (size_t)cols * 4; }
+
+int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
+                        int scale_block, void* d_sp, int64_t ld_sp_bytes, float* d_inv_scale,
+                        const float* d_fixed_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_src && d_sp, "tfgnn_sp_split_rows: null pointer");
+  TFGNN_REQUIRE(rows >= 0 && cols > 0 && cols % 16 == 0, "tfgnn_sp_split_rows: cols must be a positive multiple of 16");
+  if (scale_block <= 0) scale_block = (int)cols;
+  if (seg_len <= 0) { seg_len = cols; seg_stride = 0; }
+  TFGNN_REQUIRE(scale_block % 16 == 0 && cols % scale_block == 0, "tfgnn_sp_split_rows: scale_block must divide cols and be a multiple of 16");
+  TFGNN_REQUIRE(seg_len % 4 == 0 && cols % seg_len == 0 && ld % 4 == 0 && seg_stride % 4 == 0 && (uintptr_t)d_src % 16 == 0,
+                "tfgnn_sp_split_rows: source must be 16-byte aligned with segment length / strides multiples of 4");
+  TFGNN_REQUIRE(ld_sp_bytes >= cols * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_rows: bad SP16 leading dimension / alignment");
+  if (rows == 0) return TFGNN_OK;
+  const int64_t items = rows * (cols / scale_block);
+  hipLaunchKernelGGL(sp_split_rows_kernel, dim3((unsigned)ceil_div(items, 4)), dim3(256), 0, (hipStream_t)stream, d_src, ld,
+                     seg_len, seg_stride, rows, cols, scale_block, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale, d_fixed_inv_scale);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                        float* d_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_src && d_sp, "tfgnn_sp_split_cols: null pointer");
+  TFGNN_REQUIRE(K > 0 && N > 0 && K % 16 == 0 && N % 4 == 0 && ld % 4 == 0 && (uintptr_t)d_src % 16 == 0,
+                "tfgnn_sp_split_cols: K must be a multiple of 16, N and ld multiples of 4");
+  TFGNN_REQUIRE(ld_sp_bytes >= K * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_cols: bad SP16 leading dimension / alignment");
+  hipLaunchKernelGGL(sp_split_cols_kernel, dim3((unsigned)ceil_div(N, 16)), dim3(256), 0, (hipStream_t)stream, d_src, ld, K, N,
+                     (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                     int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                     int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                     int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream) {
+  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C, "tfgnn_sp_gemm_nt: null pointer");
+  TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
+  const int bn = sp_tile_width(N);
+  if (!bn) {
+    set_error("tfgnn_sp_gemm_nt: N = %lld is not a multiple of 128", (long long)N);
+    return TFGNN_ERR_UNSUPPORTED;
+  }
+  TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && lda_bytes >= K * 4 && ldb_bytes >= K * 4 &&
+                    (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0,
+                "tfgnn_sp_gemm_nt: SP16 operands must be 64-byte aligned with leading dimensions >= 4 K bytes");
+  TFGNN_REQUIRE(ldc % 4 == 0 && (uintptr_t)d_C % 16 == 0 && (!d_bias || (uintptr_t)d_bias % 16 == 0) &&
+                    (!d_b_inv_scale || (uintptr_t)d_b_inv_scale % 16 == 0) && (!d_mul || (ld_mul % 4 == 0 && (uintptr_t)d_mul % 16 == 0)) &&
+                    (!d_saved || (ld_saved % 4 == 0 && (uintptr_t)d_saved % 16 == 0)),
+                "tfgnn_sp_gemm_nt: C / bias / scale / factor operands must be 16-byte aligned with ld %% 4 == 0");
+  TFGNN_REQUIRE(128 * lda_bytes < (1ll << 31) && 320 * ldb_bytes < (1ll << 31), "tfgnn_sp_gemm_nt: K too large");
+  SpArgs g{};
+  g.M = M; g.N = N; g.K = K;
+  g.A = (const uint8_t*)d_A_sp; g.lda = lda_bytes; g.a_inv = d_a_inv_scale;
+  if (a_scale_block <= 0 || a_scale_block >= K) a_scale_block = (int)K;
+  TFGNN_REQUIRE(a_scale_block % 16 == 0 && K % a_scale_block == 0, "tfgnn_sp_gemm_nt: a_scale_block must divide K and be a multiple of 16");
+  g.a_nblk = (int)(K / a_scale_block);
+  g.a_blk_steps = a_scale_block / 16;
+  g.B = (const uint8_t*)d_B_sp; g.ldb = ldb_bytes; g.b_inv = d_b_inv_scale;
+  g.C = d_C; g.ldc = ldc; g.bias = d_bias; g.act = act; g.accumulate = accumulate;
+  g.mul = d_mul; g.ld_mul = ld_mul; g.saved = d_saved; g.ld_saved = ld_saved; g.dact = act_of_saved;
+  g.n_tiles = (unsigned)(N / bn);
+  const int64_t tiles = ceil_div(M, SP_BM) * g.n_tiles;
+  TFGNN_REQUIRE(tiles <= 0x7fffffff, "tfgnn_sp_gemm_nt: too many tiles");
+  dim3 grid((unsigned)tiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (bn == 320) launch_sp_nt<5>(g, grid, s);
+  else if (bn == 256) launch_sp_nt<4>(g, grid, s);
+  else launch_sp_nt<2>(g, grid, s);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+}  // extern "C"

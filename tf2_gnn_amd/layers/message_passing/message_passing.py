@@ -80,32 +80,42 @@ def glorot_uniform(shape, fan_in=None, fan_out=None, device=None) -> torch.Tenso
 # --------------------------------------------------------------------------------------------
 # graph cache: GNN builds the Graph once per batch; stand-alone layer calls share it too
 # --------------------------------------------------------------------------------------------
-_GRAPH_CACHE: "OrderedDict[tuple, ops.Graph]" = OrderedDict()
+_GRAPH_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()  # key -> (Graph, the adjacency tensors it was built from)
 _GRAPH_CACHE_SIZE = 4
 
 
+def _graph_key(adjacency_lists, num_nodes: int) -> tuple:
+    return (int(num_nodes),) + tuple(
+        (a.data_ptr(), tuple(a.shape), tuple(a.stride()), str(a.device), a._version) for a in adjacency_lists
+    )
+
+
 def get_graph(adjacency_lists, num_nodes: int) -> "ops.Graph":
+    """The bucketed Graph of a batch, built once and shared by every layer / pass that is handed the same adjacency
+    tensors.  An entry holds references to those tensors, so their addresses cannot be given to another batch while
+    the entry is alive (a key of addresses alone would return a stale Graph when the allocator reuses them); an
+    in-place edit bumps ``_version`` and misses.  Evicted Graphs are released by reference count, not closed: a layer
+    context of an earlier forward pass may still hold them."""
     if isinstance(adjacency_lists, ops.Graph):
         if adjacency_lists.num_nodes != num_nodes:
             raise ValueError("Graph was built for a different number of nodes")
         return adjacency_lists
-    key = (int(num_nodes),) + tuple((a.data_ptr(), tuple(a.shape), a._version) for a in adjacency_lists)
-    g = _GRAPH_CACHE.get(key)
-    if g is None:
+    adjacency_lists = tuple(adjacency_lists)
+    key = _graph_key(adjacency_lists, num_nodes)
+    entry = _GRAPH_CACHE.get(key)
+    if entry is None:
         g = ops.Graph(adjacency_lists, num_nodes)
-        _GRAPH_CACHE[key] = g
+        _GRAPH_CACHE[key] = (g, adjacency_lists)
         while len(_GRAPH_CACHE) > _GRAPH_CACHE_SIZE:
-            _, old = _GRAPH_CACHE.popitem(last=False)
-            old.close()
+            _GRAPH_CACHE.popitem(last=False)
     else:
         _GRAPH_CACHE.move_to_end(key)
+        g = entry[0]
     return g
 
 
 def clear_graph_cache():
-    while _GRAPH_CACHE:
-        _, g = _GRAPH_CACHE.popitem()
-        g.close()
+    _GRAPH_CACHE.clear()
 
 
 class MessagePassing:

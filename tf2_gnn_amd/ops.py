@@ -673,3 +673,79 @@ def regression_metrics(pred: torch.Tensor, target: torch.Tensor, need_grad: bool
     _lib.check(lib.tfgnn_regression_metrics(_ptr(pred), _ptr(target), pred.numel(), _ptr(metrics), _ptr(grad), _ptr(ws),
                                             ws.numel(), _stream()))
     return metrics, grad
+
+
+# ---- split-operand ("f16x2") products: include/tfgnn.h tfgnn_sp_*, csrc/gemm_sp.hip ------------------------------
+class SplitOperand:
+    """An fp32 matrix [rows, cols] in the SP16 operand format: ``data`` uint8 [rows, 4 * cols] (per row and 16 columns
+    one 64-byte granule [16 x fp16 h | 16 x fp16 l]) and ``inv_scale`` fp32 [rows, cols // scale_block] (2^-e)."""
+
+    __slots__ = ("data", "inv_scale", "rows", "cols", "scale_block")
+
+    def __init__(self, data, inv_scale, rows, cols, scale_block):
+        self.data, self.inv_scale, self.rows, self.cols, self.scale_block = data, inv_scale, rows, cols, scale_block
+
+
+def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed_inv_scale: Optional[torch.Tensor] = None,
+                  out: Optional[SplitOperand] = None) -> SplitOperand:
+    """SP16 form of the rows of ``x`` [R, C] (unit inner stride).  ``segments = (seg_len, seg_stride, cols)``: row r is
+    assembled from cols / seg_len pieces x.data[r * ld + j * seg_stride : ... + seg_len] (e.g. row d of
+    [W_0[d, :] | W_1[d, :] | ...] from stacked kernels [L, D, H]: x = W[0], segments = (H, D * H, L * H))."""
+    lib = _lib.load()
+    _require_dev(x, torch.float32, "x")
+    x, ld = _rowmajor(x, "x")
+    rows = x.shape[0]
+    if segments is None:
+        seg_len, seg_stride, cols = 0, 0, x.shape[1]
+    else:
+        seg_len, seg_stride, cols = (int(v) for v in segments)
+    sb = int(scale_block) if scale_block and scale_block > 0 else cols
+    if out is None:
+        data = torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device)
+        inv = torch.empty((rows, cols // sb), dtype=torch.float32, device=x.device)
+        out = SplitOperand(data, inv, rows, cols, sb)
+    _lib.check(lib.tfgnn_sp_split_rows(_ptr(x), ld, seg_len, seg_stride, rows, cols, sb, _ptr(out.data), out.data.stride(0),
+                                       _ptr(out.inv_scale), _ptr(fixed_inv_scale), _stream()))
+    return out
+
+
+def sp_split_cols(w: torch.Tensor) -> SplitOperand:
+    """SP16 form of w^T for a row-major [K, N] matrix (a Keras kernel): rows = N, cols = K, one scale per row."""
+    lib = _lib.load()
+    _require_dev(w, torch.float32, "w")
+    w, ld = _rowmajor(w, "w")
+    K, N = w.shape
+    data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
+    inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
+    _lib.check(lib.tfgnn_sp_split_cols(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), _stream()))
+    return SplitOperand(data, inv, N, K, K)
+
+
+def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
+               act_grad=None) -> torch.Tensor:
+    """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt)."""
+    lib = _lib.load()
+    M, K, N = a.rows, a.cols, b.rows
+    if b.cols != K:
+        raise ValueError(f"sp_gemm_nt: inner dimensions differ ({K} vs {b.cols})")
+    if b.scale_block != K:
+        raise ValueError("sp_gemm_nt: the right operand must carry one scale per row")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.data.device)
+    out2, ldc = _rowmajor(out, "out")
+    if out2 is not out or tuple(out.shape) != (M, N):
+        raise ValueError(f"out must be [{M},{N}] with unit inner stride")
+    act_name, saved = act_grad if act_grad is not None else (None, None)
+    if bias is not None:
+        bias = bias.contiguous()
+    _lib.check(
+        lib.tfgnn_sp_gemm_nt(
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block, _ptr(b.data), b.data.stride(0),
+            _ptr(b.inv_scale), _ptr(out), ldc, _ptr(bias), act_id(act), int(accumulate), _ptr(out_mul),
+            out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
+            saved.stride(0) if saved is not None else 0, _stream(),
+        )
+    )
+    return out
