@@ -433,8 +433,8 @@ int tfgnn_permute_021(const float* d_src, int64_t A, int64_t B, int64_t C, float
  * tfgnn_sp_split_cols: SP16 row n, column k = d_src[k * ld + n] (a Keras kernel [K, N] -> the [N, K] operand).
  * tfgnn_sp_gemm_nt:   C[M,N] = epilogue( A[M,K] . B[N,K]^T ), A and B in SP16 (K contiguous);
  *   epilogue = act(. + bias) (+ C if accumulate), then * d_mul * act'(d_saved) as in tfgnn_gemm_grad_epilogue.
- *   a_scale_block: columns per scale block of A (<= 0: K); B has one scale per row (d_b_inv_scale [N]); NULL
- *   scales = 1.  N % 128 == 0 (tiles of 320, 256 or 128 columns), K % 16 == 0; TFGNN_ERR_UNSUPPORTED otherwise.
+ *   a_scale_block: columns per scale block of A (0: K, i.e. one scale per row; < 0: d_a_inv_scale points to ONE scale
+ *   for the whole tensor); B has one scale per row (d_b_inv_scale [N]); NULL scales = 1.  N % 128 == 0 (tiles of 320, 256 or 128 columns), K % 16 == 0; TFGNN_ERR_UNSUPPORTED otherwise.
  * ------------------------------------------------------------------------------------------ */
 size_t tfgnn_sp_bytes(int64_t rows, int64_t cols);
 int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
@@ -446,6 +446,38 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
                      int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                      int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                      int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream);
+
+/* tfgnn_sp_gemm_tn: the weight-gradient product C[m, n] = sum_k A[k, a_first_col + m] B[k, b_first_col + n] of two SP16
+ * operands stored with K as the row index (dW = X^T G of the Dense / edge-MLP kernels, tf.GradientTape in
+ * models/graph_task_model.py:347-357).  Scales: ONE 2^-e per operand tensor (*d_a_inv_scale, *d_b_inv_scale; NULL = 1) -
+ * a per-row scale would be a per-k factor here; producers write such operands with a caller-side bound
+ * (d_fixed_inv_scale of tfgnn_sp_split_rows / tfgnn_graph_gather_reduce_sp).  M % 128 == 0, N % 128 == 0, first columns
+ * multiples of 16.  Split-K with a deterministic second pass that also scatters the result:
+ *   C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= value
+ * (row-major [M, N]: group_rows = M, stride_row = N, stride_col = 1; dW of stacked kernels [L, D, H] from m = (l, h),
+ * n = d: group_rows = H, stride_group = D * H, stride_row = 1, stride_col = H). */
+size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                     const float* d_a_inv_scale, const void* d_B_sp, int64_t ldb_bytes, int64_t b_first_col,
+                     const float* d_b_inv_scale, float* d_C, int64_t group_rows, int64_t stride_group, int64_t stride_row,
+                     int64_t stride_col, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Tensor-wide scales for the operands of tfgnn_sp_gemm_tn: tfgnn_absmax gives *d_out = max(*d_out, scale * max |x|)
+ * (start from 0; order-independent, so reproducible), tfgnn_sp_inv_scale_from_bound turns a bound into the 2^-e that
+ * puts it in [2^14, 2^15).  A bound may exceed the true maximum (e.g. max |d_pre| times the largest weighted out-degree
+ * for the gathered gradient): every factor of two costs one bit of the 18 the format has beyond fp32's significand. */
+int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream);
+int tfgnn_sp_inv_scale_from_bound(const float* d_bound, float* d_inv_scale, void* stream);
+
+/* tfgnn_graph_gather_reduce (plain sums: embedding_lookup + 1/(c+1e-7) scaling + unsorted_segment_sum,
+ * message_passing.py:197-206,172-174, gnn_edge_mlp.py:102-106) writing its rows directly as the SP16 operand of
+ * tfgnn_sp_gemm_* - the [V, L*D] matrix of per-(node, type) sums is never stored in fp32.  Row r of the view gets
+ * its own scale d_inv_scale[r] (for a typed view the rows (v, l) are the (row v, scale block l) of the [V, L*width]
+ * operand), or every row uses the caller's *d_fixed_inv_scale.  width % 16 == 0, width <= 512. */
+int tfgnn_graph_gather_reduce_sp(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
+                                 const float* d_edge_weight, const float* d_row_scale, const float* d_in, int64_t ld_in,
+                                 int width, void* d_out_sp, int64_t ld_out_sp_bytes, float* d_inv_scale,
+                                 const float* d_fixed_inv_scale, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* [batch, rows, cols] -> [batch, cols, rows] (LDS-tiled).  Used to hand the GEMMs K-contiguous weights
  * (W^T of gnn_edge_mlp.py:100 / rgcn.py:52-56 kernels) and to bring dW^T = G^T X back to the [L, D, H] layout. */

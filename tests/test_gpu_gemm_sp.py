@@ -183,3 +183,83 @@ def test_gemm_nt_special_values(dev):
     fin = torch.isfinite(big) & (refb.abs() < 1e38)
     mag = (A.double().abs() @ Bt.double().abs().t())[[3, 4]]  # these rows cancel heavily: error relative to sum |a||b|
     assert float(((big.double() - refb)[fin].abs() / mag[fin]).max()) <= 1e-6
+
+
+# ---- weight-gradient (TN) product and the producers of tensor-scaled operands --------------------------------------
+@pytest.mark.parametrize("K,M,N,a0,b0", [(3000, 128, 320, 0, 0), (1000, 256, 128, 64, 16), (77, 128, 256, 0, 0),
+                                         (5003, 1280, 320, 0, 0)])
+def test_gemm_tn_matches_fp64(dev, K, M, N, a0, b0):
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(K + M + N)
+    X = torch.randn((K, a0 + M + 32), generator=g)
+    G = torch.randn((K, b0 + N + 16), generator=g) * 1e-4     # gradients are small: the tensor scale matters
+    G[::7] *= 30.0
+    ref = X[:, a0:a0 + M].double().t() @ G[:, b0:b0 + N].double()
+    inv_x = ops.tensor_inv_scale(ops.absmax(X.to(dev)))
+    inv_g = ops.tensor_inv_scale(ops.absmax(G.to(dev), scale=3.0))  # a loose bound (x3) must not cost accuracy
+    xs = ops.sp_split_rows(X.to(dev), fixed_inv_scale=inv_x)
+    gs = ops.sp_split_rows(G.to(dev), fixed_inv_scale=inv_g)
+    out = ops.sp_gemm_tn(xs, gs, a_cols=(a0, M), b_cols=(b0, N)).cpu()
+    mag = X[:, a0:a0 + M].double().abs().t() @ G[:, b0:b0 + N].double().abs()
+    assert float(((out.double() - ref).abs() / mag).max()) <= 4e-7
+    scale = float(ref.abs().max())
+    assert_close(out / scale, (ref / scale).float(), tol=1e-5, what=f"sp tn {K}x{M}x{N}")
+
+
+def test_gemm_tn_scatter_layout_and_accumulate(dev):
+    """dW of stacked kernels [L, D, H] from m = (l, h), n = d, and accumulation into an existing gradient."""
+    from tf2_gnn_amd import ops
+
+    L, D, H, V = 4, 128, 64, 900
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn((V, D), generator=g)
+    G = torch.randn((V, L * H), generator=g) * 0.01
+    ref = torch.einsum("vd,vlh->ldh", X.double(), G.double().view(V, L, H))
+    xs = ops.sp_split_rows(X.to(dev), fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(X.to(dev))))
+    gs = ops.sp_split_rows(G.to(dev), fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(G.to(dev))))
+    dW = torch.zeros((L, D, H), device=dev)
+    ops.sp_gemm_tn(gs, xs, out=dW, scatter=(H, D * H, 1, H))
+    assert_close(dW.cpu(), ref.float(), tol=1e-5, what="dW [L, D, H]")
+    ops.sp_gemm_tn(gs, xs, out=dW, scatter=(H, D * H, 1, H), accumulate=True)
+    assert_close(dW.cpu(), (2 * ref).float(), tol=1e-5, what="dW accumulated")
+
+
+@pytest.mark.parametrize("width", [32, 64, 128, 256, 320, 512])
+@pytest.mark.parametrize("fixed", [False, True])
+def test_gather_sp_matches_fp32_gather(dev, width, fixed):
+    """The SP16-writing gather against the fp32 gather of the same view: identical sums (same kernel, same order), so
+    the decoded operand must equal the fp32 result to the format's 2^-22, scales being powers of two; hubs (item and
+    multi-item rows) and empty buckets included."""
+    from tests.helpers import random_graph, to_dev
+    from tf2_gnn_amd import ops
+
+    V, L = 700, 3
+    adjs = random_graph(V, 9000, L, seed=width, hub=(5, 2500))
+    gr = ops.Graph(to_dev(adjs, dev), V)
+    g = torch.Generator().manual_seed(width)
+    X = (torch.randn((V, width), generator=g) * torch.exp(torch.randn((V, 1), generator=g) * 3)).to(dev)
+    rs = gr.array(ops.G_INVDEG_BY_DST)
+    XL = (torch.randn((V * L, width), generator=g) * torch.exp(torch.randn((V * L, 1), generator=g) * 3)).to(dev)
+    for view, scale in ((ops.VIEW_BY_DST_TYPED, rs), (ops.VIEW_BY_SRC_TYPED, None), (ops.VIEW_BY_DST_NODE, None)):
+        inp = XL if view == ops.VIEW_BY_DST_NODE else X  # node views gather rows (source, type) of a [V * L, .] tensor
+        ref = ops.graph_gather(gr, view, inp, row_scale=scale).cpu().double().numpy()
+        fixed_inv = ops.tensor_inv_scale(ops.absmax(torch.from_numpy(ref).float().to(dev), scale=2.0)) if fixed else None
+        R = L if view != ops.VIEW_BY_DST_NODE else 1
+        op = ops.graph_gather_sp(gr, view, inp, row_scale=scale, fixed_inv_scale=fixed_inv, rows_per_operand_row=R)
+        if fixed:
+            op = ops.SplitOperand(op.data, op.inv_scale.expand(op.rows, 1).contiguous(), op.rows, op.cols, op.cols)
+        rec = decode_sp16(op).reshape(ref.shape)
+        rowmax = np.abs(ref).max(axis=1, keepdims=True) if not fixed else np.full((ref.shape[0], 1), np.abs(ref).max() * 2)
+        bound = np.maximum(np.abs(ref) * 2.0 ** -22, rowmax * 2.0 ** -37)
+        assert np.all(np.abs(rec - ref) <= bound), (view, float(np.max(np.abs(rec - ref) / np.maximum(bound, 1e-300))))
+
+
+def test_absmax(dev):
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    for n in (1, 3, 1000, 123457):
+        x = torch.randn(n, generator=g) * 5
+        assert float(ops.absmax(x.to(dev)).cpu()) == float(x.abs().max())
+        assert float(ops.absmax(x.to(dev), scale=2.0).cpu()) == float(2.0 * x.abs().max())

@@ -152,6 +152,21 @@ _SIGNATURES = [
         [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     ("tfgnn_regression_metrics", c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    (
+        "tfgnn_graph_gather_reduce_sp",
+        c_int,
+        [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
+    ("tfgnn_sp_gemm_tn_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64]),
+    (
+        "tfgnn_sp_gemm_tn",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+         c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p],
+    ),
+    ("tfgnn_absmax", c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    ("tfgnn_sp_inv_scale_from_bound", c_int, [c_void_p, c_void_p, c_void_p]),
     ("tfgnn_sp_bytes", c_size_t, [c_int64, c_int64]),
     (
         "tfgnn_sp_split_rows",

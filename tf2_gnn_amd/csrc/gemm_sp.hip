@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "sp16.hpp"
 
 namespace tfgnn {
 
@@ -64,7 +65,8 @@ struct SpArgs {
   int64_t M, N, K;
   const uint8_t* A;   // SP16 [M rows]
   int64_t lda;        // bytes per row
-  const float* a_inv; // [M][a_nblk] 2^-e per (row, scale block) or NULL (all 1)
+  const float* a_inv; // 2^-e of (row r, scale block b) at a_inv[r * a_inv_ld + b], or NULL (all 1); a_inv_ld = 0: one
+  int64_t a_inv_ld;   // scale for the whole tensor
   int a_nblk;
   int a_blk_steps;    // k16 steps per scale block
   const uint8_t* B;   // SP16 [N rows]
@@ -86,44 +88,6 @@ struct SpArgs {
 // ------------------------------------------------------------------------------------------------------
 // fp32 -> SP16 conversion
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sp_scale_for_max(float mx, float* inv) {
-  // power of two s with mx * s in [2^14, 2^15); zero / non-finite blocks: s = 1
-  const unsigned b = __float_as_uint(mx);
-  int ex = (int)((b >> 23) & 0xffu);
-  if (ex == 255) {  // inf / nan in the block: no scaling, the result is inf / nan anyway
-    *inv = 1.f;
-    return 1.f;
-  }
-  if (mx == 0.f) {  // all-zero block: any scale represents it; the smallest one, so that among the blocks of a row (the
-    *inv = 1.1754943508222875e-38f;  // kernel normalises them to the LARGEST 2^-e) it never is the reference
-    return 1.f;
-  }
-  if (ex == 0) ex = 1;  // subnormal maximum: scale as the smallest normal exponent
-  int e = 14 - (ex - 127);
-  e = e > 126 ? 126 : e;
-  *inv = __uint_as_float((unsigned)(127 - e) << 23);
-  return __uint_as_float((unsigned)(127 + e) << 23);
-}
-
-__device__ __forceinline__ void sp_split(float xs, _Float16& h, _Float16& l) {
-  h = (_Float16)xs;  // v_cvt_f16_f32: round to nearest even
-  const float r = xs - (float)h;
-  // inf / nan: keep the class in h, nothing in l (inf - inf would make l a NaN)
-  l = (__float_as_uint(xs) & 0x7f800000u) == 0x7f800000u ? (_Float16)0.f : (_Float16)r;
-}
-
-__device__ __forceinline__ void sp_store4(uint8_t* row, int64_t c, float4 v, float s) {
-  _Float16 h[4], l[4];
-  sp_split(v.x * s, h[0], l[0]);
-  sp_split(v.y * s, h[1], l[1]);
-  sp_split(v.z * s, h[2], l[2]);
-  sp_split(v.w * s, h[3], l[3]);
-  uint8_t* g = row + (c >> 4) * 64 + (c & 15) * 2;
-  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-  *reinterpret_cast<half4*>(g) = half4{h[0], h[1], h[2], h[3]};
-  *reinterpret_cast<half4*>(g + 32) = half4{l[0], l[1], l[2], l[3]};
-}
-
 // One wave per (row, scale block).  Source element (r, c): src[r * ld + (c / seg_len) * seg_stride + c % seg_len]
 // (seg_len = C, seg_stride = 0: a plain row-major matrix; otherwise a row assembled from C / seg_len segments, e.g.
 // row d of [W_0[d,:] | W_1[d,:] | ...] from the stacked kernels [L, D, H]).  Two passes over the block (the second
@@ -163,6 +127,31 @@ __global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restr
     const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
     sp_store4(drow, cc, v, s);
   }
+}
+
+// out[0] = max(out[0], scale * max |x|): the atomic maximum of non-negative floats through their bit patterns is
+// independent of the order -> reproducible.  out must start at 0.
+__global__ void __launch_bounds__(256) sp_absmax_kernel(const float* __restrict__ x, int64_t n, float scale, float* out) {
+  float mx = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0)  // one atomic per workgroup: thousands on one address serialise (8192 of them cost 80 us)
+    atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * scale));
+}
+
+__global__ void sp_inv_scale_kernel(const float* bound, float* inv) {
+  float iv;
+  (void)sp_scale_for_max(fabsf(bound[0]), &iv);
+  inv[0] = iv;
 }
 
 // SP16 rows from the COLUMNS of a row-major fp32 matrix: dst row n, column k = src[k * ld + n]  (a Keras kernel
@@ -324,7 +313,7 @@ struct SpLoop {
       if (b < a_nblk) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const _Float16 f = (_Float16)(a_inv[a_row[t] * a_nblk + b] / a_rmax[t]);
+          const _Float16 f = (_Float16)(a_inv[a_row[t] * a_nblk + b] / a_rmax[t]);  // (a_inv_ld == a_nblk here)
           afac[t] = half2v{f, f};
         }
       }
@@ -461,9 +450,9 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
     float m = 1.f;
     if (ABLK) {
       m = 0.f;
-      for (int b = 0; b < g.a_nblk; ++b) m = fmaxf(m, g.a_inv[L.a_row[t] * g.a_nblk + b]);
+      for (int b = 0; b < g.a_nblk; ++b) m = fmaxf(m, g.a_inv[L.a_row[t] * g.a_inv_ld + b]);
     } else if (g.a_inv) {
-      m = g.a_inv[L.a_row[t]];
+      m = g.a_inv[L.a_row[t] * g.a_inv_ld];
     }
     L.a_rmax[t] = m;  // the row's epilogue factor (lane fi holds row fi of row tile t)
   }
@@ -599,6 +588,288 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   epilogue_tile(std::integral_constant<int, 1>{});
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// TN kernel: C[m, n] = sum_k A[k, m] B[k, n] - both operands stored with K as the ROW index (weight gradients
+// dW = X^T G: K runs over the nodes).  Same tile, ring, pinned main loop and MFMA order as the NT kernel; what differs:
+//   * a k16 step of the A tile is 16 operand rows x 128 columns (8 granules of 64 bytes per row), of the B tile
+//     16 rows x BN columns.  LDS image per group of 4 rows and per pair of granules (32 columns): 8 containers of 64
+//     bytes in the order (row & 3, granule & 1); containers of rows 2, 3 are stored l-plane first.  One DMA instruction
+//     = 2 granule pairs x 4 rows: every row contributes 256 contiguous source bytes.
+//   * an MFMA operand (8 consecutive k of one column per lane) is two ds_read_b64_tr_b16: a 16-lane group reads a
+//     [4 rows] x [16 columns] block - lane j supplies the address of row j / 4, columns (j % 4) * 4 .. + 3 - and gets
+//     column j.  With the image above the eight 32-byte pieces a half-wave touches lie in eight different bank
+//     groups (conflict-free).  These reads go through the builtin (the two halves must land in adjacent registers,
+//     which an asm operand cannot express); sched_barrier pins them behind their MFMA.
+//   * scales: one per TENSOR (the caller's bound, see tfgnn.h): a per-row scale would be a per-k factor here.
+//   * split-K over blockIdx.y; partial tiles go to the workspace, sp_tn_reduce_kernel sums them in split order,
+//     applies the two scales and writes C through (group, row, column) strides - dW comes out in the kernels' [L, D, H]
+//     layout without a transpose pass.
+// ------------------------------------------------------------------------------------------------------
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v lds_short4;
+__device__ __forceinline__ half4 sp_tr_read(unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(uintptr_t)lds_addr));
+#else
+  (void)lds_addr;
+  return half4{};
+#endif
+}
+
+struct SpTnArgs {
+  int64_t M, N, K;
+  const uint8_t* A;  // SP16, rows = k, this product's columns start at byte a_col_bytes of a row
+  int64_t lda;
+  const uint8_t* B;
+  int64_t ldb;
+  float* partial;    // [splits][M][N]
+  int64_t k_chunk;   // rows of K per split (a multiple of 16)
+  unsigned n_tiles;
+};
+
+template <int TNW>
+struct SpLoopTN {
+  using G = SpGeo<TNW>;
+  static constexpr int KGB_A = 2048, KGB_B = TNW * 1024;  // bytes per 4-row group: A (4 granule pairs), B (2 TNW pairs)
+  half8 (&fa)[2][2][2];
+  half8 (&fb)[2][TNW][2];
+  floatx16 (&acc)[2][TNW];
+  unsigned (&a_addr)[G::NST][2], (&b_addr)[G::NST][2];  // this lane's tr-read address per stage / plane (kb 0, tile 0)
+  unsigned (&voff_a)[G::ND_A], (&voff_b)[G::ND_B];
+  uint4v rs_a, rs_b;
+  unsigned m0_a, m0_b;
+  unsigned step_bytes_a, step_bytes_b;  // 16 rows of the operand
+  int nsteps;
+  __device__ __forceinline__ SpLoopTN(half8 (&fa_)[2][2][2], half8 (&fb_)[2][TNW][2], floatx16 (&acc_)[2][TNW],
+                                      unsigned (&aa)[G::NST][2], unsigned (&ba)[G::NST][2], unsigned (&va)[G::ND_A],
+                                      unsigned (&vb)[G::ND_B])
+      : fa(fa_), fb(fb_), acc(acc_), a_addr(aa), b_addr(ba), voff_a(va), voff_b(vb) {}
+
+  template <int I, int SET, int ST>
+  __device__ __forceinline__ void read_one() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (I < 4) {
+      constexpr int t = I >> 1, p = I & 1;
+      const half4 lo = sp_tr_read(a_addr[ST][p] + t * 512);
+      const half4 hi = sp_tr_read(a_addr[ST][p] + t * 512 + KGB_A);
+      fa[SET][t][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      constexpr int c = (I - 4) >> 1, p = (I - 4) & 1;
+      const half4 lo = sp_tr_read(b_addr[ST][p] + c * 512);
+      const half4 hi = sp_tr_read(b_addr[ST][p] + c * 512 + KGB_B);
+      fb[SET][c][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#endif
+  }
+  template <int I, int SET>
+  __device__ __forceinline__ void mfma_one() {
+    constexpr int prod = I / (2 * TNW), j = I % (2 * TNW), t = j / TNW, c = j % TNW;
+    constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t][c]) : "v"(fa[SET][t][pa]), "v"(fb[SET][c][pb]) : "memory");
+  }
+  template <int I, int ST>
+  __device__ __forceinline__ void dma_one(int step) {
+    const unsigned sidx = (unsigned)(step < nsteps ? step : nsteps - 1);
+    if constexpr (I < G::ND_A)
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                   :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(sidx * step_bytes_a) : "memory");
+    else
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                   :: "s"(m0_b), "n"(ST * G::STG + SP_BM * 64 + (I - G::ND_A) * 1024), "v"(voff_b[I - G::ND_A]), "s"(rs_b),
+                   "s"(sidx * step_bytes_b) : "memory");
+  }
+  template <int I, int N, int ST>
+  __device__ __forceinline__ void dma_all(int step) {
+    if constexpr (I < N) {
+      dma_one<I, ST>(step);
+      dma_all<I + 1, N, ST>(step);
+    }
+  }
+  template <int I, int N, int SET, int ST>
+  __device__ __forceinline__ void read_all() {
+    if constexpr (I < N) {
+      read_one<I, SET, ST>();
+      read_all<I + 1, N, SET, ST>();
+    }
+  }
+  static constexpr int NR = 4 + 2 * TNW;  // fragments per step (two tr reads each)
+  static constexpr int NM = 6 * TNW;
+  template <int S, int I>
+  __device__ __forceinline__ void step_items(int sbase) {
+    if constexpr (I < NM) {
+      mfma_one<I, (S & 1)>();
+      if constexpr (I < NR) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
+      else if constexpr (I < NR + G::ND) dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      step_items<S, I + 1>(sbase);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void step(int sbase) {
+    step_items<S, 0>(sbase);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int S>
+  __device__ __forceinline__ void steps(int sbase) {
+    if constexpr (S < G::UNR) {
+      if (sbase + S < nsteps) step<S>(sbase);
+      steps<S + 1>(sbase);
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_prologue() {
+    if constexpr (J < G::NST - 1) {
+      dma_all<0, G::ND, J>(J);
+      dma_prologue<J + 1>();
+    }
+  }
+};
+
+template <int TNW>
+__global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
+  using G = SpGeo<TNW>;
+  using LP = SpLoopTN<TNW>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned tile_n = blockIdx.x % g.n_tiles;
+  const unsigned tile_m = blockIdx.x / g.n_tiles;
+  const int64_t row0 = (int64_t)tile_m * SP_BM;   // first column of A (= output row)
+  const int64_t col0 = (int64_t)tile_n * G::BN;   // first column of B (= output column)
+  const int64_t k0 = (int64_t)blockIdx.y * g.k_chunk;
+  const int64_t krows = g.K - k0 < g.k_chunk ? g.K - k0 : g.k_chunk;
+  const int nsteps = (int)((krows + 15) >> 4);
+
+  auto make_rsrc = [](const uint8_t* p, int64_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return uint4v{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+  };
+  half8 r_fa[2][2][2];
+  half8 r_fb[2][TNW][2];
+  floatx16 r_acc[2][TNW];
+  unsigned r_aa[G::NST][2], r_ba[G::NST][2], r_va[G::ND_A], r_vb[G::ND_B];
+  LP L(r_fa, r_fb, r_acc, r_aa, r_ba, r_va, r_vb);
+  // rows past K read as zeros: the descriptors end with the last row of this split
+  L.rs_a = make_rsrc(g.A + k0 * g.lda + row0 * 4, krows * g.lda - row0 * 4);
+  L.rs_b = make_rsrc(g.B + k0 * g.ldb + col0 * 4, krows * g.ldb - col0 * 4);
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)lds;
+  L.m0_a = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_A * 1024);
+  L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
+  L.step_bytes_a = (unsigned)(16 * g.lda);
+  L.step_bytes_b = (unsigned)(16 * g.ldb);
+  L.nsteps = nsteps;
+  // DMA source of lane j of instruction d: container ct = j / 4 -> granule pair ct / 8 of the instruction's two, row
+  // (ct % 8) / 2, granule parity ct % 2; chunk j % 4 of the container, halves swapped for rows 2, 3
+  {
+    const int ct = lane >> 2, cc = lane & 3;
+    const int pin = ct >> 3, r4 = (ct & 7) >> 1, gsel = ct & 1;
+    const int src_chunk = cc ^ ((r4 >> 1) << 1);
+#pragma unroll
+    for (int i = 0; i < G::ND_A; ++i) {
+      const int d = wave * G::ND_A + i;  // 0 .. 7: row group d / 2, pair pair d % 2
+      const int kgp = d >> 1, pp = d & 1;
+      L.voff_a[i] = (unsigned)((kgp * 4 + r4) * g.lda + ((pp * 2 + pin) * 2 + gsel) * 64 + src_chunk * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < G::ND_B; ++i) {
+      const int d = wave * G::ND_B + i;  // 0 .. 4 TNW - 1: row group d / TNW, pair pair d % TNW
+      const int kgp = d / TNW, pp = d % TNW;
+      L.voff_b[i] = (unsigned)((kgp * 4 + r4) * g.ldb + ((pp * 2 + pin) * 2 + gsel) * 64 + src_chunk * 16);
+    }
+  }
+  // tr-read addresses: lane -> (column i = lane & 31, k half kg = lane >> 5); piece j = lane & 15 of its 16-lane group
+  const int fi = lane & 31, kg = lane >> 5;
+  {
+    const int j = lane & 15, r4 = j >> 2, gsel = (lane >> 4) & 1;
+#pragma unroll
+    for (int st = 0; st < G::NST; ++st)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const unsigned in_pair = (unsigned)((r4 * 2 + gsel) * 64 + 32 * (p ^ (r4 >> 1)) + (j & 3) * 8);
+        L.a_addr[st][p] = lds_base + (unsigned)(st * G::STG + kg * 2 * LP::KGB_A + (wm * 2) * 512) + in_pair;
+        L.b_addr[st][p] = lds_base + (unsigned)(st * G::STG + SP_BM * 64 + kg * 2 * LP::KGB_B + (wn * TNW) * 512) + in_pair;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L.acc[t][c][r] = 0.f;
+
+  constexpr int NR = LP::NR;
+  L.template dma_prologue<0>();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::VMW) : "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  L.template read_all<0, NR, 0, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0>(s);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // partial tile -> workspace (raw sums; the reduce pass scales)
+  float* patch = reinterpret_cast<float*>(lds) + wave * 32 * G::PATCH_LD;
+  float* __restrict__ part = g.partial + (int64_t)blockIdx.y * g.M * g.N;
+  const int64_t wcol0 = col0 + wn * 32 * TNW;
+  constexpr int C4 = 8 * TNW;
+  constexpr int NIT = 32 * C4 / 64;
+  auto store_tile = [&](auto t_c) {
+    constexpr int t = decltype(t_c)::value;
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        patch[prow * G::PATCH_LD + c * 32 + fi] = L.acc[t][c][r];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t wrow0 = row0 + wm * 64 + t * 32;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = lane + it * 64;
+      const int pr = idx / C4, c4 = idx - pr * C4;
+      const float4 v = *reinterpret_cast<const float4*>(patch + pr * G::PATCH_LD + c4 * 4);
+      *reinterpret_cast<float4*>(part + (wrow0 + pr) * g.N + wcol0 + c4 * 4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  store_tile(std::integral_constant<int, 0>{});
+  store_tile(std::integral_constant<int, 1>{});
+}
+
+// C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= inv_a * inv_b * sum_z partial[z][m][n]
+__global__ void __launch_bounds__(256) sp_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
+                                                           const float* __restrict__ inv_a, const float* __restrict__ inv_b,
+                                                           float* __restrict__ C, int64_t group_rows, int64_t stride_group,
+                                                           int64_t stride_row, int64_t stride_col, int accumulate) {
+  const int64_t total = M * N;
+  const float alpha = (inv_a ? inv_a[0] : 1.f) * (inv_b ? inv_b[0] : 1.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
+    s *= alpha;
+    const int64_t m = i / N, n = i - m * N;
+    float* c = C + (m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col;
+    *c = accumulate ? *c + s : s;
+  }
+}
+
+static int sp_tn_splits(int64_t M, int64_t N, int64_t K, int bn) {
+  const int64_t tiles = (M / SP_BM) * (N / bn);
+  const int64_t steps = (K + 15) / 16;
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(250 / std::max<int64_t>(tiles, 1), steps / 16));
+  return (int)std::max<int64_t>(1, splits);
+}
+
 template <int TNW>
 static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
   using G = SpGeo<TNW>;
@@ -687,9 +958,11 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   SpArgs g{};
   g.M = M; g.N = N; g.K = K;
   g.A = (const uint8_t*)d_A_sp; g.lda = lda_bytes; g.a_inv = d_a_inv_scale;
+  const bool a_uniform = a_scale_block < 0;  // one scale for the whole tensor
   if (a_scale_block <= 0 || a_scale_block >= K) a_scale_block = (int)K;
   TFGNN_REQUIRE(a_scale_block % 16 == 0 && K % a_scale_block == 0, "tfgnn_sp_gemm_nt: a_scale_block must divide K and be a multiple of 16");
   g.a_nblk = (int)(K / a_scale_block);
+  g.a_inv_ld = a_uniform ? 0 : g.a_nblk;
   g.a_blk_steps = a_scale_block / 16;
   g.B = (const uint8_t*)d_B_sp; g.ldb = ldb_bytes; g.b_inv = d_b_inv_scale;
   g.C = d_C; g.ldc = ldc; g.bias = d_bias; g.act = act; g.accumulate = accumulate;
@@ -702,6 +975,83 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   if (bn == 320) launch_sp_nt<5>(g, grid, s);
   else if (bn == 256) launch_sp_nt<4>(g, grid, s);
   else launch_sp_nt<2>(g, grid, s);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+
+size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int bn = sp_tile_width(N);
+  if (!bn || M % SP_BM) return 0;
+  return (size_t)sp_tn_splits(M, N, K, bn) * (size_t)M * (size_t)N * 4;
+}
+
+int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                     const float* d_a_inv_scale, const void* d_B_sp, int64_t ldb_bytes, int64_t b_first_col,
+                     const float* d_b_inv_scale, float* d_C, int64_t group_rows, int64_t stride_group, int64_t stride_row,
+                     int64_t stride_col, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream) {
+  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C, "tfgnn_sp_gemm_tn: null pointer");
+  TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
+  const int bn = sp_tile_width(N);
+  if (!bn || M % SP_BM) {
+    set_error("tfgnn_sp_gemm_tn: M = %lld must be a multiple of 128 and N = %lld of 128", (long long)M, (long long)N);
+    return TFGNN_ERR_UNSUPPORTED;
+  }
+  TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0 &&
+                    a_first_col % 16 == 0 && b_first_col % 16 == 0 && a_first_col >= 0 && b_first_col >= 0 &&
+                    lda_bytes >= (a_first_col + M) * 4 && ldb_bytes >= (b_first_col + N) * 4,
+                "tfgnn_sp_gemm_tn: SP16 operands must be 64-byte aligned, first columns multiples of 16, rows wide enough");
+  TFGNN_REQUIRE(group_rows > 0, "tfgnn_sp_gemm_tn: group_rows must be positive");
+  const int splits = sp_tn_splits(M, N, K, bn);
+  const size_t need = (size_t)splits * (size_t)M * (size_t)N * 4;
+  TFGNN_REQUIRE(d_workspace && workspace_bytes >= need, "tfgnn_sp_gemm_tn: workspace too small (need %zu bytes)", need);
+  SpTnArgs g{};
+  g.M = M; g.N = N; g.K = K;
+  g.A = (const uint8_t*)d_A_sp + a_first_col * 4; g.lda = lda_bytes;
+  g.B = (const uint8_t*)d_B_sp + b_first_col * 4; g.ldb = ldb_bytes;
+  g.partial = (float*)d_workspace;
+  const int64_t steps = (K + 15) / 16;
+  g.k_chunk = ((steps + splits - 1) / splits) * 16;
+  g.n_tiles = (unsigned)(N / bn);
+  TFGNN_REQUIRE(g.k_chunk * std::max(lda_bytes, ldb_bytes) < (1ll << 31), "tfgnn_sp_gemm_tn: K chunk too large");
+  dim3 grid((unsigned)((M / SP_BM) * g.n_tiles), (unsigned)splits);
+  hipStream_t s = (hipStream_t)stream;
+#define SP_LAUNCH_TN(T)                                                                                            \
+  do {                                                                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                SpGeo<T>::LDS_BYTES);                                                              \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeo<T>::LDS_BYTES, s, g);                      \
+  } while (0)
+  if (bn == 320) SP_LAUNCH_TN(5);
+  else if (bn == 256) SP_LAUNCH_TN(4);
+  else SP_LAUNCH_TN(2);
+#undef SP_LAUNCH_TN
+  TFGNN_LAUNCH_CHECK();
+  const int64_t total = M * N;
+  hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s,
+                     (const float*)d_workspace, splits, M, N, d_a_inv_scale, d_b_inv_scale, d_C, group_rows, stride_group,
+                     stride_row, stride_col, accumulate);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+
+int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream) {
+  TFGNN_REQUIRE(d_x && d_out && n >= 0 && scale > 0.f && (uintptr_t)d_x % 16 == 0, "tfgnn_absmax: bad arguments");
+  if (n == 0) return TFGNN_OK;
+  hipLaunchKernelGGL(sp_absmax_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 1024), 512)), dim3(256), 0, (hipStream_t)stream,
+                     d_x, n, scale, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_inv_scale_from_bound(const float* d_bound, float* d_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_bound && d_inv_scale, "tfgnn_sp_inv_scale_from_bound: null pointer");
+  hipLaunchKernelGGL(sp_inv_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_bound, d_inv_scale);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -29,6 +29,7 @@
 
 #include "common.hpp"
 #include "graph.hpp"
+#include "sp16.hpp"
 
 namespace tfgnn {
 
@@ -118,7 +119,29 @@ struct GatherArgs {
   const int32_t* multi_base;
   const int32_t* multi_n;
   int num_multi;
+  // SP16 output (kernels instantiated with SP = true; MODE_SUM, float4 path, one feature window): the row sums are
+  // written as the split fp16 operand of the f16x2 products (csrc/gemm_sp.hip) instead of fp32
+  uint8_t* out_sp;         // [rows] x ld_out_sp bytes
+  int64_t ld_out_sp;
+  float* inv_out;          // [rows] 2^-e of every output row (not written when fixed_inv is given)
+  const float* fixed_inv;  // nullable: one caller-chosen 2^-e for the whole tensor
 };
+
+// scale of one output row from the maximum over its LANES lanes (lanes of one group are contiguous)
+template <int LANES>
+__device__ __forceinline__ float sp_row_scale(const GatherArgs& a, float mx, int64_t orow, bool writer) {
+  float iv, sc;
+  if (a.fixed_inv) {
+    iv = a.fixed_inv[0];
+    sc = 1.f / iv;
+  } else {
+#pragma unroll
+    for (int o = LANES / 2; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, LANES));
+    sc = sp_scale_for_max(mx, &iv);
+    if (writer) a.inv_out[orow] = iv;
+  }
+  return sc;
+}
 
 // accumulate edges [beg, end) into acc (lane-private chunks)
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
@@ -184,7 +207,7 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
   }
 }
 
-template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned row_block, unsigned window) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;  // floats covered per pass
@@ -213,6 +236,22 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
 
   const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+  if constexpr (SP) {  // VEC == 4, one window: the lane group holds the whole row
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        acc[i][c] *= rs;
+        if (live[i]) mx = fmaxf(mx, fabsf(acc[i][c]));
+      }
+    const float sc = sp_row_scale<LPR>(a, mx, orow, gl == 0);
+    uint8_t* drow = a.out_sp + orow * a.ld_out_sp;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if (live[i]) sp_store4(drow, f0 + i * LPR * VEC, make_float4(acc[i][0], acc[i][VEC > 1 ? 1 : 0], acc[i][VEC > 2 ? 2 : 0], acc[i][VEC > 3 ? 3 : 0]), sc);
+    return;
+  }
   float* dst = a.out + orow * a.ld_out + f0;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
@@ -232,7 +271,7 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
 }
 
 // one workgroup per item (a run of <= item_chunk_edges edges of a long row)
-template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item, unsigned window,
                                                   float (&red)[256 / LPR][LPR * VPL * VEC]) {
   constexpr int GROUPS = 256 / LPR;
@@ -270,6 +309,40 @@ __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
   __syncthreads();
   const int32_t slot = a.item_slot[item];
   const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+  if constexpr (SP) {
+    if (slot < 0) {  // the item is the whole row: sums -> red[0], row maximum, split store
+      float mx = 0.f;
+      for (int f = tid; f < WINDOW; f += 256) {
+        if (w0 + f >= a.width) break;
+        float v = red[0][f];
+#pragma unroll
+        for (int g = 1; g < GROUPS; ++g) v += red[g][f];
+        v *= rs;
+        red[0][f] = v;
+        mx = fmaxf(mx, fabsf(v));
+      }
+#pragma unroll
+      for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      __syncthreads();  // every sum over red[1..] has been taken
+      if ((tid & 63) == 0) red[1][tid >> 6] = mx;
+      __syncthreads();
+      mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+      const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
+      float iv, sc;
+      if (a.fixed_inv) {
+        iv = a.fixed_inv[0];
+        sc = 1.f / iv;
+      } else {
+        sc = sp_scale_for_max(mx, &iv);
+        if (tid == 0) a.inv_out[orow] = iv;
+      }
+      uint8_t* drow = a.out_sp + orow * a.ld_out_sp;
+      for (int c4 = tid; c4 * 4 < WINDOW; c4 += 256)
+        if (w0 + c4 * 4 < a.width)
+          sp_store4(drow, w0 + c4 * 4, make_float4(red[0][c4 * 4], red[0][c4 * 4 + 1], red[0][c4 * 4 + 2], red[0][c4 * 4 + 3]), sc);
+      return;
+    }
+  }
   for (int f = tid; f < WINDOW; f += 256) {
     if (w0 + f >= a.width) break;
     float s = red[0][f];
@@ -303,9 +376,42 @@ __global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
   }
 }
 
+// SP16 output: one wave per multi-item row (width <= 2048 floats)
+__global__ void __launch_bounds__(256) csr_gather_combine_sp_kernel(GatherArgs a) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.num_multi) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = a.multi_row[m];
+  const int32_t base = a.multi_base[m], n = a.multi_n[m];
+  const float rs = a.row_scale ? a.row_scale[row] : 1.f;
+  float4 sum[8];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (lane + i * 64) * 4;
+    sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < a.width) {
+      for (int k = 0; k < n; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(a.partial + (int64_t)(base + k) * a.width + c);
+        sum[i].x += p.x; sum[i].y += p.y; sum[i].z += p.z; sum[i].w += p.w;
+      }
+      sum[i].x *= rs; sum[i].y *= rs; sum[i].z *= rs; sum[i].w *= rs;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(sum[i].x), fabsf(sum[i].y)), fmaxf(fabsf(sum[i].z), fabsf(sum[i].w))));
+    }
+  }
+  const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
+  const float sc = sp_row_scale<64>(a, mx, orow, lane == 0);
+  uint8_t* drow = a.out_sp + orow * a.ld_out_sp;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < a.width) sp_store4(drow, c, sum[i], sc);
+  }
+}
+
 // One launch covers both kinds of work: workgroups [0, num_items) each take one item of a long row
 // (longest work first), the remaining workgroups take 256/LPR short rows each.
-template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a, int num_items) {
   __shared__ float red[256 / LPR][LPR * VPL * VEC];
   unsigned unit, window;
@@ -323,12 +429,12 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a, in
     window = blockIdx.y;
   }
   if ((int)unit < num_items)
-    gather_item_block<LPR, VPL, VEC, UNROLL, MODE>(a, (int)unit, window, red);
+    gather_item_block<LPR, VPL, VEC, UNROLL, MODE, SP>(a, (int)unit, window, red);
   else
-    gather_rows_block<LPR, VPL, VEC, UNROLL, MODE>(a, unit - (unsigned)num_items, window);
+    gather_rows_block<LPR, VPL, VEC, UNROLL, MODE, SP>(a, unit - (unsigned)num_items, window);
 }
 
-template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
+template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
   constexpr int WINDOW = LPR * VPL * VEC;
@@ -336,6 +442,20 @@ static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   const unsigned units = (unsigned)(num_items + ceil_div(a.short_rows ? a.num_short : a.num_rows, GROUPS_PER_BLOCK));
   dim3 block(256);
   a.total_units = units;
+  if constexpr (SP) {
+    if (windows != 1 || a.width > 2048) {
+      set_error("SP16 gather output needs the whole row in one feature window (width %d)", a.width);
+      return TFGNN_ERR_UNSUPPORTED;
+    }
+    a.xcd_units_pad = 0;
+    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE, true>), dim3(units, 1), block, 0, s, a, num_items);
+    TFGNN_LAUNCH_CHECK();
+    if (a.num_multi > 0) {
+      hipLaunchKernelGGL(csr_gather_combine_sp_kernel, dim3((unsigned)ceil_div(a.num_multi, 4)), block, 0, s, a);
+      TFGNN_LAUNCH_CHECK();
+    }
+    return TFGNN_OK;
+  }
   if (a.xcd_units_pad && windows > 1) {
     a.xcd_units_pad = (units + 7u) & ~7u;
     hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3(a.xcd_units_pad * windows), block, 0, s,
@@ -371,13 +491,23 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
     mode = MODE_HEADS;
   }
   const bool vec4 = (a.width % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) &&
-                    (((uintptr_t)a.in | (uintptr_t)a.out) % 16 == 0) &&
+                    (((uintptr_t)a.in | (uintptr_t)a.out) % 16 == 0) && (!a.out_sp || a.ld_out_sp % 64 == 0) &&
                     (mode != MODE_HEADS || a.head_width % 4 == 0);
+  TFGNN_REQUIRE(vec4 || !a.out_sp, "SP16 gather output needs 16-byte aligned rows");
   if (!vec4) {
     // scalar path (odd widths: unit tests, tiny models): 16 lanes x 4 floats per pass
     return launch_variant<16, 4, 1, 2>(a, mode, num_items, s);
   }
   const int chunks = a.width / 4;
+  if (a.out_sp) {  // SP16 output: plain sums on the float4 path, whole rows per lane group
+    TFGNN_REQUIRE(mode == MODE_SUM && a.width % 16 == 0, "SP16 gather output: plain sums of rows with width %% 16 == 0 only");
+    if (chunks <= 8) return launch_mode<8, 1, 4, 8, MODE_SUM, true>(a, num_items, s);
+    if (chunks <= 16) return launch_mode<16, 1, 4, 8, MODE_SUM, true>(a, num_items, s);
+    if (chunks <= 32) return launch_mode<16, 2, 4, 4, MODE_SUM, true>(a, num_items, s);
+    if (chunks <= 64) return launch_mode<16, 4, 4, 2, MODE_SUM, true>(a, num_items, s);
+    if (chunks <= 80) return launch_mode<16, 5, 4, 2, MODE_SUM, true>(a, num_items, s);
+    return launch_mode<32, 4, 4, 2, MODE_SUM, true>(a, num_items, s);
+  }
   // L2-resident slicing: gather 32-float (128 B) windows of the rows, XCD by XCD, when one window of
   // ALL source rows fits an XCD's 4 MiB L2 but the full rows do not (cfg-2: 3.84 MB vs 38 MB).
   static const int sliced_knob = [] { const char* e = getenv("TFGNN_GATHER_SLICED"); return e ? atoi(e) : -1; }();
@@ -437,11 +567,12 @@ extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int v
   return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
 }
 
-extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const int32_t* d_col_override,
-                                         const float* d_edge_weight, int ew_heads, const float* d_row_scale,
-                                         const float* d_in, int64_t ld_in, int width, float* d_out,
-                                         int64_t ld_out, int reduce_op, int pre_act, int post_act,
-                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_col_override,
+                             const float* d_edge_weight, int ew_heads, const float* d_row_scale,
+                             const float* d_in, int64_t ld_in, int width, float* d_out,
+                             int64_t ld_out, int reduce_op, int pre_act, int post_act,
+                             void* d_workspace, size_t workspace_bytes, void* stream, void* d_out_sp, int64_t ld_out_sp,
+                             float* d_inv_scale, const float* d_fixed_inv) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   TFGNN_REQUIRE(view >= 0 && view <= 5, "unknown graph view %d", view);
@@ -454,7 +585,8 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   }
   const GraphView& gv = g->views[view];
   if (gv.num_rows == 0 || width == 0) return TFGNN_OK;
-  int rc = check_common(gv.num_rows, gv.rowptr, d_in, d_out, ld_in, ld_out, width, reduce_op);
+  int rc = check_common(gv.num_rows, gv.rowptr, d_in, d_out_sp ? (const void*)d_out_sp : (const void*)d_out, ld_in,
+                        d_out_sp ? (int64_t)width : ld_out, width, reduce_op);
   if (rc) return rc;
   const CsrPlan& p = gv.plan;
   TFGNN_REQUIRE(p.num_partials == 0 || (d_workspace && workspace_bytes >= (size_t)p.num_partials * width * 4),
@@ -462,7 +594,8 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
   GatherArgs a{};
   a.rowptr = gv.rowptr; a.col = d_col_override ? d_col_override : gv.col; a.ew = d_edge_weight;
   a.row_scale = d_row_scale; a.num_rows = gv.num_rows; a.in = d_in; a.ld_in = ld_in; a.width = width;
-  a.out = d_out; a.ld_out = ld_out; a.pre_act = pre_act; a.post_act = post_act;
+  a.out = d_out; a.ld_out = d_out_sp ? (int64_t)width : ld_out; a.pre_act = pre_act; a.post_act = post_act;
+  a.out_sp = (uint8_t*)d_out_sp; a.ld_out_sp = ld_out_sp; a.inv_out = d_inv_scale; a.fixed_inv = d_fixed_inv;
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = p.long_threshold;
   a.out_row_map = out_map;
@@ -477,4 +610,27 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
     a.num_short = p.num_short;
   }
   return gather_dispatch(a, p.num_items, (hipStream_t)stream);
+}
+
+extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const int32_t* d_col_override,
+                                         const float* d_edge_weight, int ew_heads, const float* d_row_scale,
+                                         const float* d_in, int64_t ld_in, int width, float* d_out,
+                                         int64_t ld_out, int reduce_op, int pre_act, int post_act,
+                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  return graph_gather_impl(g, view, d_col_override, d_edge_weight, ew_heads, d_row_scale, d_in, ld_in, width, d_out, ld_out,
+                           reduce_op, pre_act, post_act, d_workspace, workspace_bytes, stream, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int tfgnn_graph_gather_reduce_sp(const tfgnn_graph* g, int view, const int32_t* d_col_override,
+                                            const float* d_edge_weight, const float* d_row_scale, const float* d_in,
+                                            int64_t ld_in, int width, void* d_out_sp, int64_t ld_out_sp_bytes,
+                                            float* d_inv_scale, const float* d_fixed_inv_scale, void* d_workspace,
+                                            size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(d_out_sp && (d_inv_scale || d_fixed_inv_scale), "tfgnn_graph_gather_reduce_sp: NULL output");
+  TFGNN_REQUIRE(ld_out_sp_bytes >= (int64_t)width * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0,
+                "tfgnn_graph_gather_reduce_sp: bad SP16 leading dimension / alignment");
+  return graph_gather_impl(g, view, d_col_override, d_edge_weight, 1, d_row_scale, d_in, ld_in, width, nullptr, 0,
+                           TFGNN_REDUCE_SUM, TFGNN_ACT_NONE, TFGNN_ACT_NONE, d_workspace, workspace_bytes, stream, d_out_sp,
+                           ld_out_sp_bytes, d_inv_scale, d_fixed_inv_scale);
 }

@@ -702,10 +702,13 @@ def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed
     sb = int(scale_block) if scale_block and scale_block > 0 else cols
     if out is None:
         data = torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device)
-        inv = torch.empty((rows, cols // sb), dtype=torch.float32, device=x.device)
-        out = SplitOperand(data, inv, rows, cols, sb)
+        if fixed_inv_scale is not None:
+            out = SplitOperand(data, fixed_inv_scale, rows, cols, 0)  # one scale for the whole tensor
+        else:
+            out = SplitOperand(data, torch.empty((rows, cols // sb), dtype=torch.float32, device=x.device), rows, cols, sb)
     _lib.check(lib.tfgnn_sp_split_rows(_ptr(x), ld, seg_len, seg_stride, rows, cols, sb, _ptr(out.data), out.data.stride(0),
-                                       _ptr(out.inv_scale), _ptr(fixed_inv_scale), _stream()))
+                                       None if fixed_inv_scale is not None else _ptr(out.inv_scale), _ptr(fixed_inv_scale),
+                                       _stream()))
     return out
 
 
@@ -742,10 +745,95 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
         bias = bias.contiguous()
     _lib.check(
         lib.tfgnn_sp_gemm_nt(
-            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block, _ptr(b.data), b.data.stride(0),
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
+            b.data.stride(0),
             _ptr(b.inv_scale), _ptr(out), ldc, _ptr(bias), act_id(act), int(accumulate), _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
             saved.stride(0) if saved is not None else 0, _stream(),
         )
     )
+    return out
+
+
+def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, edge_weight=None, row_scale=None,
+                    fixed_inv_scale: Optional[torch.Tensor] = None, rows_per_operand_row: int = 1) -> SplitOperand:
+    """graph_gather (plain sums) with the result written as an SP16 operand (tfgnn_graph_gather_reduce_sp).
+    ``rows_per_operand_row`` = L folds the rows (v, l) of a typed view into the [V, L * width] operand with one scale
+    block per edge type."""
+    lib = _lib.load()
+    _require_dev(inp, torch.float32, "inp")
+    if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
+        raise ValueError("graph_gather_sp: compact views are not supported")
+    num_rows = graph.num_nodes * (graph.num_edge_types if view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED) else 1)
+    inp, ld_in = _rowmajor(inp, "inp")
+    width = inp.shape[1]
+    R = int(rows_per_operand_row)
+    if num_rows % R:
+        raise ValueError("rows_per_operand_row must divide the number of rows of the view")
+    data = torch.empty((num_rows // R, R * width * 4), dtype=torch.uint8, device=inp.device)
+    inv = None
+    if fixed_inv_scale is None:
+        inv = torch.empty((num_rows // R, R), dtype=torch.float32, device=inp.device)
+    ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, width)
+    ws = _workspace(inp.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_graph_gather_reduce_sp(
+            graph._h, view, _ptr(col), _ptr(edge_weight), _ptr(row_scale), _ptr(inp), ld_in, width, _ptr(data), width * 4,
+            _ptr(inv), _ptr(fixed_inv_scale), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    if fixed_inv_scale is not None:
+        return SplitOperand(data, fixed_inv_scale, num_rows // R, R * width, 0)  # scale_block 0: one scale for the tensor
+    return SplitOperand(data, inv, num_rows // R, R * width, width)
+
+
+def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
+               scatter=None, accumulate: bool = False) -> torch.Tensor:
+    """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn); both operands carry ONE scale (scale_block 0).
+    ``a_cols`` / ``b_cols`` = (first column, count) select column ranges.  ``scatter`` = (group_rows, stride_group,
+    stride_row, stride_col) writes element (m, n) at out.flatten()[(m // group_rows) * stride_group + (m % group_rows) *
+    stride_row + n * stride_col]; default: row-major [M, N]."""
+    lib = _lib.load()
+    if a.scale_block != 0 or b.scale_block != 0:
+        raise ValueError("sp_gemm_tn: operands need one scale per tensor (fixed_inv_scale)")
+    if a.rows != b.rows:
+        raise ValueError(f"sp_gemm_tn: K differs ({a.rows} vs {b.rows})")
+    a0, M = a_cols if a_cols is not None else (0, a.cols)
+    b0, N = b_cols if b_cols is not None else (0, b.cols)
+    K = a.rows
+    if out is None:
+        if scatter is not None or accumulate:
+            raise ValueError("scatter / accumulate need out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.data.device)
+    if not out.is_contiguous() or out.numel() != M * N:
+        raise ValueError(f"out must be contiguous with {M * N} elements")
+    gr, sg, sr, sc = scatter if scatter is not None else (M, 0, N, 1)
+    ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(M, N, K)
+    ws = _workspace(a.data.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_sp_gemm_tn(
+            M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), _ptr(b.data), b.data.stride(0), b0,
+            _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), _ptr(ws), ws.numel() if ws is not None else 0,
+            _stream(),
+        )
+    )
+    return out
+
+
+def tensor_inv_scale(bound: torch.Tensor) -> torch.Tensor:
+    """2^-e with bound * 2^e in [2^14, 2^15) for a positive finite device scalar ``bound`` (>= the largest magnitude
+    of the tensor that will be written with this scale): the fixed_inv_scale of the SP16 producers."""
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=bound.device)
+    _lib.check(lib.tfgnn_sp_inv_scale_from_bound(_ptr(bound.contiguous()), _ptr(out), _stream()))
+    return out
+
+
+def absmax(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """device scalar scale * max |x| (tfgnn_absmax; order-independent, hence reproducible)."""
+    lib = _lib.load()
+    _require_dev(x, torch.float32, "x")
+    x = x.contiguous()
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    _lib.check(lib.tfgnn_absmax(_ptr(x), x.numel(), float(scale), _ptr(out), _stream()))
     return out

@@ -27,9 +27,7 @@ def timeit(fn, iters=30, warm=5):
 
 
 res = {}
-for name, M, N, K, sb in [("fwd 30000x320x1280", 30000, 320, 1280, 320), ("fwd per-row scale", 30000, 320, 1280, 0),
-                          ("dense 30000x320x320", 30000, 320, 320, 0), ("qm9 gru 1.15Mx384x128", 1150000, 384, 128, 0),
-                          ("arxiv 170000x512x512", 170000, 512, 512, 0)]:
+for name, M, N, K, sb in [("fwd 30000x320x1280", 30000, 320, 1280, 320), ("fwd per-row scale", 30000, 320, 1280, 0)]:
     g = torch.Generator(device="cpu").manual_seed(0)
     A = torch.randn((M, K), device=dev)
     Bt = torch.randn((N, K), device=dev) * 0.05
@@ -48,4 +46,32 @@ for name, M, N, K, sb in [("fwd 30000x320x1280", 30000, 320, 1280, 320), ("fwd p
     row["f16x2_mfma_frac_of_2.5PF"] = 3 * flops / (t_sp[0] * 1e-6) / 2.5e15
     res[name] = row
     print(name, json.dumps(row), flush=True)
+
+# weight-gradient product and the SP16-writing gather at the cfg-2 shapes
+from tf2_gnn_amd.data import make_synthetic_batch  # noqa: E402
+
+V, E, L, H = 30000, 900000, 4, 320
+_, adjs = make_synthetic_batch(V, E, L, 8, seed=1)
+gr = ops.Graph(tuple(torch.from_numpy(a).to(dev) for a in adjs), V)
+X = torch.randn((V, H), device=dev)
+Gm = torch.randn((V, L * H), device=dev) * 1e-3
+xs = ops.sp_split_rows(X, fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(X)))
+gs = ops.sp_split_rows(Gm, fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(Gm)))
+dW = torch.empty((L, H, H), device=dev)
+row = {"f16x2_tn_us": timeit(lambda: ops.sp_gemm_tn(gs, xs, out=dW, scatter=(H, H * H, 1, H)))}
+for mode in ("bf16x3", "fp32"):
+    prev = ops.set_gemm_mode(mode)
+    row[mode + "_tn_us"] = timeit(lambda: ops.gemm(Gm, X, trans_a=True))
+    ops.set_gemm_mode(prev)
+row["absmax_X_us"] = timeit(lambda: ops.absmax(X))
+row["split_X_fixed_us"] = timeit(lambda: ops.sp_split_rows(X, fixed_inv_scale=xs.inv_scale))
+res["dW 1280x320 K=30000"] = row
+print("dW", json.dumps(row), flush=True)
+rs = gr.array(ops.G_INVDEG_BY_DST)
+A = torch.empty((V * L, H), device=dev)
+row = {"gather_fp32_us": timeit(lambda: ops.graph_gather(gr, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, out=A)),
+       "gather_sp_us": timeit(lambda: ops.graph_gather_sp(gr, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, rows_per_operand_row=L)),
+       "gather_sp_fixed_us": timeit(lambda: ops.graph_gather_sp(gr, ops.VIEW_BY_SRC_TYPED, X, fixed_inv_scale=xs.inv_scale, rows_per_operand_row=L))}
+res["gather cfg-2"] = row
+print("gather", json.dumps(row), flush=True)
 json.dump(res, open("gpurun_out/sp_probe.json", "w"), indent=1)
