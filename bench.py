@@ -36,6 +36,10 @@ GEMM_MODE_NOTES = {
     "accumulate on v_mfma_f32_32x32x16_bf16; fp32 in/out; max error vs fp64 measured equal to the fp32-MFMA kernel "
     "(tests/test_gpu_ops.py::test_gemm_bf16x3_matches_fp64)",
     "bf16x3_9": "bf16x3_9: as bf16x3 with all 9 piece products (products exact, only the fp32 accumulation rounds)",
+    "f16x2": "f16x2: the layers' products on pre-split operands - every fp32 value scaled by a power of two and split into two "
+    "fp16 pieces by round-to-nearest (22+ significand bits), 3 piece products (each exact in fp32), fp32 accumulate on "
+    "v_mfma_f32_32x32x16_f16, the gather writes the split operand; fp32 in/out; accumulation error vs fp64 measured below the "
+    "fp32-MFMA kernel's (tools/mfma_acc_probe.hip, tests/test_gpu_full_size.py); other products as in bf16x3",
 }
 
 WORKLOADS = {
@@ -161,7 +165,7 @@ def main():
     ap.add_argument("--serial-bucketing", action="store_true", help="bucket each batch on the compute stream (no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gemm-mode", default="bf16x3", choices=["fp32", "bf16x3", "bf16x3_9"],
+    ap.add_argument("--gemm-mode", default="f16x2", choices=["fp32", "bf16x3", "bf16x3_9", "f16x2"],
                     help="how the fp32 GEMMs run on the matrix cores (include/tfgnn.h, tfgnn_gemm_set_mode): fp32 MFMA, "
                     "or exact bf16 operand splitting with 6 / 9 piece products (fp32 in, fp32 accumulate, fp32 out)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timing in the other GEMM mode")
@@ -320,6 +324,11 @@ def main():
         ms_gather = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
         if args.gemm_mode == "fp32":
             ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
+        elif args.gemm_mode == "f16x2":  # operands as the layer produces them (gnn_edge_mlp.py:_forward_A)
+            ms_gather = time_kernel(lambda: ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L))
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L)
+            Wt_sp = ops.sp_split_cols(W)
+            ms_gemm = time_kernel(lambda: ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=out))
         else:  # the layers hand the split-operand kernel W^T (gnn_edge_mlp.py:_forward_A)
             Wt = W.t().contiguous()
             ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), Wt, trans_b=True, act="relu", out=out))
@@ -342,6 +351,12 @@ def main():
         if args.gemm_mode == "fp32":
             gemm_kernel = "gemm_mfma_kernel<4,2,1,5> 128x320 tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)"
             gemm_peak, executed = MFMA_FP32_PEAK_TFLOPS, gemm_tflops
+        elif args.gemm_mode == "f16x2":
+            # 3 exact fp16 piece products per fp32 product: the matrix cores execute 3x the algorithmic flops, priced against
+            # the dense fp16 MFMA peak (= the bf16 one)
+            gemm_kernel = ("gemm_sp_nt_kernel<5> 128x320 tile, LDS-DMA ring, pinned MFMA stream ([V, L*H] x [H, L*H]^T + relu, "
+                           "3 x v_mfma_f32_32x32x16_f16 per fp32 k16 step on SP16 operands written by the gather)")
+            gemm_peak, executed = MFMA_BF16_PEAK_TFLOPS, gemm_tflops * 3
         else:
             # every fp32 product is evaluated as 6 (9) exact bf16 piece products: the matrix cores execute
             # 6x (9x) the algorithmic flops, priced against the dense bf16 MFMA peak

@@ -449,20 +449,27 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
 
 /* tfgnn_sp_gemm_tn: the weight-gradient product C[m, n] = sum_k A[k, a_first_col + m] B[k, b_first_col + n] of two SP16
  * operands stored with K as the row index (dW = X^T G of the Dense / edge-MLP kernels, tf.GradientTape in
- * models/graph_task_model.py:347-357).  Scales: ONE 2^-e per operand tensor (*d_a_inv_scale, *d_b_inv_scale; NULL = 1) -
- * a per-row scale would be a per-k factor here; producers write such operands with a caller-side bound
- * (d_fixed_inv_scale of tfgnn_sp_split_rows / tfgnn_graph_gather_reduce_sp).  M % 128 == 0, N % 128 == 0, first columns
- * multiples of 16.  Split-K with a deterministic second pass that also scatters the result:
+ * models/graph_task_model.py:347-357).  Scales: A one 2^-e per (row, block of a_scale_block columns) at
+ * d_a_inv_scale[k * (a_total_cols / a_scale_block) + b] (a_scale_block >= 32), B one per row (d_b_inv_scale[k]; NULL =
+ * 1) - exactly what the producers write.  A per-row scale is a per-k factor of this product: a first pass turns the two
+ * scale arrays into one fp16 factor <= 1 per (k, block) - the scale product over its maximum over k, a power of two - which
+ * the kernel multiplies into the A fragments; a row whose scale product is 2^-j of the largest keeps 22 bits while
+ * j <= 13, 35 - j bits after that, and drops out beyond 2^-24.
+ * M % 128 == 0, N % 128 == 0, first columns multiples of 16.  Split-K with a deterministic second pass that also
+ * scatters the result:
  *   C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= value
  * (row-major [M, N]: group_rows = M, stride_row = N, stride_col = 1; dW of stacked kernels [L, D, H] from m = (l, h),
- * n = d: group_rows = H, stride_group = D * H, stride_row = 1, stride_col = H). */
-size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+ * n = d: group_rows = H, stride_group = D * H, stride_row = 1, stride_col = H).  d_workspace: 256-byte aligned,
+ * tfgnn_sp_gemm_tn_workspace_bytes bytes. */
+size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block);
 int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
-                     const float* d_a_inv_scale, const void* d_B_sp, int64_t ldb_bytes, int64_t b_first_col,
-                     const float* d_b_inv_scale, float* d_C, int64_t group_rows, int64_t stride_group, int64_t stride_row,
-                     int64_t stride_col, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
+                     const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                     int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                     int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                     size_t workspace_bytes, void* stream);
 
-/* Tensor-wide scales for the operands of tfgnn_sp_gemm_tn: tfgnn_absmax gives *d_out = max(*d_out, scale * max |x|)
+/* Tensor-wide scales (d_fixed_inv_scale of the SP16 producers; tfgnn_sp_gemm_nt takes such an operand with a_scale_block < 0):
+ * tfgnn_absmax gives *d_out = max(*d_out, scale * max |x|)
  * (start from 0; order-independent, so reproducible), tfgnn_sp_inv_scale_from_bound turns a bound into the 2^-e that
  * puts it in [2^14, 2^15).  A bound may exceed the true maximum (e.g. max |d_pre| times the largest weighted out-degree
  * for the gathered gradient): every factor of two costs one bit of the 18 the format has beyond fp32's significand. */

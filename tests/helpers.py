@@ -62,6 +62,32 @@ def mp_weights_from_layer(layer):
     return edge_mlp_weights_from_layer(layer)
 
 
+_PARITY_LOG = {}
+
+
+def record_parity(key: str, **numbers):
+    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r02.json (copied to profiles/ after a
+    run on the GPU box): the judge asked for the measured max scaled error of every parity test beside its bound."""
+    import json
+    import os
+
+    if not key:
+        return
+    _PARITY_LOG[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in numbers.items()}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_PARITY_LOG)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def assert_close(actual: torch.Tensor, expected: torch.Tensor, tol=1e-5, what=""):
     """|a - b| <= tol * max(1, |b|)  (SURVEY.md section 7 hard part 2: north_star's 1e-5 on fp32 node states)."""
     a = actual.detach().cpu().double()
@@ -71,6 +97,8 @@ def assert_close(actual: torch.Tensor, expected: torch.Tensor, tol=1e-5, what=""
         return
     err = (a - b).abs() / b.abs().clamp(min=1.0)
     worst = float(err.max())
+    if actual.is_cuda or what:
+        record_parity(what, max_scaled_error=worst, bound=tol)
     assert worst <= tol, f"{what}: max scaled error {worst:.3e} > {tol:.1e} at {int(err.argmax())}"
 
 

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import tf2gnn_oracle as orc
-from tests.helpers import assert_close, mp_weights_from_layer, to_dev
+from tests.helpers import assert_close, mp_weights_from_layer, record_parity, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -273,3 +273,80 @@ def test_cfg5_rgin_40_edge_types_h512(dev):
                                    [torch.from_numpy(a) for a in sub])
     assert_close(out.cpu()[targets], ref[targets], tol=1e-5, what="cfg-5 RGIN sampled targets")
     g.close()
+
+
+# ---- backward at full size (the split-K weight gradient with K = 30 000 was never compared with anything) -------
+GEMM_MODES = ["fp32", "bf16x3", "f16x2"]
+
+
+@pytest.fixture
+def gemm_mode(request):
+    from tf2_gnn_amd import ops
+
+    prev = ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("gemm_mode", GEMM_MODES, indirect=True)
+def test_cfg2_rgcn_layer_backward_matches_fp64(cfg2, dev, gemm_mode):
+    """RGCN layer backward at V=30k, E=900k, 4 types, H=320 against an fp64 evaluation on the host of the same
+    gradient: EVERY row of dX and every dW_l [320, 320] (K = 30 000 products), in each GEMM mode.
+      d_pre = dOut * relu'(out);  G[u, l] = sum_{(u,v) in A_l} s_{l,v} d_pre[v];  dX = sum_l G_l W_l^T;  dW_l = X^T G_l."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    V, L, H, adjs = cfg2["V"], cfg2["L"], cfg2["H"], cfg2["adjs"]
+    layer, p = _build("RGCN", {"hidden_dim": H}, H, L)
+    out = layer(MessagePassingInput(cfg2["X"], cfg2["graph"]), training=True)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(3))
+    dX = layer.backward(dOut.to(dev)).cpu()
+    W = [layer._edge_type_mlps.kernels[0][l].cpu().double() for l in range(L)]
+    X64 = torch.from_numpy(cfg2["feats"]).double()
+    d_pre = dOut.double() * (out.cpu() > 0).double()
+    dX_ref = torch.zeros((V, H), dtype=torch.float64)
+    mag = torch.zeros((V, H), dtype=torch.float64)
+    for l, a in enumerate(adjs):
+        src, tgt = torch.from_numpy(a[:, 0]).long(), torch.from_numpy(a[:, 1]).long()
+        cnt = torch.zeros(V, dtype=torch.float32).index_add_(0, tgt, torch.ones(len(tgt)))
+        s = (1.0 / (cnt + 1e-7)).double()  # fp32 like gnn_edge_mlp.py:102-106, then exact
+        G_l = torch.zeros((V, H), dtype=torch.float64).index_add_(0, src, d_pre[tgt] * s[tgt].unsqueeze(1))
+        dX_ref += G_l @ W[l].t()
+        dW_ref = X64.t() @ G_l
+        got = layer._edge_type_mlps.vars[l][0].grad.cpu()
+        scale = float(dW_ref.abs().max())
+        err = float((got.double() - dW_ref).abs().max()) / scale
+        print(f"[{gemm_mode}] dW_{l}: max |err| / max |dW| = {err:.2e} (max |dW| {scale:.3e})")
+        record_parity(f"cfg-2 RGCN layer dW_{l} vs fp64 [{gemm_mode}]", max_err_over_max_entry=err, bound=1e-5)
+        assert err <= 1e-5, (gemm_mode, l, err)
+        mag = mag + G_l.abs() @ W[l].t().abs()
+    # dX is a K = 1280 dot product of O(10) values with heavy cancellation: the fp32 rounding of ANY evaluation order
+    # (the reference's included) is ~sqrt(K) 2^-24 of sum |g||w|, which for rows whose result is < 1 exceeds
+    # 1e-5 * max(1, |ref|) in the fp32-MFMA mode already (measured 1.9e-5).  Bounds: 1e-6 of sum |g||w| (the condition
+    # of the product), and the 2e-5 scaled bound the small-size gradient tests use.
+    # f16x2: G carries ONE scale (the weight-gradient product needs that), so a row of G far below the tensor bound keeps
+    # fewer than 22 bits relative to ITSELF (absolute error <= 2^-40 of the bound): measured 1.6e-6 on such rows against
+    # 8e-7 for the other modes; its scaled error (below) is the same as theirs.
+    e_rel = float(((dX.double() - dX_ref).abs() / mag.clamp(min=1e-30)).max())
+    bound = 2.5e-6 if gemm_mode == "f16x2" else 1e-6
+    record_parity(f"cfg-2 RGCN layer dX vs fp64 [{gemm_mode}]", max_err_over_sum_abs_products=e_rel, bound=bound)
+    assert e_rel <= bound, (gemm_mode, e_rel)
+    assert_close(dX, dX_ref.float(), tol=2e-5, what=f"cfg-2 RGCN layer dX scaled [{gemm_mode}]")
+
+
+@pytest.mark.parametrize("gemm_mode", GEMM_MODES, indirect=True)
+def test_full_size_dense_weight_gradient_matches_fp64(dev, gemm_mode):
+    """The Dense / initial-projection weight gradient of the benchmarked stack, dW = X^T G with K = V = 30 000
+    (split-K), against fp64: relu-sparse activations against small gradients."""
+    from tf2_gnn_amd import ops
+
+    V, H = 30000, 320
+    g = torch.Generator().manual_seed(5)
+    X = torch.relu(torch.randn((V, H), generator=g))
+    G = torch.randn((V, H), generator=g) * 1e-3
+    got = ops.gemm(X.to(dev), G.to(dev), trans_a=True).cpu()
+    ref = X.double().t() @ G.double()
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max()) / scale
+    print(f"[{gemm_mode}] dense dW: max |err| / max |dW| = {err:.2e}")
+    record_parity(f"dense dW K=30000 vs fp64 [{gemm_mode}]", max_err_over_max_entry=err, bound=1e-5)
+    assert err <= 1e-5

@@ -193,16 +193,23 @@ def test_gemm_tn_matches_fp64(dev, K, M, N, a0, b0):
 
     g = torch.Generator().manual_seed(K + M + N)
     X = torch.randn((K, a0 + M + 32), generator=g)
-    G = torch.randn((K, b0 + N + 16), generator=g) * 1e-4     # gradients are small: the tensor scale matters
+    G = torch.randn((K, b0 + N + 16), generator=g) * 1e-4     # gradients are small
     G[::7] *= 30.0
-    ref = X[:, a0:a0 + M].double().t() @ G[:, b0:b0 + N].double()
-    inv_x = ops.tensor_inv_scale(ops.absmax(X.to(dev)))
-    inv_g = ops.tensor_inv_scale(ops.absmax(G.to(dev), scale=3.0))  # a loose bound (x3) must not cost accuracy
-    xs = ops.sp_split_rows(X.to(dev), fixed_inv_scale=inv_x)
-    gs = ops.sp_split_rows(G.to(dev), fixed_inv_scale=inv_g)
-    out = ops.sp_gemm_tn(xs, gs, a_cols=(a0, M), b_cols=(b0, N)).cpu()
-    mag = X[:, a0:a0 + M].double().abs().t() @ G[:, b0:b0 + N].double().abs()
-    assert float(((out.double() - ref).abs() / mag).max()) <= 4e-7
+    rows = torch.randn((K, 1), generator=g)
+    for spread, bound in ((2.0, 6e-7), (4.0, 3e-5)):
+        # rows (= k) on different scales: the per-k factors at work.  exp(2 N(0,1)): rows spread over 2^+-9 - every term
+        # keeps its 22 bits; exp(4 N(0,1)) (with the x30 rows of G): 2^+-20 - rows more than 2^13 below the largest
+        # scale product lose low bits gracefully, rows 2^24 below drop out: the documented limit of the format
+        # (csrc/gemm_sp.hip sp_tn_factors_kernel), not reached by the node states / gradients of one batch
+        Xs = X * torch.exp(rows * spread)
+        xs = ops.sp_split_rows(Xs.to(dev), scale_block=32)  # up to four scale blocks per 128-column tile
+        gs = ops.sp_split_rows(G.to(dev))
+        out = ops.sp_gemm_tn(xs, gs, a_cols=(a0, M), b_cols=(b0, N)).cpu()
+        ref = Xs[:, a0:a0 + M].double().t() @ G[:, b0:b0 + N].double()
+        mag = Xs[:, a0:a0 + M].double().abs().t() @ G[:, b0:b0 + N].double().abs()
+        e = float(((out.double() - ref).abs() / mag).max())
+        print(f"tn {K}x{M}x{N} row spread exp({spread} N): max err / sum|a||b| = {e:.2e}")
+        assert e <= bound, (spread, e)
     scale = float(ref.abs().max())
     assert_close(out / scale, (ref / scale).float(), tol=1e-5, what=f"sp tn {K}x{M}x{N}")
 
@@ -216,8 +223,8 @@ def test_gemm_tn_scatter_layout_and_accumulate(dev):
     X = torch.randn((V, D), generator=g)
     G = torch.randn((V, L * H), generator=g) * 0.01
     ref = torch.einsum("vd,vlh->ldh", X.double(), G.double().view(V, L, H))
-    xs = ops.sp_split_rows(X.to(dev), fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(X.to(dev))))
-    gs = ops.sp_split_rows(G.to(dev), fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(G.to(dev))))
+    xs = ops.sp_split_rows(X.to(dev))
+    gs = ops.sp_split_rows(G.to(dev), scale_block=H)
     dW = torch.zeros((L, D, H), device=dev)
     ops.sp_gemm_tn(gs, xs, out=dW, scatter=(H, D * H, 1, H))
     assert_close(dW.cpu(), ref.float(), tol=1e-5, what="dW [L, D, H]")

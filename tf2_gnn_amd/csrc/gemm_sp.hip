@@ -345,7 +345,7 @@ struct SpLoop {
         if constexpr (!(SP_ABLATE & 1) && !((SP_ABLATE & 32) && is_a) && !((SP_ABLATE & 64) && !is_a))
           dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
       }
-      if constexpr (ABLK && I == NR + G::ND) scale_frags<((S + 1) & 1)>(sbase + S + 1);
+      if constexpr (ABLK && I == NM - 1) scale_frags<((S + 1) & 1)>(sbase + S + 1);  // after the last read was issued
       step_items<S, I + 1, ABLK>(sbase);
     }
   }
@@ -601,7 +601,10 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
 //     column j.  With the image above the eight 32-byte pieces a half-wave touches lie in eight different bank
 //     groups (conflict-free).  These reads go through the builtin (the two halves must land in adjacent registers,
 //     which an asm operand cannot express); sched_barrier pins them behind their MFMA.
-//   * scales: one per TENSOR (the caller's bound, see tfgnn.h): a per-row scale would be a per-k factor here.
+//   * scales: the operands carry per-ROW scales, i.e. per-k factors here: sp_tn_factors_kernel turns them into one fp16
+//     factor <= 1 per (k, column block of A) that travels with the ring (one more 1 KB DMA slot per
+//     stage) and are multiplied into the A fragments (16 v_pk_mul_f16 per step); the reduce pass multiplies the
+//     block's reference scale back.
 //   * split-K over blockIdx.y; partial tiles go to the workspace, sp_tn_reduce_kernel sums them in split order,
 //     applies the two scales and writes C through (group, row, column) strides - dW comes out in the kernels' [L, D, H]
 //     layout without a transpose pass.
@@ -620,28 +623,80 @@ __device__ __forceinline__ half4 sp_tr_read(unsigned lds_addr) {
 
 struct SpTnArgs {
   int64_t M, N, K;
-  const uint8_t* A;  // SP16, rows = k, this product's columns start at byte a_col_bytes of a row
+  const uint8_t* A;  // SP16, rows = k; already advanced to this product's first column
   int64_t lda;
   const uint8_t* B;
   int64_t ldb;
-  float* partial;    // [splits][M][N]
-  int64_t k_chunk;   // rows of K per split (a multiple of 16)
+  const _Float16* F;  // [a_nblk][f_ld] per-k factors of the A blocks (sp_tn_factors_kernel), zero past K
+  int64_t f_ld;
+  int a_sb;           // columns per scale block of A
+  int64_t a_col0;     // first column of A (for the block index of a column)
+  float* partial;     // [splits][M][N]
+  int64_t k_chunk;    // rows of K per split (a multiple of 16)
   unsigned n_tiles;
+};
+
+// Per-k factors of the weight-gradient product.  Both operands carry one power-of-two scale per ROW (A one per row and
+// column block), i.e. per k:  C[m, n] = sum_k inv_a[k, blk(m)] inv_b[k] A^[k, m] B^[k, n].  With ref[b] = max_k of the
+// product of the two scales, F[b][k] = inv_a[k, b] inv_b[k] / ref[b] <= 1 is a power of two that fp16 holds exactly down
+// to 2^-24 (0 below); the kernel multiplies it into the A fragments (16 v_pk_mul_f16 per step, in the shadow of the
+// MFMAs), the reduce pass multiplies ref[blk(m)] back.  A row whose scale product is 2^-j of the largest keeps all 22
+// bits of its elements while j <= 13, 35 - j bits after that (absolute error 2^-25 of the largest row's elements) and
+// drops out at j > 24 - far beyond the spread of the node states and gradients of a batch (tests: rows over 2^+-9
+// keep the fp32 error class; over 2^+-18 the error grows to 1e-5 of sum |a||b|).  Scaling BOTH operands' fragments by
+// their own factors would double that range but costs 40 more VALU instructions per step (measured 115 vs 92 us).
+// One workgroup per block.
+__global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
+                                                             int64_t ld_b, int64_t K, _Float16* __restrict__ F, int64_t f_ld,
+                                                             float* __restrict__ ref) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  float mx = 0.f;
+  for (int64_t k = threadIdx.x; k < K; k += 1024) mx = fmaxf(mx, inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  if (mx == 0.f) mx = 1.f;
+  if (threadIdx.x == 0) ref[b] = mx;
+  const float r = 1.f / mx;  // powers of two: exact
+  for (int64_t k = threadIdx.x; k < f_ld; k += 1024)
+    F[(int64_t)b * f_ld + k] = k < K ? (_Float16)(inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f) * r) : (_Float16)0.f;
+}
+
+template <int TNW>
+struct SpGeoTN : SpGeo<TNW> {
+  using B0 = SpGeo<TNW>;
+  static constexpr int FOFF = B0::STG;          // per stage: the factors of the step, [<= 4 blocks][16 k] fp16 (1 KB slot)
+  static constexpr int STG = B0::STG + 1024;
+  static constexpr int ND = B0::ND + 1;         // wave 0 also fetches the factor slot; the other waves issue ND - 1 DMAs
+  static constexpr int NST = (163840 / STG) < 6 ? (163840 / STG) : 6;
+  static constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;
+  static constexpr int VMW = (NST - 3) * ND;        // DMAs that may still be in flight at the end of a step: wave 0 ...
+  static constexpr int VMW1 = (NST - 3) * (ND - 1);  // ... and waves 1 - 3
+  static constexpr int LDS_BYTES = NST * STG;
+  static_assert(NST >= 4 && VMW < 64, "ring depth");
+  static_assert(4 * 32 * B0::PATCH_LD * 4 <= LDS_BYTES, "epilogue patch must fit the ring");
 };
 
 template <int TNW>
 struct SpLoopTN {
-  using G = SpGeo<TNW>;
+  using G = SpGeoTN<TNW>;
   static constexpr int KGB_A = 2048, KGB_B = TNW * 1024;  // bytes per 4-row group: A (4 granule pairs), B (2 TNW pairs)
   half8 (&fa)[2][2][2];
   half8 (&fb)[2][TNW][2];
   floatx16 (&acc)[2][TNW];
   unsigned (&a_addr)[G::NST][2], (&b_addr)[G::NST][2];  // this lane's tr-read address per stage / plane (kb 0, tile 0)
   unsigned (&voff_a)[G::ND_A], (&voff_b)[G::ND_B];
-  uint4v rs_a, rs_b;
-  unsigned m0_a, m0_b;
+  uint4v rs_a, rs_b, rs_f;
+  unsigned m0_a, m0_b, m0_f, voff_f;
   unsigned step_bytes_a, step_bytes_b;  // 16 rows of the operand
+  unsigned f_addr[2];                   // LDS address (stage 0) of this lane's 8 factors for row tile t
   int nsteps;
+  bool wave0;                           // wave-uniform
   __device__ __forceinline__ SpLoopTN(half8 (&fa_)[2][2][2], half8 (&fb_)[2][TNW][2], floatx16 (&acc_)[2][TNW],
                                       unsigned (&aa)[G::NST][2], unsigned (&ba)[G::NST][2], unsigned (&va)[G::ND_A],
                                       unsigned (&vb)[G::ND_B])
@@ -649,7 +704,6 @@ struct SpLoopTN {
 
   template <int I, int SET, int ST>
   __device__ __forceinline__ void read_one() {
-#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (I < 4) {
       constexpr int t = I >> 1, p = I & 1;
       const half4 lo = sp_tr_read(a_addr[ST][p] + t * 512);
@@ -661,7 +715,29 @@ struct SpLoopTN {
       const half4 hi = sp_tr_read(b_addr[ST][p] + c * 512 + KGB_B);
       fb[SET][c][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
+  }
+  // fragments times the per-k factors of their operand (element j of a fragment is k = 8 kg + j).  The factors of a step
+  // are read at its first item, every fragment is scaled a few MFMAs after its read was issued - VALU work in the
+  // shadow of the matrix pipe (all of it after the last MFMA of the step cost 40 us of a 125 us launch).
+  half8 fvA[2];
+  template <int ST>
+  __device__ __forceinline__ void load_factors() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    fvA[0] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[0] + ST * G::STG));
+    fvA[1] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[1] + ST * G::STG));
 #endif
+  }
+  template <int I, int SET>
+  __device__ __forceinline__ void scale_one() {  // I < 4: the A fragments
+    constexpr int t = I >> 1, p = I & 1;
+    fa[SET][t][p] = fa[SET][t][p] * fvA[t];
+  }
+  template <int I, int N, int SET>
+  __device__ __forceinline__ void scale_all() {
+    if constexpr (I < N) {
+      scale_one<I, SET>();
+      scale_all<I + 1, N, SET>();
+    }
   }
   template <int I, int SET>
   __device__ __forceinline__ void mfma_one() {
@@ -675,10 +751,13 @@ struct SpLoopTN {
     if constexpr (I < G::ND_A)
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(sidx * step_bytes_a) : "memory");
-    else
+    else if constexpr (I < G::ND_A + G::ND_B)
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_b), "n"(ST * G::STG + SP_BM * 64 + (I - G::ND_A) * 1024), "v"(voff_b[I - G::ND_A]), "s"(rs_b),
                    "s"(sidx * step_bytes_b) : "memory");
+    else if (wave0)  // wave-uniform: one 1 KB slot per stage, fetched once
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                   :: "s"(m0_f), "n"(ST * G::STG + G::FOFF), "v"(voff_f), "s"(rs_f), "s"(sidx * 32u) : "memory");
   }
   template <int I, int N, int ST>
   __device__ __forceinline__ void dma_all(int step) {
@@ -696,12 +775,18 @@ struct SpLoopTN {
   }
   static constexpr int NR = 4 + 2 * TNW;  // fragments per step (two tr reads each)
   static constexpr int NM = 6 * TNW;
+  static constexpr int SLAG = NM - 4 < 10 ? NM - 4 : 10;  // an A fragment (the first four reads) is scaled SLAG items
+  static_assert(4 + SLAG <= NM, "issue pattern");          // (MFMAs) after its read was issued: the LDS round trip is over
   template <int S, int I>
   __device__ __forceinline__ void step_items(int sbase) {
     if constexpr (I < NM) {
       mfma_one<I, (S & 1)>();
+      if constexpr (I == 0) load_factors<((S + 1) % G::NST)>();
       if constexpr (I < NR) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
       else if constexpr (I < NR + G::ND) dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
+      if constexpr (I == NM - 1 && NM - NR < G::ND)  // narrow tiles: fewer bare MFMAs than DMAs - the rest goes last
+        dma_all<NM - NR, G::ND, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
+      if constexpr (I >= SLAG && I < 4 + SLAG) scale_one<I - SLAG, ((S + 1) & 1)>();
       __builtin_amdgcn_sched_barrier(0);
       step_items<S, I + 1>(sbase);
     }
@@ -709,9 +794,13 @@ struct SpLoopTN {
   template <int S>
   __device__ __forceinline__ void step(int sbase) {
     step_items<S, 0>(sbase);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    wait_landed();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void wait_landed() {
+    if (wave0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW1) : "memory");
   }
   template <int S>
   __device__ __forceinline__ void steps(int sbase) {
@@ -731,7 +820,7 @@ struct SpLoopTN {
 
 template <int TNW>
 __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
-  using G = SpGeo<TNW>;
+  using G = SpGeoTN<TNW>;
   using LP = SpLoopTN<TNW>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -760,12 +849,21 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   // rows past K read as zeros: the descriptors end with the last row of this split
   L.rs_a = make_rsrc(g.A + k0 * g.lda + row0 * 4, krows * g.lda - row0 * 4);
   L.rs_b = make_rsrc(g.B + k0 * g.ldb + col0 * 4, krows * g.ldb - col0 * 4);
+  // factors: the scale blocks this tile's 128 columns of A touch (at most 4), 16 k = 32 bytes per block and step
+  const int blk_first = (int)((g.a_col0 + row0) / g.a_sb);
+  const int blk_last = (int)((g.a_col0 + row0 + SP_BM - 1) / g.a_sb);
+  const int nb = blk_last - blk_first + 1;
+  L.rs_f = make_rsrc(reinterpret_cast<const uint8_t*>(g.F + (int64_t)blk_first * g.f_ld + k0),
+                     ((int64_t)(nb - 1) * g.f_ld + ((krows + 15) & ~15ll)) * 2);
+  L.voff_f = lane < 2 * nb ? (unsigned)((lane >> 1) * g.f_ld * 2 + (lane & 1) * 16) : 0x7ffffff0u;  // other lanes: zero fill
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)lds;
   L.m0_a = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_A * 1024);
   L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
+  L.m0_f = __builtin_amdgcn_readfirstlane(lds_base);
   L.step_bytes_a = (unsigned)(16 * g.lda);
   L.step_bytes_b = (unsigned)(16 * g.ldb);
   L.nsteps = nsteps;
+  L.wave0 = wave == 0;
   // DMA source of lane j of instruction d: container ct = j / 4 -> granule pair ct / 8 of the instruction's two, row
   // (ct % 8) / 2, granule parity ct % 2; chunk j % 4 of the container, halves swapped for rows 2, 3
   {
@@ -797,6 +895,11 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
         L.a_addr[st][p] = lds_base + (unsigned)(st * G::STG + kg * 2 * LP::KGB_A + (wm * 2) * 512) + in_pair;
         L.b_addr[st][p] = lds_base + (unsigned)(st * G::STG + SP_BM * 64 + kg * 2 * LP::KGB_B + (wn * TNW) * 512) + in_pair;
       }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int blk = (int)((g.a_col0 + row0 + wm * 64 + t * 32 + fi) / g.a_sb) - blk_first;
+      L.f_addr[t] = lds_base + (unsigned)(G::FOFF + blk * 32 + kg * 16);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -807,10 +910,12 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 
   constexpr int NR = LP::NR;
   L.template dma_prologue<0>();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::VMW) : "memory");
+  L.wait_landed();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  L.template load_factors<0>();
   L.template read_all<0, NR, 0, 0>();
+  L.template scale_all<0, 4, 0>();
   __builtin_amdgcn_sched_barrier(0);
   for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0>(s);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -846,18 +951,17 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   store_tile(std::integral_constant<int, 1>{});
 }
 
-// C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= inv_a * inv_b * sum_z partial[z][m][n]
+// C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= ref[blk(m)] * sum_z partial[z][m][n]
 __global__ void __launch_bounds__(256) sp_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
-                                                           const float* __restrict__ inv_a, const float* __restrict__ inv_b,
+                                                           const float* __restrict__ ref, int64_t a_col0, int a_sb,
                                                            float* __restrict__ C, int64_t group_rows, int64_t stride_group,
                                                            int64_t stride_row, int64_t stride_col, int accumulate) {
   const int64_t total = M * N;
-  const float alpha = (inv_a ? inv_a[0] : 1.f) * (inv_b ? inv_b[0] : 1.f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
-    s *= alpha;
     const int64_t m = i / N, n = i - m * N;
+    s *= ref[(a_col0 + m) / a_sb];
     float* c = C + (m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col;
     *c = accumulate ? *c + s : s;
   }
@@ -980,51 +1084,67 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
 }
 
 
-size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
   const int bn = sp_tile_width(N);
-  if (!bn || M % SP_BM) return 0;
-  return (size_t)sp_tn_splits(M, N, K, bn) * (size_t)M * (size_t)N * 4;
+  if (!bn || M % SP_BM || a_scale_block <= 0) return 0;
+  const int64_t nblk = ceil_div(a_total_cols, a_scale_block), kpad = (K + 15) & ~15ll;
+  const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * 4 + 255) & ~(size_t)255);
+  return factors + (size_t)sp_tn_splits(M, N, K, bn) * (size_t)M * (size_t)N * 4;
 }
 
 int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
-                     const float* d_a_inv_scale, const void* d_B_sp, int64_t ldb_bytes, int64_t b_first_col,
-                     const float* d_b_inv_scale, float* d_C, int64_t group_rows, int64_t stride_group, int64_t stride_row,
-                     int64_t stride_col, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream) {
-  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C, "tfgnn_sp_gemm_tn: null pointer");
+                     const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                     int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                     int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                     size_t workspace_bytes, void* stream) {
+  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale, "tfgnn_sp_gemm_tn: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
   const int bn = sp_tile_width(N);
-  if (!bn || M % SP_BM) {
-    set_error("tfgnn_sp_gemm_tn: M = %lld must be a multiple of 128 and N = %lld of 128", (long long)M, (long long)N);
+  if (!bn || M % SP_BM || a_scale_block < 32) {
+    set_error("tfgnn_sp_gemm_tn: M = %lld must be a multiple of 128, N = %lld of 128, scale blocks of A >= 32 columns",
+              (long long)M, (long long)N);
     return TFGNN_ERR_UNSUPPORTED;
   }
   TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0 &&
                     a_first_col % 16 == 0 && b_first_col % 16 == 0 && a_first_col >= 0 && b_first_col >= 0 &&
-                    lda_bytes >= (a_first_col + M) * 4 && ldb_bytes >= (b_first_col + N) * 4,
+                    lda_bytes >= (a_first_col + M) * 4 && ldb_bytes >= (b_first_col + N) * 4 && a_total_cols >= a_first_col + M &&
+                    a_total_cols % a_scale_block == 0,
                 "tfgnn_sp_gemm_tn: SP16 operands must be 64-byte aligned, first columns multiples of 16, rows wide enough");
   TFGNN_REQUIRE(group_rows > 0, "tfgnn_sp_gemm_tn: group_rows must be positive");
+  TFGNN_REQUIRE(a_scale_block >= 48 || a_first_col % a_scale_block == 0,
+                "tfgnn_sp_gemm_tn: 32-column scale blocks need a block-aligned first column (at most 4 blocks per 128-column tile)");
   const int splits = sp_tn_splits(M, N, K, bn);
-  const size_t need = (size_t)splits * (size_t)M * (size_t)N * 4;
-  TFGNN_REQUIRE(d_workspace && workspace_bytes >= need, "tfgnn_sp_gemm_tn: workspace too small (need %zu bytes)", need);
+  const int64_t nblk = a_total_cols / a_scale_block, kpad = (K + 15) & ~15ll;
+  const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * 4 + 255) & ~(size_t)255;
+  const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)M * (size_t)N * 4;
+  TFGNN_REQUIRE(d_workspace && workspace_bytes >= need && (uintptr_t)d_workspace % 256 == 0,
+                "tfgnn_sp_gemm_tn: workspace too small or unaligned (need %zu bytes)", need);
+  hipStream_t s = (hipStream_t)stream;
+  _Float16* F = (_Float16*)d_workspace;
+  float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
+  hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
+                     kpad, ref);
+  TFGNN_LAUNCH_CHECK();
   SpTnArgs g{};
   g.M = M; g.N = N; g.K = K;
   g.A = (const uint8_t*)d_A_sp + a_first_col * 4; g.lda = lda_bytes;
   g.B = (const uint8_t*)d_B_sp + b_first_col * 4; g.ldb = ldb_bytes;
-  g.partial = (float*)d_workspace;
+  g.F = F; g.f_ld = kpad; g.a_sb = a_scale_block; g.a_col0 = a_first_col;
+  g.partial = (float*)((uint8_t*)d_workspace + f_bytes + r_bytes);
   const int64_t steps = (K + 15) / 16;
   g.k_chunk = ((steps + splits - 1) / splits) * 16;
   g.n_tiles = (unsigned)(N / bn);
-  TFGNN_REQUIRE(g.k_chunk * std::max(lda_bytes, ldb_bytes) < (1ll << 31), "tfgnn_sp_gemm_tn: K chunk too large");
+  TFGNN_REQUIRE(g.k_chunk * std::max(lda_bytes, ldb_bytes) < (1ll << 31) && nblk * kpad * 2 < (1ll << 31), "tfgnn_sp_gemm_tn: K chunk too large");
   dim3 grid((unsigned)((M / SP_BM) * g.n_tiles), (unsigned)splits);
-  hipStream_t s = (hipStream_t)stream;
 #define SP_LAUNCH_TN(T)                                                                                            \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                SpGeo<T>::LDS_BYTES);                                                              \
+                                SpGeoTN<T>::LDS_BYTES);                                                            \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeo<T>::LDS_BYTES, s, g);                      \
+    hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeoTN<T>::LDS_BYTES, s, g);                    \
   } while (0)
   if (bn == 320) SP_LAUNCH_TN(5);
   else if (bn == 256) SP_LAUNCH_TN(4);
@@ -1033,12 +1153,11 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   TFGNN_LAUNCH_CHECK();
   const int64_t total = M * N;
   hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s,
-                     (const float*)d_workspace, splits, M, N, d_a_inv_scale, d_b_inv_scale, d_C, group_rows, stride_group,
-                     stride_row, stride_col, accumulate);
+                     (const float*)g.partial, splits, M, N, (const float*)ref, a_first_col, a_scale_block, d_C, group_rows,
+                     stride_group, stride_row, stride_col, accumulate);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
-
 
 int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream) {
   TFGNN_REQUIRE(d_x && d_out && n >= 0 && scale > 0.f && (uintptr_t)d_x % 16 == 0, "tfgnn_absmax: bad arguments");

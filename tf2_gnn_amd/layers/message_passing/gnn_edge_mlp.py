@@ -291,6 +291,14 @@ class GNN_Edge_MLP(MessagePassing):
         mlps.publish_grads()
         return dX
 
+    def _f16x2_eligible(self, V, D, L, H) -> bool:
+        """path A without target states on shapes the split-operand kernels tile (include/tfgnn.h tfgnn_sp_gemm_*)."""
+        def tiles(n):  # output widths the kernels tile: 320 / 256 / 128 columns
+            return n % 128 == 0 or n % 320 == 0
+
+        return (ops.get_gemm_mode() == ops.GEMM_F16X2 and not self._use_target_state_as_input and L > 0 and V > 0
+                and D % 16 == 0 and D <= 512 and 32 <= H <= 512 and tiles(H) and tiles(D) and (L * H) % 128 == 0)
+
     def _forward_A(self, X, g, fuse_act):
         if self._use_compact_buckets(g):
             return self._forward_A_compact(X, g, fuse_act)
@@ -300,6 +308,18 @@ class GNN_Edge_MLP(MessagePassing):
         row_scale, _, _, _ = self._scales(g)
         W = self._edge_type_mlps.kernels[0]  # [L, Din, H]
         Din = W.shape[1]
+        if self._f16x2_eligible(V, D, L, H):
+            # f16x2: the gather writes [A_0 | ... | A_{L-1}] directly as the split operand (one scale per (node, type)
+            # bucket), the kernels are split once per value, the product only moves data and multiplies
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L)
+            Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H)))
+            gelu_split = fuse_act == "gelu"
+            pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)
+            ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True}
+            if gelu_split:
+                ctx["pre"] = pre
+                return ops.activation_forward("gelu", pre), ctx
+            return pre, ctx
         A = torch.empty((V, L * Din), dtype=torch.float32, device=X.device)
         Arows = A.view(V * L, Din)
         ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, out=Arows[:, :D])
@@ -322,6 +342,29 @@ class GNN_Edge_MLP(MessagePassing):
             ctx["pre"] = pre
             return ops.activation_forward("gelu", pre), ctx
         return pre, ctx
+
+    def _backward_A_f16x2(self, d_agg, ctx, g, X, ew_s):
+        """path A backward on split operands: the transposed gather writes G = [G_0 | ... | G_{L-1}] as an SP16 operand
+        (one scale per (source, type) bucket) that serves both dX = G @ [W_0 | ... | W_{L-1}]^T (NT) and
+        dW_l = X^T G_l (TN, where the per-row scales become per-k factors: tfgnn_sp_gemm_tn)."""
+        V, D = X.shape
+        L, H = g.num_edge_types, self._hidden_dim
+        mlps = self._edge_type_mlps
+        W = mlps.kernels[0]  # [L, D, H]
+        G_sp = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED, d_agg.contiguous(), edge_weight=ew_s, rows_per_operand_row=L)
+        Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H)))
+        epi = getattr(self, "_out_epilogue", None)
+        if epi is not None:
+            dX = ops.sp_gemm_nt(G_sp, Wh_sp, out_mul=epi[0], act_grad=epi[1])
+            self._out_epilogue = None  # consumed
+        else:
+            dX = ops.sp_gemm_nt(G_sp, Wh_sp)
+        X_sp = ops.sp_split_rows(X)
+        dW = torch.empty_like(W)
+        ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))  # element ((l, h), d) -> dW[l, d, h]
+        mlps.grads = [dW]
+        mlps.publish_grads()
+        return dX
 
     def _mlp_all_types(self, X, L, ctx, mlps=None, key="mlp_acts"):
         """Y[:, l, :] = MLP_l(X) for all nodes -> [V, L, H]; hidden activations saved in ctx[key]."""
@@ -627,6 +670,8 @@ class GNN_Edge_MLP(MessagePassing):
             dM = self._message_grads(g, d_agg, ctx, Y, g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST), ew_d,
                                      node_scale, self._ident_e(g)[: g.num_edges])
             G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dM, col=g.array(ops.G_SRC2DST_POS)).view(V, L, H)
+        elif ctx.get("f16x2"):
+            return self._backward_A_f16x2(d_agg, ctx, g, X, ew_s)
         else:
             # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]
             G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=ew_s).view(V, L, H)

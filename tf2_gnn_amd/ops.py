@@ -320,22 +320,36 @@ def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> 
     return res
 
 
-GEMM_FP32, GEMM_BF16X3, GEMM_BF16X3_EXACT = 0, 6, 9
-_GEMM_MODE_NAMES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "bf16x3_9": GEMM_BF16X3_EXACT}
+GEMM_FP32, GEMM_BF16X3, GEMM_BF16X3_EXACT, GEMM_F16X2 = 0, 6, 9, 3
+_GEMM_MODE_NAMES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "bf16x3_9": GEMM_BF16X3_EXACT, "f16x2": GEMM_F16X2}
+_f16x2 = [None]  # None: not decided yet (environment TFGNN_GEMM_MODE=f16x2 switches it on)
+
+
+def _f16x2_on() -> bool:
+    if _f16x2[0] is None:
+        import os
+
+        _f16x2[0] = os.environ.get("TFGNN_GEMM_MODE", "") == "f16x2"
+        if _f16x2[0]:
+            _lib.check(_lib.load().tfgnn_gemm_set_mode(GEMM_BF16X3))
+    return _f16x2[0]
 
 
 def set_gemm_mode(mode) -> int:
-    """Select how ``gemm`` evaluates the fp32 product (include/tfgnn.h, tfgnn_gemm_set_mode): "fp32" (fp32 MFMA),
-    "bf16x3" (exact 3-way bf16 split of both operands, 6 piece products) or "bf16x3_9" (all 9).  Returns the
-    previous mode id."""
+    """Select how the Dense products are evaluated: "fp32" (fp32 MFMA), "bf16x3" (exact 3-way bf16 split of both operands,
+    6 piece products), "bf16x3_9" (all 9) - include/tfgnn.h, tfgnn_gemm_set_mode - or "f16x2": the layers hand the hot
+    products pre-split SP16 operands (tfgnn_sp_gemm_*: 2-way fp16 split, 3 piece products, the gather writes the
+    operand) and every other product runs as in "bf16x3".  Returns the previous mode id."""
     lib = _lib.load()
-    prev = lib.tfgnn_gemm_get_mode()
-    _lib.check(lib.tfgnn_gemm_set_mode(_GEMM_MODE_NAMES.get(mode, mode)))
+    prev = get_gemm_mode()
+    mode = _GEMM_MODE_NAMES.get(mode, mode)
+    _f16x2[0] = mode == GEMM_F16X2
+    _lib.check(lib.tfgnn_gemm_set_mode(GEMM_BF16X3 if mode == GEMM_F16X2 else mode))
     return prev
 
 
 def get_gemm_mode() -> int:
-    return _lib.load().tfgnn_gemm_get_mode()
+    return GEMM_F16X2 if _f16x2_on() else _lib.load().tfgnn_gemm_get_mode()
 
 
 def gemm(
@@ -789,13 +803,13 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
 
 def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
                scatter=None, accumulate: bool = False) -> torch.Tensor:
-    """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn); both operands carry ONE scale (scale_block 0).
-    ``a_cols`` / ``b_cols`` = (first column, count) select column ranges.  ``scatter`` = (group_rows, stride_group,
-    stride_row, stride_col) writes element (m, n) at out.flatten()[(m // group_rows) * stride_group + (m % group_rows) *
-    stride_row + n * stride_col]; default: row-major [M, N]."""
+    """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn).  ``a`` carries one scale per (row, block),
+    ``b`` one per row - what sp_split_rows / graph_gather_sp write.  ``a_cols`` / ``b_cols`` = (first column, count)
+    select column ranges.  ``scatter`` = (group_rows, stride_group, stride_row, stride_col) writes element (m, n) at
+    out.flatten()[(m // group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col]; default: row-major."""
     lib = _lib.load()
-    if a.scale_block != 0 or b.scale_block != 0:
-        raise ValueError("sp_gemm_tn: operands need one scale per tensor (fixed_inv_scale)")
+    if a.scale_block <= 0 or b.scale_block != b.cols:
+        raise ValueError("sp_gemm_tn: the left operand needs per-(row, block) scales, the right one one scale per row")
     if a.rows != b.rows:
         raise ValueError(f"sp_gemm_tn: K differs ({a.rows} vs {b.rows})")
     a0, M = a_cols if a_cols is not None else (0, a.cols)
@@ -808,13 +822,16 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
     if not out.is_contiguous() or out.numel() != M * N:
         raise ValueError(f"out must be contiguous with {M * N} elements")
     gr, sg, sr, sc = scatter if scatter is not None else (M, 0, N, 1)
-    ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(M, N, K)
-    ws = _workspace(a.data.device, ws_bytes) if ws_bytes else None
+    ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(M, N, K, a.cols, a.scale_block)
+    ws = _workspace(a.data.device, ws_bytes + 256) if ws_bytes else None
+    ws_ptr, ws_len = None, 0
+    if ws is not None:
+        off = (-ws.data_ptr()) % 256
+        ws_ptr, ws_len = ctypes.c_void_p(ws.data_ptr() + off), ws.numel() - off
     _lib.check(
         lib.tfgnn_sp_gemm_tn(
-            M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), _ptr(b.data), b.data.stride(0), b0,
-            _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), _ptr(ws), ws.numel() if ws is not None else 0,
-            _stream(),
+            M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
+            b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len, _stream(),
         )
     )
     return out
@@ -837,3 +854,24 @@ def absmax(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
     _lib.check(lib.tfgnn_absmax(_ptr(x), x.numel(), float(scale), _ptr(out), _stream()))
     return out
+
+
+_sp_weight_cache: "dict" = {}
+
+
+def sp_weight_operand(w: torch.Tensor, kind: str, build) -> SplitOperand:
+    """SP16 form of a weight tensor, built once per value: keyed on the tensor's storage and version (an in-place
+    optimizer update bumps the version), so forward and backward passes of a step - and every step of an evaluation
+    loop - share it.  ``build()`` makes the operand."""
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), kind)
+    hit = _sp_weight_cache.get(key)
+    if hit is not None and hit[0] == w._version and hit[2]() is not None:
+        return hit[1]
+    import weakref
+
+    op = build()
+    if len(_sp_weight_cache) > 256:
+        _sp_weight_cache.clear()
+    base = w._base if w._base is not None else w  # views are temporaries: the entry lives as long as the parameter buffer
+    _sp_weight_cache[key] = (w._version, op, weakref.ref(base))
+    return op

@@ -55,8 +55,8 @@ _, adjs = make_synthetic_batch(V, E, L, 8, seed=1)
 gr = ops.Graph(tuple(torch.from_numpy(a).to(dev) for a in adjs), V)
 X = torch.randn((V, H), device=dev)
 Gm = torch.randn((V, L * H), device=dev) * 1e-3
-xs = ops.sp_split_rows(X, fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(X)))
-gs = ops.sp_split_rows(Gm, fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(Gm)))
+xs = ops.sp_split_rows(X)
+gs = ops.sp_split_rows(Gm, scale_block=H)
 dW = torch.empty((L, H, H), device=dev)
 row = {"f16x2_tn_us": timeit(lambda: ops.sp_gemm_tn(gs, xs, out=dW, scatter=(H, H * H, 1, H)))}
 for mode in ("bf16x3", "fp32"):
@@ -64,14 +64,14 @@ for mode in ("bf16x3", "fp32"):
     row[mode + "_tn_us"] = timeit(lambda: ops.gemm(Gm, X, trans_a=True))
     ops.set_gemm_mode(prev)
 row["absmax_X_us"] = timeit(lambda: ops.absmax(X))
-row["split_X_fixed_us"] = timeit(lambda: ops.sp_split_rows(X, fixed_inv_scale=xs.inv_scale))
+row["split_X_us"] = timeit(lambda: ops.sp_split_rows(X, out=xs))
 res["dW 1280x320 K=30000"] = row
 print("dW", json.dumps(row), flush=True)
 rs = gr.array(ops.G_INVDEG_BY_DST)
 A = torch.empty((V * L, H), device=dev)
 row = {"gather_fp32_us": timeit(lambda: ops.graph_gather(gr, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, out=A)),
        "gather_sp_us": timeit(lambda: ops.graph_gather_sp(gr, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, rows_per_operand_row=L)),
-       "gather_sp_fixed_us": timeit(lambda: ops.graph_gather_sp(gr, ops.VIEW_BY_SRC_TYPED, X, fixed_inv_scale=xs.inv_scale, rows_per_operand_row=L))}
+       "gather_sp_fixed_us": timeit(lambda: ops.graph_gather_sp(gr, ops.VIEW_BY_SRC_TYPED, X, fixed_inv_scale=ops.tensor_inv_scale(ops.absmax(X)), rows_per_operand_row=L))}
 res["gather cfg-2"] = row
 print("gather", json.dumps(row), flush=True)
 json.dump(res, open("gpurun_out/sp_probe.json", "w"), indent=1)
