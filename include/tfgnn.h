@@ -232,6 +232,17 @@ int tfgnn_film_combine_backward(const float* d_grad_pre, const float* d_Z, const
  *                               (_compute_type_to_num_inedges, :116-124); targets outside [0, V) are skipped here and
  *                               reported by tfgnn_graph_create
  * Edge lists are int32 [n, 2], 8-byte aligned. */
+/* Batching of graph samples into one disjoint-union graph (data/graph_dataset.py:161-246: _add_graph_to_batch shifts
+ * graph i's node ids by the nodes before it, :210-222; node_to_graph_map, :211-217; _finalise_batch concatenates).  Per
+ * edge type the host lays the graphs' edge lists end to end with their LOCAL node ids (d_local_edges int32 [E, 2]) and
+ * passes the prefix sums d_edge_ptr [G+1] (edges of graphs 0..i-1) and d_node_ptr [G+1] (nodes):
+ *   tfgnn_batch_offset_edges      d_out[e] = d_local_edges[e] + d_node_ptr[graph of e]; *d_bad_flag (nullable, zeroed by
+ *                                 the caller) is set when a local id is outside its graph
+ *   tfgnn_batch_node_to_graph_map d_out[v] = graph of node v */
+int tfgnn_batch_offset_edges(const int32_t* d_local_edges, int64_t num_edges, const int32_t* d_edge_ptr,
+                             const int32_t* d_node_ptr, int num_graphs, int32_t* d_out, int* d_bad_flag, void* stream);
+int tfgnn_batch_node_to_graph_map(const int32_t* d_node_ptr, int num_graphs, int64_t num_nodes, int32_t* d_out,
+                                  void* stream);
 int tfgnn_adjacency_append(const int32_t* d_edges, int64_t num_edges, int flip, int32_t* d_out, void* stream);
 int tfgnn_adjacency_self_loops(int64_t num_nodes, int32_t* d_out, void* stream);
 int tfgnn_adjacency_in_degrees(const int32_t* d_edges, int64_t num_edges, int64_t num_nodes, float* d_counts,

@@ -54,6 +54,45 @@ def process_adjacency_lists(
     return arrays, counts
 
 
+# --- tf2_gnn/data/graph_dataset.py:161-246 --------------------------------------------------------
+def batch_graph_samples(samples, num_edge_types: int, max_nodes_per_batch: int):
+    """graph_batch_iterator_from_graph_iterator with _new_batch / _batch_would_be_too_full / _add_graph_to_batch /
+    _finalise_batch restated: ``samples`` = [(adjacency_lists per type (local ids, [E, 2]), node_features)].  A graph
+    that would push the node count over ``max_nodes_per_batch`` closes the batch (:167-171); graph i's node ids are
+    shifted by the nodes of the graphs before it (:210-222); node_to_graph_map holds the graph index per node (:211-217);
+    empty types become int32 [0, 2] (:239-243).  Pinned by tests/golden/reference_molecule_batch.json (the reference's
+    own output).  -> list of dicts with the reference's batch keys."""
+    batches, cur, nodes = [], [], 0
+
+    def finalise(graphs):
+        out = {"node_features": [], "node_to_graph_map": [], "num_graphs_in_batch": len(graphs)}
+        adj = [[] for _ in range(num_edge_types)]
+        offset = 0
+        for gi, (lists, feats) in enumerate(graphs):
+            n = len(feats)
+            out["node_features"].extend(feats)
+            out["node_to_graph_map"].append(np.full(n, gi, dtype=np.int32))
+            for t in range(num_edge_types):
+                adj[t].append(np.asarray(lists[t], dtype=np.int64).reshape(-1, 2) + offset)
+            offset += n
+        out["node_features"] = np.array(out["node_features"])
+        out["node_to_graph_map"] = np.concatenate(out["node_to_graph_map"]) if graphs else np.zeros(0, np.int32)
+        for t in range(num_edge_types):
+            a = np.concatenate(adj[t]) if adj[t] else np.zeros((0, 2), dtype=np.int64)
+            out[f"adjacency_list_{t}"] = a.astype(np.int32) if a.size else np.zeros((0, 2), dtype=np.int32)
+        return out
+
+    for lists, feats in samples:
+        n = len(feats)
+        if nodes + n > max_nodes_per_batch:
+            batches.append(finalise(cur))
+            cur, nodes = [], 0
+        cur.append((lists, feats))
+        nodes += n
+    batches.append(finalise(cur))
+    return batches
+
+
 # --- bucketing used by the HIP path (ours; the reference has no equivalent, it concatenates edge
 # --- lists and scatter-adds, message_passing.py:166-174) -----------------------------------------
 def bucket_edges(adjacency_lists: Sequence[np.ndarray], num_nodes: int, by: str = "dst"):

@@ -139,3 +139,40 @@ def test_gnn_film_oracle_doctest_shape_and_identity_modulation():
     a = orc.message_passing_call("gnn_film", params, {"edge_mlps": edge, "film_mlps": ident}, Xc, adjs)
     b = orc.message_passing_call("gnn_edge_mlp", params, {"edge_mlps": edge}, Xc, adjs)
     assert torch.allclose(a, b, atol=1e-12)
+
+
+# ---- the reference's own real-graph fixture, run through the reference's own data pipeline ------------------------
+@pytest.fixture(scope="module")
+def molecule_fixture():
+    import json
+    from pathlib import Path
+
+    return json.loads((Path(__file__).resolve().parent / "golden" / "reference_molecule_batch.json").read_text())
+
+
+@pytest.mark.parametrize("cfg_idx", [0, 1])
+def test_molecule_fixture_samples_and_batches(molecule_fixture, cfg_idx):
+    """tests/golden/reference_molecule_batch.json (made by executing JsonLGraphPropertyDataset on
+    tf2_gnn/test/test_datasets/train.jsonl.gz): the oracle's process_adjacency_lists reproduces every per-graph sample
+    and its batch_graph_samples every batch (node offsets, node_to_graph_map, batch boundaries), bit for bit."""
+    cfg = molecule_fixture["configs"][cfg_idx]
+    p = cfg["params"]
+    tied = ao.get_tied_edge_types(p["tie_fwd_bkwd_edges"], p["num_fwd_edge_types"])
+    samples = []
+    for g, ref in zip(molecule_fixture["graphs"], cfg["samples"]):
+        adj, counts = ao.process_adjacency_lists([list(map(tuple, a)) for a in g["adjacency_lists"]], len(g["node_features"]),
+                                                 p["add_self_loop_edges"], tied)
+        assert len(adj) == cfg["num_edge_types"] == len(ref["adjacency_lists"])
+        for got, exp in zip(adj, ref["adjacency_lists"]):
+            assert np.array_equal(got, np.array(exp, dtype=np.int32).reshape(-1, 2))
+        assert np.array_equal(counts, np.array(ref["type_to_node_to_num_inedges"]))
+        samples.append((adj, g["node_features"]))
+    batches = ao.batch_graph_samples(samples, cfg["num_edge_types"], p["max_nodes_per_batch"])
+    assert len(batches) == len(cfg["batches"])
+    for got, exp in zip(batches, cfg["batches"]):
+        assert got["num_graphs_in_batch"] == exp["num_graphs_in_batch"]
+        assert np.array_equal(got["node_to_graph_map"], np.array(exp["node_to_graph_map"], dtype=np.int32))
+        assert np.array_equal(got["node_features"], np.array(exp["node_features"]))
+        for t in range(cfg["num_edge_types"]):
+            assert got[f"adjacency_list_{t}"].dtype == np.int32
+            assert np.array_equal(got[f"adjacency_list_{t}"], np.array(exp["adjacency_lists"][t], dtype=np.int32).reshape(-1, 2))

@@ -140,6 +140,8 @@ _SIGNATURES = [
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    ("tfgnn_batch_offset_edges", c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    ("tfgnn_batch_node_to_graph_map", c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     ("tfgnn_adjacency_append", c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     ("tfgnn_adjacency_self_loops", c_int, [c_int64, c_void_p, c_void_p]),
     ("tfgnn_adjacency_in_degrees", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -273,6 +273,38 @@ adjacency_in_degrees_kernel(const int32_t* __restrict__ edges, int64_t n, int64_
     atomicAdd(&counts[d], 1.0f);  // integer-valued: exact and order-independent below 2^24 edges per node
   }
 }
+
+// ---- batching of graph samples (tf2_gnn/data/graph_dataset.py:202-246) ------------------------------------------
+// A batch is the disjoint union of its graphs: graph i's node ids are shifted by the number of nodes of the graphs
+// before it (_add_graph_to_batch, :210-222) and node_to_graph_map[v] = i (:211-217).  The host hands over, per edge
+// type, the graphs' edge lists laid end to end WITH THEIR LOCAL node ids plus the prefix sums; the offsets are added
+// here, one thread per edge / node, by a binary search of the element's position in the prefix array.
+__device__ __forceinline__ int upper_bound_minus_one(const int32_t* __restrict__ ptr, int n, int64_t pos) {
+  int lo = 0, hi = n;  // ptr[0] = 0 <= pos < ptr[n]; returns i with ptr[i] <= pos < ptr[i + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)ptr[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) batch_offset_edges_kernel(const int32_t* __restrict__ local_edges, int64_t num_edges,
+                                                                 const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ node_ptr,
+                                                                 int num_graphs, int32_t* __restrict__ out, int* __restrict__ bad) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges; e += (int64_t)gridDim.x * blockDim.x) {
+    const int g = upper_bound_minus_one(edge_ptr, num_graphs, e);
+    const int2 le = reinterpret_cast<const int2*>(local_edges)[e];
+    const int base = node_ptr[g], n = node_ptr[g + 1] - base;
+    if (bad && ((unsigned)le.x >= (unsigned)n || (unsigned)le.y >= (unsigned)n)) *bad = 1;
+    reinterpret_cast<int2*>(out)[e] = make_int2(le.x + base, le.y + base);
+  }
+}
+
+__global__ void __launch_bounds__(256) batch_node_to_graph_kernel(const int32_t* __restrict__ node_ptr, int num_graphs, int64_t num_nodes,
+                                                                  int32_t* __restrict__ out) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < num_nodes; v += (int64_t)gridDim.x * blockDim.x)
+    out[v] = upper_bound_minus_one(node_ptr, num_graphs, v);
+}
 }  // namespace tfgnn
 
 extern "C" int tfgnn_adjacency_append(const int32_t* d_edges, int64_t num_edges, int flip, int32_t* d_out, void* stream) {
@@ -309,6 +341,31 @@ extern "C" int tfgnn_adjacency_in_degrees(const int32_t* d_edges, int64_t num_ed
   TFGNN_REQUIRE(d_edges != nullptr, "NULL pointer");
   hipLaunchKernelGGL(adjacency_in_degrees_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_edges, 256), 65535)),
                      dim3(256), 0, (hipStream_t)stream, d_edges, num_edges, num_nodes, d_counts, (int*)nullptr);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_batch_offset_edges(const int32_t* d_local_edges, int64_t num_edges, const int32_t* d_edge_ptr,
+                                        const int32_t* d_node_ptr, int num_graphs, int32_t* d_out, int* d_bad_flag, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && num_graphs >= 0, "negative size");
+  if (num_edges == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_local_edges && d_edge_ptr && d_node_ptr && d_out && num_graphs > 0, "NULL pointer / no graphs");
+  TFGNN_REQUIRE(((uintptr_t)d_local_edges | (uintptr_t)d_out) % 8 == 0, "edge lists must be 8-byte aligned");
+  hipLaunchKernelGGL(batch_offset_edges_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_edges, 256), 65535)), dim3(256), 0,
+                     (hipStream_t)stream, d_local_edges, num_edges, d_edge_ptr, d_node_ptr, num_graphs, d_out, d_bad_flag);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_batch_node_to_graph_map(const int32_t* d_node_ptr, int num_graphs, int64_t num_nodes, int32_t* d_out,
+                                             void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_graphs >= 0, "negative size");
+  if (num_nodes == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_node_ptr && d_out && num_graphs > 0, "NULL pointer / no graphs");
+  hipLaunchKernelGGL(batch_node_to_graph_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_nodes, 256), 65535)), dim3(256), 0,
+                     (hipStream_t)stream, d_node_ptr, num_graphs, num_nodes, d_out);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
