@@ -86,7 +86,9 @@ __device__ __forceinline__ float4 grad_epilogue(const X3Args& g, float4 v, int64
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
   const unsigned xb = __float_as_uint(x);
   const unsigned hb = xb & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hb);
+  // +-inf / nan: the class stays in h, the lower pieces are 0 (inf - inf would make them NaN and turn a product that
+  // is +-inf in fp32 into NaN); one v_cmp_class + one v_cndmask per element
+  const float r1 = __builtin_isfinite(x) ? x - __uint_as_float(hb) : 0.f;
   const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
   const float r2 = r1 - __uint_as_float(mb);
   h = hb;
