@@ -340,6 +340,10 @@ int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const 
                              const float* d_h, float* d_dmx, float* d_dmh, float* d_dh_direct,
                              int64_t V, int H, void* stream);
 
+/* tf.maximum(x, lower) then tf.minimum(., upper) (nodes_to_graph_representation.py:194-197; pass -inf / +inf for an absent
+ * bound) and its gradient: dx = dy where lower <= x <= upper, else 0 (TensorFlow's MaximumMinimumGrad). */
+int tfgnn_clip(const float* d_x, int64_t n, float lower, float upper, float* d_y, void* stream);
+int tfgnn_clip_backward(const float* d_dy, const float* d_x, int64_t n, float lower, float upper, float* d_dx, void* stream);
 /* out[n] = sum_m in[m, n] (bias gradients of Dense / GRUCell). */
 size_t tfgnn_colsum_workspace_bytes(int64_t M, int N);
 int tfgnn_colsum(const float* d_in, int64_t M, int N, int64_t ld, float* d_out, void* d_workspace,
@@ -396,6 +400,11 @@ int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, con
  *   *_backward: gradients of the two ops above (tf.GradientTape in the reference).
  * ------------------------------------------------------------------------------------------ */
 int tfgnn_segment_offsets(const int32_t* d_ids, int64_t V, int64_t G, int32_t* d_ptr, void* stream);
+/* The same without the validity read-back: no allocation, no synchronisation.  *d_error_flag (zeroed by the caller) gets
+ * bit 0 = an id outside [0, G), bit 1 = ids not sorted; the caller reads it when it wants to know (the host mirror does so
+ * once per batch and shares the offsets between the pooling layers, the global exchanges and the task head). */
+int tfgnn_segment_offsets_async(const int32_t* d_ids, int64_t V, int64_t G, int32_t* d_ptr, int32_t* d_error_flag,
+                                void* stream);
 int tfgnn_segment_softmax(const float* d_scores, int64_t ld, int heads, const int32_t* d_ptr, int64_t G,
                           float* d_out, int64_t ld_out, void* stream);
 int tfgnn_segment_weighted_sum(const float* d_R, const float* d_w, const int32_t* d_ptr, int64_t G, int GD,

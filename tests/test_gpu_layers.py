@@ -684,3 +684,84 @@ def test_gnn_with_graph_global_exchange_parity(dev, mode, wf):
     out_t = gnn(inp, training=True)
     gnn.backward(dOut.to(dev))
     assert bool(torch.isfinite(out_t).all())
+
+
+@pytest.mark.parametrize("wf", ["softmax", "sigmoid"])
+def test_pooling_training_mode_dropout_and_clipping_parity(dev, wf):
+    """Training mode of WeightedSumGraphRepresentation: tf.nn.dropout on the inputs of the MLPs' hidden layers (default
+    rate 0.2, nodes_to_graph_representation.py:130-148) and the result clipping (:194-197), forward and backward, with
+    the masks the HIP path DREW handed to the oracle; and: the masks are real (rate, scaling), eval mode draws none."""
+    from tf2_gnn_amd.layers import NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
+
+    g = torch.Generator().manual_seed(5)
+    sizes = [4, 9, 1, 30, 7]
+    ids = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)])
+    V, VD, GD, heads = int(ids.numel()), 24, 16, 4
+    X = torch.randn((V, VD), generator=g)
+    layer = WeightedSumGraphRepresentation(GD, heads, weighting_fun=wf, scoring_mlp_layers=[32], transformation_mlp_layers=[32, 16],
+                                           transformation_mlp_activation_fun="tanh", scoring_mlp_dropout_rate=0.25,
+                                           transformation_mlp_dropout_rate=0.5, transformation_mlp_result_lower_bound=-0.3,
+                                           transformation_mlp_result_upper_bound=0.4)
+    inp = NodesToGraphRepresentationInput(X.to(dev), ids.to(dev), len(sizes))
+    out = layer(inp, training=True)
+    masks = {"scoring": [None if m is None else m.cpu() for m in layer._scoring_mlp.last_dropout_masks],
+             "transformation": [None if m is None else m.cpu() for m in layer._transformation_mlp.last_dropout_masks]}
+    assert masks["scoring"][0] is not None and masks["scoring"][-1] is None  # hidden-layer inputs only
+    assert masks["transformation"][0] is not None and masks["transformation"][1] is not None and masks["transformation"][2] is None
+    m0 = masks["transformation"][0]
+    assert set(torch.unique(m0).tolist()) <= {0.0, 2.0} and 0.3 < float((m0 == 0).float().mean()) < 0.7
+    cfg = {"graph_representation_size": GD, "num_heads": heads, "weighting_fun": wf, "scoring_mlp_activation_fun": "ReLU",
+           "transformation_mlp_activation_fun": "tanh", "transformation_mlp_result_lower_bound": -0.3,
+           "transformation_mlp_result_upper_bound": 0.4}
+    w = _pool_weights(layer)
+    X64 = X.double().requires_grad_(True)
+    w64 = {k: ([t.double().requires_grad_(True) for t in ks], [None if b is None else b.double() for b in bs]) for k, (ks, bs) in w.items()}
+    m64 = {k: [None if m is None else m.double() for m in v] for k, v in masks.items()}
+    ref = orc.weighted_sum_graph_representation(cfg, w64, X64, ids, len(sizes), dropout_masks=m64)
+    assert_close(out.cpu(), ref.detach().float(), tol=1e-5, what=f"pool training {wf}")
+    dOut = torch.randn((len(sizes), GD), generator=g)
+    dX = layer.backward(dOut.to(dev))
+    leaves = [X64] + w64["transformation"][0] + w64["scoring"][0]
+    grads = torch.autograd.grad((ref * dOut.double()).sum(), leaves)
+    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=f"pool training {wf} dX")
+    got_k = [v.grad.cpu() for v in layer._transformation_mlp.kernels] + [v.grad.cpu() for v in layer._scoring_mlp.kernels]
+    for a, b in zip(got_k, grads[1:]):
+        assert_close(a, b.float(), tol=2e-5, what=f"pool training {wf} dKernel")
+    # the same masks injected reproduce the forward bit for bit; eval mode draws none
+    layer.dropout_masks = {k: [None if m is None else m.to(dev) for m in v] for k, v in masks.items()}
+    assert torch.equal(layer(inp, training=True), out)
+    layer.dropout_masks = None
+    layer(inp, training=False)
+    assert all(m is None for m in layer._transformation_mlp.last_dropout_masks)
+
+
+def test_graph_cache_does_not_return_a_stale_graph_for_reallocated_adjacency_tensors(dev):
+    """the Graph cache was keyed on tensor addresses only - a new batch whose adjacency tensors got the freed
+    addresses of the previous one (same shapes, fresh version counters) was handed the old bucketing."""
+    import gc
+
+    from tf2_gnn_amd.layers import MessagePassingInput, RGCN
+    from tf2_gnn_amd.layers.message_passing import clear_graph_cache
+
+    V, L, H = 50, 2, 8
+    layer = RGCN(dict(RGCN.get_default_hyperparameters(), hidden_dim=H))
+    layer.build(MessagePassingInput((None, H), tuple((None, 2) for _ in range(L))))
+    X = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
+    clear_graph_cache()
+    outs, ptrs = [], []
+    for seed in range(4):
+        adjs = random_graph(V, 400, L, seed=seed)
+        adj_dev = to_dev(adjs, dev)
+        ptrs.append(tuple(a.data_ptr() for a in adj_dev))
+        out = layer(MessagePassingInput(X, adj_dev), training=False)
+        ref = orc.message_passing_call("rgcn", layer._params if hasattr(layer, "_params") else dict(RGCN.get_default_hyperparameters(), hidden_dim=H),
+                                       mp_weights_from_layer(layer), X.cpu(), [torch.from_numpy(a) for a in adjs])
+        assert_close(out.cpu(), ref, tol=1e-5, what=f"graph cache batch {seed}")
+        del adj_dev, out
+        gc.collect()
+    # strides and devices are part of the key: a transposed view of the same storage is a different graph
+    a = torch.randint(0, V, (2, 300), dtype=torch.int32, device=dev)
+    view = a.t()  # [300, 2] with strides (1, 300)
+    o1 = layer(MessagePassingInput(X, (view, view.contiguous())), training=False)
+    o2 = layer(MessagePassingInput(X, (view.contiguous(), view.contiguous())), training=False)
+    assert torch.allclose(o1, o2)

@@ -114,6 +114,9 @@ _SIGNATURES = [
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     ),
     ("tfgnn_segment_offsets", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_segment_offsets_async", c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    ("tfgnn_clip", c_int, [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    ("tfgnn_clip_backward", c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
     ("tfgnn_segment_softmax", c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     ("tfgnn_segment_weighted_sum", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     (

@@ -480,6 +480,20 @@ transpose_batched_kernel(const float* __restrict__ src, int64_t rows, int64_t co
     if (r < rows && c < cols) d[c * rows + r] = tile[tx][ty + 8 * i];
   }
 }
+// tf.maximum(x, lo) / tf.minimum(x, hi) and their gradient (the gradient flows where lo <= x <= hi, TensorFlow's
+// MaximumMinimumGrad: x >= lo for the maximum, x <= hi for the minimum) - nodes_to_graph_representation.py:194-197
+__global__ void __launch_bounds__(256) clip_kernel(const float* __restrict__ x, int64_t n, float lo, float hi, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+__global__ void __launch_bounds__(256) clip_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t n, float lo,
+                                                            float hi, float* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    dx[i] = (v >= lo && v <= hi) ? dy[i] : 0.f;
+  }
+}
+
 }  // namespace tfgnn
 
 extern "C" int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_t rows, int64_t cols, float* d_dst,
@@ -491,6 +505,29 @@ extern "C" int tfgnn_transpose_batched(const float* d_src, int64_t batch, int64_
   TFGNN_REQUIRE(batch < 65536 && ceil_div(rows, 32) < 65536, "transpose grid too large");
   dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32), (unsigned)batch);
   hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, d_dst);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+/* lower / upper: the bounds, or -inf / +inf for "no bound" */
+extern "C" int tfgnn_clip(const float* d_x, int64_t n, float lower, float upper, float* d_y, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_y, "NULL pointer");
+  hipLaunchKernelGGL(clip_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 16384)), dim3(256), 0, (hipStream_t)stream, d_x, n,
+                     lower, upper, d_y);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_clip_backward(const float* d_dy, const float* d_x, int64_t n, float lower, float upper, float* d_dx, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_dy && d_x && d_dx, "NULL pointer");
+  hipLaunchKernelGGL(clip_backward_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 16384)), dim3(256), 0, (hipStream_t)stream,
+                     d_dy, d_x, n, lower, upper, d_dx);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

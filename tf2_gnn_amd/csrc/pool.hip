@@ -133,6 +133,19 @@ static unsigned blocks_for(int64_t n) { return (unsigned)std::max<int64_t>(1, st
 
 }  // namespace tfgnn
 
+// no allocation, no synchronisation: the caller owns the error word (zeroed by it), reads it when it wants to know
+extern "C" int tfgnn_segment_offsets_async(const int32_t* d_ids, int64_t V, int64_t G, int32_t* d_ptr, int32_t* d_error_flag,
+                                           void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && G >= 0, "negative size");
+  TFGNN_REQUIRE(d_ptr && d_error_flag && (V == 0 || d_ids), "NULL pointer");
+  TFGNN_REQUIRE(G < ((int64_t)1 << 31) - 1 && V < ((int64_t)1 << 31) - 1, "too large");
+  hipLaunchKernelGGL(segment_offsets_kernel, dim3(blocks_for(std::max(V, G + 1))), dim3(256), 0, (hipStream_t)stream, d_ids, V, G,
+                     d_ptr, d_error_flag);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
 extern "C" int tfgnn_segment_offsets(const int32_t* d_ids, int64_t V, int64_t G, int32_t* d_ptr, void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(V >= 0 && G >= 0, "negative size");

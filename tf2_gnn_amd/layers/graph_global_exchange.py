@@ -165,7 +165,7 @@ class GraphGlobalMLPExchange(GraphGlobalExchange):
         cat = torch.empty((X.shape[0], 2 * H), dtype=torch.float32, device=X.device)
         cat[:, :H].copy_(per_node)
         cat[:, H:].copy_(X)
-        return self._mlp(cat)
+        return self._mlp(cat, training=training, dropout_masks=getattr(self, "mlp_dropout_masks", None))
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
         H = self._hidden_dim

@@ -35,18 +35,29 @@ def get_activation_function_by_name(name: Optional[str]) -> Optional[str]:
 
 
 class MLP:
-    """[ext] dpu_utils.tf2utils.MLP on the HIP GEMM: hidden Dense layers (activation), final linear
-    Dense; optional biases.  Dropout on layer inputs in training mode is NOT applied (the pooling
-    MLPs are evaluated deterministically)."""
+    """[ext] dpu_utils.tf2utils.MLP on the HIP GEMMs: hidden Dense layers (activation), final linear Dense; optional
+    biases; in training mode tf.nn.dropout(rate) on the input of every HIDDEN Dense layer (call sites:
+    nodes_to_graph_representation.py:130-148 with rate 0.2 by default, graph_global_exchange.py:171-183,
+    models/graph_regression_task.py:65-69).  [ext] dpu_utils is not installed here, so which layer inputs are dropped
+    is unpinned; the choice "all but the final layer" is the one under which the reference's own QM9 task works:
+    models/qm9_regression.py:49-62 passes out_layer_dropout_keep_prob = 1.0 as the dropout RATE of two MLPs without
+    hidden layers - tf.nn.dropout(rate=1.0) on their inputs would raise (rate must be in [0, 1)) or zero them.
+    ``dropout_masks`` (one tensor per Dense layer, already scaled by 1/(1-rate), or None entries) replaces the drawn
+    masks - the parity tests hand the oracle the same masks."""
+
+    _seed_counter = [0]
 
     def __init__(self, out_size, hidden_layers, use_biases=False, activation_fun="relu", dropout_rate=0.0, name="MLP"):
         self._out_size = out_size
         self._sizes = ([out_size] * hidden_layers if isinstance(hidden_layers, int) else list(hidden_layers)) + [out_size]
         self._use_biases = use_biases
         self._act = activation_fun
+        self._dropout_rate = float(dropout_rate)
         self._name = name
         self.kernels: List[Variable] = []
         self.biases: List[Optional[Variable]] = []
+        self.dropout_seed = 0
+        self.last_dropout_masks: List[Optional[torch.Tensor]] = []
         self._ctx = None
 
     def build(self, in_size: int):
@@ -71,12 +82,24 @@ class MLP:
                 out.append(b)
         return out
 
-    def __call__(self, x, final_act=None):
+    def __call__(self, x, final_act=None, training: bool = False, dropout_masks=None):
         """-> MLP(x), optionally with ``final_act`` applied to the output."""
-        hs, pres = [x], []
+        ins, outs, pres, masks = [], [], [], []
         cur = x
         n = len(self.kernels)
         for j, (k, b) in enumerate(zip(self.kernels, self.biases)):
+            mask = None
+            if dropout_masks is not None:
+                mask = dropout_masks[j]
+                if mask is not None:
+                    cur = ops.mul(cur, mask)
+            elif training and self._dropout_rate > 0.0 and j < n - 1:
+                if self._dropout_rate >= 1.0:
+                    raise ValueError("rate must be a scalar tensor or a float in the range [0, 1), got %g" % self._dropout_rate)
+                MLP._seed_counter[0] += 1
+                cur, mask = ops.dropout_forward(cur, self._dropout_rate, self.dropout_seed * 1000003 + MLP._seed_counter[0])
+            masks.append(mask)
+            ins.append(cur)  # the (dropped) input of Dense layer j
             act = self._act if j < n - 1 else final_act
             bias = None if b is None else b.value
             if act == "gelu":
@@ -86,22 +109,25 @@ class MLP:
             else:
                 cur = ops.gemm(cur, k.value, bias=bias, act=act)
                 pres.append(None)
-            hs.append(cur)
-        self._ctx = (hs, pres, final_act)
+            outs.append(cur)  # the output of layer j (before the next layer's dropout)
+        self.last_dropout_masks = masks
+        self._ctx = (ins, outs, pres, final_act, masks)
         return cur
 
     def backward(self, grad):
-        hs, pres, final_act = self._ctx
+        ins, outs, pres, final_act, masks = self._ctx
         n = len(self.kernels)
         d = grad
         for j in range(n - 1, -1, -1):
             act = self._act if j < n - 1 else final_act
             if act is not None:
-                d = ops.activation_backward(act, d, pres[j] if act == "gelu" else hs[j + 1])
-            self.kernels[j].grad = ops.gemm(hs[j], d, trans_a=True)
+                d = ops.activation_backward(act, d, pres[j] if act == "gelu" else outs[j])
+            self.kernels[j].grad = ops.gemm(ins[j], d, trans_a=True)
             if self.biases[j] is not None:
                 self.biases[j].grad = ops.colsum(d)
             d = ops.gemm(d, self.kernels[j].value, trans_b=True)
+            if masks[j] is not None:
+                d = ops.mul(d, masks[j])
         return d
 
 
@@ -126,10 +152,34 @@ class NodesToGraphRepresentation:
         """-> float32 [G, GD]"""
 
 
+_OFFSETS_CACHE: "dict" = {}
+
+
 def segment_offsets(node_to_graph_map: torch.Tensor, num_graphs: int) -> torch.Tensor:
-    ids = node_to_graph_map.to(torch.int32).contiguous()
+    """ptr [G + 1] of the sorted node_to_graph_map (tfgnn_segment_offsets_async), computed and VALIDATED once per batch:
+    the pooling layers, the global exchanges and the task head of a step all ask for the same map - the entry is keyed
+    on the tensor (address, length, version, G) and keeps it alive; only the first request reads the error word back
+    (unsorted / out-of-range ids raise like tf.math.segment_sum's InvalidArgument).  No allocation or synchronisation
+    inside the library."""
+    ids = node_to_graph_map
+    if ids.dtype != torch.int32 or not ids.is_contiguous():
+        ids = ids.to(torch.int32).contiguous()
+    key = (ids.data_ptr(), ids.numel(), ids._version, int(num_graphs), str(ids.device))
+    hit = _OFFSETS_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
     ptr = torch.empty(num_graphs + 1, dtype=torch.int32, device=ids.device)
-    _lib.check(_lib.load().tfgnn_segment_offsets(ops._ptr(ids), ids.numel(), num_graphs, ops._ptr(ptr), ops._stream()))
+    flag = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    _lib.check(_lib.load().tfgnn_segment_offsets_async(ops._ptr(ids), ids.numel(), num_graphs, ops._ptr(ptr), ops._ptr(flag),
+                                                       ops._stream()))
+    err = int(flag.item())  # the one read-back per batch
+    if err & 1:
+        raise ValueError(f"tfgnn: node_to_graph_map contains an id outside [0, {num_graphs})")
+    if err & 2:
+        raise ValueError("tfgnn: node_to_graph_map is not sorted (tf.math.segment_sum requires sorted segment ids)")
+    if len(_OFFSETS_CACHE) >= 8:
+        _OFFSETS_CACHE.pop(next(iter(_OFFSETS_CACHE)))
+    _OFFSETS_CACHE[key] = (ptr, ids)
     return ptr
 
 
@@ -188,6 +238,8 @@ class WeightedSumGraphRepresentation(NodesToGraphRepresentation):
             name="TransformationMLP",
         )
         self._ctx = None
+        # tests: {"scoring": [mask per Dense layer], "transformation": [...]} replaces the drawn dropout masks
+        self.dropout_masks = None
 
     def build(self, input_shapes: NodesToGraphRepresentationInput):
         vd = int(input_shapes.node_embeddings[-1])
@@ -209,22 +261,27 @@ class WeightedSumGraphRepresentation(NodesToGraphRepresentation):
         V = X.shape[0]
         G = int(inputs.num_graphs)
         GD, heads = self._graph_representation_size, self._num_heads
-        if self._transformation_mlp_result_lower_bound is not None or self._transformation_mlp_result_upper_bound is not None:
-            raise NotImplementedError("transformation_mlp_result_{lower,upper}_bound clipping")
         lib = _lib.load()
         ids = inputs.node_to_graph_map.to(torch.int32).contiguous()
         ptr = segment_offsets(ids, G)
+        masks = self.dropout_masks or {}
         w = None
         if self._weighting_fun == "sigmoid":
-            w = self._scoring_mlp(X, final_act="sigmoid")  # [V, heads]
+            w = self._scoring_mlp(X, final_act="sigmoid", training=training, dropout_masks=masks.get("scoring"))  # [V, heads]
         elif self._weighting_fun == "softmax":
-            scores = self._scoring_mlp(X)
+            scores = self._scoring_mlp(X, training=training, dropout_masks=masks.get("scoring"))
             w = torch.empty_like(scores)
             _lib.check(
                 lib.tfgnn_segment_softmax(ops._ptr(scores), heads, heads, ops._ptr(ptr), G, ops._ptr(w), heads, ops._stream())
             )
         # nodes_to_graph_representation.py:191-193: the activation is applied to the MLP *output* too
-        R = self._transformation_mlp(X, final_act=self._transformation_mlp_activation_fun)  # [V, GD]
+        R = self._transformation_mlp(X, final_act=self._transformation_mlp_activation_fun, training=training,
+                                     dropout_masks=masks.get("transformation"))  # [V, GD]
+        lo, hi = self._transformation_mlp_result_lower_bound, self._transformation_mlp_result_upper_bound
+        R_unclipped = None
+        if lo is not None or hi is not None:  # :194-197
+            R_unclipped = R
+            R = ops.clip(R, lo, hi)
         out = torch.empty((G, GD), dtype=torch.float32, device=X.device)
         _lib.check(
             lib.tfgnn_segment_weighted_sum(
@@ -232,7 +289,7 @@ class WeightedSumGraphRepresentation(NodesToGraphRepresentation):
                 ops._ptr(out), ops._stream(),
             )
         )
-        self._ctx = {"ids": ids, "ptr": ptr, "w": w, "R": R, "V": V, "G": G}
+        self._ctx = {"ids": ids, "ptr": ptr, "w": w, "R": R, "V": V, "G": G, "R_unclipped": R_unclipped}
         return out
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
@@ -252,6 +309,9 @@ class WeightedSumGraphRepresentation(NodesToGraphRepresentation):
                 ops._stream(),
             )
         )
+        if c["R_unclipped"] is not None:
+            dR = ops.clip_backward(dR, c["R_unclipped"], self._transformation_mlp_result_lower_bound,
+                                   self._transformation_mlp_result_upper_bound)
         dX = self._transformation_mlp.backward(dR)
         if self._weighting_fun == "sigmoid":
             dXs = self._scoring_mlp.backward(dW)  # sigmoid handled as the MLP's final activation

@@ -520,6 +520,27 @@ def dropout_forward(x: torch.Tensor, rate: float, seed: int):
     return y, mask
 
 
+def clip(x: torch.Tensor, lower: Optional[float], upper: Optional[float]) -> torch.Tensor:
+    """tf.minimum(tf.maximum(x, lower), upper); None = no bound."""
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lo = float("-inf") if lower is None else float(lower)
+    hi = float("inf") if upper is None else float(upper)
+    _lib.check(lib.tfgnn_clip(_ptr(x), x.numel(), lo, hi, _ptr(y), _stream()))
+    return y
+
+
+def clip_backward(dy: torch.Tensor, x: torch.Tensor, lower: Optional[float], upper: Optional[float]) -> torch.Tensor:
+    lib = _lib.load()
+    dy, x = dy.contiguous(), x.contiguous()
+    dx = torch.empty_like(dy)
+    lo = float("-inf") if lower is None else float(lower)
+    hi = float("inf") if upper is None else float(upper)
+    _lib.check(lib.tfgnn_clip_backward(_ptr(dy), _ptr(x), x.numel(), lo, hi, _ptr(dx), _stream()))
+    return dx
+
+
 def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     a = a.contiguous()

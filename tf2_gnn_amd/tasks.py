@@ -9,8 +9,8 @@ of ``GraphDataset._finalise_batch``: "node_features", "adjacency_list_<i>", "nod
 of every trainable variable with d loss / d variable.  The optimizer, the epoch loop, datasets and checkpoint I/O are
 the reference's control plane and stay out (out of scope).
 
-MLP-input dropout of the heads (``out_layer_dropout_keep_prob``, ``regression_mlp_dropout``,
-``graph_aggregation_dropout_rate``) is not applied, as in the pooling layers.
+MLP-input dropout of the heads (``regression_mlp_dropout``, ``graph_aggregation_dropout_rate``; QM9 hands
+``out_layer_dropout_keep_prob`` over as a rate) is applied in training mode as in the pooling layers (layers/nodes_to_graph_representation.py MLP).
 """
 from __future__ import annotations
 
@@ -220,8 +220,11 @@ class QM9RegressionTask(GraphTaskModel):
                  num_edge_types: Optional[int] = None, task_id: int = 0):
         super().__init__(params, dataset=dataset, name=name, num_edge_types=num_edge_types)
         self._task_id = int(getattr(dataset, "_params", {}).get("task_id", task_id)) if dataset is not None else int(task_id)
-        self._regression_gate = MLP(out_size=1, hidden_layers=[], use_biases=True, name="gate")
-        self._regression_transform = MLP(out_size=1, hidden_layers=[], use_biases=True, name="transform")
+        # qm9_regression.py:49-62: the "keep prob" hyper-parameter is handed over as the dropout RATE; without hidden layers
+        # the MLPs never draw a mask (see layers/nodes_to_graph_representation.py MLP)
+        rate = float(self._params["out_layer_dropout_keep_prob"])
+        self._regression_gate = MLP(out_size=1, hidden_layers=[], use_biases=True, dropout_rate=rate, name="gate")
+        self._regression_transform = MLP(out_size=1, hidden_layers=[], use_biases=True, dropout_rate=rate, name="transform")
 
     def build(self, input_shapes):
         H = int(self._params["gnn_hidden_dim"])
@@ -238,8 +241,8 @@ class QM9RegressionTask(GraphTaskModel):
         h = final_node_representations
         x0 = batch_features["node_features"]
         G = int(batch_features["num_graphs_in_batch"])
-        per_node_output = self._regression_transform(h)  # [V, 1]
-        per_node_weight = self._regression_gate(torch.cat([x0, h], dim=1), final_act="sigmoid")  # [V, 1], sigmoid applied
+        per_node_output = self._regression_transform(h, training=training)  # [V, 1]
+        per_node_weight = self._regression_gate(torch.cat([x0, h], dim=1), final_act="sigmoid", training=training)  # [V, 1]
         ids = batch_features["node_to_graph_map"].to(torch.int32).contiguous()
         ptr = segment_offsets(ids, G)
         out = torch.empty((G, 1), dtype=torch.float32, device=h.device)
@@ -319,7 +322,8 @@ class GraphRegressionTask(GraphTaskModel):
         self._weighted_avg_of_nodes_to_graph_repr = pooling("softmax")
         self._weighted_sum_of_nodes_to_graph_repr = pooling("sigmoid")
         self._regression_mlp = MLP(out_size=1, hidden_layers=params["regression_mlp_layers"], use_biases=True,
-                                   activation_fun="relu", name="regression_mlp")
+                                   activation_fun="relu", dropout_rate=params["regression_mlp_dropout"], name="regression_mlp")
+        self.regression_mlp_dropout_masks = None  # tests: masks per Dense layer instead of drawn ones
 
     def build(self, input_shapes):
         D0 = int(input_shapes["node_features"][-1])
@@ -355,7 +359,8 @@ class GraphRegressionTask(GraphTaskModel):
         avg = self._weighted_avg_of_nodes_to_graph_repr(pool_in, training=training)
         tot = self._weighted_sum_of_nodes_to_graph_repr(pool_in, training=training)
         graph_representations = torch.cat([avg, tot], dim=1)  # [G, 2 GD]
-        per_graph_results = self._regression_mlp(graph_representations)  # [G, 1]
+        per_graph_results = self._regression_mlp(graph_representations, training=training,
+                                                 dropout_masks=self.regression_mlp_dropout_masks)  # [G, 1]
         self._step = {"widths": [p.shape[1] for p in pieces], "GD": avg.shape[1]}
         return per_graph_results.view(-1)
 
