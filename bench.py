@@ -1,67 +1,88 @@
 #!/usr/bin/env python3
-"""Benchmark of the message-passing hot path: edges/sec (fwd+bwd), RGCN H=320 L=4 on an R-MAT batch
-shaped like BASELINE.json configs[1] (30k nodes, 900k edges, 4 edge types), 1..8 MI355X.
+"""Benchmark of the message-passing hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-One "step" = one pass of the hot path over one batch: bucket the batch's edges (ops.Graph), GNN
-forward (initial projection, 4 RGCN layers, dropout, the Dense after layer 0 - the op sequence of
-tf2_gnn_train RGCN PPI) and the full backward (all weight gradients).  Inputs are
-resident in HBM before the timed region.  Multi-GPU: graph batches are independent, each rank
-processes its own batch of the same shape (weak scaling, no data-path collective); one RCCL
-all-gather collects the per-rank edge counts / times for the metric.
+Headline (default workload ``rmat30k``): BASELINE.json's metric - edges/sec (fwd+bwd), RGCN H=320 L=4 on an R-MAT batch
+shaped like configs[1] (30k nodes, 900k edges, 4 edge types) with the PPI_RGCN.json hyper-parameters.  The other
+BASELINE configs are workloads of the same script (``rgat``, ``qm9-ggnn``, ``qm9-edgemlp``, ``arxiv-rgin``), each with its
+own roofline block.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel, measured live with HIP
-events on the launch stream; `cpu_baseline` times the CPU oracle (reference op sequence, torch-CPU)
-on rank 0 when N == 1.
+One "step" = one pass of the hot path over one batch: bucket the batch's edges (ops.Graph), GNN forward in training mode
+(dropout) and the full backward (all weight gradients) - plus node->graph pooling forward/backward for the QM9-shaped
+workloads.  Inputs are resident in HBM before the timed region.
+
+Multi-GPU (one process per GPU, torch.distributed backend nccl = RCCL over xGMI).  With N > 1 and no torchrun environment
+the script re-executes itself under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` (rendezvous on
+127.0.0.1), so ``python bench.py --gpus 8`` IS an 8-rank run; the world size of the communicator is asserted against
+--gpus and reported as ``n_gpus``.
+  * single-graph workloads (rmat30k, rgat, arxiv-rgin): one independently seeded batch of the same shape per rank -
+    replicas, weak scaling, no data-path collective;
+  * QM9-shaped workloads: ONE batch of 128k graphs (the same on every rank, seeded), sharded by graph
+    (parallel.shard_batch: LPT by edges + nodes, node ids re-based); every rank runs its shard through the HIP path -
+    strong scaling, no data-path collective;
+  * the only collectives: the barrier, the MAX-reduce of the step time, one all-gather of per-rank scalars (edges,
+    nodes) for the metric; --allreduce-grads adds the training-step exchange (one bucketed all-reduce of the weight
+    gradients, parallel.allreduce_gradients).
+
+Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant kernel of the workload, timed live with HIP events on
+the launch stream; ``cpu_baseline`` times the CPU oracle (the reference's op sequence, torch-CPU) on rank 0 at N == 1.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
 import torch
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_FP32_PEAK_TFLOPS = 157.3
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
 GEMM_MODE_NOTES = {
     "fp32": "fp32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
     "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 largest piece products (each exact in fp32), fp32 "
-    "accumulate on v_mfma_f32_32x32x16_bf16; fp32 in/out; max error vs fp64 measured equal to the fp32-MFMA kernel "
-    "(tests/test_gpu_ops.py::test_gemm_bf16x3_matches_fp64)",
+    "accumulate on v_mfma_f32_32x32x16_bf16; fp32 in/out",
     "bf16x3_9": "bf16x3_9: as bf16x3 with all 9 piece products (products exact, only the fp32 accumulation rounds)",
-    "f16x2": "f16x2: the layers' products on pre-split operands - every fp32 value scaled by a power of two and split into two "
-    "fp16 pieces by round-to-nearest (22+ significand bits), 3 piece products (each exact in fp32), fp32 accumulate on "
-    "v_mfma_f32_32x32x16_f16, the gather writes the split operand; fp32 in/out; accumulation error vs fp64 measured below the "
-    "fp32-MFMA kernel's (tools/mfma_acc_probe.hip, tests/test_gpu_full_size.py); other products as in bf16x3",
+    "f16x2": "f16x2: the layers' products on pre-split operands - every fp32 value scaled by a power of two per row and split "
+    "into two fp16 pieces by round-to-nearest (22+ significand bits), 3 piece products (each exact in fp32), fp32 accumulate "
+    "on v_mfma_f32_32x32x16_f16, the gather writes the split operand; fp32 in/out; error vs fp64 measured at or below the "
+    "fp32-MFMA kernel's (profiles/parity_r02.json, tools/mfma_acc_probe.hip); products without a split producer run as bf16x3",
 }
 
+# BASELINE.json configs -> workloads.  ``sharded``: one global batch split by graph over the ranks (strong scaling);
+# otherwise every rank owns a replica batch (weak scaling).
 WORKLOADS = {
-    # BASELINE.json configs[1] shape + metric's model (RGCN H=320, 4 layers, PPI_RGCN.json hypers)
-    "rmat30k": dict(num_nodes=30000, num_edges=900000, num_edge_types=4, feature_dim=320, hidden_dim=320, num_layers=4),
-    # small variant for smoke runs
-    "tiny": dict(num_nodes=2000, num_edges=40000, num_edge_types=4, feature_dim=64, hidden_dim=64, num_layers=4),
+    # configs[1] shape + the metric's model (RGCN H=320, 4 layers, PPI_RGCN.json hypers)
+    "rmat30k": dict(model="rgcn", num_nodes=30000, num_edges=900000, num_edge_types=4, feature_dim=320, hidden_dim=320, num_layers=4),
+    "tiny": dict(model="rgcn", num_nodes=2000, num_edges=40000, num_edge_types=4, feature_dim=64, hidden_dim=64, num_layers=4),
+    # configs[2]: RGAT, 8 heads, H=256, 8 layers on the same graph
+    "rgat": dict(model="rgat", num_nodes=30000, num_edges=900000, num_edge_types=4, feature_dim=256, hidden_dim=256, num_layers=8, num_heads=8),
+    # configs[3]: GGNN / GNN_Edge_MLP on a QM9-shaped batch (128k molecules, H=128) + node->graph pooling, graph-sharded
+    "qm9-ggnn": dict(model="ggnn", num_graphs=128000, feature_dim=128, hidden_dim=128, num_layers=8, sharded=True),
+    "qm9-edgemlp": dict(model="gnn_edge_mlp", num_graphs=128000, feature_dim=128, hidden_dim=128, num_layers=4, sharded=True),
+    "qm9-tiny": dict(model="ggnn", num_graphs=2000, feature_dim=64, hidden_dim=64, num_layers=2, sharded=True),
+    # configs[4]: RGIN, 40 edge types (Zipf), H=512 on an ogbn-arxiv-scale graph
+    "arxiv-rgin": dict(model="rgin", num_nodes=170000, num_edges=1200000, num_edge_types=40, feature_dim=512, hidden_dim=512, num_layers=4),
 }
 
 
-def ppi_rgcn_params(hidden_dim, num_layers):
-    """tf2_gnn/cli_utils/default_hypers/PPI_RGCN.json:6-19 on top of GNN/RGCN defaults."""
+def model_params(model, hidden_dim, num_layers, num_heads=None):
+    """GNN hyper-parameters of a workload: the message passing class' defaults, the stack settings of
+    tf2_gnn/cli_utils/default_hypers/PPI_RGCN.json:6-19 (no residual / LayerNorm / global exchange, one Dense after
+    layer 0, input dropout 0.1) and the BASELINE config's sizes."""
     from tf2_gnn_amd.layers import GNN
 
-    p = GNN.get_default_hyperparameters("rgcn")
+    p = GNN.get_default_hyperparameters(model)
     p.update(
         {
             "num_layers": num_layers,
             "hidden_dim": hidden_dim,
-            "use_target_state_as_input": False,
-            "normalize_by_num_incoming": True,
-            "num_edge_MLP_hidden_layers": 0,
             "layer_input_dropout_rate": 0.1,
             "dense_every_num_layers": 10000,
             "residual_every_num_layers": 10000,
@@ -69,11 +90,18 @@ def ppi_rgcn_params(hidden_dim, num_layers):
             "use_inter_layer_layernorm": False,
             "initial_node_representation_activation": "tanh",
             "dense_intermediate_layer_activation": "tanh",
-            "message_activation_function": "ReLU",
-            "aggregation_function": "sum",
         }
     )
+    if model == "rgcn":
+        p.update({"use_target_state_as_input": False, "normalize_by_num_incoming": True, "num_edge_MLP_hidden_layers": 0,
+                  "message_activation_function": "ReLU", "aggregation_function": "sum"})
+    if model == "rgat":
+        p.update({"num_heads": num_heads or 8})
     return p
+
+
+def ppi_rgcn_params(hidden_dim, num_layers):
+    return model_params("rgcn", hidden_dim, num_layers)
 
 
 def baseline_metric():
@@ -100,14 +128,18 @@ def time_kernel(fn, iters=20, warmup=3):
     return start.elapsed_time(end) / iters
 
 
-def cpu_baseline(wl, feats, adjs, params, max_seconds=30.0):
-    """The reference's CPU cost structure: oracle restatement (per-edge gathers and matmuls, concat,
-    scatter-add; torch-CPU fp32, autograd for the backward), all host cores."""
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's op sequence (oracle), SURVEY.md 8d protocol (warm-up, median) on a bounded sample
+# --------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, feats, adjs, params, budget_seconds=30.0):
+    """The oracle's RGCN step (per-edge gathers and matmuls, concat, scatter-add; torch-CPU fp32, autograd for the
+    backward) on all host cores: 1 warm-up run, then the median of as many timed runs (<= 5) as fit the budget, on an
+    edge sample sized so that a run takes a few seconds; scaled linearly to the full batch and stack."""
     from oracle import tf2gnn_oracle as orc
 
     torch.set_num_threads(os.cpu_count() or 1)
     cores = torch.get_num_threads()
-    H, NL, L = wl["hidden_dim"], wl["num_layers"], wl["num_edge_types"]
+    H, NL, L = wl["hidden_dim"], wl["num_layers"], len(adjs)
     g = torch.Generator().manual_seed(0)
 
     def glorot(i, o):
@@ -115,44 +147,80 @@ def cpu_baseline(wl, feats, adjs, params, max_seconds=30.0):
         return ((torch.rand((i, o), generator=g) * 2 - 1) * lim).requires_grad_(True)
 
     weights = {
-        "initial_projection": glorot(wl["feature_dim"], H),
+        "initial_projection": glorot(feats.shape[1], H),
         "mp": [{"edge_mlps": [[glorot(H, H)] for _ in range(L)]} for _ in range(NL)],
         "dense": {0: glorot(H, H)},
         "layernorm": [],
     }
     leaves = [weights["initial_projection"], weights["dense"][0]] + [w[0] for m in weights["mp"] for w in m["edge_mlps"]]
     X = torch.from_numpy(feats)
-    adj_t = [torch.from_numpy(a) for a in adjs]
     E = sum(a.shape[0] for a in adjs)
 
-    def step(layers):
+    def run(frac, layers):
+        adj_t = [torch.from_numpy(a[: max(1, int(a.shape[0] * frac))]) for a in adjs]
         p = dict(params, num_layers=layers)
+        t0 = time.perf_counter()
         out, _ = orc.gnn_internal_call(p, weights, X, adj_t)
         torch.autograd.grad(out.sum(), leaves[:2] + leaves[2 : 2 + layers * L])
+        return time.perf_counter() - t0
 
-    # calibrate on one layer, then time as many layers as fit the budget (scaled to the full stack)
-    t0 = time.perf_counter()
-    step(1)
-    t1 = time.perf_counter() - t0
-    layers = NL if t1 * NL * 1.2 < max_seconds else max(1, int(max_seconds / (1.2 * t1)))
-    if layers == 1:
-        t = t1  # the calibration run is the sample (one layer of this batch already takes ~20 s on 256 threads)
-    else:
-        t0 = time.perf_counter()
-        step(layers)
-        t = time.perf_counter() - t0
-    # the initial projection / dense glue is <2% of a layer: scale linearly in the number of layers
-    t_full = t * NL / layers
+    # calibrate the sample on 1/16 of the edges of one layer, aim at ~4 s per run
+    t_cal = run(1.0 / 16, 1)
+    frac = float(min(1.0, max(1.0 / 16, (4.0 / max(t_cal, 1e-3)) / 16)))
+    layers = 1
+    t_used = t_cal + run(frac, layers)  # warm-up at the sample size
+    times = []
+    while len(times) < 5 and (not times or t_used + times[-1] < budget_seconds):
+        times.append(run(frac, layers))
+        t_used += times[-1]
+    t = float(np.median(times))
+    t_full = t / frac * NL / layers  # per-edge cost dominates (matmul + gather + scatter per edge), layers are alike
     return {
         "value": E / t_full,
         "unit": "edges/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{layers} of {NL} RGCN layers fwd+bwd on the full batch ({t:.2f} s measured"
-        f"{'' if layers == NL else ', scaled to ' + str(NL) + ' layers'}); torch-CPU fp32 restatement of the "
-        "reference op sequence (TensorFlow unavailable offline)",
+        "sample": f"{layers} of {NL} RGCN layers (+ projection / Dense) fwd+bwd on {frac:.3f} of the batch's edges, all nodes: 1 warm-up, "
+        f"median of {len(times)} runs = {t:.2f} s, scaled to the full batch and stack; torch-CPU fp32 restatement of the reference op "
+        "sequence (TensorFlow unavailable offline)",
         "seconds_per_step": t_full,
     }
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# workload construction / launch
+# --------------------------------------------------------------------------------------------------------------------
+def build_batch(wl, rank, world):
+    """-> dict(feats, adjs, n2g, num_graphs)"""
+    from tf2_gnn_amd import parallel
+    from tf2_gnn_amd.data import make_qm9_shaped_batch, make_synthetic_batch, make_zipf_typed_batch
+
+    if wl.get("sharded"):
+        feats, adjs, n2g, _ = make_qm9_shaped_batch(wl["num_graphs"], seed=1, feature_dim=wl["feature_dim"])  # same on every rank
+        G = wl["num_graphs"]
+        if world > 1:
+            feats, adjs, n2g, G, _, _ = parallel.shard_batch(feats, adjs, n2g, G, world, rank)
+        return dict(feats=feats, adjs=adjs, n2g=np.ascontiguousarray(n2g, dtype=np.int32), num_graphs=G)
+    if wl["model"] == "rgin":
+        feats, adjs = make_zipf_typed_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank)
+    else:  # timing seeds 1.. (SURVEY 8d)
+        feats, adjs = make_synthetic_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank)
+    return dict(feats=feats, adjs=adjs, n2g=np.zeros(feats.shape[0], dtype=np.int32), num_graphs=1)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(args):
+    """``python bench.py --gpus N`` without a torchrun environment: become N ranks."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -166,45 +234,79 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-mode", default="f16x2", choices=["fp32", "bf16x3", "bf16x3_9", "f16x2"],
-                    help="how the fp32 GEMMs run on the matrix cores (include/tfgnn.h, tfgnn_gemm_set_mode): fp32 MFMA, "
-                    "or exact bf16 operand splitting with 6 / 9 piece products (fp32 in, fp32 accumulate, fp32 out)")
-    ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timing in the other GEMM mode")
+                    help="how the fp32 products run on the matrix cores (include/tfgnn.h): fp32 MFMA, exact bf16 operand splitting "
+                    "with 6 / 9 piece products, or pre-split fp16 operands with 3 piece products (fp32 in, fp32 accumulate, fp32 out)")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timing in another GEMM mode")
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="N > 1: add the training-step exchange (one bucketed RCCL all-reduce of the weight gradients) to every "
                          "step; off by default - the fwd+bwd metric itself has no collective")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no device work: spawn / rendezvous (gloo) / sharding / collectives only - the CPU test of the N > 1 launch path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from tf2_gnn_amd import parallel
+
+    wl = WORKLOADS[args.workload]
+    sharded = bool(wl.get("sharded"))
+    if args.plumbing_only:
+        rank, world, dist = parallel.init_distributed(backend="gloo")
+        assert world == args.gpus, f"communicator has {world} ranks, --gpus says {args.gpus}"
+        batch = build_batch(wl, rank, world)
+        parallel.barrier(dist)
+        dt = parallel.reduce_max(0.001 * (rank + 1), dist)
+        gathered = parallel.all_gather_scalars([float(sum(a.shape[0] for a in batch["adjs"])), float(batch["feats"].shape[0]),
+                                                float(batch["num_graphs"])], dist)
+        if rank == 0:
+            print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "edges/s", "n_gpus": world, "plumbing_only": True,
+                              "edges_per_rank": gathered[:, 0].tolist(), "nodes_per_rank": gathered[:, 1].tolist(),
+                              "graphs_per_rank": gathered[:, 2].tolist(), "max_time": dt,
+                              "scaling": "strong" if sharded else "weak"}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm device (there is no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from tf2_gnn_amd import parallel
-
     rank, world, dist = parallel.init_distributed(device=dev)  # nccl == RCCL over xGMI on ROCm
+    assert world == args.gpus, f"communicator has {world} ranks, --gpus says {args.gpus}"
 
     from tf2_gnn_amd import ops
-    from tf2_gnn_amd.data import make_synthetic_batch
-    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers import GNN, GNNInput, NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
     from tf2_gnn_amd.layers.message_passing import set_seed
 
-    wl = WORKLOADS[args.workload]
-    V, E, L, D, H, NL = (wl[k] for k in ("num_nodes", "num_edges", "num_edge_types", "feature_dim", "hidden_dim", "num_layers"))
-    feats, adjs = make_synthetic_batch(V, E, L, D, seed=1 + rank)  # timing seeds 1..
+    batch = build_batch(wl, rank, world)
+    feats, adjs = batch["feats"], batch["adjs"]
+    V, D = feats.shape
+    L = len(adjs)
+    E = sum(a.shape[0] for a in adjs)
+    H, NL = wl["hidden_dim"], wl["num_layers"]
     X = torch.from_numpy(feats).to(dev)
-    adj_dev = tuple(torch.from_numpy(a).to(dev) for a in adjs)
-    n2g = torch.zeros(V, dtype=torch.int32, device=dev)
-    params = ppi_rgcn_params(H, NL)
+    adj_dev = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in adjs)
+    n2g = torch.from_numpy(batch["n2g"]).to(dev)
+    G = int(batch["num_graphs"])
+    params = model_params(wl["model"], H, NL, wl.get("num_heads"))
     set_seed(0)
     gnn = GNN(params)
-    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
+    pool = None
+    if sharded:  # QM9 head: node -> graph pooling (GD=32, 4 heads, softmax weights)
+        pool = WeightedSumGraphRepresentation(graph_representation_size=32, num_heads=4, weighting_fun="softmax",
+                                              scoring_mlp_layers=[H], transformation_mlp_layers=[H])
+        dOut = torch.randn((G, 32), generator=torch.Generator().manual_seed(0)).to(dev)
+    else:
+        dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
     graph = ops.Graph(adj_dev, V) if args.reuse_graph else None
-    # Input pipeline: every step buckets one batch's edges (ops.Graph).  Like the reference, whose
-    # batches are prepared by a background thread + tf.data prefetch while the previous step trains
-    # (data/graph_dataset.py:292-295, cli_utils/training_utils.py:114-115), the bucketing of batch
-    # i+1 is enqueued on a second HIP stream at the start of step i and overlaps with its compute.
-    # --serial-bucketing keeps it on the compute stream instead.
+    # Input pipeline: every step buckets one batch's edges (ops.Graph).  Like the reference, whose batches are prepared by
+    # a background thread + tf.data prefetch while the previous step trains (data/graph_dataset.py:292-295,
+    # cli_utils/training_utils.py:114-115), the bucketing of batch i+1 is enqueued on a second HIP stream at the start
+    # of step i and overlaps with its compute.  --serial-bucketing keeps it on the compute stream instead.
     side = torch.cuda.Stream() if (graph is None and not args.serial_bucketing) else None
     pending = []
 
@@ -226,33 +328,41 @@ def main():
             torch.cuda.current_stream().wait_stream(side)  # compute waits for THIS batch's bucketing
             g.wait()
             pending.append(enqueue_bucketing())  # next batch, overlapped with this step
-        gnn(GNNInput(X, g, n2g, 1), training=True)
-        gnn.backward(dOut)
+        out = gnn(GNNInput(X, g, n2g, G), training=True)
+        if pool is not None:
+            pool(NodesToGraphRepresentationInput(out, n2g, G), training=True)
+            gnn.backward(pool.backward(dOut))
+        else:
+            gnn.backward(dOut)
         if args.allreduce_grads:
-            parallel.allreduce_gradients(gnn.trainable_variables, dist)
+            parallel.allreduce_gradients(gnn.trainable_variables, dist, local_count=float(G if pool is not None else V))
         if graph is None:
             g.close()
 
     def barrier():
         parallel.barrier(dist)
 
-    def settle(max_batches=40, batch=10, tol=0.03, min_batches=8):
-        """Untimed extra warm-up: at least ``min_batches`` short batches, then until two consecutive ones take the
-        same time.  Every process shows one ~35 ms host-side stall around its 4000th kernel launch (step 45-50 here;
-        TFGNN_BENCH_TRACE=1 prints the batch times) - inside a 20-step timed region it reads as 4.9 instead of
-        3.1 ms per step; this loop runs past it and past any clock ramp."""
+    ms_guess = [3.0]
+
+    def settle(max_batches=40, tol=0.03, min_batches=8):
+        """Untimed extra warm-up: short batches of steps until two consecutive ones take the same time (clock ramp,
+        first-touch allocations, the host-side stall around the ~4000th launch of a process: TFGNN_BENCH_TRACE=1 prints
+        the batch times).  Batches are ~30 ms of steps; at least ``min_batches`` of them for a fast workload."""
         prev = None
         trace = os.environ.get("TFGNN_BENCH_TRACE") == "1"
-        for i in range(max_batches if not trace else 150):
+        for i in range(max_batches):
+            nb = int(min(10, max(2, round(30.0 / max(ms_guess[0], 0.3)))))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(batch):
+            for _ in range(nb):
                 step()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = (time.perf_counter() - t0) / nb
+            ms_guess[0] = 1000.0 * dt
             if trace:
-                print(f"settle batch {i}: {1000 * dt / batch:.3f} ms/step", file=sys.stderr)
-            elif i + 1 >= min_batches and prev is not None and abs(dt - prev) <= tol * prev:
+                print(f"settle batch {i}: {1000 * dt:.3f} ms/step", file=sys.stderr)
+            need = min_batches if ms_guess[0] < 10 else 3
+            if i + 1 >= need and prev is not None and abs(dt - prev) <= tol * prev:
                 return
             prev = dt
 
@@ -274,11 +384,21 @@ def main():
 
     ops.set_gemm_mode(args.gemm_mode)
     elapsed = timed(args.warmup, args.steps)
-    # final metric reduction: all-gather of the per-rank edge counts (north_star: the only collective)
-    total_edges_per_step = float(parallel.all_gather_scalars([float(E)], dist, dev)[:, 0].sum())
+    # final metric reduction: all-gather of the per-rank edge / node counts (north_star: the only collective)
+    gathered = parallel.all_gather_scalars([float(E), float(V), float(G)], dist, dev)
+    total_edges_per_step = float(gathered[:, 0].sum())
     ms_per_step = 1000.0 * elapsed / args.steps
     value = total_edges_per_step * args.steps / elapsed
 
+    if sharded:
+        shape = (f"G={int(gathered[:, 2].sum())} graphs V={int(gathered[:, 1].sum())} E={int(total_edges_per_step)} (whole job; sharded by graph "
+                 f"over {world} rank{'s' if world > 1 else ''})")
+        data = "synthetic: QM9-shaped molecules (5..13 nodes, random tree + ~0.8 extra bonds, 4 tied bond types + self loops), N(0,1) features, Glorot weights"
+    else:
+        shape = f"V={V} E={E} per GPU (one batch per rank, replicas)"
+        data = ("synthetic: R-MAT (0.57,0.19,0.19,0.05)" + (", Zipf(1) edge types" if wl["model"] == "rgin" else "")
+                + ", N(0,1) features, Glorot weights")
+    bucketing = " (hoisted)" if args.reuse_graph else (" (on the compute stream)" if args.serial_bucketing else " of the next batch (2nd stream, overlapped)")
     result = {
         "metric": baseline_metric(),
         "value": value,
@@ -288,22 +408,24 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic R-MAT (0.57,0.19,0.19,0.05), N(0,1) features, Glorot weights",
+        "data": data,
         "config": {
-            "workload": f"{args.workload}: V={V} E={E} edge_types={L} D={D} H={H} layers={NL} RGCN (PPI_RGCN.json hypers), "
-            f"step = edge bucketing{' (hoisted)' if args.reuse_graph else (' (on the compute stream)' if args.serial_bucketing else ' of the next batch (2nd stream, overlapped)')} + GNN fwd + full bwd, one batch per GPU",
+            "workload": f"{args.workload}: {shape} edge_types={L} D={D} H={H} layers={NL} {wl['model'].upper()}"
+            f"{' + WeightedSum pooling (GD=32, 4 heads, softmax)' if pool is not None else ''} (PPI_RGCN.json stack settings), "
+            f"step = edge bucketing{bucketing} + forward (training mode) + full backward",
             "per_layer_traversal_rate_edges_per_s": value * NL,
             "gemm_mode": GEMM_MODE_NOTES[args.gemm_mode],
             "collectives_per_step": ("1 bucketed all-reduce of the weight gradients (--allreduce-grads)"
-                                     if (args.allreduce_grads and world > 1) else "none (graph-sharded batches)"),
+                                     if (args.allreduce_grads and world > 1) else "none (graph-sharded batches / replicas)"),
+            "edges_per_rank": gathered[:, 0].tolist(),
         },
     }
     if not args.no_alt_mode:
-        # the same job with the GEMMs in the other evaluation mode, for reference (not the headline value)
-        alt = "fp32" if args.gemm_mode != "fp32" else "bf16x3"
+        # the same job with the products in another evaluation mode, for reference (not the headline value)
+        alt = "bf16x3" if args.gemm_mode != "bf16x3" else "fp32"
         ops.set_gemm_mode(alt)
         alt_steps = max(3, args.steps // 2)
         alt_elapsed = timed(2, alt_steps)
@@ -314,86 +436,15 @@ def main():
         }
 
     if rank == 0 and not args.no_roofline:
-        # ---- dominant kernels, measured live on the launch stream -------------------------------
-        g = graph if graph is not None else ops.Graph(adj_dev, V)
-        rs = g.array(ops.G_INVDEG_BY_DST)
-        Hx = torch.randn((V, H), device=dev)
-        A = torch.empty((V * L, H), device=dev)
-        W = torch.randn((L * H, H), device=dev) * 0.05
-        out = torch.empty((V, H), device=dev)
-        ms_gather = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
-        if args.gemm_mode == "fp32":
-            ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), W, act="relu", out=out))
-        elif args.gemm_mode == "f16x2":  # operands as the layer produces them (gnn_edge_mlp.py:_forward_A)
-            ms_gather = time_kernel(lambda: ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L))
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L)
-            Wt_sp = ops.sp_split_cols(W)
-            ms_gemm = time_kernel(lambda: ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=out))
-        else:  # the layers hand the split-operand kernel W^T (gnn_edge_mlp.py:_forward_A)
-            Wt = W.t().contiguous()
-            ms_gemm = time_kernel(lambda: ops.gemm(A.view(V, L * H), Wt, trans_b=True, act="relu", out=out))
-        ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
-        # algorithmic bytes of one gather launch: one fp32 source row + one int32 col per
-        # edge, the row pointer and scale once, one output row per (node, type) bucket
-        gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4
-        gemm_flops = 2.0 * V * (L * H) * H
-        gather_gbs = gather_bytes / (ms_gather * 1e-3) / 1e9
-        gemm_tflops = gemm_flops / (ms_gemm * 1e-3) / 1e12
-        # per step: 2 gathers and 3 GEMM-equivalents per layer
-        share_gather = 2 * NL * ms_gather / ms_per_step
-        share_gemm = 3 * NL * ms_gemm / ms_per_step
-        roof_gather = {
-            "kernel": "csr_gather_reduce_kernel (aggregate source rows per (node, type) bucket)",
-            "bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gather_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_gather,
-            "algorithmic_bytes_per_launch": gather_bytes, "share_of_step": share_gather,
-        }
-        if args.gemm_mode == "fp32":
-            gemm_kernel = "gemm_mfma_kernel<4,2,1,5> 128x320 tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)"
-            gemm_peak, executed = MFMA_FP32_PEAK_TFLOPS, gemm_tflops
-        elif args.gemm_mode == "f16x2":
-            # 3 exact fp16 piece products per fp32 product: the matrix cores execute 3x the algorithmic flops, priced against
-            # the dense fp16 MFMA peak (= the bf16 one)
-            gemm_kernel = ("gemm_sp_nt_kernel<5> 128x320 tile, LDS-DMA ring, pinned MFMA stream ([V, L*H] x [H, L*H]^T + relu, "
-                           "3 x v_mfma_f32_32x32x16_f16 per fp32 k16 step on SP16 operands written by the gather)")
-            gemm_peak, executed = MFMA_BF16_PEAK_TFLOPS, gemm_tflops * 3
-        else:
-            # every fp32 product is evaluated as 6 (9) exact bf16 piece products: the matrix cores execute
-            # 6x (9x) the algorithmic flops, priced against the dense bf16 MFMA peak
-            nprod = 6 if args.gemm_mode == "bf16x3" else 9
-            gemm_kernel = (f"gemm_x3s_kernel 128x320 tile, 4 multiplying + 4 staging waves ([V, L*H] x [H, L*H]^T + relu, {nprod} x v_mfma_f32_32x32x16_bf16 "
-                           "per fp32 k16 step on exactly split operands)")
-            gemm_peak, executed = MFMA_BF16_PEAK_TFLOPS, gemm_tflops * nprod
-        roof_gemm = {
-            "kernel": gemm_kernel,
-            "bound": "mfma", "achieved": executed, "peak": gemm_peak, "unit": "TFLOP/s",
-            "frac": executed / gemm_peak, "traffic": None, "ms_per_launch": ms_gemm,
-            "algorithmic_flops_per_launch": gemm_flops, "algorithmic_tflops": gemm_tflops, "share_of_step": share_gemm,
-        }
-        if args.gemm_mode != "fp32":
-            # tools/mfma_dep_probe.hip on this part: back-to-back v_mfma_f32_32x32x16_bf16 sustains 2.47 PFLOP/s on smooth
-            # operands and 1.87 PFLOP/s on operands with random significands (the clock drops to 1.78 GHz)
-            roof_gemm["peak_measured_random_operands"] = 1870.0
-            roof_gemm["frac_of_measured_random_operand_peak"] = executed / 1870.0
-        # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_probe.py, tools/parse_pmc.py;
-        # FETCH_SIZE corrected x2 as calibrated on gfx950), committed under profiles/
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_{args.workload}.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            roof_gather["traffic"] = pmc["gather"]["hbm_bytes_per_launch"]
-            key = "gemm" if args.gemm_mode == "fp32" else "gemm_bf16x3"
-            if key in pmc:
-                roof_gemm["traffic"] = pmc[key]["hbm_bytes_per_launch"]
-            roof_gather["traffic_source"] = roof_gemm["traffic_source"] = os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))
-        if share_gemm >= share_gather:
-            result["roofline"], result["roofline_secondary"] = roof_gemm, roof_gather
-        else:
-            result["roofline"], result["roofline_secondary"] = roof_gather, roof_gemm
-        result["config"]["ms_edge_bucketing"] = ms_graph
-        if graph is None:
-            g.close()
+        roofs = roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step)
+        roofs.sort(key=lambda r: -r["share_of_step"])
+        result["roofline"] = roofs[0]
+        if len(roofs) > 1:
+            result["roofline_secondary"] = roofs[1]
+        if len(roofs) > 2:
+            result["roofline_other"] = roofs[2:]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["model"] == "rgcn":
         result["cpu_baseline"] = cpu_baseline(wl, feats, adjs, params)
 
     if rank == 0:
@@ -401,6 +452,141 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# rooflines: the dominant kernels of a workload, timed live (HIP events on the launch stream) at the workload's shapes
+# --------------------------------------------------------------------------------------------------------------------
+def _pmc_traffic(workload, name):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic_<workload>.json;
+    FETCH_SIZE corrected x2 as calibrated on gfx950, MI355X_MICROARCH.md), or None."""
+    if name is None:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
+    g = ops.Graph(adj_dev, V)
+    out = []
+    model, mode = wl["model"], args.gemm_mode
+    Hx = torch.randn((V, H), device=dev)
+    split_peak = MFMA_FP32_PEAK_TFLOPS if mode == "fp32" else MFMA_16BIT_PEAK_TFLOPS
+    nprod = {"fp32": 1, "bf16x3_9": 9}.get(mode, 6)  # piece products of the generic split-operand GEMM
+
+    def hbm_block(kernel, ms, alg_bytes, launches, traffic_key=None):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        traffic = _pmc_traffic(args.workload, traffic_key)
+        blk = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": launches,
+               "share_of_step": launches * ms / ms_per_step}
+        if traffic:  # a gather re-reads source rows through L2 / Infinity Cache: price the MEASURED fabric bytes as well
+            blk["achieved_on_counter_bytes"] = traffic / (ms * 1e-3) / 1e9
+            blk["frac_on_counter_bytes"] = blk["achieved_on_counter_bytes"] / HBM_PEAK_GBS
+        if blk["frac"] > 1.0:
+            blk["note"] = ("algorithmic bytes follow SURVEY.md 8d's no-reuse model (one fp32 source row per EDGE); rows are re-read from L2 / "
+                           "Infinity Cache, so the model rate can exceed the HBM peak - "
+                           + ("frac_on_counter_bytes prices the fabric bytes the counters saw" if traffic else
+                              "counter traffic was not collected for this workload"))
+        return blk
+
+    def mfma_block(kernel, ms, flops, executed_factor, peak, launches, traffic_key=None):
+        tf = flops / (ms * 1e-3) / 1e12
+        blk = {"kernel": kernel, "bound": "mfma", "achieved": tf * executed_factor, "peak": peak, "unit": "TFLOP/s",
+               "frac": tf * executed_factor / peak, "traffic": _pmc_traffic(args.workload, traffic_key), "ms_per_launch": ms,
+               "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tf, "piece_products_per_fp32_product": executed_factor,
+               "launches_per_step": launches, "share_of_step": launches * ms / ms_per_step}
+        if peak == MFMA_16BIT_PEAK_TFLOPS:
+            # tools/mfma_dep_probe.hip: back-to-back 32x32x16 16-bit MFMAs sustain 2.47 PFLOP/s on smooth operands and
+            # 1.87 PFLOP/s on operands with random significands (the clock drops to 1.78 GHz)
+            blk["peak_measured_random_operands"] = 1870.0
+            blk["frac_of_measured_random_operand_peak"] = tf * executed_factor / 1870.0
+        return blk
+
+    if model in ("rgcn", "ggnn", "gnn_edge_mlp"):
+        rs = g.array(ops.G_INVDEG_BY_DST) if model == "rgcn" else None
+        gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4
+        f16 = mode == "f16x2" and model == "rgcn"
+        if f16:
+            ms = time_kernel(lambda: ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L))
+            name = "csr_gather_reduce_kernel<SP16> (aggregate source rows per (node, type) bucket, written as the split fp16 operand)"
+        else:
+            A = torch.empty((V * L, H), device=dev)
+            ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
+            name = "csr_gather_reduce_kernel (aggregate source rows per (node, type) bucket)"
+        out.append(hbm_block(name, ms, gather_bytes, 2 * NL, "gather_sp" if f16 else "gather"))
+    if model == "rgcn":
+        W = torch.randn((L * H, H), device=dev) * 0.05
+        res = torch.empty((V, H), device=dev)
+        flops = 2.0 * V * (L * H) * H
+        if mode == "f16x2":
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=g.array(ops.G_INVDEG_BY_DST), rows_per_operand_row=L)
+            Wt_sp = ops.sp_split_cols(W)
+            ms = time_kernel(lambda: ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=res))
+            out.append(mfma_block("gemm_sp_nt_kernel 128 x N tile, LDS-DMA ring, pinned MFMA stream ([V, L*H] x [H, L*H]^T + relu: 3 x "
+                                  "v_mfma_f32_32x32x16_f16 per fp32 k16 step on SP16 operands written by the gather); forward + dX launches",
+                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, 2 * NL, "gemm_sp_nt"))
+            Xs = ops.sp_split_rows(Hx)
+            Gs = ops.sp_split_rows(torch.randn((V, L * H), device=dev) * 1e-3, scale_block=H)
+            dW = torch.empty((L, H, H), device=dev)
+            ms = time_kernel(lambda: ops.sp_gemm_tn(Gs, Xs, out=dW, scatter=(H, H * H, 1, H)))
+            out.append(mfma_block("gemm_sp_tn_kernel + factor / split-K reduce kernels (dW = X^T G over K = V rows, transposing LDS reads)",
+                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, NL, "gemm_sp_tn"))
+        elif mode == "fp32":
+            A = torch.randn((V, L * H), device=dev)
+            ms = time_kernel(lambda: ops.gemm(A, W, act="relu", out=res))
+            out.append(mfma_block("gemm_mfma_kernel 128 x N tile ([V, L*H] x [L*H, H] + relu, v_mfma_f32_32x32x2_f32)", ms, flops, 1,
+                                  MFMA_FP32_PEAK_TFLOPS, 3 * NL, "gemm"))
+        else:
+            A = torch.randn((V, L * H), device=dev)
+            Wt = W.t().contiguous()
+            ms = time_kernel(lambda: ops.gemm(A, Wt, trans_b=True, act="relu", out=res))
+            out.append(mfma_block(f"gemm_x3s_kernel 128 x N tile, 4 multiplying + 4 staging waves ({nprod} x v_mfma_f32_32x32x16_bf16 per fp32 "
+                                  "k16 step on exactly split operands)", ms, flops, nprod, MFMA_16BIT_PEAK_TFLOPS, 3 * NL, "gemm_bf16x3"))
+    if model in ("ggnn", "gnn_edge_mlp"):
+        # node-level products [V, H] x [H, 3H] (GRU gates) / [V*L.., 2H] x [2H, H] (edge MLP): M in the millions, K and N
+        # small -> bandwidth-bound (operand + result bytes), whatever the multiply mode
+        N = 3 * H if model == "ggnn" else H
+        Wk = torch.randn((H, N), device=dev) * 0.05
+        ms = time_kernel(lambda: ops.gemm(Hx, Wk))
+        out.append(hbm_block(f"dense product [V, {H}] x [{H}, {N}] (skinny GEMM: bytes of A and C bound it, not the matrix cores)", ms,
+                             V * H * 4 + V * N * 4 + H * N * 4, (4 if model == "ggnn" else 6) * NL))
+    if model == "rgat":
+        K = wl.get("num_heads", 8)
+        Wc = torch.randn((H, L * H), device=dev) * 0.05
+        Y = torch.empty((V, L * H), device=dev)
+        ms = time_kernel(lambda: ops.gemm(Hx, Wc, out=Y))
+        out.append(mfma_block("Y = X [W_0 | ... | W_{L-1}] ([V, H] x [H, L*H]; forward, dX and dW launches)", ms, 2.0 * V * H * L * H, nprod,
+                              split_peak, 3 * NL))
+        ew = torch.rand((E, K), device=dev)
+        agg = torch.empty((V, H), device=dev)
+        ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=ew, out=agg))
+        out.append(hbm_block(f"csr_gather_reduce_kernel<HEADS> (attention-weighted sum over all in-edges of a node, {K} heads)", ms,
+                             E * (4 * H + 4 * K + 4) + (V + 1) * 4 + V * H * 4, 2 * NL))
+    if model == "rgin":
+        # per-relation 2-layer edge MLP over the non-empty (source, type) pairs: grouped GEMMs over compact rows
+        off_h = g.nonempty_offsets(True)
+        nz = off_h[-1]
+        Ac = torch.randn((nz, H), device=dev)
+        W = torch.randn((L, H, H), device=dev) * 0.05
+        off_d = g.array(ops.G_NZ_OFF_BY_SRC)
+        ms = time_kernel(lambda: ops.gemm_grouped_rows(Ac, off_d, off_h, W, act="relu"))
+        out.append(mfma_block(f"grouped GEMM over the {nz} non-empty (source, type) rows in {L} relation groups ([rows_l, H] x [H, H])", ms,
+                              2.0 * nz * H * H, nprod, split_peak, 6 * NL))
+        colc = g.array(ops.G_NZ_CPOS_BY_SRC)[g.array(ops.G_COLL_BY_DST).long()].contiguous()
+        agg = torch.empty((V, H), device=dev)
+        ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Ac, col=colc, out=agg))
+        out.append(hbm_block("csr_gather_reduce_kernel (messages of all edge types summed per target node)", ms,
+                             E * (4 * H + 4) + (V + 1) * 4 + V * H * 4, 2 * NL))
+    ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
+    for r in out:
+        r["ms_edge_bucketing_per_batch"] = ms_graph
+    g.close()
+    return out
 
 
 if __name__ == "__main__":

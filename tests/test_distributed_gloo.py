@@ -89,6 +89,14 @@ def _worker(rank, world, port, tmpdir):
     assert torch.allclose(vs[1].grad, torch.full((5,), (world - 1) / world))
     assert torch.allclose(vs[2].grad, torch.arange(4.0).view(2, 2) * mean_scale)
     assert parallel.allreduce_gradients(vs, None) == 0
+    # weighted form: every rank's gradient is the mean over ITS n_r nodes; the exchange must give the mean over all nodes
+    n_r = float(3 + 5 * rank)  # unequal shards
+    per_node = torch.arange(6.0).view(2, 3) + rank  # the rank's mean gradient
+    wv = [Var(torch.zeros(2, 3), per_node.clone())]
+    parallel.allreduce_gradients(wv, dist, local_count=n_r)
+    ns = [3.0 + 5 * r for r in range(world)]
+    want = sum(n * (torch.arange(6.0).view(2, 3) + r) for r, n in enumerate(ns)) / sum(ns)
+    assert torch.allclose(wv[0].grad, want)
     torch.save({"node_ids": node_ids, "edges": local_edges}, os.path.join(tmpdir, f"rank{rank}.pt"))
     parallel.barrier(dist)
     dist.destroy_process_group()

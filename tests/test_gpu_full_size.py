@@ -175,30 +175,9 @@ def test_cfg3_rgat_8_heads_h256(dev):
 
 
 def _qm9_shaped_batch(num_graphs, seed=0, D=128):
-    """QM9-shaped batch: graphs of 5..13 nodes, a random tree + ~0.8 extra bonds,
-    4 bond types tied fwd/bkwd + self-loop type 0 (tf2_gnn/data/qm9_dataset.py:54-77) -> 5 edge types."""
-    rng = np.random.default_rng(seed)
-    sizes = rng.integers(5, 14, size=num_graphs)
-    offs = np.concatenate([[0], np.cumsum(sizes)])
-    V = int(offs[-1])
-    n2g = np.repeat(np.arange(num_graphs, dtype=np.int32), sizes)
-    # tree edges: node i>0 of a graph attaches to a random earlier node of the same graph
-    local = np.arange(V) - offs[n2g]
-    child = np.where(local > 0)[0]
-    parent = offs[n2g[child]] + (rng.random(child.shape[0]) * local[child]).astype(np.int64)
-    extra_g = np.where(rng.random(num_graphs) < 0.8)[0]
-    ea = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
-    eb = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
-    src = np.concatenate([child, ea])
-    dst = np.concatenate([parent, eb])
-    bond = rng.integers(1, 5, size=src.shape[0])
-    adjs = [np.stack([np.arange(V), np.arange(V)], axis=1).astype(np.int32)]  # type 0: self loops
-    for b in range(1, 5):
-        m = bond == b
-        fwd = np.stack([src[m], dst[m]], axis=1)
-        adjs.append(np.concatenate([fwd, fwd[:, ::-1]], axis=0).astype(np.int32))  # tied fwd/bkwd
-    feats = rng.standard_normal((V, D), dtype=np.float32)
-    return feats, adjs, n2g, offs
+    from tf2_gnn_amd.data import make_qm9_shaped_batch
+
+    return make_qm9_shaped_batch(num_graphs, seed=seed, feature_dim=D)
 
 
 @pytest.mark.parametrize("cls_name,over", [("GGNN", {"normalize_by_num_incoming": False}), ("GNN_Edge_MLP", {})])

@@ -46,3 +46,43 @@ def make_synthetic_batch(
     adjacency_lists = [np.ascontiguousarray(edges[types == l]) for l in range(num_edge_types)]
     feats = rng.standard_normal((num_nodes, feature_dim), dtype=np.float32)
     return feats, adjacency_lists
+
+
+def make_qm9_shaped_batch(num_graphs: int, seed: int = 0, feature_dim: int = 128):
+    """QM9-shaped batch: graphs of 5..13 nodes, a random tree + ~0.8 extra bonds, 4 bond types
+    tied fwd/bkwd + self-loop type 0 (tf2_gnn/data/qm9_dataset.py:54-77) -> 5 edge types.
+    -> (node_features [V, D], adjacency_lists, node_to_graph_map [V] (sorted), node offsets [G + 1])."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(5, 14, size=num_graphs)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    V = int(offs[-1])
+    n2g = np.repeat(np.arange(num_graphs, dtype=np.int32), sizes)
+    # tree edges: node i>0 of a graph attaches to a random earlier node of the same graph
+    local = np.arange(V) - offs[n2g]
+    child = np.where(local > 0)[0]
+    parent = offs[n2g[child]] + (rng.random(child.shape[0]) * local[child]).astype(np.int64)
+    extra_g = np.where(rng.random(num_graphs) < 0.8)[0]
+    ea = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
+    eb = offs[extra_g] + (rng.random(extra_g.shape[0]) * sizes[extra_g]).astype(np.int64)
+    src = np.concatenate([child, ea])
+    dst = np.concatenate([parent, eb])
+    bond = rng.integers(1, 5, size=src.shape[0])
+    adjs = [np.stack([np.arange(V), np.arange(V)], axis=1).astype(np.int32)]  # type 0: self loops
+    for b in range(1, 5):
+        m = bond == b
+        fwd = np.stack([src[m], dst[m]], axis=1)
+        adjs.append(np.concatenate([fwd, fwd[:, ::-1]], axis=0).astype(np.int32))  # tied fwd/bkwd
+    feats = rng.standard_normal((V, feature_dim), dtype=np.float32)
+    return feats, adjs, n2g, offs
+
+
+def make_zipf_typed_batch(num_nodes: int, num_edges: int, num_edge_types: int, feature_dim: int, seed: int = 0):
+    """ogbn-arxiv-scale stand-in: one R-MAT graph whose edge types follow Zipf(1.0) over
+    ``num_edge_types`` (ragged relation groups)."""
+    rng = np.random.default_rng(seed)
+    edges = rmat_edges(num_nodes, num_edges, rng)
+    pz = 1.0 / np.arange(1, num_edge_types + 1)
+    types = rng.choice(num_edge_types, size=num_edges, p=pz / pz.sum())
+    adjs = [np.ascontiguousarray(edges[types == l]) for l in range(num_edge_types)]
+    feats = rng.standard_normal((num_nodes, feature_dim), dtype=np.float32)
+    return feats, adjs

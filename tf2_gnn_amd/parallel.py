@@ -141,9 +141,15 @@ def all_gather_scalars(values: Sequence[float], dist, device=None) -> np.ndarray
     return torch.stack(out).cpu().numpy()
 
 
-def allreduce_gradients(variables, dist, average: bool = True, bucket_bytes: int = 64 << 20):
+def allreduce_gradients(variables, dist, average: bool = True, bucket_bytes: int = 64 << 20,
+                        local_count: Optional[float] = None):
     """The one exchange step of a data-parallel *training* step: sum (or mean) over ranks of
-    d loss / d variable, in place on ``variable.grad``.  The reference has no distributed code; this is what a
+    d loss / d variable, in place on ``variable.grad``.
+
+    ``local_count`` (nodes for a node-level loss, graphs for a graph-level one): each rank's loss is a MEAN over its own
+    shard and the shards are balanced by cost, not by count, so the plain mean of the ranks' gradients is a mean of means.
+    With ``local_count`` the gradients are weighted n_local / n_global (one extra scalar rides in the first bucket) and
+    the result equals the single-device gradient of the whole batch.  The reference has no distributed code; this is what a
     weight update over graph shards needs and nothing more - the forward / backward passes stay collective-free.
 
     Gradients are packed into flat fp32 buckets and each bucket is one all-reduce: over xGMI a ring all-reduce is
@@ -158,6 +164,12 @@ def allreduce_gradients(variables, dist, average: bool = True, bucket_bytes: int
     for v in variables:
         if v.grad is None:
             v.grad = torch.zeros_like(v.value)
+    weight = None
+    if local_count is not None:  # weighted mean: sum_r n_r g_r / sum_r n_r
+        dev0 = variables[0].grad.device if variables else "cpu"
+        weight = torch.tensor([float(local_count)], dtype=torch.float32, device=dev0)
+        for v in variables:
+            v.grad = v.grad * float(local_count)
     calls, start = 0, 0
     while start < len(variables):
         end, nbytes = start, 0
@@ -165,9 +177,17 @@ def allreduce_gradients(variables, dist, average: bool = True, bucket_bytes: int
             nbytes += variables[end].grad.numel() * 4
             end += 1
         group = variables[start:end]
-        flat = torch.cat([v.grad.reshape(-1) for v in group])
+        pieces = [v.grad.reshape(-1) for v in group]
+        if weight is not None and start == 0:
+            pieces.append(weight.to(pieces[0].device))
+        flat = torch.cat(pieces)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        if average:
+        if weight is not None and start == 0:
+            total = flat[-1].clone()
+            flat = flat[:-1]
+        if weight is not None:
+            flat = flat / total
+        elif average:
             flat /= world
         off = 0
         for v in group:

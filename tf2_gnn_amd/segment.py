@@ -33,11 +33,13 @@ def unsorted_segment_reduce(name: str, data: torch.Tensor, segment_ids: torch.Te
         row_scale = (1.0 / cnt) if name == "mean" else torch.rsqrt(cnt)
         if name == "sqrt_n":
             row_scale = 1.0 / torch.sqrt(cnt)
-    if width == 0 or num_segments == 0:
-        return torch.zeros((num_segments,) + tuple(data.shape[1:]), dtype=data.dtype, device=dev)
-    out = ops.gather_reduce(
-        rowptr, col, flat, row_scale=row_scale,
-        reduce=ops.REDUCE_MAX if name == "max" else ops.REDUCE_SUM,
-    )
-    g.close()
+    try:
+        if width == 0 or num_segments == 0:
+            return torch.zeros((num_segments,) + tuple(data.shape[1:]), dtype=data.dtype, device=dev)
+        out = ops.gather_reduce(
+            rowptr, col, flat, row_scale=row_scale,
+            reduce=ops.REDUCE_MAX if name == "max" else ops.REDUCE_SUM,
+        )
+    finally:
+        g.close()
     return out.reshape((num_segments,) + tuple(data.shape[1:]))
