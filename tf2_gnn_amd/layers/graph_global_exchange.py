@@ -13,6 +13,7 @@ import torch
 from .. import ops
 from .message_passing.message_passing import _INIT_GEN, Variable, default_device, glorot_uniform
 from .nodes_to_graph_representation import (
+    prefix_names,
     MLP,
     NodesToGraphRepresentationInput,
     WeightedSumGraphRepresentation,
@@ -50,6 +51,8 @@ class GraphGlobalExchange:
         self._node_to_graph_representation_layer.build(
             NodesToGraphRepresentationInput(tensor_shapes.node_embeddings, tensor_shapes.node_to_graph_map, tensor_shapes.num_graphs)
         )
+        # graph_global_exchange.py:119,141,170: the subclasses build everything under tf.name_scope(<class name>)
+        prefix_names(self._node_to_graph_representation_layer.trainable_variables, self.__class__.__name__)
 
     @property
     def trainable_variables(self) -> List[Variable]:
@@ -111,9 +114,9 @@ class GraphGlobalGRUExchange(GraphGlobalExchange):
         kernel = glorot_uniform((H, 3 * H), device=dev)
         q, _ = torch.linalg.qr(torch.randn((3 * H, H), generator=_INIT_GEN, dtype=torch.float32))  # [ext] orthogonal
         self._gru = {
-            "kernel": Variable("GraphGlobalGRUExchange/gru_cell/kernel", kernel),
-            "recurrent_kernel": Variable("GraphGlobalGRUExchange/gru_cell/recurrent_kernel", q.t().contiguous().to(dev)),
-            "bias": Variable("GraphGlobalGRUExchange/gru_cell/bias", torch.zeros((2, 3 * H), dtype=torch.float32, device=dev)),
+            "kernel": Variable("GraphGlobalGRUExchange/kernel", kernel),
+            "recurrent_kernel": Variable("GraphGlobalGRUExchange/recurrent_kernel", q.t().contiguous().to(dev)),
+            "bias": Variable("GraphGlobalGRUExchange/bias", torch.zeros((2, 3 * H), dtype=torch.float32, device=dev)),
         }
         super().build(tensor_shapes)
 
@@ -151,8 +154,9 @@ class GraphGlobalMLPExchange(GraphGlobalExchange):
     one hidden layer of out_size units, relu, no biases)."""
 
     def build(self, tensor_shapes: GraphGlobalExchangeInput):
-        self._mlp = MLP(out_size=self._hidden_dim, hidden_layers=1, name="GraphGlobalMLPExchange")
+        self._mlp = MLP(out_size=self._hidden_dim, hidden_layers=1)  # default name "MLP"
         self._mlp.build(2 * self._hidden_dim)
+        prefix_names(self._mlp.variables, self.__class__.__name__)
         super().build(tensor_shapes)
 
     def _own_variables(self):

@@ -48,9 +48,9 @@ class GGNN(GNN_Edge_MLP):
             raise ValueError("GGNN requires hidden_dim == node embedding dimension (GRU state size)")
         bias = torch.zeros((2, 3 * H), dtype=torch.float32, device=dev)
         self._recurrent_unit = {
-            "kernel": self.add_weight("gru_cell/kernel", kernel),
-            "recurrent_kernel": self.add_weight("gru_cell/recurrent_kernel", recurrent),
-            "bias": self.add_weight("gru_cell/bias", bias),
+            "kernel": self.add_weight("kernel", kernel),
+            "recurrent_kernel": self.add_weight("recurrent_kernel", recurrent),
+            "bias": self.add_weight("bias", bias),
         }
         super().build(input_shapes)
 

@@ -41,6 +41,18 @@ class Variable:
     def shape(self):
         return tuple(self.value.shape)
 
+    def assign(self, value) -> "Variable":
+        """In-place update (tf.Variable.assign).  ``value`` tensors of several layers are VIEWS into one fused buffer (the
+        per-type kernels of an edge-MLP stack, the RGAT kernels): an optimizer or a checkpoint loader must write through
+        ``assign`` / ``value.copy_`` / in-place arithmetic - rebinding ``var.value`` to a new tensor detaches the variable
+        from the buffer the kernels read.  copy_ bumps the tensor version, which invalidates cached split operands."""
+        new = torch.as_tensor(value, dtype=self.value.dtype)
+        if tuple(new.shape) != tuple(self.value.shape):
+            raise ValueError(f"Shape mismatch for {self.name}: {tuple(self.value.shape)} vs {tuple(new.shape)}")
+        with torch.no_grad():
+            self.value.copy_(new.to(self.value.device))
+        return self
+
     def __repr__(self):
         return f"Variable({self.name!r}, shape={self.shape})"
 

@@ -34,6 +34,12 @@ def get_activation_function_by_name(name: Optional[str]) -> Optional[str]:
     return name
 
 
+def prefix_names(variables, prefix: str) -> None:
+    """What building under ``with tf.name_scope(prefix)`` does to the variables' names."""
+    for v in variables:
+        v.name = f"{prefix}/{v.name}"
+
+
 class MLP:
     """[ext] dpu_utils.tf2utils.MLP on the HIP GEMMs: hidden Dense layers (activation), final linear Dense; optional
     biases; in training mode tf.nn.dropout(rate) on the input of every HIDDEN Dense layer (call sites:
@@ -61,13 +67,15 @@ class MLP:
         self._ctx = None
 
     def build(self, in_size: int):
+        """Variable names: the dpu_utils MLP [ext] builds every Dense under tf.name_scope(f"{name}_dense_{i}") /
+        f"{name}_final_layer"; callers prefix the scopes they build it under (``prefix_names``)."""
         dev = default_device()
         last = in_size
         for j, size in enumerate(self._sizes):
             tag = f"dense_{j}" if j < len(self._sizes) - 1 else "final_layer"
-            self.kernels.append(Variable(f"{self._name}/{self._name}_{tag}/kernel", glorot_uniform((last, size), device=dev)))
+            self.kernels.append(Variable(f"{self._name}_{tag}/kernel", glorot_uniform((last, size), device=dev)))
             self.biases.append(
-                Variable(f"{self._name}/{self._name}_{tag}/bias", torch.zeros(size, dtype=torch.float32, device=dev))
+                Variable(f"{self._name}_{tag}/bias", torch.zeros(size, dtype=torch.float32, device=dev))
                 if self._use_biases
                 else None
             )
@@ -246,6 +254,7 @@ class WeightedSumGraphRepresentation(NodesToGraphRepresentation):
         if self._weighting_fun not in ("none", "average"):
             self._scoring_mlp.build(vd)
         self._transformation_mlp.build(vd)
+        prefix_names(self.trainable_variables, "WeightedSumGraphRepresentation")  # nodes_to_graph_representation.py:151
         super().build(input_shapes)
 
     @property
@@ -358,12 +367,14 @@ class WASGraphRepresentation(NodesToGraphRepresentation):
         self._ctx = None
 
     def build(self, input_shapes: NodesToGraphRepresentationInput):
+        # nodes_to_graph_representation.py:281-291: scopes <class name>/Weighted{Avg,Sum}GraphRepresentation/...
+        cls = self.__class__.__name__
         self._weighted_avg_graph_repr_layer.build(input_shapes)
+        prefix_names(self._weighted_avg_graph_repr_layer.trainable_variables, f"{cls}/WeightedAvgGraphRepresentation")
         self._weighted_sum_graph_repr_layer.build(input_shapes)
+        prefix_names(self._weighted_sum_graph_repr_layer.trainable_variables, f"{cls}/WeightedSumGraphRepresentation")
         GD = self._graph_representation_size
-        self._out_projection = Variable(
-            "WASGraphRepresentation/dense/kernel", glorot_uniform((2 * GD, GD), device=default_device())
-        )
+        self._out_projection = Variable(f"{cls}/kernel", glorot_uniform((2 * GD, GD), device=default_device()))
         super().build(input_shapes)
 
     @property

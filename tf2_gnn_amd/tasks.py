@@ -22,6 +22,7 @@ from . import _lib, ops
 from .layers.gnn import GNN, GNNInput
 from .layers.message_passing.message_passing import Variable, default_device, glorot_uniform
 from .layers.nodes_to_graph_representation import (
+    prefix_names,
     MLP,
     NodesToGraphRepresentationInput,
     WeightedSumGraphRepresentation,
@@ -94,6 +95,12 @@ class GraphTaskModel:
     def _task_variables(self) -> List[Variable]:
         return []
 
+    @property
+    def variables(self) -> List[Variable]:
+        """what save_model / load_weights_verbosely walk (utils/model_utils.py); the reference's non-trainable
+        training_step counter is not part of the hot path"""
+        return self.trainable_variables
+
     def zero_grad(self):
         for v in self.trainable_variables:
             v.grad = None
@@ -154,8 +161,10 @@ class NodeMulticlassTask(GraphTaskModel):
     def build(self, input_shapes):
         H = int(self._params["gnn_hidden_dim"])
         dev = default_device()
-        self._kernel = Variable(f"{self.name}/dense/kernel", glorot_uniform((H, self._num_labels), device=dev))
-        self._bias = Variable(f"{self.name}/dense/bias", torch.zeros(self._num_labels, dtype=torch.float32, device=dev))
+        # node_multiclass_task.py:41-43: a Dense built directly under tf.name_scope(<class name>) - Keras adds no layer name
+        cls = self.__class__.__name__
+        self._kernel = Variable(f"{cls}/kernel", glorot_uniform((H, self._num_labels), device=dev))
+        self._bias = Variable(f"{cls}/bias", torch.zeros(self._num_labels, dtype=torch.float32, device=dev))
         super().build(input_shapes)
 
     def _task_variables(self):
@@ -230,6 +239,9 @@ class QM9RegressionTask(GraphTaskModel):
         H = int(self._params["gnn_hidden_dim"])
         self._regression_gate.build(int(input_shapes["node_features"][-1]) + H)
         self._regression_transform.build(H)
+        cls = self.__class__.__name__  # qm9_regression.py:65-80
+        prefix_names(self._regression_gate.variables, f"{cls}/node_gate")
+        prefix_names(self._regression_transform.variables, f"{cls}/node_transform")
         super().build(input_shapes)
 
     def _task_variables(self):
@@ -322,7 +334,7 @@ class GraphRegressionTask(GraphTaskModel):
         self._weighted_avg_of_nodes_to_graph_repr = pooling("softmax")
         self._weighted_sum_of_nodes_to_graph_repr = pooling("sigmoid")
         self._regression_mlp = MLP(out_size=1, hidden_layers=params["regression_mlp_layers"], use_biases=True,
-                                   activation_fun="relu", dropout_rate=params["regression_mlp_dropout"], name="regression_mlp")
+                                   activation_fun="relu", dropout_rate=params["regression_mlp_dropout"])  # default name "MLP"
         self.regression_mlp_dropout_masks = None  # tests: masks per Dense layer instead of drawn ones
 
     def build(self, input_shapes):
@@ -336,6 +348,11 @@ class GraphRegressionTask(GraphTaskModel):
         self._weighted_avg_of_nodes_to_graph_repr.build(shapes)
         self._weighted_sum_of_nodes_to_graph_repr.build(shapes)
         self._regression_mlp.build(2 * int(self._params["graph_aggregation_output_size"]))
+        # graph_regression_task.py:91-106: name scopes of the reference's variables
+        cls = self.__class__.__name__
+        prefix_names(self._weighted_avg_of_nodes_to_graph_repr.trainable_variables, f"{cls}/graph_representation_computation/weighted_avg")
+        prefix_names(self._weighted_sum_of_nodes_to_graph_repr.trainable_variables, f"{cls}/graph_representation_computation/weighted_sum")
+        prefix_names(self._regression_mlp.variables, cls)
         super().build(input_shapes)
 
     def _task_variables(self):

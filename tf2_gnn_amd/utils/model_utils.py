@@ -1,0 +1,243 @@
+"""Saving and restoring model weights in the reference's checkpoint format (tf2_gnn/cli_utils/model_utils.py).
+
+A reference checkpoint is a pickle ``{model_class, model_params, dataset_class, dataset_params, dataset_metadata,
+num_edge_types, node_feature_shape[, model_weights]}`` (model_utils.py:44-58) plus - unless the weights were stored in the
+pickle (``store_weights_in_pkl``) - a Keras HDF5 weight file beside it (model_utils.py:66-70).  Weights are matched to model
+variables BY NAME (model_utils.py:19-34, 111-148): the name of a tf.Variable is the chain of ``tf.name_scope``s active
+at ``build`` time + the weight's own name + ":0", which the layers here reproduce in ``Variable.name`` (without ":0").
+
+What this module restates:
+  * ``_get_name_to_variable_map`` with the duplicate-name error                      (model_utils.py:19-34)
+  * ``save_model`` - weights in the pickle by default (h5py is not part of this image)   (model_utils.py:37-71)
+  * ``_read_weights_from_hdf5`` - only when h5py can be imported                        (model_utils.py:74-93)
+  * ``BACKWARD_COMPAT_WEIGHT_NAME_MAP`` / ``backward_compat_weight_renaming_fn``        (model_utils.py:98-108)
+  * ``load_weights_verbosely`` with its "freshly initialised" / "does not use" reports  (model_utils.py:111-148)
+
+Two things differ from the reference, both on the tolerant side:
+  * a reference pickle holds CLASS OBJECTS of tf2_gnn (model_class, dataset_class): unpickling it without tensorflow /
+    tf2_gnn installed would fail, so the loader substitutes placeholder classes for anything it cannot import;
+  * names: the MLP helper lives in dpu_utils (not vendored in the reference) and Keras inserts no layer name when
+    ``build`` is called directly.  After the exact match, leftovers are matched on a relaxed key that drops the optional
+    components ("dense", "gru_cell", an MLP's wrapper scope) when that is unambiguous and the shapes agree; every such match
+    is reported.
+
+Assignment is in place (``Variable.assign``): several layers keep their weights as views into one fused buffer (per-type
+kernels of an edge MLP stack, the RGAT kernels), so a restored value must be copied into the existing storage.
+"""
+from __future__ import annotations
+
+import io
+import pickle
+import re
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def get_model_file_path(model_path: str, target_suffix: str) -> str:
+    """tf2_gnn/cli_utils/dataset_utils.py:9-18"""
+    assert target_suffix in ("hdf5", "pkl")
+    if model_path.endswith(".hdf5"):
+        return model_path[:-4] + target_suffix
+    elif model_path.endswith(".pkl"):
+        return model_path[:-3] + target_suffix
+    raise ValueError(f"Model path has to end in hdf5/pkl, which is not the case for {model_path}!")
+
+
+def _model_variables(model) -> List[Any]:
+    if hasattr(model, "variables"):
+        v = model.variables
+        return list(v() if callable(v) else v)
+    return list(model.trainable_variables)
+
+
+def _get_name_to_variable_map(model) -> Dict[str, Any]:
+    var_name_to_variable: Dict[str, Any] = {}
+    var_names_unique = True
+    for var in _model_variables(model):
+        if var.name in var_name_to_variable:
+            print(f"E: More than one variable with name {var.name} used in model. Please use appropriate name_scopes!")
+            var_names_unique = False
+        else:
+            var_name_to_variable[var.name] = var
+    if not var_names_unique:
+        raise ValueError("Model variables have duplicate names, making weight restoring impossible.")
+    return var_name_to_variable
+
+
+def save_model(save_file: str, model, dataset=None, extra_data_to_store: Optional[Dict[str, Any]] = None,
+               store_weights_in_pkl: bool = True) -> None:
+    """model_utils.py:37-71.  Weight names carry the ":0" suffix of tf.Variable names so that the file reads back through
+    the reference's loader as well."""
+    data_to_store = {
+        "model_class": model.__class__,
+        "model_params": getattr(model, "_params", {}),
+        "dataset_class": None if dataset is None else dataset.__class__,
+        "dataset_params": getattr(dataset, "_params", {}),
+        "dataset_metadata": getattr(dataset, "_metadata", {}),
+        "num_edge_types": getattr(dataset, "num_edge_types", getattr(model, "_num_edge_types", None)),
+        "node_feature_shape": getattr(dataset, "node_feature_shape", None),
+    }
+    if not store_weights_in_pkl:
+        raise NotImplementedError("Keras HDF5 weight files need h5py, which this build does not ship: use store_weights_in_pkl=True")
+    var_name_to_variable = _get_name_to_variable_map(model)
+    data_to_store["model_weights"] = {
+        name + ":0": var.value.detach().cpu().numpy().copy() for name, var in var_name_to_variable.items()
+    }
+    data_to_store.update(extra_data_to_store or {})
+    pkl_file = get_model_file_path(save_file, "pkl")
+    with open(pkl_file, "wb") as out_file:
+        pickle.dump(data_to_store, out_file, pickle.HIGHEST_PROTOCOL)
+    print(f"   (Stored model metadata and weights to {pkl_file}).")
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    """Classes of modules that are not installed here (tf2_gnn, tensorflow, dpu_utils) become placeholders."""
+
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            return type(name, (), {"__module__": module, "_placeholder_for_missing_class": True,
+                                   "__setstate__": lambda self, state: self.__dict__.update(state if isinstance(state, dict) else {})})
+
+
+def load_pickle(path: str) -> Dict[str, Any]:
+    with open(path, "rb") as in_file:
+        return _TolerantUnpickler(io.BytesIO(in_file.read())).load()
+
+
+def _read_weights_from_hdf5(save_file: str) -> Dict[str, np.ndarray]:
+    """model_utils.py:74-93 (every dataset below the auto-named first level, keyed by its path)."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise RuntimeError(
+            f"{get_model_file_path(save_file, 'pkl')} holds no 'model_weights' and reading the Keras HDF5 file beside it needs h5py, "
+            "which is not installed; re-save the model with store_weights_in_pkl=True"
+        ) from e
+    var_name_to_weights: Dict[str, np.ndarray] = {}
+
+    def hdf5_item_visitor(name, item):
+        if not isinstance(item, h5py.Dataset):
+            return
+        if name in var_name_to_weights:
+            raise ValueError(f"More than one variable with name {name} used in hdf5 file. Please use appropriate name_scopes!")
+        var_name_to_weights[name] = np.array(item)
+
+    with h5py.File(get_model_file_path(save_file, "hdf5"), mode="r") as data_hdf5:
+        for model_sublayer in data_hdf5.values():
+            model_sublayer.visititems(hdf5_item_visitor)
+    return var_name_to_weights
+
+
+# model_utils.py:98-108
+BACKWARD_COMPAT_WEIGHT_NAME_MAP = {
+    "/Global_Exchange/graph_global_mean_exchange/": "/Global_Exchange/GraphGlobalMeanExchange/",
+    "/Global_Exchange/graph_global_gru_exchange/": "/Global_Exchange/GraphGlobalGRUExchange/",
+    "/Global_Exchange/graph_global_mlp_exchange/": "/Global_Exchange/GraphGlobalMLPExchange/",
+}
+
+
+def backward_compat_weight_renaming_fn(weight_name: str) -> str:
+    for old_name, new_name in BACKWARD_COMPAT_WEIGHT_NAME_MAP.items():
+        weight_name = weight_name.replace(old_name, new_name)
+    return weight_name
+
+
+_AUTO_LAYER_NAME = re.compile(r"^(dense|gru_cell|layer_normalization)(_\d+)?$")
+
+
+def _strip_output_index(name: str) -> str:
+    return name[:-2] if name.endswith(":0") else name
+
+
+def relaxed_weight_name(name: str) -> str:
+    """Name with the optional components removed: auto-generated Keras layer names and an MLP's wrapper scope
+    ("ScoringMLP/ScoringMLP_dense_0/kernel" and "ScoringMLP_dense_0/kernel" give the same key)."""
+    parts = _strip_output_index(name).split("/")
+    out = []
+    for i, c in enumerate(parts):
+        nxt = parts[i + 1] if i + 1 < len(parts) else ""
+        if _AUTO_LAYER_NAME.match(c) and i + 1 < len(parts):
+            continue
+        if nxt.startswith(c + "_dense_") or nxt == c + "_final_layer":
+            continue
+        out.append(c)
+    return "/".join(out)
+
+
+def assign_variable(var, value) -> None:
+    """In-place update of a variable's storage (K.batch_set_value of the reference): shape-checked, keeps fused-buffer views
+    and the cached split weight operands (keyed on the tensor version) valid."""
+    new = torch.as_tensor(np.asarray(value), dtype=var.value.dtype)
+    if tuple(new.shape) != tuple(var.value.shape):
+        raise ValueError(f"Shape mismatch for {var.name}: variable {tuple(var.value.shape)}, saved weight {tuple(new.shape)}")
+    if hasattr(var, "assign"):
+        var.assign(new)
+    else:
+        with torch.no_grad():
+            var.value.copy_(new.to(var.value.device))
+
+
+def load_weights_verbosely(
+    save_file: str,
+    model,
+    warn_about_initialisations: bool = True,
+    warn_about_ignored: bool = True,
+    weight_name_to_var_name: Optional[Callable[[str], str]] = backward_compat_weight_renaming_fn,
+) -> Dict[str, str]:
+    """model_utils.py:111-148.  Returns {variable name: saved weight name} of what was restored."""
+    var_name_to_variable = _get_name_to_variable_map(model)
+    data_to_load = load_pickle(get_model_file_path(save_file, "pkl"))
+    var_name_to_weights = data_to_load.get("model_weights")
+    if var_name_to_weights is None:
+        var_name_to_weights = _read_weights_from_hdf5(save_file)
+    if weight_name_to_var_name is not None:
+        var_name_to_weights = {weight_name_to_var_name(n): w for n, w in var_name_to_weights.items()}
+
+    saved_by_plain = {}
+    for n, w in var_name_to_weights.items():
+        saved_by_plain.setdefault(_strip_output_index(n), (n, w))
+    assignments: List[Tuple[Any, np.ndarray]] = []
+    restored: Dict[str, str] = {}
+    used_saved = set()
+    pending = []
+    for var_name, var in var_name_to_variable.items():
+        hit = saved_by_plain.get(_strip_output_index(var_name))
+        if hit is None:
+            pending.append((var_name, var))
+        else:
+            used_saved.add(hit[0])
+            restored[var_name] = hit[0]
+            assignments.append((var, hit[1]))
+    if pending:  # relaxed pass over what is left on both sides
+        left = {}
+        ambiguous = set()
+        for n, w in var_name_to_weights.items():
+            if n in used_saved:
+                continue
+            key = relaxed_weight_name(n)
+            if key in left:
+                ambiguous.add(key)
+            left[key] = (n, w)
+        var_keys = [relaxed_weight_name(n) for n, _ in pending]
+        for (var_name, var), key in zip(pending, var_keys):
+            hit = left.get(key)
+            if (hit is None or key in ambiguous or var_keys.count(key) > 1
+                    or tuple(np.shape(hit[1])) != tuple(var.value.shape)):
+                if warn_about_initialisations:
+                    print(f"I: Weights for {var_name} freshly initialised.")
+                continue
+            print(f"I: Restoring {var_name} from saved weight {hit[0]} (names differ only in optional scope components).")
+            used_saved.add(hit[0])
+            restored[var_name] = hit[0]
+            assignments.append((var, hit[1]))
+    if warn_about_ignored:
+        for n in var_name_to_weights.keys():
+            if n not in used_saved:
+                print(f"I: Model does not use saved weights for {n}.")
+    for var, w in assignments:
+        assign_variable(var, w)
+    return restored

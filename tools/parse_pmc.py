@@ -22,8 +22,9 @@ def load(d, counter):
 
 
 def pick(d, needle):
+    needles = (needle,) if isinstance(needle, str) else needle
     for k, v in d.items():
-        if needle in k:
+        if all(n in k for n in needles):
             return v
     return None
 
@@ -36,7 +37,9 @@ cal_w = pick(write, "act_forward_kernel") * 1024.0
 kf, kw = known / cal_f, known / cal_w
 res = {"calibration": {"known_bytes_each_way": known, "fetch_raw_bytes": cal_f, "write_raw_bytes": cal_w,
                        "fetch_factor": kf, "write_factor": kw}}
-for name, needle in (("gather", "csr_gather_reduce_kernel"), ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel")):
+for name, needle in (("gather", ("csr_gather_reduce_kernel", "false>")), ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel"),
+                     ("gather_sp", ("csr_gather_reduce_kernel", "true>")), ("gemm_sp_nt", "gemm_sp_nt_kernel"),
+                     ("gemm_sp_tn", "gemm_sp_tn_kernel")):
     if pick(fetch, needle) is None:
         continue
     f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0

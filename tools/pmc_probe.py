@@ -23,6 +23,10 @@ big = torch.randn(V * L * H, device=dev)  # 153.6 MB
 big2 = torch.empty_like(big)
 rs = g.array(ops.G_INVDEG_BY_DST)
 Wt = W.t().contiguous()
+Wt_sp = ops.sp_split_cols(W)
+X_sp = ops.sp_split_rows(X)
+G_sp = ops.sp_split_rows(torch.randn((V, L * H), device=dev) * 1e-3, scale_block=H)
+dW = torch.empty((L, H, H), device=dev)
 for _ in range(5):
     ops.activation_forward("relu", big, out=big2)  # calibration: 153.6 MB read + 153.6 MB written
     ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, out=A)
@@ -30,5 +34,9 @@ for _ in range(5):
     ops.gemm(A.view(V, L * H), W, act="relu", out=out)
     ops.set_gemm_mode("bf16x3")  # the same product on the split-operand kernel (W^T, as the layers call it)
     ops.gemm(A.view(V, L * H), Wt, trans_b=True, act="relu", out=out)
+    # f16x2 mode: the gather writes the split operand, NT product forward, TN product for the weight gradient
+    A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=rs, rows_per_operand_row=L)
+    ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=out)
+    ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, H * H, 1, H))
 torch.cuda.synchronize()
 print("pmc probe done")
