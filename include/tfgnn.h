@@ -420,6 +420,12 @@ int tfgnn_segment_softmax_backward(const float* d_w, const float* d_dw, int head
  * The stream of random numbers is this library's own (counter-based), not TensorFlow's. */
 int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask, int64_t n, float rate,
                           uint64_t seed, void* stream);
+/* The same dropout (same random numbers: element (r, c) draws that of flat index r * cols + c) that also writes its result
+ * in the SP16 operand format with one power-of-two scale per row (see "Split fp16 operands"): the layer input is an
+ * operand of the weight-gradient product downstream, and splitting it where it is produced saves one pass over it.
+ * cols % 16 == 0, cols <= 512; d_out_sp 64-byte aligned rows of ld_out_sp_bytes >= 4 * cols; d_inv_scale [rows]. */
+int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_mask, int64_t rows, int64_t cols, float rate,
+                             uint64_t seed, void* d_out_sp, int64_t ld_out_sp_bytes, float* d_inv_scale, void* stream);
 int tfgnn_mul(const float* d_a, const float* d_b, float* d_out, int64_t n, void* stream);
 
 /* Inter-layer LayerNormalization of the GNN stack (gnn.py:157-161,318-321; [ext] Keras defaults

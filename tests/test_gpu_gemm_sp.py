@@ -270,3 +270,31 @@ def test_absmax(dev):
         x = torch.randn(n, generator=g) * 5
         assert float(ops.absmax(x.to(dev)).cpu()) == float(x.abs().max())
         assert float(ops.absmax(x.to(dev), scale=2.0).cpu()) == float(2.0 * x.abs().max())
+
+
+def test_dropout_writes_the_same_split_operand_as_a_split_pass(dev):
+    """ops.dropout_forward in f16x2 mode: y and mask bit-equal to the flat kernel, SP16 bytes and scales bit-equal to
+    sp_split_rows(y); the memo hands the operand out for that tensor only while its version is unchanged."""
+    from tf2_gnn_amd import ops
+
+    for rows, cols in ((1000, 320), (37, 64), (513, 512), (5, 128)):
+        x = torch.randn((rows, cols), device=dev)
+        x[0] = 0.0
+        ops.set_gemm_mode("bf16x3")
+        y0, m0 = ops.dropout_forward(x, 0.1, 1234)
+        ops.set_gemm_mode("f16x2")
+        try:
+            y1, m1 = ops.dropout_forward(x, 0.1, 1234)
+            op = ops.sp_rows_of(y1)
+            ref = ops.sp_split_rows(y1)
+            assert torch.equal(y0, y1) and torch.equal(m0, m1)
+            # the pieces of a dropped negative element are (-0, +0) here and (+0, -0) from the split pass: compare values
+            assert op is not ref and torch.equal(op.inv_scale.view(-1), ref.inv_scale.view(-1))
+            assert np.array_equal(decode_sp16(op), decode_sp16(ref))
+            assert ops.sp_rows_of(y1) is op
+            y1.mul_(2.0)  # version bump: the remembered operand is stale
+            assert ops.sp_rows_of(y1) is not op
+        finally:
+            ops.set_gemm_mode("bf16x3")
+    keep = float((m0 != 0).float().mean())
+    assert abs(keep - 0.9) < 0.05

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "sp16.hpp"
 
 namespace tfgnn {
 
@@ -214,6 +215,52 @@ dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float
   }
 }
 
+// dropout + the SP16 form of the result (the split operand of the weight-gradient product downstream: saves the separate
+// split pass over the layer input).  16 lanes per row, a row's float4s held in registers between the mask pass and the
+// split pass; the random number of element (r, c) is that of the flat kernel at index r * cols + c, so both kernels
+// produce the same y and mask.
+template <int VPL>
+__global__ void __launch_bounds__(256)
+dropout_forward_sp_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t rows, int cols,
+                          float rate, uint64_t seed, uint8_t* __restrict__ out_sp, int64_t ld_sp, float* __restrict__ inv_out) {
+  const float scale = 1.f / (1.f - rate);
+  const int sub = threadIdx.x & 15;
+  const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (r >= rows) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
+  const int64_t base = r * cols;
+  float4 v[VPL];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (sub + 16 * j) * 4;
+    if (c < cols) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
+      float m[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = (float)(mix_hash(seed * 0xD1342543DE82EF95ull + (uint64_t)(base + c + e)) >> 8) * (1.0f / 16777216.0f);
+        m[e] = u >= rate ? scale : 0.f;
+      }
+      v[j] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
+      *reinterpret_cast<float4*>(mask + base + c) = make_float4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<float4*>(y + base + c) = v[j];
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+      if (v[j].x != v[j].x || v[j].y != v[j].y || v[j].z != v[j].z || v[j].w != v[j].w) mx = __builtin_inff();
+    }
+  }
+#pragma unroll
+  for (int o = 8; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float inv;
+  const float sc = sp_scale_for_max(mx, &inv);
+  if (sub == 0) inv_out[r] = inv;
+  uint8_t* row = out_sp + r * ld_sp;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (sub + 16 * j) * 4;
+    if (c < cols) sp_store4(row, c, v[j], sc);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -393,6 +440,35 @@ extern "C" int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask
   TFGNN_REQUIRE(d_x && d_y && d_mask, "NULL pointer");
   hipLaunchKernelGGL(dropout_forward_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask,
                      n, rate, seed);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_mask, int64_t rows, int64_t cols, float rate,
+                                        uint64_t seed, void* d_out_sp, int64_t ld_out_sp_bytes, float* d_inv_scale,
+                                        void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(rows >= 0 && cols > 0, "bad sizes");
+  TFGNN_REQUIRE(rate >= 0.f && rate < 1.f, "dropout rate must be in [0, 1), got %f", (double)rate);
+  if (cols % 16 != 0 || cols > 512) {
+    set_error("tfgnn_dropout_forward_sp: cols = %lld must be a multiple of 16 and at most 512", (long long)cols);
+    return TFGNN_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_y && d_mask && d_out_sp && d_inv_scale, "NULL pointer");
+  TFGNN_REQUIRE(ld_out_sp_bytes >= cols * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0 &&
+                    (uintptr_t)d_x % 16 == 0 && (uintptr_t)d_y % 16 == 0 && (uintptr_t)d_mask % 16 == 0,
+                "tfgnn_dropout_forward_sp: SP16 rows must be 64-byte aligned, fp32 tensors 16-byte aligned");
+  const dim3 grid((unsigned)ceil_div(rows, 16));
+  const int vpl = (int)ceil_div(cols, 64);
+#define DROP_SP(V)                                                                                                      \
+  hipLaunchKernelGGL((dropout_forward_sp_kernel<V>), grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask, rows, (int)cols, \
+                     rate, seed, (uint8_t*)d_out_sp, ld_out_sp_bytes, d_inv_scale)
+  if (vpl <= 2) DROP_SP(2);
+  else if (vpl <= 4) DROP_SP(4);
+  else if (vpl <= 5) DROP_SP(5);
+  else DROP_SP(8);
+#undef DROP_SP
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

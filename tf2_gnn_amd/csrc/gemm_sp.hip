@@ -634,6 +634,7 @@ struct SpTnArgs {
   float* partial;     // [splits][M][N]
   int64_t k_chunk;    // rows of K per split (a multiple of 16)
   unsigned n_tiles;
+  unsigned tiles, splits, per_xcd;  // output tiles, K splits, workgroups per XCD (grid = 8 * per_xcd)
 };
 
 // Per-k factors of the weight-gradient product.  Both operands carry one power-of-two scale per ROW (A one per row and
@@ -645,14 +646,26 @@ struct SpTnArgs {
 // drops out at j > 24 - far beyond the spread of the node states and gradients of a batch (tests: rows over 2^+-9
 // keep the fp32 error class; over 2^+-18 the error grows to 1e-5 of sum |a||b|).  Scaling BOTH operands' fragments by
 // their own factors would double that range but costs 40 more VALU instructions per step (measured 115 vs 92 us).
-// One workgroup per block.
+// SP_TN_FCHUNKS workgroups per block: each one takes the maximum over ALL k itself (the scales are 4 bytes per row, L2
+// resident; loads issued eight at a time) and writes its own slice of the factors - no second launch, no atomics.
+constexpr int SP_TN_FCHUNKS = 16;
 __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
                                                              int64_t ld_b, int64_t K, _Float16* __restrict__ F, int64_t f_ld,
                                                              float* __restrict__ ref) {
   __shared__ float red[16];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / SP_TN_FCHUNKS, chunk = blockIdx.x % SP_TN_FCHUNKS;
   float mx = 0.f;
-  for (int64_t k = threadIdx.x; k < K; k += 1024) mx = fmaxf(mx, inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f));
+  for (int64_t k0 = threadIdx.x; k0 < K; k0 += 8 * 1024) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t k = k0 + u * 1024;
+      va[u] = k < K ? inv_a[k * ld_a + b] : 0.f;
+      vb[u] = (k < K && inv_b) ? inv_b[k * ld_b] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = fmaxf(mx, va[u] * vb[u]);
+  }
 #pragma unroll
   for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -661,9 +674,11 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
   if (mx == 0.f) mx = 1.f;
-  if (threadIdx.x == 0) ref[b] = mx;
+  if (threadIdx.x == 0 && chunk == 0) ref[b] = mx;
   const float r = 1.f / mx;  // powers of two: exact
-  for (int64_t k = threadIdx.x; k < f_ld; k += 1024)
+  const int64_t per = ((f_ld + SP_TN_FCHUNKS - 1) / SP_TN_FCHUNKS + 7) & ~7ll;
+  const int64_t kend = (chunk + 1) * per < f_ld ? (chunk + 1) * per : f_ld;
+  for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 1024)
     F[(int64_t)b * f_ld + k] = k < K ? (_Float16)(inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f) * r) : (_Float16)0.f;
 }
 
@@ -827,11 +842,19 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const unsigned tile_n = blockIdx.x % g.n_tiles;
-  const unsigned tile_m = blockIdx.x / g.n_tiles;
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  All tiles of one
+  // K split read the same rows of both operands: lay the (split, tile) pairs out so that one XCD owns whole splits -
+  // the B rows of a split are then fetched over the fabric once instead of once per XCD (counters: 500 MB -> the
+  // operands' own bytes).
+  const unsigned logical = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
+  if (logical >= g.tiles * g.splits) return;
+  const unsigned split = logical / g.tiles;
+  const unsigned tile = logical - split * g.tiles;
+  const unsigned tile_n = tile % g.n_tiles;
+  const unsigned tile_m = tile / g.n_tiles;
   const int64_t row0 = (int64_t)tile_m * SP_BM;   // first column of A (= output row)
   const int64_t col0 = (int64_t)tile_n * G::BN;   // first column of B (= output column)
-  const int64_t k0 = (int64_t)blockIdx.y * g.k_chunk;
+  const int64_t k0 = (int64_t)split * g.k_chunk;
   const int64_t krows = g.K - k0 < g.k_chunk ? g.K - k0 : g.k_chunk;
   const int nsteps = (int)((krows + 15) >> 4);
 
@@ -923,7 +946,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 
   // partial tile -> workspace (raw sums; the reduce pass scales)
   float* patch = reinterpret_cast<float*>(lds) + wave * 32 * G::PATCH_LD;
-  float* __restrict__ part = g.partial + (int64_t)blockIdx.y * g.M * g.N;
+  float* __restrict__ part = g.partial + (int64_t)split * g.M * g.N;
   const int64_t wcol0 = col0 + wn * 32 * TNW;
   constexpr int C4 = 8 * TNW;
   constexpr int NIT = 32 * C4 / 64;
@@ -1122,7 +1145,7 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   hipStream_t s = (hipStream_t)stream;
   _Float16* F = (_Float16*)d_workspace;
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
-  hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
+  hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * SP_TN_FCHUNKS), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
                      kpad, ref);
   TFGNN_LAUNCH_CHECK();
   SpTnArgs g{};
@@ -1135,7 +1158,10 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   g.k_chunk = ((steps + splits - 1) / splits) * 16;
   g.n_tiles = (unsigned)(N / bn);
   TFGNN_REQUIRE(g.k_chunk * std::max(lda_bytes, ldb_bytes) < (1ll << 31) && nblk * kpad * 2 < (1ll << 31), "tfgnn_sp_gemm_tn: K chunk too large");
-  dim3 grid((unsigned)((M / SP_BM) * g.n_tiles), (unsigned)splits);
+  g.tiles = (unsigned)((M / SP_BM) * g.n_tiles);
+  g.splits = (unsigned)splits;
+  g.per_xcd = (g.tiles * g.splits + 7) / 8;
+  dim3 grid(8 * g.per_xcd);
 #define SP_LAUNCH_TN(T)                                                                                            \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \

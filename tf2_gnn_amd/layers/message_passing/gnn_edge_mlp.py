@@ -359,7 +359,7 @@ class GNN_Edge_MLP(MessagePassing):
             self._out_epilogue = None  # consumed
         else:
             dX = ops.sp_gemm_nt(G_sp, Wh_sp)
-        X_sp = ops.sp_split_rows(X)
+        X_sp = ops.sp_rows_of(X)  # written by the dropout kernel when X came out of one
         dW = torch.empty_like(W)
         ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))  # element ((l, h), d) -> dW[l, d, h]
         mlps.grads = [dW]

@@ -509,11 +509,20 @@ def add_scale(x: torch.Tensor, y: torch.Tensor, alpha: float) -> torch.Tensor:
 
 
 def dropout_forward(x: torch.Tensor, rate: float, seed: int):
-    """-> (y, mask) with mask in {0, 1/(1-rate)}"""
+    """-> (y, mask) with mask in {0, 1/(1-rate)}.  In f16x2 mode a 2-D result that can be a split operand (width a
+    multiple of 16, <= 512) is also written in the SP16 format by the same kernel and remembered for ``sp_rows_of``."""
     lib = _lib.load()
     x = x.contiguous()
     y = torch.empty_like(x)
     mask = torch.empty_like(x)
+    if _f16x2_on() and x.dim() == 2 and x.shape[1] % 16 == 0 and 32 <= x.shape[1] <= 512 and x.shape[0] > 0:
+        rows, cols = x.shape
+        op = SplitOperand(torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device),
+                          torch.empty((rows, 1), dtype=torch.float32, device=x.device), rows, cols, cols)
+        _lib.check(lib.tfgnn_dropout_forward_sp(_ptr(x), _ptr(y), _ptr(mask), rows, cols, float(rate), int(seed) & (2**64 - 1),
+                                                _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale), _stream()))
+        _remember_split_rows(y, op)
+        return y, mask
     _lib.check(
         lib.tfgnn_dropout_forward(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & (2**64 - 1), _stream())
     )
@@ -745,6 +754,26 @@ def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed
                                        None if fixed_inv_scale is not None else _ptr(out.inv_scale), _ptr(fixed_inv_scale),
                                        _stream()))
     return out
+
+
+_sp_rows_memo = {}  # id(tensor) -> (weakref, version, SplitOperand): split forms written by the kernel that produced the tensor
+
+
+def _remember_split_rows(t: torch.Tensor, op: SplitOperand) -> None:
+    import weakref
+
+    for k in [k for k, (ref, _, _) in _sp_rows_memo.items() if ref() is None]:  # a handful of entries: layer inputs of one step
+        del _sp_rows_memo[k]
+    _sp_rows_memo[id(t)] = (weakref.ref(t), t._version, op)
+
+
+def sp_rows_of(x: torch.Tensor) -> SplitOperand:
+    """SP16 rows (one scale per row) of ``x``: the form its producer already wrote (dropout_forward in f16x2 mode), when that
+    is still valid for this very tensor object and version, else a split pass."""
+    hit = _sp_rows_memo.get(id(x))
+    if hit is not None and hit[0]() is x and hit[1] == x._version:
+        return hit[2]
+    return sp_split_rows(x)
 
 
 def sp_split_cols(w: torch.Tensor) -> SplitOperand:
