@@ -196,6 +196,18 @@ int tfgnn_edge_pair_combine(const int32_t* d_index_a, const int32_t* d_index_b, 
                             const float* d_Q, int64_t num_edges, int width, int act, float* d_out,
                             void* stream);
 
+/* GNN_FiLM in its per-edge form (gnn_film.py:83-108), for the configurations whose modulated messages go through a max
+ * aggregation or a per-message activation (sums are modulated on the node side: tfgnn_film_combine_*):
+ *   out[e,:] = gamma[film_row[e],:] * (weight[e] * msg[msg_row[e],:]) + beta[film_row[e],:]
+ * d_film rows are [gamma | beta] of width 2 * width; msg_row NULL = identity, edge_weight NULL = 1.  The backward entry
+ * writes per-edge terms: grad_msg [E, width] and grad_film [E, 2 * width]; the caller reduces them over message rows /
+ * (target, type) buckets with the gather kernel. */
+int tfgnn_film_edge_forward(const float* d_msg, const int32_t* d_msg_row, const float* d_film, const int32_t* d_film_row,
+                            const float* d_edge_weight, int64_t num_edges, int width, float* d_out, void* stream);
+int tfgnn_film_edge_backward(const float* d_grad, const float* d_msg, const int32_t* d_msg_row, const float* d_film,
+                             const int32_t* d_film_row, const float* d_edge_weight, int64_t num_edges, int width,
+                             float* d_grad_msg, float* d_grad_film, void* stream);
+
 /* Backward through a general aggregation, i.e. the cases the sum-only algebra does not cover:
  * aggregation_function "max" (utils/param_helpers.py:11) and message_activation_before_aggregation
  * (message_passing.py:169-172).  Forward: agg[t,:] = node_scale[t] * REDUCE_{e->t} pre_act(w_e * msg[row_e,:])

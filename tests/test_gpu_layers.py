@@ -531,6 +531,19 @@ FILM_CASES = [
     ("film_hidden_edge_mlp_gelu", {"num_edge_MLP_hidden_layers": 1, "message_activation_function": "gelu"}),
     ("film_hidden_film_mlp_sqrt_n", {"film_parameter_MLP_hidden_layers": [20], "aggregation_function": "sqrt_n",
                                      "normalize_by_num_incoming": True}),
+    # per-edge form (tfgnn_film_edge_*): max aggregation, activation before aggregation, target states as edge-MLP input
+    ("film_max", {"aggregation_function": "max"}),
+    ("film_max_norm_hidden_tanh", {"aggregation_function": "max", "normalize_by_num_incoming": True, "num_edge_MLP_hidden_layers": 1,
+                                   "message_activation_function": "tanh"}),
+    ("film_act_before_sum_elu", {"message_activation_before_aggregation": True, "message_activation_function": "elu",
+                                 "normalize_by_num_incoming": True}),
+    ("film_act_before_mean_gelu", {"message_activation_before_aggregation": True, "message_activation_function": "gelu",
+                                   "aggregation_function": "mean", "film_parameter_MLP_hidden_layers": [12]}),
+    ("film_target_input_sum", {"use_target_state_as_input": True}),
+    ("film_target_input_hidden_sqrt_n_norm", {"use_target_state_as_input": True, "num_edge_MLP_hidden_layers": 1,
+                                              "aggregation_function": "sqrt_n", "normalize_by_num_incoming": True}),
+    ("film_target_input_max_act_before", {"use_target_state_as_input": True, "aggregation_function": "max",
+                                          "message_activation_before_aggregation": True, "message_activation_function": "tanh"}),
 ]
 
 
@@ -568,7 +581,7 @@ def test_gnn_film_forward_backward_parity(dev, name, over):
         assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=2e-5, what=f"{name} d{v.name}")
 
 
-def test_gnn_film_in_a_gnn_stack_and_unsupported_modes(dev):
+def test_gnn_film_in_a_gnn_stack_and_without_edges(dev):
     from tf2_gnn_amd.layers import GNN, GNNInput, MessagePassingInput
 
     V, L, Din, H = 60, 2, 7, 16
@@ -582,9 +595,13 @@ def test_gnn_film_in_a_gnn_stack_and_unsupported_modes(dev):
     assert out.shape == (V, H) and bool(torch.isfinite(out).all())
     gnn.backward(torch.ones_like(out))
     assert all(v.grad is not None and bool(torch.isfinite(v.grad).all()) for v in gnn.trainable_variables)
-    layer, _ = _build("GNN_FiLM", {"hidden_dim": H, "aggregation_function": "max"}, H, L)
-    with pytest.raises(NotImplementedError):
-        layer(MessagePassingInput(torch.zeros((V, H), device=dev), to_dev(adjs, dev)))
+    # the per-edge form on a batch without edges: activation of the empty aggregate, zero gradients
+    layer, _ = _build("GNN_FiLM", {"hidden_dim": H, "aggregation_function": "mean", "use_target_state_as_input": True}, H, L)
+    empty = tuple(torch.zeros((0, 2), dtype=torch.int32, device=dev) for _ in range(L))
+    out = layer(MessagePassingInput(torch.ones((V, H), device=dev), empty))
+    assert float(out.abs().max()) == 0.0
+    dX = layer.backward(torch.ones_like(out))
+    assert float(dX.abs().max()) == 0.0 and all(float(v.grad.abs().max()) == 0.0 for v in layer.trainable_variables)
 
 
 # ---- graph global exchange ("next" row f3) --------------------------------------------------------------
@@ -765,3 +782,85 @@ def test_graph_cache_does_not_return_a_stale_graph_for_reallocated_adjacency_ten
     o1 = layer(MessagePassingInput(X, (view, view.contiguous())), training=False)
     o2 = layer(MessagePassingInput(X, (view.contiguous(), view.contiguous())), training=False)
     assert torch.allclose(o1, o2)
+
+
+# ---- user-defined message functions: the generic path and its backward ------------------------------------------
+@pytest.mark.parametrize("agg,act,before", [("sum", "relu", False), ("mean", "tanh", True), ("max", "elu", False),
+                                            ("sqrt_n", "gelu", False), ("max", "tanh", True)])
+def test_generic_message_passing_forward_backward_with_a_user_message_function(dev, agg, act, before):
+    """A subclass that only implements _message_function (as the reference's extension point, message_passing.py:64-93):
+    forward through the gather / aggregation kernels, backward = kernels + torch autograd of the user's function,
+    against a plain fp64 torch restatement."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+    from tf2_gnn_amd.layers.message_passing import MessagePassing
+    from tf2_gnn_amd.layers.message_passing.message_passing import glorot_uniform
+
+    class UserLayer(MessagePassing):
+        def build(self, input_shapes):
+            D = int(input_shapes.node_embeddings[-1])
+            L = len(input_shapes.adjacency_lists)
+            self.w_src = [self.add_weight(f"edge_type_{l}/w_src", glorot_uniform((D, self._hidden_dim))) for l in range(L)]
+            self.w_tgt = [self.add_weight(f"edge_type_{l}/w_tgt", glorot_uniform((D, self._hidden_dim))) for l in range(L)]
+            super().build(input_shapes)
+
+        def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message, edge_type_idx,
+                              training):
+            m = edge_source_states @ self.w_src[edge_type_idx].value + torch.sin(edge_target_states @ self.w_tgt[edge_type_idx].value)
+            return m / (num_incoming_to_node_per_message + 1.0).unsqueeze(-1)
+
+    V, L, D, H = 70, 3, 12, 20
+    adjs = random_graph(V, 600, L, seed=21, empty_types=(1,), hub=(5, 40))
+    p = MessagePassing.get_default_hyperparameters()
+    p.update({"hidden_dim": H, "aggregation_function": agg, "message_activation_function": act,
+              "message_activation_before_aggregation": before})
+    layer = UserLayer(p)
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn((V, D), generator=gen)
+    dOut = torch.randn((V, H), generator=gen)
+    out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
+    dX = layer.backward(dOut.to(dev))
+    assert all(not v.value.requires_grad for v in layer.trainable_variables)
+
+    # fp64 restatement
+    X64 = X.double().requires_grad_(True)
+    ws = [v.value.detach().cpu().double().requires_grad_(True) for v in layer.w_src]
+    wt = [v.value.detach().cpu().double().requires_grad_(True) for v in layer.w_tgt]
+    cnt = orc.calculate_type_to_num_incoming_edges(X64, [torch.from_numpy(a) for a in adjs])
+    msgs, tgts = [], []
+    for l, a in enumerate(adjs):
+        a = torch.from_numpy(a).long()
+        m = X64[a[:, 0]] @ ws[l] + torch.sin(X64[a[:, 1]] @ wt[l])
+        msgs.append(m / (cnt[l][a[:, 1]] + 1.0).unsqueeze(-1))
+        tgts.append(a[:, 1])
+    m_all, t_all = torch.cat(msgs), torch.cat(tgts)
+    act_fn = orc.get_activation_function(act)
+    if before:
+        m_all = act_fn(m_all)
+    ref = orc.get_aggregation_function(agg)(m_all, t_all, V)
+    if not before:
+        ref = act_fn(ref)
+    assert_close(out.cpu(), ref.detach().float(), tol=2e-5, what=f"generic {agg}/{act}/{before} fwd")
+    grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + ws + wt)
+    assert_close(dX.cpu(), grads[0].float(), tol=5e-5, what=f"generic {agg}/{act}/{before} dX")
+    for v, r in zip(layer.w_src + layer.w_tgt, grads[1:]):
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=5e-5, what=f"generic {agg}/{act}/{before} d{v.name}")
+
+
+def test_generic_backward_refuses_what_it_cannot_differentiate(dev):
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers import MessagePassingInput
+    from tf2_gnn_amd.layers.message_passing import MessagePassing
+
+    class KernelOnly(MessagePassing):
+        def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message, edge_type_idx,
+                              training):
+            return ops.activation_forward("tanh", edge_source_states.detach())  # a HIP call: no autograd history
+
+    p = MessagePassing.get_default_hyperparameters()
+    p["hidden_dim"] = 8
+    layer = KernelOnly(p)
+    adjs = random_graph(20, 60, 2, seed=1)
+    out = layer(MessagePassingInput(torch.randn((20, 8), device=dev), to_dev(adjs, dev)))
+    with pytest.raises(NotImplementedError, match="autograd history"):
+        layer.backward(torch.ones_like(out))

@@ -126,6 +126,9 @@ _SIGNATURES = [
     ),
     ("tfgnn_segment_softmax_backward", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     ("tfgnn_dropout_forward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p]),
+    ("tfgnn_film_edge_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    ("tfgnn_film_edge_backward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                         c_void_p]),
     ("tfgnn_dropout_forward_sp", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_int64,
                                          c_void_p, c_void_p]),
     ("tfgnn_transpose_batched", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),

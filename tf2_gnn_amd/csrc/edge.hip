@@ -92,6 +92,73 @@ extern "C" int tfgnn_graph_original_order(const tfgnn_graph* g, const float* d_w
   return TFGNN_OK;
 }
 
+// ---- FiLM, per-edge form (gnn_film.py:83-108) --------------------------------------------------------
+// modulated[e, :] = gamma[frow_e, :] * (w_e * msg[mrow_e, :]) + beta[frow_e, :]     film = [gamma | beta] rows of width 2 * width
+// needed when the modulated messages go through a max aggregation or an activation before the aggregation (the node-side
+// form of tfgnn_film_combine_* covers sums).  mrow == NULL: identity; w == NULL: 1.
+namespace tfgnn {
+__global__ void __launch_bounds__(256)
+film_edge_forward_kernel(const float* __restrict__ msg, const int32_t* __restrict__ mrow, const float* __restrict__ film,
+                         const int32_t* __restrict__ frow, const float* __restrict__ w, int64_t E, int width,
+                         float* __restrict__ out) {
+  const int64_t total = E * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / width;
+    const int c = (int)(i - e * width);
+    const float m = msg[(mrow ? (int64_t)mrow[e] : e) * width + c] * (w ? w[e] : 1.f);
+    const float* f = film + (int64_t)frow[e] * 2 * width;
+    out[i] = f[c] * m + f[width + c];
+  }
+}
+
+// d_msg[e, :] = d[e, :] * gamma * w_e      d_film[e, :] = [ d[e, :] * (w_e * msg) | d[e, :] ]   (per edge; the caller sums
+// d_film over the edges of a (target, type) bucket and d_msg over the edges sharing a message row)
+__global__ void __launch_bounds__(256)
+film_edge_backward_kernel(const float* __restrict__ d, const float* __restrict__ msg, const int32_t* __restrict__ mrow,
+                          const float* __restrict__ film, const int32_t* __restrict__ frow, const float* __restrict__ w,
+                          int64_t E, int width, float* __restrict__ d_msg, float* __restrict__ d_film) {
+  const int64_t total = E * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / width;
+    const int c = (int)(i - e * width);
+    const float we = w ? w[e] : 1.f;
+    const float m = msg[(mrow ? (int64_t)mrow[e] : e) * width + c] * we;
+    const float g = film[(int64_t)frow[e] * 2 * width + c];
+    const float dv = d[i];
+    d_msg[i] = dv * g * we;
+    d_film[e * 2 * width + c] = dv * m;
+    d_film[e * 2 * width + width + c] = dv;
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_film_edge_forward(const float* d_msg, const int32_t* d_msg_row, const float* d_film, const int32_t* d_film_row,
+                                       const float* d_edge_weight, int64_t num_edges, int width, float* d_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && width >= 0, "negative size");
+  if (num_edges == 0 || width == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_msg && d_film && d_film_row && d_out, "NULL pointer");
+  unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(num_edges * width, 256), 65536));
+  hipLaunchKernelGGL(film_edge_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_msg, d_msg_row, d_film, d_film_row,
+                     d_edge_weight, num_edges, width, d_out);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_film_edge_backward(const float* d_grad, const float* d_msg, const int32_t* d_msg_row, const float* d_film,
+                                        const int32_t* d_film_row, const float* d_edge_weight, int64_t num_edges, int width,
+                                        float* d_grad_msg, float* d_grad_film, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_edges >= 0 && width >= 0, "negative size");
+  if (num_edges == 0 || width == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_grad && d_msg && d_film && d_film_row && d_grad_msg && d_grad_film, "NULL pointer");
+  unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(num_edges * width, 256), 65536));
+  hipLaunchKernelGGL(film_edge_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_grad, d_msg, d_msg_row, d_film,
+                     d_film_row, d_edge_weight, num_edges, width, d_grad_msg, d_grad_film);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
 // ---- backward through a general aggregation ---------------------------------------------------------
 // forward (spmm.hip, MODE_GENERAL):  agg[t, :] = node_scale[t] * REDUCE_{e -> t} pre_act( w_e * msg[row_e, :] )
 // phase 0 (max only): out[e, :] = 1 where the edge attains the maximum of its target, else 0

@@ -502,23 +502,24 @@ class GNN_Edge_MLP(MessagePassing):
             g._cache[key] = cached
         return cached
 
-    def _forward_C(self, X, g, fuse_act):
-        """per-edge MLP (target states + hidden layers); see csrc/edge.hip."""
+    def _edge_messages_C(self, X, g, ew_d):
+        """per-edge MLP outputs [E, H] in edge-list order (target states + hidden layers); see csrc/edge.hip."""
         from ... import _lib
 
         V, D = X.shape
-        L, H, E = g.num_edge_types, self._hidden_dim, g.num_edges
+        L, E = g.num_edge_types, g.num_edges
         mlps = self._edge_type_mlps
-        _, ew_d, _, node_scale = self._scales(g)
         src_l, tgt_l, tgt_node, _, off, _ = self._original_order(g, ew_d)
         Wh = ops.permute_021(mlps.kernels[0])  # [2D, L, H0]
         H0 = mlps.kernels[0].shape[2]
         P = ops.gemm(X, Wh[:D].view(D, L * H0))  # x_u W_s for every (node, type)
         Q = ops.gemm(X, Wh[D:].view(D, L * H0))  # x_v W_t
         Z = torch.empty((E, H0), dtype=torch.float32, device=X.device)
+        # a single Dense layer has no activation (dpu_utils MLP [ext]: the final layer is linear)
+        first_act = "relu" if mlps.num_layers > 1 else None
         _lib.check(
             _lib.load().tfgnn_edge_pair_combine(
-                ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(P), ops._ptr(Q), E, H0, ops.act_id("relu"), ops._ptr(Z),
+                ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(P), ops._ptr(Q), E, H0, ops.act_id(first_act), ops._ptr(Z),
                 ops._stream(),
             )
         )
@@ -533,22 +534,32 @@ class GNN_Edge_MLP(MessagePassing):
                     ops.gemm(cur[off[l] : off[l + 1]], W[l], act=None if last else "relu", out=nxt[off[l] : off[l + 1]])
             acts.append(nxt)
             cur = nxt
-        is_max = self._aggregation_name == "max"
-        gelu_split = fuse_act == "gelu"
-        ctx = {"path": "C", "fused_act": fuse_act, "edge_acts": acts, "P_shape": (V, L * H0)}
-        if E == 0:
-            out = torch.zeros((V, H), dtype=torch.float32, device=X.device)
-            if is_max:
-                out.fill_(torch.finfo(torch.float32).min)
-            if gelu_split:
-                ctx["pre"] = out
-                return ops.activation_forward("gelu", out), ctx
-            if fuse_act is not None:
-                out = ops.activation_forward(fuse_act, out)
-            return out, ctx
+        return cur, acts
+
+    def _aggregate_nothing(self, V, X, fuse_act, ctx):
+        """aggregation over zero edges: zeros (sum-like) / the float minimum (max), then the activation."""
+        out = torch.zeros((V, self._hidden_dim), dtype=torch.float32, device=X.device)
+        if self._aggregation_name == "max":
+            out.fill_(torch.finfo(torch.float32).min)
+        if fuse_act == "gelu":
+            ctx["pre"] = out
+            return ops.activation_forward("gelu", out)
+        if fuse_act is not None:
+            out = ops.activation_forward(fuse_act, out)
+        return out
+
+    def _forward_C(self, X, g, fuse_act):
+        V = X.shape[0]
+        _, ew_d, _, node_scale = self._scales(g)
+        cur, acts = self._edge_messages_C(X, g, ew_d)
+        H0 = self._edge_type_mlps.kernels[0].shape[2]
+        ctx = {"path": "C", "fused_act": fuse_act, "edge_acts": acts, "P_shape": (V, g.num_edge_types * H0)}
+        if g.num_edges == 0:
+            return self._aggregate_nothing(V, X, fuse_act, ctx), ctx
         return self._gather_messages(g, cur, g.array(ops.G_EID_BY_DST), ew_d, node_scale, fuse_act, ctx), ctx
 
-    def _backward_C(self, d_agg, ctx):
+    def _backward_C(self, d_agg, ctx, dcur=None):
+        """``dcur``: d(per-edge MLP outputs) [E, H] in edge-list order when the caller already has it (GNN_FiLM)."""
         g, X = ctx["graph"], ctx["X"]
         V, D = X.shape
         L, E = g.num_edge_types, g.num_edges
@@ -559,23 +570,20 @@ class GNN_Edge_MLP(MessagePassing):
             return torch.zeros_like(X)
         _, ew_d, _, node_scale = self._scales(g)
         general = self._agg_general()
-        # per-edge weight of the aggregation in by-dst order, including the mean / sqrt_n factor
-        if node_scale is not None:
-            tgt_d = g.array(ops.G_TARGET_BY_DST)
-            ident = g._cache.get("ident_e")
-            if ident is None:
-                ident = torch.arange(E + 1, dtype=torch.int32, device=X.device)
-                g._cache["ident_e"] = ident
-            m_e = ops.gather_reduce(ident, tgt_d, node_scale.view(-1, 1)).view(-1)
-            w_full = m_e if ew_d is None else ops.mul(m_e, ew_d)
-        else:
-            w_full = ew_d
         acts = ctx["edge_acts"]
-        if general:
+        if dcur is not None:
+            off = self._original_order(g, ew_d)[4]
+        elif general:
             # per-edge messages are acts[-1] in edge-list order; the normalisation weight in that order
             src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, ew_d)
             dcur = self._message_grads(g, d_agg, ctx, acts[-1], None, tgt_node, w_orig, node_scale, g.array(ops.G_EID_BY_DST))
         else:
+            # per-edge weight of the aggregation in by-dst order, including the mean / sqrt_n factor
+            if node_scale is not None:
+                m_e = ops.gather_reduce(self._ident_e(g), g.array(ops.G_TARGET_BY_DST), node_scale.view(-1, 1)).view(-1)
+                w_full = m_e if ew_d is None else ops.mul(m_e, ew_d)
+            else:
+                w_full = ew_d
             src_l, tgt_l, tgt_node, w_orig, off, ident = self._original_order(g, w_full)
             # d messages, in edge-list order: dM[e] = w_e * d_agg[target_e]
             dcur = ops.gather_reduce(ident, tgt_node, d_agg, edge_weight=w_orig)

@@ -23,9 +23,11 @@ class GNN_FiLM(GNN_Edge_MLP):
     On the device every edge of a (target, type) bucket shares gamma / beta, so the modulation is applied to the
     bucket sums Z[v,l] (gather kernel + MFMA GEMMs as in GNN_Edge_MLP) by a node-side epilogue
     (csrc/edge.hip tfgnn_film_combine_*):  out[v] = sigma( scale_v * sum_l (gamma_{l,v} * Z[v,l] + cnt[v,l] * beta_{l,v}) ).
-    Covered: sum / mean / sqrt_n aggregation with the activation after aggregation, source-only edge MLPs of any
-    depth (the class defaults).  Max aggregation, activation before aggregation and use_target_state_as_input need
-    the per-edge form and raise NotImplementedError."""
+    That form covers sum / mean / sqrt_n aggregation with the activation after aggregation and source-only edge MLPs of
+    any depth (the class defaults).  Max aggregation, message_activation_before_aggregation and
+    use_target_state_as_input take the per-edge form of the reference (``_call_per_edge``): messages per edge from the
+    edge-MLP machinery of GNN_Edge_MLP, modulated per edge (csrc/edge.hip tfgnn_film_edge_*), then the general
+    aggregation kernel."""
 
     @classmethod
     def get_default_hyperparameters(cls):
@@ -59,13 +61,8 @@ class GNN_FiLM(GNN_Edge_MLP):
             "the per-edge form lives in oracle/tf2gnn_oracle.py:message_passing_call"
         )
 
-    def _check_supported(self):
-        if self._aggregation_name == "max" or self._pre_activation() or self._use_target_state_as_input:
-            raise NotImplementedError(
-                "GNN_FiLM on the device covers sum/mean/sqrt_n aggregation, activation after aggregation and "
-                "source-only edge MLPs (the class defaults); max aggregation, message_activation_before_aggregation "
-                "and use_target_state_as_input need per-edge modulation"
-            )
+    def _node_side(self) -> bool:
+        return not (self._aggregation_name == "max" or self._pre_activation() or self._use_target_state_as_input)
 
     def _film_scales(self, g):
         """(per-bucket 1/(c+1e-7) | None, the same per edge in by-src order | None, mean / sqrt_n factor per node | None):
@@ -76,9 +73,80 @@ class GNN_FiLM(GNN_Edge_MLP):
         node_scale = graph_scales(g, bool(self._normalize_by_num_incoming), self._aggregation_name)[3]
         return row_scale, ew_s, node_scale
 
+    # ---- per-edge form: gamma_{l,v} * (w_e * MLP_l([x_u | x_v])) + beta_{l,v} per edge, then any aggregation --------------
+    def _call_per_edge(self, X, g):
+        V, D = X.shape
+        L, H, E = g.num_edge_types, self._hidden_dim, g.num_edges
+        lib = _lib.load()
+        _, ew_d, _, node_scale = self._scales(g)
+        fuse_act = self._post_activation_name()
+        ctx = {"graph": g, "X": X, "per_edge": True, "fused_act": fuse_act}
+        film = self._mlp_all_types(X, L, ctx, mlps=self._film_mlps, key="film_acts")  # [V, L, 2H]
+        if E == 0:
+            ctx["out"] = self._aggregate_nothing(V, X, fuse_act, ctx)
+            self._ctx = ctx
+            return ctx["out"]
+        src_l, tgt_l, tgt_node, w_orig, off, _ = self._original_order(g, ew_d)  # edge-list order
+        if self._use_target_state_as_input:
+            msgs, ctx["edge_acts"] = self._edge_messages_C(X, g, ew_d)  # [E, H]
+            mrow = None
+        else:
+            msgs = self._mlp_all_types(X, L, ctx).view(V * L, H)  # row (u, l) = MLP_l(x_u)
+            mrow = src_l
+        M = torch.empty((E, H), dtype=torch.float32, device=X.device)
+        _lib.check(lib.tfgnn_film_edge_forward(ops._ptr(msgs), ops._ptr(mrow), ops._ptr(film), ops._ptr(tgt_l), ops._ptr(w_orig),
+                                               E, H, ops._ptr(M), ops._stream()))
+        ctx.update({"film": film, "msgs": msgs, "mrow": mrow, "M": M})
+        out = self._gather_messages(g, M, g.array(ops.G_EID_BY_DST), None, node_scale, fuse_act, ctx)
+        ctx["out"] = out
+        self._ctx = ctx
+        return out
+
+    def _backward_per_edge(self, grad_output, ctx):
+        g, X = ctx["graph"], ctx["X"]
+        V, D = X.shape
+        L, H, E = g.num_edge_types, self._hidden_dim, g.num_edges
+        lib = _lib.load()
+        mlps = self._edge_type_mlps
+        dX = torch.empty_like(X)
+        if E == 0:
+            dfilm = torch.zeros((V, L, 2 * H), dtype=torch.float32, device=X.device)
+            self._mlp_all_types_backward(self._film_mlps, X, ctx["film_acts"], dfilm, dX, accumulate=False)
+            self._film_mlps.publish_grads()
+            mlps.grads = [torch.zeros_like(W) for W in mlps.kernels]
+            mlps.publish_grads()
+            return dX
+        d_agg = self._backward_finish(grad_output, ctx)
+        _, ew_d, _, node_scale = self._scales(g)
+        src_l, tgt_l, tgt_node, w_orig, off, _ = self._original_order(g, ew_d)
+        eid_d = g.array(ops.G_EID_BY_DST)
+        dM = self._message_grads(g, d_agg, ctx, ctx["M"], None, tgt_node, None, node_scale, eid_d)  # [E, H], edge-list order
+        dmsg = torch.empty((E, H), dtype=torch.float32, device=X.device)
+        dfilm_e = torch.empty((E, 2 * H), dtype=torch.float32, device=X.device)
+        _lib.check(lib.tfgnn_film_edge_backward(ops._ptr(dM), ops._ptr(ctx["msgs"]), ops._ptr(ctx["mrow"]), ops._ptr(ctx["film"]),
+                                                ops._ptr(tgt_l), ops._ptr(w_orig), E, H, ops._ptr(dmsg), ops._ptr(dfilm_e),
+                                                ops._stream()))
+        # gamma / beta of (v, l) were used by every edge of that bucket
+        dfilm = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, dfilm_e, col=eid_d).view(V, L, 2 * H)
+        self._mlp_all_types_backward(self._film_mlps, X, ctx["film_acts"], dfilm, dX, accumulate=False)
+        self._film_mlps.publish_grads()
+        if self._use_target_state_as_input:
+            dX = ops.add_scale(dX, self._backward_C(None, ctx, dcur=dmsg), 1.0)
+        else:
+            # MLP_l(x_u) was used by every edge leaving (u, l)
+            G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dmsg, col=g.array(ops.G_EID_BY_SRC)).view(V, L, H)
+            self._mlp_all_types_backward(mlps, X, ctx["mlp_acts"], G, dX, accumulate=True)
+            mlps.publish_grads()
+        return dX
+
     def call(self, inputs: MessagePassingInput, training: bool = False):
-        self._check_supported()
         X = inputs.node_embeddings
+        if not self._node_side():
+            V = X.shape[0]
+            g = get_graph(inputs.adjacency_lists, V)
+            if g.num_edge_types != self._num_edge_types:
+                raise ValueError(f"layer was built for {self._num_edge_types} edge types, got {g.num_edge_types}")
+            return self._call_per_edge(X, g)
         V, D = X.shape
         g = get_graph(inputs.adjacency_lists, V)
         L, H = g.num_edge_types, self._hidden_dim
@@ -119,6 +187,8 @@ class GNN_FiLM(GNN_Edge_MLP):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
+        if ctx.get("per_edge"):
+            return self._backward_per_edge(grad_output, ctx)
         g, X, Z, film = ctx["graph"], ctx["X"], ctx["Z"], ctx["film"]
         V, D = X.shape
         L, H = g.num_edge_types, self._hidden_dim

@@ -219,16 +219,28 @@ class MessagePassing:
         (message_passing.py:64-93): [E, D], [E, D], [E] -> [E, H]."""
 
     def call(self, inputs: MessagePassingInput, training: bool = False):
-        """message_passing.py:95-133 (generic path).  Returns float32 [V, hidden_dim]."""
+        """message_passing.py:95-133 (generic path).  Returns float32 [V, hidden_dim].
+
+        The user's ``_message_function`` runs under torch autograd on the gathered per-edge states (leaf tensors) and the
+        layer's variables; gather, aggregation and activation are this library's kernels.  ``backward`` then needs no
+        code from the subclass (the reference gets the same from tf.GradientTape)."""
         node_embeddings, adjacency_lists = inputs.node_embeddings, inputs.adjacency_lists
         if isinstance(adjacency_lists, ops.Graph):
             raise ValueError("the generic MessagePassing path needs the adjacency list tensors")
         num_nodes = node_embeddings.shape[0]
-        messages_per_type = self._calculate_messages_per_type(adjacency_lists, node_embeddings, training)
+        record = {"per_type": []}
+        self._generic_record = record
+        try:
+            messages_per_type = self._calculate_messages_per_type(adjacency_lists, node_embeddings, training)
+        finally:
+            self._generic_record = None
         edge_type_to_message_targets = [adj[:, 1] for adj in adjacency_lists]
-        return self._compute_new_node_embeddings(
-            node_embeddings, messages_per_type, edge_type_to_message_targets, num_nodes, training
+        out = self._compute_new_node_embeddings(
+            node_embeddings, [m.detach() for m in messages_per_type], edge_type_to_message_targets, num_nodes, training
         )
+        record.update({"X": node_embeddings, "adjacency_lists": adjacency_lists, "messages": messages_per_type, "out": out})
+        self._ctx = record
+        return out
 
     def _compute_new_node_embeddings(
         self,
@@ -262,18 +274,94 @@ class MessagePassing:
             num_incoming = gather_rows(
                 type_to_num_incoming_edges[edge_type_idx].reshape(-1, 1), edge_targets
             ).reshape(-1)
-            messages_per_type.append(
-                self._message_function(
-                    edge_source_states, edge_target_states, num_incoming, edge_type_idx, training
+            record = getattr(self, "_generic_record", None)
+            if record is None:
+                messages_per_type.append(
+                    self._message_function(edge_source_states, edge_target_states, num_incoming, edge_type_idx, training)
                 )
-            )
+                continue
+            # recorded forward: the states are autograd leaves, the variables' tensors take part in the tape
+            edge_source_states.requires_grad_(True)
+            edge_target_states.requires_grad_(True)
+            for v in self._variables:
+                if v.trainable and not v.value.requires_grad:
+                    v.value.requires_grad_(True)
+            with torch.enable_grad():
+                m = self._message_function(edge_source_states, edge_target_states, num_incoming, edge_type_idx, training)
+            record["per_type"].append((edge_source_states, edge_target_states))
+            messages_per_type.append(m)
         return messages_per_type
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            f"{type(self).__name__} runs on the generic message-passing path, which has no backward; "
-            "the built-in layers (RGCN, RGAT, RGIN, GGNN, GNN_Edge_MLP) implement it"
-        )
+        """Generic backward: d out / d messages through this library's activation / aggregation kernels, the user's
+        ``_message_function`` through torch autograd, the two per-edge state gradients scattered back to the nodes by the
+        gather kernel.  Fills ``Variable.grad`` and returns d(node_embeddings)."""
+        ctx = self._ctx
+        if ctx is None or "per_type" not in ctx:
+            raise RuntimeError("backward called before a forward pass")
+        if type(self)._compute_new_node_embeddings is not MessagePassing._compute_new_node_embeddings:
+            raise NotImplementedError(
+                f"{type(self).__name__} overrides _compute_new_node_embeddings; the generic backward covers the base class "
+                "aggregation (message_passing.py:135-179) - implement backward() next to the override"
+            )
+        X, adjacency_lists, messages_per_type = ctx["X"], ctx["adjacency_lists"], ctx["messages"]
+        V, H = X.shape[0], self._hidden_dim
+        g = get_graph(adjacency_lists, V)
+        E = g.num_edges
+        dX = torch.zeros_like(X)
+        for v in self._variables:
+            v.grad = None
+        if E == 0:
+            for v in self._variables:
+                if v.trainable:
+                    v.grad = torch.zeros_like(v.value)
+            return dX
+        from ..graph_scales import graph_scales
+
+        act = self._activation_name
+        pre = act if self._message_activation_before_aggregation else None
+        is_max = self._aggregation_name == "max"
+        node_scale = graph_scales(g, False, self._aggregation_name)[3]
+        eid_d = g.array(ops.G_EID_BY_DST)
+        messages = torch.cat([m.detach() for m in messages_per_type], dim=0).contiguous()  # edge-list order
+        target = torch.cat([a[:, 1] for a in adjacency_lists], dim=0).to(torch.int32).contiguous()
+        agg_raw = None
+        if is_max or (pre is None and act == "gelu"):  # the raw aggregate: maxima for the tie split, gelu's argument
+            agg_raw = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, messages, col=eid_d, row_scale=node_scale,
+                                       reduce=ops.REDUCE_MAX if is_max else ops.REDUCE_SUM, pre_act=pre)
+        d_agg = grad_output.contiguous()
+        if pre is None and act is not None:
+            d_agg = ops.activation_backward(act, d_agg, agg_raw if act == "gelu" else ctx["out"])
+        if is_max:
+            sel = ops.edge_aggregate_backward(messages, target, None, pre_act=pre, reduce=ops.REDUCE_MAX, agg_max=agg_raw, phase=0)
+            nsel = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, sel, col=eid_d)
+            dM = ops.edge_aggregate_backward(messages, target, d_agg, pre_act=pre, reduce=ops.REDUCE_MAX, agg_max=agg_raw,
+                                             num_selected=nsel)
+        else:
+            dM = ops.edge_aggregate_backward(messages, target, d_agg, node_scale=node_scale, pre_act=pre, reduce=ops.REDUCE_SUM)
+        d_src, d_tgt, off = [], [], 0
+        leaves = [v.value for v in self._variables if v.trainable]
+        for (xs, xt), m in zip(ctx["per_type"], messages_per_type):
+            n = m.shape[0]
+            if n and m.grad_fn is None:
+                raise NotImplementedError(
+                    f"{type(self).__name__}._message_function returned a tensor without an autograd history (built from "
+                    "kernels outside torch autograd?): write it with torch operations, or override backward()"
+                )
+            if n:
+                torch.autograd.backward([m], [dM[off : off + n]], inputs=[xs, xt] + leaves)
+            d_src.append(xs.grad if xs.grad is not None else torch.zeros_like(xs))
+            d_tgt.append(xt.grad if xt.grad is not None else torch.zeros_like(xt))
+            off += n
+        # d X[u] += sum over out-edges of d(source state); d X[v] += sum over in-edges of d(target state)
+        dX = ops.graph_gather(g, ops.VIEW_BY_SRC_NODE, torch.cat(d_src, dim=0).contiguous(), col=g.array(ops.G_EID_BY_SRC))
+        dX = ops.add_scale(dX, ops.graph_gather(g, ops.VIEW_BY_DST_NODE, torch.cat(d_tgt, dim=0).contiguous(), col=eid_d), 1.0)
+        for v in self._variables:
+            if v.trainable:
+                v.grad = v.value.grad if v.value.grad is not None else torch.zeros_like(v.value)
+                v.value.grad = None
+                v.value.requires_grad_(False)  # plain tensors again: optimizers update them in place
+        return dX
 
     # ---- hooks that let the layer stack fold element-wise backward steps into this layer's last GEMM ----------
     def activation_backward_spec(self):
