@@ -330,6 +330,9 @@ def main():
             return ops.Graph(adj_dev, V, wait=False)
 
     def step():
+        # a training step ends with an in-place weight update, which invalidates the split forms of the weights the f16x2
+        # products cache per value: drop them here so every timed step splits its weights like a training step does
+        ops.clear_weight_operand_cache()
         if graph is not None:
             g = graph
         elif side is None:
@@ -491,20 +494,22 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
     split_peak = MFMA_FP32_PEAK_TFLOPS if mode == "fp32" else MFMA_16BIT_PEAK_TFLOPS
     nprod = {"fp32": 1, "bf16x3_9": 9}.get(mode, 6)  # piece products of the generic split-operand GEMM
 
-    def hbm_block(kernel, ms, alg_bytes, launches, traffic_key=None):
-        gbs = alg_bytes / (ms * 1e-3) / 1e9
+    def hbm_block(kernel, ms, alg_bytes, launches, traffic_key=None, compulsory_bytes=None):
+        """``achieved`` prices bytes that really crossed the fabric: the rocprofv3 counter bytes of this kernel at this shape
+        when they were collected (profiles/r02_pmc_traffic_<workload>.json), else the compulsory bytes (every distinct input /
+        output byte once).  SURVEY.md 8d's no-reuse gather model (one source row per EDGE) is reported beside it: its rate
+        exceeds the HBM peak whenever rows are re-read from L2 / Infinity Cache, so it is not a fraction of any roof."""
         traffic = _pmc_traffic(args.workload, traffic_key)
+        basis_bytes = traffic if traffic else (compulsory_bytes if compulsory_bytes else alg_bytes)
+        gbs = basis_bytes / (ms * 1e-3) / 1e9
         blk = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-               "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": launches,
+               "achieved_basis": ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch (gfx950-corrected)" if traffic else
+                                  ("compulsory bytes (distinct inputs and outputs once)" if compulsory_bytes else "algorithmic bytes")),
+               "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes,
+               "no_reuse_model_rate_GBs": alg_bytes / (ms * 1e-3) / 1e9, "launches_per_step": launches,
                "share_of_step": launches * ms / ms_per_step}
-        if traffic:  # a gather re-reads source rows through L2 / Infinity Cache: price the MEASURED fabric bytes as well
-            blk["achieved_on_counter_bytes"] = traffic / (ms * 1e-3) / 1e9
-            blk["frac_on_counter_bytes"] = blk["achieved_on_counter_bytes"] / HBM_PEAK_GBS
-        if blk["frac"] > 1.0:
-            blk["note"] = ("algorithmic bytes follow SURVEY.md 8d's no-reuse model (one fp32 source row per EDGE); rows are re-read from L2 / "
-                           "Infinity Cache, so the model rate can exceed the HBM peak - "
-                           + ("frac_on_counter_bytes prices the fabric bytes the counters saw" if traffic else
-                              "counter traffic was not collected for this workload"))
+        if compulsory_bytes:
+            blk["compulsory_bytes_per_launch"] = compulsory_bytes
         return blk
 
     def mfma_block(kernel, ms, flops, executed_factor, peak, launches, traffic_key=None):
@@ -522,7 +527,8 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
 
     if model in ("rgcn", "ggnn", "gnn_edge_mlp"):
         rs = g.array(ops.G_INVDEG_BY_DST) if model == "rgcn" else None
-        gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4
+        gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4  # one source row per edge
+        gather_compulsory = V * H * 4 + E * 4 + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4  # every source row once
         f16 = mode == "f16x2" and model == "rgcn"
         if f16:
             ms = time_kernel(lambda: ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L))
@@ -531,7 +537,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
             A = torch.empty((V * L, H), device=dev)
             ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, out=A))
             name = "csr_gather_reduce_kernel (aggregate source rows per (node, type) bucket)"
-        out.append(hbm_block(name, ms, gather_bytes, 2 * NL, "gather_sp" if f16 else "gather"))
+        out.append(hbm_block(name, ms, gather_bytes, 2 * NL, "gather_sp" if f16 else "gather", gather_compulsory))
     if model == "rgcn":
         W = torch.randn((L * H, H), device=dev) * 0.05
         res = torch.empty((V, H), device=dev)
@@ -579,7 +585,8 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         agg = torch.empty((V, H), device=dev)
         ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=ew, out=agg))
         out.append(hbm_block(f"csr_gather_reduce_kernel<HEADS> (attention-weighted sum over all in-edges of a node, {K} heads)", ms,
-                             E * (4 * H + 4 * K + 4) + (V + 1) * 4 + V * H * 4, 2 * NL))
+                             E * (4 * H + 4 * K + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, None,
+                             V * L * H * 4 + E * (4 * K + 4) + (V + 1) * 4 + V * H * 4))
     if model == "rgin":
         # per-relation 2-layer edge MLP over the non-empty (source, type) pairs: grouped GEMMs over compact rows
         off_h = g.nonempty_offsets(True)
@@ -594,7 +601,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         agg = torch.empty((V, H), device=dev)
         ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Ac, col=colc, out=agg))
         out.append(hbm_block("csr_gather_reduce_kernel (messages of all edge types summed per target node)", ms,
-                             E * (4 * H + 4) + (V + 1) * 4 + V * H * 4, 2 * NL))
+                             E * (4 * H + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, None, nz * H * 4 + E * 4 + (V + 1) * 4 + V * H * 4))
     ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
     for r in out:
         r["ms_edge_bucketing_per_batch"] = ms_graph

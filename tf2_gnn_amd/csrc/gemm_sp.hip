@@ -155,7 +155,9 @@ __global__ void sp_inv_scale_kernel(const float* bound, float* inv) {
 }
 
 // SP16 rows from the COLUMNS of a row-major fp32 matrix: dst row n, column k = src[k * ld + n]  (a Keras kernel
-// [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  One workgroup per 16 dst rows.
+// [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  Workgroup (x, y): 16 dst rows, the
+// y-th slice of K; every workgroup takes the column maxima over ALL k itself (a weight matrix is L2 resident), so the
+// slices need no second launch.
 __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
                                                             uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv) {
   __shared__ float red[64][4];
@@ -166,11 +168,17 @@ __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restr
   const int kq = tid >> 2, nq = (tid & 3) * 4;  // this thread: k = kq + 64 i, columns n0 + nq .. +3
   const bool ok = n0 + nq < N;                  // N % 4 == 0
   float4 mx = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t k = kq; k < K; k += 64) {
-    if (ok) {
-      const float4 v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
-      mx.x = fmaxf(mx.x, fabsf(v.x)); mx.y = fmaxf(mx.y, fabsf(v.y));
-      mx.z = fmaxf(mx.z, fabsf(v.z)); mx.w = fmaxf(mx.w, fabsf(v.w));
+  for (int64_t k0 = kq; k0 < K; k0 += 4 * 64) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = k0 + u * 64;
+      v[u] = (ok && k < K) ? *reinterpret_cast<const float4*>(src + k * ld + n0 + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mx.x = fmaxf(mx.x, fabsf(v[u].x)); mx.y = fmaxf(mx.y, fabsf(v[u].y));
+      mx.z = fmaxf(mx.z, fabsf(v[u].z)); mx.w = fmaxf(mx.w, fabsf(v[u].w));
     }
   }
   // reduce over the 64 k-rows of threads with the same nq
@@ -182,11 +190,13 @@ __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restr
       for (int i = 0; i < 64; ++i) m = fmaxf(m, red[i][tid]);
       float iv;
       sc[tid * 4 + j] = sp_scale_for_max(m, &iv);
-      if (inv && n0 + tid * 4 + j < N) inv[n0 + tid * 4 + j] = iv;
+      if (inv && blockIdx.y == 0 && n0 + tid * 4 + j < N) inv[n0 + tid * 4 + j] = iv;
     }
     __syncthreads();
   }
-  for (int64_t kb = 0; kb < K; kb += 64) {
+  const int64_t kper = (((K + gridDim.y - 1) / gridDim.y) + 63) & ~63ll;
+  const int64_t kend = (blockIdx.y + 1) * kper < K ? (blockIdx.y + 1) * kper : K;
+  for (int64_t kb = blockIdx.y * kper; kb < kend; kb += 64) {
     const int64_t k = kb + kq;
     float4 v = {0.f, 0.f, 0.f, 0.f};
     if (ok && k < K) v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
@@ -1057,7 +1067,7 @@ int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, vo
   TFGNN_REQUIRE(K > 0 && N > 0 && K % 16 == 0 && N % 4 == 0 && ld % 4 == 0 && (uintptr_t)d_src % 16 == 0,
                 "tfgnn_sp_split_cols: K must be a multiple of 16, N and ld multiples of 4");
   TFGNN_REQUIRE(ld_sp_bytes >= K * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_cols: bad SP16 leading dimension / alignment");
-  hipLaunchKernelGGL(sp_split_cols_kernel, dim3((unsigned)ceil_div(N, 16)), dim3(256), 0, (hipStream_t)stream, d_src, ld, K, N,
+  hipLaunchKernelGGL(sp_split_cols_kernel, dim3((unsigned)ceil_div(N, 16), (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, K / 128))), dim3(256), 0, (hipStream_t)stream, d_src, ld, K, N,
                      (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;

@@ -505,7 +505,7 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
     if (chunks <= 16) return launch_mode<16, 1, 4, 8, MODE_SUM, true>(a, num_items, s);
     if (chunks <= 32) return launch_mode<16, 2, 4, 4, MODE_SUM, true>(a, num_items, s);
     if (chunks <= 64) return launch_mode<16, 4, 4, 2, MODE_SUM, true>(a, num_items, s);
-    if (chunks <= 80) return launch_mode<16, 5, 4, 2, MODE_SUM, true>(a, num_items, s);
+    if (chunks <= 80) return launch_mode<16, 5, 4, 2, MODE_SUM, true>(a, num_items, s);  // UNROLL 1 / 4 and 32 lanes per row measured slower (tools/gather_l2_probe.py)
     return launch_mode<32, 4, 4, 2, MODE_SUM, true>(a, num_items, s);
   }
   // L2-resident slicing: gather 32-float (128 B) windows of the rows, XCD by XCD, when one window of

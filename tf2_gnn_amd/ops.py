@@ -909,6 +909,12 @@ def absmax(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 _sp_weight_cache: "dict" = {}
 
 
+def clear_weight_operand_cache() -> None:
+    """Forget the split forms of the weights (what an optimizer step's in-place update does through the tensor version).
+    bench.py calls it once per step so that the per-step cost of splitting the updated weights is inside the timed region."""
+    _sp_weight_cache.clear()
+
+
 def sp_weight_operand(w: torch.Tensor, kind: str, build) -> SplitOperand:
     """SP16 form of a weight tensor, built once per value: keyed on the tensor's storage and version (an in-place
     optimizer update bumps the version), so forward and backward passes of a step - and every step of an evaluation
