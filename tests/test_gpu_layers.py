@@ -864,3 +864,60 @@ def test_generic_backward_refuses_what_it_cannot_differentiate(dev):
     out = layer(MessagePassingInput(torch.randn((20, 8), device=dev), to_dev(adjs, dev)))
     with pytest.raises(NotImplementedError, match="autograd history"):
         layer.backward(torch.ones_like(out))
+
+
+@pytest.mark.parametrize("cls_name,over", [("RGCN", {}), ("GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 1}),
+                                           ("GNN_FiLM", {"normalize_by_num_incoming": True})])
+def test_overriding_message_function_on_a_builtin_layer(dev, cls_name, over):
+    """A user subclass of a built-in layer that post-processes ``super()._message_function`` (the reference's plug-in
+    point, message_passing.py:64-93): runs on the generic path with the built-in's weights.  Doubling every message
+    must double the relu output and every gradient of the built-in layer."""
+    import tf2_gnn_amd.layers as layers
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    base = getattr(layers, cls_name)
+
+    class Doubled(base):
+        def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message, edge_type_idx,
+                              training):
+            return 2.0 * super()._message_function(edge_source_states, edge_target_states, num_incoming_to_node_per_message,
+                                                   edge_type_idx, training)
+
+    V, L, H = 80, 3, 16
+    adjs = random_graph(V, 700, L, seed=4, hub=(2, 50))
+    p = base.get_default_hyperparameters()
+    p.update(dict(over, hidden_dim=H, message_activation_function="relu"))
+    builtin, user = base(p), Doubled(p)
+    shapes = MessagePassingInput((None, H), tuple((None, 2) for _ in range(L)))
+    builtin.build(shapes)
+    user.build(shapes)
+    for a, b in zip(builtin.trainable_variables, user.trainable_variables):
+        b.assign(a.value)
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn((V, H), generator=g).to(dev)
+    dOut = torch.randn((V, H), generator=g).to(dev)
+    inp = MessagePassingInput(X, to_dev(adjs, dev))
+    o1 = builtin(inp, training=True)
+    dx1 = builtin.backward(dOut)
+    o2 = user(inp, training=True)
+    dx2 = user.backward(dOut)
+    assert_close(o2.cpu(), 2.0 * o1.cpu(), tol=2e-5, what=f"{cls_name} user override fwd")
+    assert_close(dx2.cpu(), 2.0 * dx1.cpu(), tol=5e-5, what=f"{cls_name} user override dX")
+    for a, b in zip(builtin.trainable_variables, user.trainable_variables):
+        scale = max(1.0, float(a.grad.abs().max()))
+        assert_close(b.grad.cpu() / scale, 2.0 * a.grad.cpu() / scale, tol=5e-5, what=f"{cls_name} user override d{a.name}")
+
+
+def test_overriding_message_function_where_the_aggregation_is_not_the_base_class_raises(dev):
+    from tf2_gnn_amd.layers import GGNN, RGAT, MessagePassingInput
+
+    for base, extra in ((GGNN, {}), (RGAT, {"num_heads": 2})):
+        class Mine(base):
+            def _message_function(self, *args, **kwargs):
+                return args[0]
+
+        p = base.get_default_hyperparameters()
+        p.update(dict(extra, hidden_dim=8))
+        layer = Mine(p)
+        with pytest.raises(NotImplementedError, match="override call"):
+            layer(MessagePassingInput(torch.zeros((10, 8), device=dev), to_dev(random_graph(10, 20, 2, seed=0), dev)))

@@ -54,7 +54,6 @@ struct GemmArgs {
   const int32_t* group_off;
   int64_t strideB, strideC;
   int wide_store;  // C rows are 16-byte aligned and N % 4 == 0: float4 epilogue
-  int debug;  // probe knobs (TFGNN_GEMM_DEBUG): 1 = no staging after the first tile, 2 = no fragment reads
 };
 
 // ---- staging of one operand tile -------------------------------------------------------------
@@ -209,11 +208,6 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int li = lane & 31, lk = lane >> 5;
-  long long probe_c0 = 0, probe_w0 = 0;
-  if (g.debug & 4) {
-    probe_c0 = clock64();
-    probe_w0 = wall_clock64();
-  }
 
   if (k_begin < k_end) {
     SA sa;
@@ -227,7 +221,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
     __syncthreads();
     int stage = 0;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK, stage ^= 1) {
-      const bool more = k0 + BK < k_end && !(g.debug & 1);
+      const bool more = k0 + BK < k_end;
       if (more) {
         sa.load(k_end - k0 - BK, g.lda);
         sb.load(k_end - k0 - BK, g.ldb);
@@ -243,7 +237,7 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2 && !(g.debug & 2)) {
+        if (kk + 1 < BK / 2) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[nxt][i] = SA::frag(la, (wm * TM + i) * 32 + li, 2 * (kk + 1) + lk);
 #pragma unroll
@@ -264,13 +258,6 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
     }
   }
 
-  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0) {
-    // probe: per workgroup {shader clocks of the main loop, wall start, wall end of loop} (100 MHz wall clock)
-    long long* pr = reinterpret_cast<long long*>(g.partial) + 4 * blockIdx.x;
-    pr[0] = clock64() - probe_c0;
-    pr[1] = probe_w0;
-    pr[2] = wall_clock64();
-  }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool split = g.splits > 1;
   float* outp = split ? g.partial + partial_slab * g.M * g.N : Cp;
@@ -338,8 +325,6 @@ __global__ void __launch_bounds__(64 * WM_ * WN_) gemm_mfma_kernel(GemmArgs g) {
       }
     }
   }
-  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0)
-    reinterpret_cast<long long*>(g.partial)[4 * blockIdx.x + 3] = wall_clock64();
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g) {
@@ -522,10 +507,6 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   g.k_chunk = p.k_chunk; g.splits = p.splits; g.partial = (float*)d_workspace;
   g.group_mode = 0; g.group_off = nullptr; g.strideB = 0; g.strideC = 0;
   {
-    static const int dbg = [] { const char* e = getenv("TFGNN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    g.debug = dbg;
-  }
-  {
     const bool split = p.splits > 1;
     const float* cbase = split ? (const float*)d_workspace : d_C;
     const int64_t ldo = split ? N : ldc;
@@ -587,7 +568,6 @@ extern "C" int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_
   g.k_chunk = ceil_div(K > 0 ? K : 1, BK) * BK; g.splits = 1; g.partial = nullptr;
   g.group_mode = 1; g.group_off = d_group_offsets; g.strideB = stride_b; g.strideC = 0;
   g.wide_store = vec && (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)d_C % 16 == 0);
-  g.debug = 0;
   g.n_tiles = (unsigned)ceil_div(N, p.bn);
   dim3 grid((unsigned)(ceil_div(max_group_rows, p.bm) * g.n_tiles), (unsigned)num_groups, 1);
   hipStream_t s = (hipStream_t)stream;
@@ -637,7 +617,6 @@ extern "C" int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offse
   g.group_mode = 2; g.group_off = d_group_offsets; g.strideB = 0; g.strideC = stride_c;
   g.wide_store = vec && (N % 4 == 0) && ((splits > 1) || ((ldc % 4 == 0) && (stride_c % 4 == 0) && ((uintptr_t)d_C % 16 == 0))) &&
                  (splits == 1 || (uintptr_t)d_workspace % 16 == 0);
-  g.debug = 0;
   g.n_tiles = (unsigned)ceil_div(N, p.bn);
   dim3 grid((unsigned)(ceil_div(M, p.bm) * g.n_tiles), (unsigned)num_groups, (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;

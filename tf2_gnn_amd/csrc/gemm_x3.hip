@@ -50,7 +50,6 @@ struct X3Args {
   int splits;
   float* partial;
   unsigned n_tiles;
-  int debug;  // TFGNN_GEMM_DEBUG probe bits (pipelined kernel: 1 = no split/store/fetch in the loop, 2 = no multiply; 4 / 8: clocks)
   // gradient epilogue (tfgnn_gemm_grad_epilogue): C = (A B) * mul * act'(saved); NULL = factor absent
   const float* mul;
   int64_t ld_mul;
@@ -511,9 +510,6 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
 // (the pipelined kernel above) is issue-bound.  Here the multiplying wave issues one MFMA per 32 cycles plus a
 // ds_read every third MFMA, and its partner's VALU work runs beside it.  Same three-stage LDS ring and one
 // barrier per K tile.
-#ifndef X3_PROBE
-#define X3_PROBE 0
-#endif
 constexpr int S_PT = 256;  // producer threads
 
 template <bool B_KM, int TN>
@@ -532,9 +528,6 @@ struct Producer<false, TN> {  // NT: A 512 items, B 256 TN items of one float4 -
   __device__ __forceinline__ void load(int64_t k_left, int adv) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].template load<MASKED>(k_left, adv);
-#if X3_PROBE == 1  // probe: no global reads of B in the steady state (results wrong)
-    if (MASKED)
-#endif
 #pragma unroll
     for (int i = 0; i < TN; ++i) b[i].template load<MASKED>(k_left, adv);
   }
@@ -547,20 +540,8 @@ struct Producer<false, TN> {  // NT: A 512 items, B 256 TN items of one float4 -
   __device__ __forceinline__ void store(unsigned short* stage) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i].store(stage);
-#if X3_PROBE == 2  // probe: B is fetched but neither split nor stored (results wrong)
-#pragma unroll
-    for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(b[i].r.x), "v"(b[i].r.y), "v"(b[i].r.z), "v"(b[i].r.w));
-#elif X3_PROBE == 3  // probe: B is fetched and split, not stored
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      unsigned h, m, l;
-      split3(b[i].r.x + b[i].r.y + b[i].r.z + b[i].r.w, h, m, l);
-      asm volatile("" ::"v"(h), "v"(m), "v"(l));
-    }
-#else
 #pragma unroll
     for (int i = 0; i < TN; ++i) b[i].store(stage);
-#endif
   }
 };
 template <int TN>
@@ -631,11 +612,6 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
   const int T = k_len > 0 ? (int)((k_len + X3_BK - 1) / X3_BK) : 0;
   const int wm = wave & 1, wn = (wave >> 1) & 1;
   const int li = lane & 31, lk = lane >> 5;
-  long long probe_c0 = 0, probe_w0 = 0;
-  if (g.debug & 4) {
-    probe_c0 = clock64();
-    probe_w0 = wall_clock64();
-  }
   floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -690,10 +666,6 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
     const int b_frag = (X3_BM + wn * TN * 32 + li) * P_ROW + half * 8;
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();  // tiles 0 and 1 are in stages 0 and 1
-    if (g.debug & 8) {
-      probe_c0 = clock64();
-      probe_w0 = wall_clock64();
-    }
     bf16x8 ah[TM], am[TM], al[TM], bh, bm, bl;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -721,15 +693,9 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
 #define X3S_PAIR(PA, PB)                                                                   \
         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[0], PB, acc[0][j], 0, 0, 0); \
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[1], PB, acc[1][j], 0, 0, 0);
-#if X3_PROBE == 4  // probe: half the MFMAs (results wrong)
-        X3S_PAIR(al, bl) X3S_PAIR(am, bm) X3S_PAIR(ah, bh)
-#elif X3_PROBE == 5  // probe: the staging side alone - fragment reads kept alive, no MFMA at all (results wrong)
-        asm volatile("" ::"v"(al[0]), "v"(am[0]), "v"(ah[0]), "v"(al[1]), "v"(am[1]), "v"(ah[1]), "v"(bl), "v"(bm), "v"(bh));
-#else
         if (NPROD >= 9) { X3S_PAIR(al, bl) }
         if (NPROD >= 8) { X3S_PAIR(am, bl) X3S_PAIR(al, bm) }
         X3S_PAIR(al, bh) X3S_PAIR(ah, bl) X3S_PAIR(am, bm) X3S_PAIR(am, bh) X3S_PAIR(ah, bm) X3S_PAIR(ah, bh)
-#endif
 #undef X3S_PAIR
         bh = nh; bm = nm; bl = nl;
         __builtin_amdgcn_sched_barrier(0);
@@ -745,12 +711,6 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
       s_nxt = s_nxt == 2 * STAGE ? 0 : s_nxt + STAGE;
     }
     __builtin_amdgcn_s_setprio(0);
-  }
-  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0) {
-    long long* pr = reinterpret_cast<long long*>(g.partial) + 4 * blockIdx.x;
-    pr[0] = clock64() - probe_c0;
-    pr[1] = probe_w0;
-    pr[2] = wall_clock64();
   }
 
   // Epilogue in two rounds of 32 rows per multiplying wave: the accumulators go to LDS as four 32 x 32 TN
@@ -847,8 +807,6 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
     }
     __syncthreads();
   }
-  if ((g.debug & 4) && g.partial && blockIdx.z == 0 && tid == 0)
-    reinterpret_cast<long long*>(g.partial)[4 * blockIdx.x + 3] = wall_clock64();
 }
 
 __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
@@ -966,10 +924,6 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     }
   }
   g.partial = (float*)workspace;
-  {
-    static const int dbg = [] { const char* e = getenv("TFGNN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    g.debug = dbg;
-  }
   dim3 grid((unsigned)tiles, 1, (unsigned)g.splits);
   if (bn == 320) launch_x3<5>(g, grid, nprod, trans_a, trans_b, s);
   else if (bn == 256) launch_x3<4>(g, grid, nprod, trans_a, trans_b, s);

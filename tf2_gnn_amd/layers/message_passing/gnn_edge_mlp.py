@@ -118,13 +118,28 @@ class GNN_Edge_MLP(MessagePassing):
         )
         super().build(input_shapes)
 
-    # the reference's per-edge definition, kept for user subclasses / documentation of semantics
+    # The reference's per-edge definition (gnn_edge_mlp.py:84-107), written with torch operations on the layer's
+    # variables.  The built-in classes never call it (they evaluate the same function on the node side, module
+    # docstring); it exists for USER subclasses that override ``_message_function`` and call ``super()`` - those run on
+    # the generic path of MessagePassing (library kernels around the user function, torch autograd through it).
     def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message,
                           edge_type_idx, training):
-        raise NotImplementedError(
-            "GNN_Edge_MLP evaluates its message function on the node side (see module docstring); "
-            "the per-edge form lives in oracle/tf2gnn_oracle.py:_edge_mlp_message"
-        )
+        cur = (torch.cat([edge_source_states, edge_target_states], dim=-1) if self._use_target_state_as_input
+               else edge_source_states)
+        kernels = self._edge_type_mlps.vars[edge_type_idx]
+        for j, var in enumerate(kernels):
+            cur = cur @ var.value
+            if j < len(kernels) - 1:
+                cur = torch.relu(cur)  # dpu_utils MLP [ext]: relu between the bias-free Dense layers
+        if self._normalize_by_num_incoming:
+            cur = (1.0 / (num_incoming_to_node_per_message + 1e-7)).unsqueeze(-1) * cur
+        return cur
+
+    _message_function._tfgnn_builtin = True
+
+    def _user_message_function(self) -> bool:
+        """Did a subclass replace the message function?  Then the node-side formulations below do not apply."""
+        return not getattr(type(self)._message_function, "_tfgnn_builtin", False)
 
     # ---- which formulation ------------------------------------------------------------------
     def _path(self) -> str:
@@ -157,6 +172,13 @@ class GNN_Edge_MLP(MessagePassing):
 
     # ---- forward ----------------------------------------------------------------------------
     def call(self, inputs: MessagePassingInput, training: bool = False):
+        if self._user_message_function():
+            if not self._uses_base_aggregation():
+                raise NotImplementedError(
+                    f"{type(self).__name__} overrides _message_function on a layer whose aggregation is not the base class's "
+                    "(RGIN / GGNN): override call() and backward() as well"
+                )
+            return MessagePassing.call(self, inputs, training)
         X = inputs.node_embeddings
         V = X.shape[0]
         g = get_graph(inputs.adjacency_lists, V)
@@ -620,6 +642,8 @@ class GNN_Edge_MLP(MessagePassing):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
+        if "per_type" in ctx:  # the forward pass ran a user message function on the generic path
+            return MessagePassing.backward(self, grad_output)
         d_agg = self._backward_finish(grad_output, ctx)
         return self._backward_messages(d_agg, ctx)
 
@@ -635,7 +659,7 @@ class GNN_Edge_MLP(MessagePassing):
         return act, (ctx["pre"] if act == "gelu" else ctx["out"])
 
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
-        if not self._plain_base_backward():
+        if not self._plain_base_backward() or (self._ctx is not None and "per_type" in self._ctx):
             return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
         ctx = self._ctx
         if ctx is None:

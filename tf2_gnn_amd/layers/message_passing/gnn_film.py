@@ -6,6 +6,7 @@ import torch
 from ... import _lib, ops
 from .gnn_edge_mlp import GNN_Edge_MLP, StackedEdgeMLPs
 from .message_passing import (
+    MessagePassing,
     MessagePassingInput,
     default_device,
     get_graph,
@@ -56,10 +57,19 @@ class GNN_FiLM(GNN_Edge_MLP):
 
     def _message_function(self, edge_source_states, edge_target_states, num_incoming_to_node_per_message,
                           edge_type_idx, training):
-        raise NotImplementedError(
-            "GNN_FiLM modulates the per-bucket message sums on the node side (see class docstring); "
-            "the per-edge form lives in oracle/tf2gnn_oracle.py:message_passing_call"
-        )
+        """gnn_film.py:83-108 in torch operations, for user subclasses (see GNN_Edge_MLP._message_function)."""
+        messages = GNN_Edge_MLP._message_function(self, edge_source_states, edge_target_states,
+                                                  num_incoming_to_node_per_message, edge_type_idx, training)
+        film = edge_target_states
+        kernels = self._film_mlps.vars[edge_type_idx]
+        for j, var in enumerate(kernels):
+            film = film @ var.value
+            if j < len(kernels) - 1:
+                film = torch.relu(film)
+        H = self._hidden_dim
+        return film[:, :H] * messages + film[:, H:]
+
+    _message_function._tfgnn_builtin = True
 
     def _node_side(self) -> bool:
         return not (self._aggregation_name == "max" or self._pre_activation() or self._use_target_state_as_input)
@@ -140,6 +150,8 @@ class GNN_FiLM(GNN_Edge_MLP):
         return dX
 
     def call(self, inputs: MessagePassingInput, training: bool = False):
+        if self._user_message_function():
+            return MessagePassing.call(self, inputs, training)
         X = inputs.node_embeddings
         if not self._node_side():
             V = X.shape[0]
@@ -187,6 +199,8 @@ class GNN_FiLM(GNN_Edge_MLP):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
+        if "per_type" in ctx:  # user message function on the generic path
+            return MessagePassing.backward(self, grad_output)
         if ctx.get("per_edge"):
             return self._backward_per_edge(grad_output, ctx)
         g, X, Z, film = ctx["graph"], ctx["X"], ctx["Z"], ctx["film"]

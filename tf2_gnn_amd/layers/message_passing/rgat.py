@@ -77,7 +77,14 @@ class RGAT(MessagePassing):
             "oracle/tf2gnn_oracle.py:_rgat_message"
         )
 
+    _message_function._tfgnn_builtin = True
+
     def call(self, inputs: MessagePassingInput, training: bool = False):
+        if not getattr(type(self)._message_function, "_tfgnn_builtin", False):
+            raise NotImplementedError(
+                f"{type(self).__name__} overrides RGAT._message_function: RGAT's aggregation (per-head softmax over all incoming "
+                "edges, rgat.py:125-163) is not the base class's, override call() and backward() as well"
+            )
         X = inputs.node_embeddings
         V = X.shape[0]
         g = get_graph(inputs.adjacency_lists, V)

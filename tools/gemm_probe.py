@@ -1,4 +1,6 @@
 """GEMM probe: where does the fp32 MFMA kernel lose time?  (run on the GPU box)
+NOTE: the TFGNN_GEMM_DEBUG / X3_PROBE arms this script drives were part of the round-1 kernels (commit 058dff9) and have been
+removed from the shipped sources; with the current library every setting times the full kernel.
   TFGNN_GEMM_DEBUG=0 full kernel | 1 no staging after the first tile | 2 no LDS fragment reads | 3 both
 Results are wrong for debug != 0; only the time matters."""
 import os
