@@ -323,28 +323,47 @@ def main():
     side = torch.cuda.Stream() if (graph is None and not args.serial_bucketing) else None
     pending = []
 
-    def enqueue_bucketing():
+    # f16x2: the first product takes the node features as a split operand; preparing it is part of the batch preparation,
+    # like the bucketing.  Two copies of the feature tensor alternate so that the preparation of batch i+1 (second stream)
+    # never touches what step i reads.
+    f16_features = args.gemm_mode == "f16x2" and D % 16 == 0 and D >= 32
+    feats_dev = [X, X.clone()] if (f16_features and graph is None and not args.serial_bucketing) else [X]
+    prepared = [0]
+
+    def prepare_batch():
+        """-> (Graph, features): bucket the edges and (f16x2) split the node features for the first product"""
+        x = feats_dev[prepared[0] % len(feats_dev)]
+        prepared[0] += 1
         if side is None:
-            return ops.Graph(adj_dev, V)
+            if f16_features:
+                ops.split_rows_remembered(x)
+            return ops.Graph(adj_dev, V), x
+        # the preparation may start once the steps enqueued so far are done (the step before last used this copy of the
+        # features); it then runs under the step that is enqueued next
+        side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            return ops.Graph(adj_dev, V, wait=False)
+            if f16_features:
+                ops.split_rows_remembered(x)
+            return ops.Graph(adj_dev, V, wait=False), x
 
     def step():
         # a training step ends with an in-place weight update, which invalidates the split forms of the weights the f16x2
         # products cache per value: drop them here so every timed step splits its weights like a training step does
         ops.clear_weight_operand_cache()
         if graph is not None:
-            g = graph
+            g, x = graph, X
+            if f16_features:
+                ops.split_rows_remembered(x)
         elif side is None:
-            g = enqueue_bucketing()
+            g, x = prepare_batch()
         else:
             if not pending:
-                pending.append(enqueue_bucketing())
-            g = pending.pop(0)
-            torch.cuda.current_stream().wait_stream(side)  # compute waits for THIS batch's bucketing
+                pending.append(prepare_batch())
+            g, x = pending.pop(0)
+            torch.cuda.current_stream().wait_stream(side)  # compute waits for THIS batch's preparation
             g.wait()
-            pending.append(enqueue_bucketing())  # next batch, overlapped with this step
-        out = gnn(GNNInput(X, g, n2g, G), training=True)
+            pending.append(prepare_batch())  # next batch, overlapped with this step
+        out = gnn(GNNInput(x, g, n2g, G), training=True)
         if pool is not None:
             pool(NodesToGraphRepresentationInput(out, n2g, G), training=True)
             gnn.backward(pool.backward(dOut))
@@ -392,7 +411,7 @@ def main():
             step()
         barrier()
         dt = time.perf_counter() - t0
-        for g_ in pending:  # the batch prepared for the step after the last one
+        for g_, _x in pending:  # the batch prepared for the step after the last one
             g_.wait()
             g_.close()
         pending.clear()

@@ -484,6 +484,17 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
                      int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                      int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                      int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream);
+/* The same product whose epilogue ALSO writes the result as an SP16 operand with one power-of-two scale per row
+ * (d_out_sp rows of ld_out_sp_bytes >= 4 N, 64-byte aligned; d_out_inv_scale [M]) - the operand of the next product
+ * (a Dense layer behind a message-passing layer, the weight-gradient products of the backward pass) without a split
+ * pass.  The row maximum is taken over the FINAL values (after bias / activation / the gradient factors).  N must be
+ * one column tile (128, 256 or 320: a workgroup holds whole rows); no accumulation; d_C may be NULL when only the
+ * split form is needed. */
+int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                        int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                        int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
+                        const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
+                        float* d_out_inv_scale, void* stream);
 
 /* tfgnn_sp_gemm_tn: the weight-gradient product C[m, n] = sum_k A[k, a_first_col + m] B[k, b_first_col + n] of two SP16
  * operands stored with K as the row index (dW = X^T G of the Dense / edge-MLP kernels, tf.GradientTape in
@@ -493,7 +504,8 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
  * scale arrays into one fp16 factor <= 1 per (k, block) - the scale product over its maximum over k, a power of two - which
  * the kernel multiplies into the A fragments; a row whose scale product is 2^-j of the largest keeps 22 bits while
  * j <= 13, 35 - j bits after that, and drops out beyond 2^-24.
- * M % 128 == 0, N % 128 == 0, first columns multiples of 16.  Split-K with a deterministic second pass that also
+ * M % 16 == 0 (row tiles are 128 columns of A; the last one may run past M: it reads neighbouring bytes of the operand rows and
+ * its surplus result rows stay in the workspace), N % 128 == 0, first columns multiples of 16.  Split-K with a deterministic second pass that also
  * scatters the result:
  *   C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= value
  * (row-major [M, N]: group_rows = M, stride_row = N, stride_col = 1; dW of stacked kernels [L, D, H] from m = (l, h),

@@ -9,6 +9,7 @@ from tests.test_gpu_full_size import (  # noqa: F401  (collected here again, und
     test_cfg2_rgcn_gnn_step_gradients_finite_and_reproducible,
     test_cfg2_rgcn_layer_matches_oracle_on_sampled_targets,
 )
+from tests.helpers import assert_close
 from tests.test_gpu_layers import check_layer_backward
 
 pytestmark = pytest.mark.gpu
@@ -61,3 +62,45 @@ def test_modes_agree_on_the_benchmarked_layer(dev, cfg2):
     out32 = layer(inp, training=False)
     scale = float(out32.abs().max())
     assert float((out2 - out32).abs().max()) <= 2e-6 * max(1.0, scale)
+
+
+def test_gnn_stack_with_dense_products_on_split_operands_matches_the_default_path(dev, monkeypatch):
+    """TFGNN_DENSE_F16X2=1: projection / Dense products and their gradients through tfgnn_sp_gemm_nt(_sp) / _tn, operands
+    split by the epilogues of the products before them.  Same stack, same weights, same dropout masks as the default
+    path (Dense products in bf16x3): outputs and gradients agree to the error class of the modes."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import GNN, GNNInput
+
+    V, E, L, H = 3000, 40000, 4, 320
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=3)
+    params = GNN.get_default_hyperparameters("rgcn")
+    params.update({"hidden_dim": H, "num_layers": 2, "dense_every_num_layers": 1, "residual_every_num_layers": 10000,
+                   "global_exchange_every_num_layers": 10000, "layer_input_dropout_rate": 0.1})
+    X = torch.from_numpy(feats).to(dev)
+    adj = tuple(torch.from_numpy(a).to(dev) for a in adjs)
+    n2g = torch.zeros(V, dtype=torch.int32, device=dev)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(1)).to(dev)
+    results = {}
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("f16x2")
+    try:
+        for flag in ("0", "1"):
+            monkeypatch.setenv("TFGNN_DENSE_F16X2", flag)
+            from tf2_gnn_amd.layers.message_passing import set_seed
+
+            set_seed(7)
+            gnn = GNN(params)
+            gnn.dropout_seed = 11
+            out = gnn(GNNInput(X, adj, n2g, 1), training=True)
+            dX = gnn.backward(dOut, need_input_grad=True)
+            results[flag] = (out.cpu(), dX.cpu(), [v.grad.cpu() for v in gnn.trainable_variables])
+    finally:
+        ops.set_gemm_mode(prev)
+    o0, x0, g0 = results["0"]
+    o1, x1, g1 = results["1"]
+    assert_close(o1, o0, tol=1e-5, what="dense f16x2 stack output")
+    assert_close(x1 / float(x0.abs().max()), x0 / float(x0.abs().max()), tol=1e-5, what="dense f16x2 stack dX")
+    for a, b in zip(g1, g0):
+        s = max(1.0, float(b.abs().max()))
+        assert_close(a / s, b / s, tol=2e-5, what="dense f16x2 stack weight gradient")

@@ -298,3 +298,60 @@ def test_dropout_writes_the_same_split_operand_as_a_split_pass(dev):
             ops.set_gemm_mode("bf16x3")
     keep = float((m0 != 0).float().mean())
     assert abs(keep - 0.9) < 0.05
+
+
+@pytest.mark.parametrize("M,N,K,grad,want_fp32", [(300, 320, 1280, False, True), (1000, 320, 320, True, False), (129, 128, 64, True, True),
+                                                  (2050, 256, 336, False, False), (64, 320, 16, True, True)])
+def test_gemm_nt_split_result_equals_a_split_pass_over_the_fp32_result(dev, M, N, K, grad, want_fp32):
+    """tfgnn_sp_gemm_nt_sp: the epilogue writes the result as an SP16 operand (one scale per row over all N columns -
+    two waves exchange their half-row maxima).  It must be the split of exactly the values the fp32 epilogue stores."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=g)
+    A[3] = 0.0  # a zero row: smallest-normal scale, zero pieces
+    A[5] *= 1e-20
+    Bt = torch.randn((N, K), generator=g) * 0.05
+    mul = ((torch.rand((M, N), generator=g) > 0.2).float() * 1.25).to(dev) if grad else None
+    saved = torch.tanh(torch.randn((M, N), generator=g)).to(dev) if grad else None
+    a_op, b_op = ops.sp_split_rows(A.to(dev)), ops.sp_split_rows(Bt.to(dev))
+    kw = dict(act=None if grad else "relu", out_mul=mul, act_grad=None if saved is None else ("tanh", saved))
+    plain = ops.sp_gemm_nt(a_op, b_op, **kw)
+    out, op = ops.sp_gemm_nt_split(a_op, b_op, want_fp32=want_fp32, **kw)
+    ref = ops.sp_split_rows(plain)
+    if want_fp32:
+        assert torch.equal(out, plain)
+        assert ops.sp_rows_of(out) is op
+    else:
+        assert out is None
+    assert op.scale_block == N and torch.equal(op.inv_scale.view(-1), ref.inv_scale.view(-1))
+    assert np.array_equal(decode_sp16(op), decode_sp16(ref))
+
+
+def test_gemm_nt_split_result_needs_a_single_column_tile(dev):
+    from tf2_gnn_amd import ops
+
+    a_op = ops.sp_split_rows(torch.randn((64, 64), device=dev))
+    b_op = ops.sp_split_rows(torch.randn((640, 64), device=dev))
+    with pytest.raises(ValueError, match="split result needs N"):
+        ops.sp_gemm_nt_split(a_op, b_op)
+
+
+@pytest.mark.parametrize("K,M,N", [(3000, 320, 320), (777, 64, 128), (2000, 336, 256), (30000, 320, 320), (29999, 128, 128)])
+def test_gemm_tn_row_count_not_a_multiple_of_the_tile(dev, K, M, N):
+    """M % 128 != 0 (dW of a 320 x 320 Dense kernel): the last row tile runs past M and its surplus rows stay in the
+    workspace; both operands with one scale per row, as the product epilogues write them."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(K + M)
+    X = torch.randn((K, M), generator=g) * torch.exp(torch.randn((K, 1), generator=g))
+    G = torch.randn((K, N), generator=g) * 1e-3
+    out = ops.sp_gemm_tn(ops.sp_split_rows(X.to(dev)), ops.sp_split_rows(G.to(dev))).cpu()
+    ref = X.double().t() @ G.double()
+    mag = X.double().abs().t() @ G.double().abs()
+    e = float(((out.double() - ref).abs() / mag).max())
+    assert out.shape == (M, N) and e <= 6e-7, e
+    # into a strided destination (the [in, out] kernel of a Dense layer from dW^T = G^T X)
+    dW = torch.zeros((N, M), device=dev)
+    ops.sp_gemm_tn(ops.sp_split_rows(X.to(dev)), ops.sp_split_rows(G.to(dev)), out=dW, scatter=(M, 0, 1, M))
+    assert torch.equal(dW.cpu().t(), out)

@@ -83,6 +83,10 @@ struct SpArgs {
   int64_t ld_saved;
   int dact;
   unsigned n_tiles;
+  // OUT_SP kernels: the result also (or only, C == NULL) as an SP16 operand with one scale per row (N == tile width)
+  uint8_t* out_sp;
+  int64_t ld_out_sp;
+  float* out_inv;  // [M]
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -181,19 +185,26 @@ __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restr
       mx.z = fmaxf(mx.z, fabsf(v[u].z)); mx.w = fmaxf(mx.w, fabsf(v[u].w));
     }
   }
-  // reduce over the 64 k-rows of threads with the same nq
-  for (int j = 0; j < 4; ++j) {
-    red[kq][tid & 3] = j == 0 ? mx.x : (j == 1 ? mx.y : (j == 2 ? mx.z : mx.w));
-    __syncthreads();
-    if (tid < 4) {
-      float m = 0.f;
-      for (int i = 0; i < 64; ++i) m = fmaxf(m, red[i][tid]);
-      float iv;
-      sc[tid * 4 + j] = sp_scale_for_max(m, &iv);
-      if (inv && blockIdx.y == 0 && n0 + tid * 4 + j < N) inv[n0 + tid * 4 + j] = iv;
-    }
-    __syncthreads();
+  // reduce over the 64 k-rows of threads with the same nq: lanes 4 apart inside a wave (xor 4 .. 32), then the 4 waves
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
+    mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
   }
+  if ((tid & 63) < 4) {
+    float* r = &red[(tid >> 6) * 4 + (tid & 3)][0];
+    r[0] = mx.x; r[1] = mx.y; r[2] = mx.z; r[3] = mx.w;
+  }
+  __syncthreads();
+  if (tid < 16) {  // column n0 + tid = chunk tid / 4, component tid % 4
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w * 4 + (tid >> 2)][tid & 3]);
+    float iv;
+    sc[tid] = sp_scale_for_max(m, &iv);
+    if (inv && blockIdx.y == 0 && n0 + tid < N) inv[n0 + tid] = iv;
+  }
+  __syncthreads();
   const int64_t kper = (((K + gridDim.y - 1) / gridDim.y) + 63) & ~63ll;
   const int64_t kend = (blockIdx.y + 1) * kper < K ? (blockIdx.y + 1) * kper : K;
   for (int64_t kb = blockIdx.y * kper; kb < kend; kb += 64) {
@@ -382,7 +393,7 @@ struct SpLoop {
   }
 };
 
-template <int TNW, bool ABLK, bool GRAD>
+template <int TNW, bool ABLK, bool GRAD, bool OUT_SP = false>
 __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   using G = SpGeo<TNW>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -542,6 +553,91 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
     const float* __restrict__ mulp = g.mul;
     const float* __restrict__ savp = g.saved;
     float* __restrict__ cptr = g.C;
+    if constexpr (OUT_SP) {
+      // The result as a split operand of the next product (one scale per row): 8 lanes own a row of this wave's
+      // 32 TNW columns (TNW float4 each), four row groups per 32-row block; the row maximum of the FINAL values (after
+      // the gradient factors) is reduced over the 8 lanes, exchanged with the wave that holds the other half of the
+      // row through LDS, then every lane splits and stores its chunks (and the fp32 form when C is given).
+      float* xmax = reinterpret_cast<float*>(lds) + 4 * 32 * G::PATCH_LD + t * 4 * 32;  // [tile][wave][32 rows]
+      const int rgrp = lane >> 3, l8 = lane & 7;
+      float4 w[4][TNW];
+      float rmax[4];
+      bool okq[4];
+      int64_t rowq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pr = q * 8 + rgrp;
+        const int64_t row = wrow0 + pr;
+        okq[q] = row < g.M;
+        rowq[q] = okq[q] ? row : g.M - 1;
+        float4 m[TNW], sv[TNW];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int c4 = l8 + 8 * j;
+          const int64_t col = wcol0 + c4 * 4;
+          w[q][j] = *reinterpret_cast<const float4*>(patch + pr * G::PATCH_LD + c4 * 4);
+          if (GRAD) {
+            m[j] = mulp ? *reinterpret_cast<const float4*>(mulp + rowq[q] * g.ld_mul + col) : float4{1.f, 1.f, 1.f, 1.f};
+            sv[j] = savp ? *reinterpret_cast<const float4*>(savp + rowq[q] * g.ld_saved + col) : float4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        if (GRAD && savp) {
+          auto dact_row = [&](auto act_c) {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+              sv[j].x = act_grad(decltype(act_c)::value, sv[j].x); sv[j].y = act_grad(decltype(act_c)::value, sv[j].y);
+              sv[j].z = act_grad(decltype(act_c)::value, sv[j].z); sv[j].w = act_grad(decltype(act_c)::value, sv[j].w);
+            }
+          };
+          switch (g.dact) {
+            case TFGNN_ACT_RELU: dact_row(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+            case TFGNN_ACT_TANH: dact_row(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+            case TFGNN_ACT_LEAKY_RELU: dact_row(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+            case TFGNN_ACT_ELU: dact_row(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+            case TFGNN_ACT_SELU: dact_row(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+            case TFGNN_ACT_GELU: dact_row(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+            case TFGNN_ACT_SIGMOID: dact_row(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+            default: dact_row(std::integral_constant<int, TFGNN_ACT_NONE>{}); break;
+          }
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          if (GRAD) {
+            w[q][j].x *= m[j].x; w[q][j].y *= m[j].y; w[q][j].z *= m[j].z; w[q][j].w *= m[j].w;
+            if (savp) { w[q][j].x *= sv[j].x; w[q][j].y *= sv[j].y; w[q][j].z *= sv[j].z; w[q][j].w *= sv[j].w; }
+          }
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(w[q][j].x), fabsf(w[q][j].y)), fmaxf(fabsf(w[q][j].z), fabsf(w[q][j].w))));
+          if (w[q][j].x != w[q][j].x || w[q][j].y != w[q][j].y || w[q][j].z != w[q][j].z || w[q][j].w != w[q][j].w)
+            mx = __builtin_inff();
+        }
+#pragma unroll
+        for (int o = 4; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        rmax[q] = mx;
+        if (l8 == 0) xmax[wave * 32 + pr] = mx;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // all four waves run the two row tiles in step
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pr = q * 8 + rgrp;
+        const float full = fmaxf(rmax[q], xmax[(wave ^ 1) * 32 + pr]);  // the wave with the other column half: same wm
+        float iv;
+        const float sc = sp_scale_for_max(full, &iv);
+        if (okq[q]) {
+          if (wn == 0 && l8 == 0) g.out_inv[rowq[q]] = iv;
+          uint8_t* drow = g.out_sp + rowq[q] * g.ld_out_sp;
+#pragma unroll
+          for (int j = 0; j < TNW; ++j) {
+            const int64_t col = wcol0 + (l8 + 8 * j) * 4;
+            if (cptr) *reinterpret_cast<float4*>(cptr + rowq[q] * g.ldc + col) = w[q][j];
+            sp_store4(drow, col, w[q][j], sc);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      return;
+    }
 #pragma unroll
     for (int it0 = 0; it0 < NIT; it0 += 4) {
       float4 v[4], m[4], sv[4], o[4];
@@ -641,6 +737,7 @@ struct SpTnArgs {
   int64_t f_ld;
   int a_sb;           // columns per scale block of A
   int64_t a_col0;     // first column of A (for the block index of a column)
+  int a_nblk;         // scale blocks per row of A
   float* partial;     // [splits][M][N]
   int64_t k_chunk;    // rows of K per split (a multiple of 16)
   unsigned n_tiles;
@@ -884,7 +981,9 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   L.rs_b = make_rsrc(g.B + k0 * g.ldb + col0 * 4, krows * g.ldb - col0 * 4);
   // factors: the scale blocks this tile's 128 columns of A touch (at most 4), 16 k = 32 bytes per block and step
   const int blk_first = (int)((g.a_col0 + row0) / g.a_sb);
-  const int blk_last = (int)((g.a_col0 + row0 + SP_BM - 1) / g.a_sb);
+  // (M is padded to a multiple of 128: columns past the operand's last block use that block's factors - their rows of
+  // the partial result are never read)
+  const int blk_last = min((int)((g.a_col0 + row0 + SP_BM - 1) / g.a_sb), g.a_nblk - 1);
   const int nb = blk_last - blk_first + 1;
   L.rs_f = make_rsrc(reinterpret_cast<const uint8_t*>(g.F + (int64_t)blk_first * g.f_ld + k0),
                      ((int64_t)(nb - 1) * g.f_ld + ((krows + 15) & ~15ll)) * 2);
@@ -930,7 +1029,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
       }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int blk = (int)((g.a_col0 + row0 + wm * 64 + t * 32 + fi) / g.a_sb) - blk_first;
+      const int blk = min((int)((g.a_col0 + row0 + wm * 64 + t * 32 + fi) / g.a_sb), blk_last) - blk_first;
       L.f_addr[t] = lds_base + (unsigned)(G::FOFF + blk * 32 + kg * 16);
     }
   }
@@ -988,11 +1087,11 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 __global__ void __launch_bounds__(256) sp_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
                                                            const float* __restrict__ ref, int64_t a_col0, int a_sb,
                                                            float* __restrict__ C, int64_t group_rows, int64_t stride_group,
-                                                           int64_t stride_row, int64_t stride_col, int accumulate) {
-  const int64_t total = M * N;
+                                                           int64_t stride_row, int64_t stride_col, int accumulate, int64_t slab) {
+  const int64_t total = M * N;  // slab >= total: floats per split (the product pads M to a multiple of 128)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * slab + i];
     const int64_t m = i / N, n = i - m * N;
     s *= ref[(a_col0 + m) / a_sb];
     float* c = C + (m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col;
@@ -1012,22 +1111,30 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
   using G = SpGeo<TNW>;
   const bool ablk = g.a_inv && g.a_nblk > 1;
   const bool grad = g.mul || g.saved;
-#define SP_LAUNCH(AB, GR)                                                                                          \
+#define SP_LAUNCH(AB, GR, OS)                                                                                      \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_sp_nt_kernel<TNW, AB, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_nt_kernel<TNW, AB, GR, OS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 G::LDS_BYTES);                                                                     \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_sp_nt_kernel<TNW, AB, GR>), grid, dim3(SP_NT), G::LDS_BYTES, s, g);                   \
+    hipLaunchKernelGGL((gemm_sp_nt_kernel<TNW, AB, GR, OS>), grid, dim3(SP_NT), G::LDS_BYTES, s, g);               \
   } while (0)
-  if (ablk) {
-    if (grad) SP_LAUNCH(true, true);
-    else SP_LAUNCH(true, false);
+  if (g.out_sp) {
+    if (ablk) {
+      if (grad) SP_LAUNCH(true, true, true);
+      else SP_LAUNCH(true, false, true);
+    } else {
+      if (grad) SP_LAUNCH(false, true, true);
+      else SP_LAUNCH(false, false, true);
+    }
+  } else if (ablk) {
+    if (grad) SP_LAUNCH(true, true, false);
+    else SP_LAUNCH(true, false, false);
   } else {
-    if (grad) SP_LAUNCH(false, true);
-    else SP_LAUNCH(false, false);
+    if (grad) SP_LAUNCH(false, true, false);
+    else SP_LAUNCH(false, false, false);
   }
 #undef SP_LAUNCH
 }
@@ -1073,11 +1180,12 @@ int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, vo
   return TFGNN_OK;
 }
 
-int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
-                     int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
-                     int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
-                     int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream) {
-  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C, "tfgnn_sp_gemm_nt: null pointer");
+static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                           int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                           int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                           int act_of_saved, const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
+                           float* d_out_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_A_sp && d_B_sp && (d_C || d_out_sp), "tfgnn_sp_gemm_nt: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
   const int bn = sp_tile_width(N);
   if (!bn) {
@@ -1087,7 +1195,7 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && lda_bytes >= K * 4 && ldb_bytes >= K * 4 &&
                     (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0,
                 "tfgnn_sp_gemm_nt: SP16 operands must be 64-byte aligned with leading dimensions >= 4 K bytes");
-  TFGNN_REQUIRE(ldc % 4 == 0 && (uintptr_t)d_C % 16 == 0 && (!d_bias || (uintptr_t)d_bias % 16 == 0) &&
+  TFGNN_REQUIRE((!d_C || (ldc % 4 == 0 && (uintptr_t)d_C % 16 == 0)) && (!d_bias || (uintptr_t)d_bias % 16 == 0) &&
                     (!d_b_inv_scale || (uintptr_t)d_b_inv_scale % 16 == 0) && (!d_mul || (ld_mul % 4 == 0 && (uintptr_t)d_mul % 16 == 0)) &&
                     (!d_saved || (ld_saved % 4 == 0 && (uintptr_t)d_saved % 16 == 0)),
                 "tfgnn_sp_gemm_nt: C / bias / scale / factor operands must be 16-byte aligned with ld %% 4 == 0");
@@ -1105,6 +1213,13 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   g.C = d_C; g.ldc = ldc; g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.mul = d_mul; g.ld_mul = ld_mul; g.saved = d_saved; g.ld_saved = ld_saved; g.dact = act_of_saved;
   g.n_tiles = (unsigned)(N / bn);
+  if (d_out_sp) {
+    TFGNN_REQUIRE(N == bn && !accumulate && d_out_inv_scale, "tfgnn_sp_gemm_nt_sp: the split result needs N = 128, 256 or 320 (one column "
+                  "tile holds whole rows), no accumulation and an inverse-scale array");
+    TFGNN_REQUIRE(ld_out_sp_bytes >= N * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0,
+                  "tfgnn_sp_gemm_nt_sp: SP16 result rows must be 64-byte aligned and at least 4 N bytes");
+    g.out_sp = (uint8_t*)d_out_sp; g.ld_out_sp = ld_out_sp_bytes; g.out_inv = d_out_inv_scale;
+  }
   const int64_t tiles = ceil_div(M, SP_BM) * g.n_tiles;
   TFGNN_REQUIRE(tiles <= 0x7fffffff, "tfgnn_sp_gemm_nt: too many tiles");
   dim3 grid((unsigned)tiles);
@@ -1117,12 +1232,32 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
 }
 
 
+int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                     int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                     int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                     int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream) {
+  TFGNN_REQUIRE(d_C, "tfgnn_sp_gemm_nt: null pointer");
+  return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
+                         act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, nullptr, 0, nullptr, stream);
+}
+
+int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                        int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                        int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
+                        const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
+                        float* d_out_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_out_sp, "tfgnn_sp_gemm_nt_sp: null pointer");
+  return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
+                         act, 0, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale, stream);
+}
+
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
   const int bn = sp_tile_width(N);
-  if (!bn || M % SP_BM || a_scale_block <= 0) return 0;
+  if (!bn || M <= 0 || a_scale_block <= 0) return 0;
+  const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
   const int64_t nblk = ceil_div(a_total_cols, a_scale_block), kpad = (K + 15) & ~15ll;
   const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * 4 + 255) & ~(size_t)255);
-  return factors + (size_t)sp_tn_splits(M, N, K, bn) * (size_t)M * (size_t)N * 4;
+  return factors + (size_t)sp_tn_splits(Mp, N, K, bn) * (size_t)Mp * (size_t)N * 4;
 }
 
 int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
@@ -1133,11 +1268,14 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale, "tfgnn_sp_gemm_tn: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
   const int bn = sp_tile_width(N);
-  if (!bn || M % SP_BM || a_scale_block < 32) {
-    set_error("tfgnn_sp_gemm_tn: M = %lld must be a multiple of 128, N = %lld of 128, scale blocks of A >= 32 columns",
+  if (!bn || M % 16 || a_scale_block < 32) {
+    set_error("tfgnn_sp_gemm_tn: M = %lld must be a multiple of 16, N = %lld of 128, scale blocks of A >= 32 columns",
               (long long)M, (long long)N);
     return TFGNN_ERR_UNSUPPORTED;
   }
+  // row tiles are 128 columns of A: the last one may run past M (it reads the neighbouring bytes of the operand rows,
+  // zeros past the operand's end; its surplus result rows stay in the workspace)
+  const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
   TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0 &&
                     a_first_col % 16 == 0 && b_first_col % 16 == 0 && a_first_col >= 0 && b_first_col >= 0 &&
                     lda_bytes >= (a_first_col + M) * 4 && ldb_bytes >= (b_first_col + N) * 4 && a_total_cols >= a_first_col + M &&
@@ -1146,10 +1284,10 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   TFGNN_REQUIRE(group_rows > 0, "tfgnn_sp_gemm_tn: group_rows must be positive");
   TFGNN_REQUIRE(a_scale_block >= 48 || a_first_col % a_scale_block == 0,
                 "tfgnn_sp_gemm_tn: 32-column scale blocks need a block-aligned first column (at most 4 blocks per 128-column tile)");
-  const int splits = sp_tn_splits(M, N, K, bn);
+  const int splits = sp_tn_splits(Mp, N, K, bn);
   const int64_t nblk = a_total_cols / a_scale_block, kpad = (K + 15) & ~15ll;
   const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * 4 + 255) & ~(size_t)255;
-  const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)M * (size_t)N * 4;
+  const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)Mp * (size_t)N * 4;
   TFGNN_REQUIRE(d_workspace && workspace_bytes >= need && (uintptr_t)d_workspace % 256 == 0,
                 "tfgnn_sp_gemm_tn: workspace too small or unaligned (need %zu bytes)", need);
   hipStream_t s = (hipStream_t)stream;
@@ -1159,17 +1297,18 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
                      kpad, ref);
   TFGNN_LAUNCH_CHECK();
   SpTnArgs g{};
-  g.M = M; g.N = N; g.K = K;
+  g.M = Mp; g.N = N; g.K = K;
   g.A = (const uint8_t*)d_A_sp + a_first_col * 4; g.lda = lda_bytes;
   g.B = (const uint8_t*)d_B_sp + b_first_col * 4; g.ldb = ldb_bytes;
-  g.F = F; g.f_ld = kpad; g.a_sb = a_scale_block; g.a_col0 = a_first_col;
+  g.F = F; g.f_ld = kpad; g.a_sb = a_scale_block; g.a_col0 = a_first_col; g.a_nblk = (int)nblk;
   g.partial = (float*)((uint8_t*)d_workspace + f_bytes + r_bytes);
   const int64_t steps = (K + 15) / 16;
   g.k_chunk = ((steps + splits - 1) / splits) * 16;
+  const int splits_used = (int)ceil_div(K, g.k_chunk);  // rounding the chunk up to whole steps can leave the last splits empty
   g.n_tiles = (unsigned)(N / bn);
   TFGNN_REQUIRE(g.k_chunk * std::max(lda_bytes, ldb_bytes) < (1ll << 31) && nblk * kpad * 2 < (1ll << 31), "tfgnn_sp_gemm_tn: K chunk too large");
-  g.tiles = (unsigned)((M / SP_BM) * g.n_tiles);
-  g.splits = (unsigned)splits;
+  g.tiles = (unsigned)((Mp / SP_BM) * g.n_tiles);
+  g.splits = (unsigned)splits_used;
   g.per_xcd = (g.tiles * g.splits + 7) / 8;
   dim3 grid(8 * g.per_xcd);
 #define SP_LAUNCH_TN(T)                                                                                            \
@@ -1189,8 +1328,8 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   TFGNN_LAUNCH_CHECK();
   const int64_t total = M * N;
   hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s,
-                     (const float*)g.partial, splits, M, N, (const float*)ref, a_first_col, a_scale_block, d_C, group_rows,
-                     stride_group, stride_row, stride_col, accumulate);
+                     (const float*)g.partial, splits_used, M, N, (const float*)ref, a_first_col, a_scale_block, d_C, group_rows,
+                     stride_group, stride_row, stride_col, accumulate, Mp * N);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -50,6 +50,8 @@ struct X3Args {
   int splits;
   float* partial;
   unsigned n_tiles;
+  // plain form, XCD-aware order: a 1-D grid of 8 * per_xcd workgroups; 0 = (x, z) grid as launched
+  unsigned per_xcd, tiles_x;
   // gradient epilogue (tfgnn_gemm_grad_epilogue): C = (A B) * mul * act'(saved); NULL = factor absent
   const float* mul;
   int64_t ld_mul;
@@ -313,6 +315,21 @@ struct StagerKC {
   }
 };
 
+// Which (tile, K split) does this workgroup own?  Workgroups are dealt to the 8 XCDs round-robin by linear id and each
+// XCD has its own L2; with the XCD-aware order one XCD walks consecutive logical ids - the column tiles of one row
+// tile (they share the A rows), then the next row tile, then the next K split - so operand rows shared by neighbouring
+// tiles are fetched over the fabric once, not once per XCD.
+struct X3Tile {
+  unsigned x, z;
+  bool valid;
+};
+__device__ __forceinline__ X3Tile x3_tile(const X3Args& g) {
+  if (g.per_xcd == 0) return {blockIdx.x, blockIdx.z, true};
+  const unsigned logical = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
+  if (logical >= g.tiles_x * (unsigned)g.splits) return {0u, 0u, false};
+  return {logical % g.tiles_x, logical / g.tiles_x, true};
+}
+
 template <int NPROD, int TN, bool NT = false>
 __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
   constexpr int PLANE = Geo<TN>::PLANE, STAGE = Geo<TN>::STAGE, BN = Geo<TN>::BN;
@@ -324,20 +341,23 @@ __global__ void __launch_bounds__(X3_NT) gemm_x3p_kernel(X3Args g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
-  const int64_t m0 = (int64_t)(blockIdx.x / g.n_tiles) * X3_BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % g.n_tiles) * BN;
-  int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  const X3Tile tile = x3_tile(g);
+  if (!tile.valid) return;  // uniform for the whole workgroup
+  const unsigned bx = tile.x, bz = tile.z;
+  const int64_t m0 = (int64_t)(bx / g.n_tiles) * X3_BM;
+  const int64_t n0 = (int64_t)(bx % g.n_tiles) * BN;
+  int64_t k_begin = (int64_t)bz * g.k_chunk;
   int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
   float* Cp = g.C;
-  int64_t partial_slab = blockIdx.z;
+  int64_t partial_slab = bz;
   if (g.group_mode == 2) {  // the K range is the group's rows; every group has its own output
     const int64_t gb = g.group_off[blockIdx.y], ge = g.group_off[blockIdx.y + 1];
     const int64_t per = (ge - gb + g.splits - 1) / g.splits;
     const int64_t chunk = (per + X3_BK - 1) / X3_BK * X3_BK;
-    k_begin = gb + (int64_t)blockIdx.z * chunk;
+    k_begin = gb + (int64_t)bz * chunk;
     k_end = k_begin + chunk < ge ? k_begin + chunk : ge;
     Cp += (int64_t)blockIdx.y * g.strideC;
-    partial_slab = (int64_t)blockIdx.y * g.splits + blockIdx.z;
+    partial_slab = (int64_t)blockIdx.y * g.splits + bz;
   }
 
   floatx16 acc[TN];
@@ -592,8 +612,11 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool multiplier = wave < 4;
-  const int64_t m0 = (int64_t)(blockIdx.x / g_in.n_tiles) * X3_BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % g_in.n_tiles) * BN;
+  const X3Tile tile = x3_tile(g_in);
+  if (!tile.valid) return;  // uniform for the whole workgroup
+  const unsigned bx = tile.x, bz = tile.z;
+  const int64_t m0 = (int64_t)(bx / g_in.n_tiles) * X3_BM;
+  const int64_t n0 = (int64_t)(bx % g_in.n_tiles) * BN;
   if (g_in.group_mode == 1) {  // rows [off[y], off[y+1]) of A and C with the group's own B
     const int64_t gb = g_in.group_off[blockIdx.y], ge = g_in.group_off[blockIdx.y + 1];
     if (m0 >= ge - gb) return;  // uniform for the whole workgroup
@@ -606,7 +629,7 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
     g.C += gb * g.ldc;
     g.B += (int64_t)blockIdx.y * g.strideB;
   }
-  const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
+  const int64_t k_begin = (int64_t)bz * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
   const int64_t k_len = k_end - k_begin;
   const int T = k_len > 0 ? (int)((k_len + X3_BK - 1) / X3_BK) : 0;
@@ -717,7 +740,7 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
   // blocks, then all eight waves stream them out with bias / activation / accumulate (and the gradient factors)
   // applied in a compact loop (row-contiguous 16-byte stores; no wait on earlier stores anywhere).
   const bool split = g.splits > 1;
-  float* outp = split ? g.partial + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  float* outp = split ? g.partial + (int64_t)bz * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   float* ep = reinterpret_cast<float*>(lds);
   constexpr int ROW4 = EP_COLS / 4;  // float4 per block row
@@ -925,6 +948,11 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   }
   g.partial = (float*)workspace;
   dim3 grid((unsigned)tiles, 1, (unsigned)g.splits);
+  g.per_xcd = 0; g.tiles_x = (unsigned)tiles;
+  if ((g.n_tiles > 1 || g.splits > 1) && tiles * g.splits < (1ll << 30)) {  // tiles share operand rows: XCD-aware order (x3_tile)
+    g.per_xcd = (unsigned)ceil_div(tiles * g.splits, 8);
+    grid = dim3(8 * g.per_xcd, 1, 1);
+  }
   if (bn == 320) launch_x3<5>(g, grid, nprod, trans_a, trans_b, s);
   else if (bn == 256) launch_x3<4>(g, grid, nprod, trans_a, trans_b, s);
   else launch_x3<2>(g, grid, nprod, trans_a, trans_b, s);
@@ -954,8 +982,13 @@ int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t 
   g.n_tiles = (unsigned)(3 * H / 192);
   g.gru_mh = mh; g.gru_h = h; g.gru_gates = gates; g.gru_H = H;
   const int64_t tiles = ceil_div(M, X3_BM) * g.n_tiles;
-  if (tiles > 0x7fffffff) return 0;
+  if (tiles > 0x3fffffff) return 0;
   dim3 grid((unsigned)tiles, 1, 1);
+  if (g.n_tiles > 1) {  // the column tiles of a row tile share the A rows: XCD-aware order (x3_tile)
+    g.tiles_x = (unsigned)tiles;
+    g.per_xcd = (unsigned)ceil_div(tiles, 8);
+    grid = dim3(8 * g.per_xcd, 1, 1);
+  }
   if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   return 1;

@@ -182,12 +182,50 @@ class GNN:
             return cur, all_reprs
         return cur
 
+    @staticmethod
+    def _tiles(n: int) -> bool:
+        return n % 128 == 0 or n % 320 == 0  # output widths the split-operand products tile
+
+    def _dense_f16x2(self, in_dim: int, out_dim: int) -> bool:
+        """Dense products on split operands (mode f16x2): the operands come split from their producers - the epilogue of
+        the product before (tfgnn_sp_gemm_nt_sp), the dropout kernel, the input pipeline (ops.split_rows_remembered) -
+        or from one split pass where no producer wrote them."""
+        import os
+
+        # Opt-in (TFGNN_DENSE_F16X2=1): measured break-even on the benchmark stack (2.66 vs 2.65 ms per step) - the three
+        # K = 320 products get 26 us faster each, the per-step splits of two more weight matrices, the factor and reduce
+        # passes of two more weight-gradient products and the split-writing epilogues take it back (DESIGN.md 4.4)
+        if os.environ.get("TFGNN_DENSE_F16X2", "0") != "1":
+            return False
+        return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
+
     def _dense(self, x, w: Variable, act_name):
         """bias-free Dense + activation (gnn.py:136-141,163-170); gelu keeps its pre-activation."""
+        if x.shape[0] > 0 and self._dense_f16x2(w.value.shape[0], w.value.shape[1]):
+            wt = ops.sp_weight_operand(w.value, "cols", lambda: ops.sp_split_cols(w.value))
+            if act_name == "gelu":
+                pre = ops.sp_gemm_nt(ops.sp_rows_of(x), wt)
+                return ops.activation_forward("gelu", pre), pre
+            return ops.sp_gemm_nt(ops.sp_rows_of(x), wt, act=act_name), None
         if act_name == "gelu":
             pre = ops.gemm(x, w.value)
             return ops.activation_forward("gelu", pre), pre
         return ops.gemm(x, w.value, act=act_name), None
+
+    def _dense_backward(self, x, w: Variable, gpre, act_grad=None, need_input_grad=True):
+        """w.grad = x^T gpre; returns gpre w^T (* act'(saved) of the op below, ``act_grad``) or None."""
+        d_in, d_out = w.value.shape
+        if x.shape[0] > 0 and self._dense_f16x2(d_in, d_out):
+            g_sp = ops.sp_rows_of(gpre)  # written by the epilogue of the product above when that is a split-operand product
+            w.grad = ops.sp_gemm_tn(ops.sp_rows_of(x), g_sp)  # [in, out] = x^T gpre
+            if not need_input_grad:
+                return None
+            if self._tiles(d_in):
+                wr = ops.sp_weight_operand(w.value, "rows", lambda: ops.sp_split_rows(w.value))
+                return ops.sp_gemm_nt(g_sp, wr, act_grad=act_grad)
+            return ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=act_grad)
+        w.grad = ops.gemm(x, gpre, trans_a=True)
+        return ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=act_grad) if need_input_grad else None
 
     def _internal_call(self, inputs: GNNInput, training: bool = False):
         """gnn.py:276-329, same op order."""
@@ -210,6 +248,11 @@ class GNN:
                 if layer_idx > 0:
                     cur = ops.add_scale(cur, last, 0.5)
                 last = tmp
+            # a Dense right behind this layer takes its input as a split operand: let the layer's product write it
+            mp_layer._want_split_output = (
+                layer_idx % self._dense_every_num_layers == 0 and str(layer_idx) not in self._global_exchange_layers
+                and not self._use_inter_layer_layernorm and self._dense_f16x2(self._hidden_dim, self._hidden_dim)
+            )
             cur = mp_layer(MessagePassingInput(node_embeddings=cur, adjacency_lists=graph), training=training)
             all_reprs.append(cur)
             if str(layer_idx) in self._global_exchange_layers:  # gnn.py:307-315
@@ -284,9 +327,8 @@ class GNN:
                     gpre = ops.activation_backward(
                         self._dense_act, g, st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"]
                     )
-                w.grad = ops.gemm(st["dense_in"], gpre, trans_a=True)
                 nxt = None if (has_ln or has_ex or extras[layer_idx + 1] is not None) else mp.activation_backward_spec()
-                g = ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=nxt)
+                g = self._dense_backward(st["dense_in"], w, gpre, act_grad=nxt)
                 g_is_pre = nxt is not None
             if has_ln:
                 gam, bet = self._inter_layer_layernorms[layer_idx]
@@ -299,6 +341,10 @@ class GNN:
             mask = st.get("mask")
             if not residual_here:
                 nxt = None if extras[layer_idx] is not None else self._tail_first_backward_op(layer_idx, ctx)
+                # the gradient this layer hands down goes straight into a Dense / projection weight-gradient product when
+                # the op below is one and its activation derivative is folded in here: ask for it as a split operand too
+                below_is_dense = layer_idx == 0 or (layer_idx - 1) % self._dense_every_num_layers == 0
+                mp._want_split_input_grad = nxt is not None and below_is_dense and self._dense_f16x2(self._hidden_dim, self._hidden_dim)
                 g = mp.backward_with_epilogue(g, grad_is_pre_activation=g_is_pre, out_mul=mask, out_act_grad=nxt)
                 g_is_pre = nxt is not None
             else:
@@ -318,10 +364,7 @@ class GNN:
         gpre = g
         if self._init_act is not None and not g_is_pre:
             gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
-        self._initial_projection_layer.grad = ops.gemm(ctx["X"], gpre, trans_a=True)
-        if need_input_grad:
-            return ops.gemm(gpre, self._initial_projection_layer.value, trans_b=True)
-        return None
+        return self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
 
 
 def _act_name(fn):

@@ -336,7 +336,10 @@ class GNN_Edge_MLP(MessagePassing):
             A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L)
             Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H)))
             gelu_split = fuse_act == "gelu"
-            pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)
+            if getattr(self, "_want_split_output", False) and not gelu_split and H in (128, 256, 320):
+                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act)  # the consumer finds the split form with sp_rows_of
+            else:
+                pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)
             ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True}
             if gelu_split:
                 ctx["pre"] = pre
@@ -377,7 +380,10 @@ class GNN_Edge_MLP(MessagePassing):
         Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H)))
         epi = getattr(self, "_out_epilogue", None)
         if epi is not None:
-            dX = ops.sp_gemm_nt(G_sp, Wh_sp, out_mul=epi[0], act_grad=epi[1])
+            if getattr(self, "_want_split_input_grad", False) and D in (128, 256, 320):
+                dX, _ = ops.sp_gemm_nt_split(G_sp, Wh_sp, out_mul=epi[0], act_grad=epi[1])
+            else:
+                dX = ops.sp_gemm_nt(G_sp, Wh_sp, out_mul=epi[0], act_grad=epi[1])
             self._out_epilogue = None  # consumed
         else:
             dX = ops.sp_gemm_nt(G_sp, Wh_sp)

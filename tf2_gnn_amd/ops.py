@@ -773,7 +773,9 @@ def sp_rows_of(x: torch.Tensor) -> SplitOperand:
     hit = _sp_rows_memo.get(id(x))
     if hit is not None and hit[0]() is x and hit[1] == x._version:
         return hit[2]
-    return sp_split_rows(x)
+    op = sp_split_rows(x)
+    _remember_split_rows(x, op)  # forward and backward products of a step share it
+    return op
 
 
 def sp_split_cols(w: torch.Tensor) -> SplitOperand:
@@ -817,6 +819,46 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
         )
     )
     return out
+
+
+def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out_mul=None, act_grad=None,
+                     want_fp32: bool = True):
+    """As sp_gemm_nt, with the result ALSO (or only: want_fp32=False) written as an SP16 operand with one scale per row
+    by the product's epilogue (tfgnn_sp_gemm_nt_sp): the next product's operand without a split pass.  N must be one
+    column tile (128, 256 or 320).  -> (fp32 [M, N] | None, SplitOperand); the fp32 tensor remembers its split form
+    (``sp_rows_of``)."""
+    lib = _lib.load()
+    M, K, N = a.rows, a.cols, b.rows
+    if b.cols != K:
+        raise ValueError(f"sp_gemm_nt_split: inner dimensions differ ({K} vs {b.cols})")
+    if b.scale_block != K:
+        raise ValueError("sp_gemm_nt_split: the right operand must carry one scale per row")
+    dev = a.data.device
+    out = torch.empty((M, N), dtype=torch.float32, device=dev) if want_fp32 else None
+    op = SplitOperand(torch.empty((M, N * 4), dtype=torch.uint8, device=dev), torch.empty((M, 1), dtype=torch.float32, device=dev),
+                      M, N, N)
+    act_name, saved = act_grad if act_grad is not None else (None, None)
+    if bias is not None:
+        bias = bias.contiguous()
+    _lib.check(
+        lib.tfgnn_sp_gemm_nt_sp(
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
+            b.data.stride(0), _ptr(b.inv_scale), _ptr(out), N, _ptr(bias), act_id(act), _ptr(out_mul),
+            out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
+            saved.stride(0) if saved is not None else 0, _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale), _stream(),
+        )
+    )
+    if out is not None:
+        _remember_split_rows(out, op)
+    return out, op
+
+
+def split_rows_remembered(x: torch.Tensor) -> SplitOperand:
+    """Split ``x`` now and remember the operand for ``sp_rows_of(x)`` (an input pipeline preparing the node features of a
+    batch for the first product, e.g. on the stream that also buckets the batch's edges)."""
+    op = sp_split_rows(x)
+    _remember_split_rows(x, op)
+    return op
 
 
 def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, edge_weight=None, row_scale=None,
