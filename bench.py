@@ -286,9 +286,14 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm device (there is no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # TFGNN_BENCH_SINGLE_DEVICE=1 (tests/test_gpu_bench_multirank.py): all ranks on cuda:0 with gloo collectives - the N > 1
+    # code path (sharding, per-rank batches, metric collectives around the HIP step) on a box with one GPU
+    single_device = os.environ.get("TFGNN_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rank, world, dist = parallel.init_distributed(device=dev)  # nccl == RCCL over xGMI on ROCm
+    rank, world, dist = parallel.init_distributed(device=dev, backend="gloo" if single_device else None)  # nccl == RCCL over xGMI
     assert world == args.gpus, f"communicator has {world} ranks, --gpus says {args.gpus}"
 
     from tf2_gnn_amd import ops
@@ -509,6 +514,8 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
     g = ops.Graph(adj_dev, V)
     out = []
     model, mode = wl["model"], args.gemm_mode
+    if mode == "f16x2" and not ((H % 128 == 0 or H % 320 == 0) and (L * H) % 128 == 0):
+        mode = "bf16x3"  # widths the split-operand products do not tile (the tiny workloads): the layers run bf16x3 there
     Hx = torch.randn((V, H), device=dev)
     split_peak = MFMA_FP32_PEAK_TFLOPS if mode == "fp32" else MFMA_16BIT_PEAK_TFLOPS
     nprod = {"fp32": 1, "bf16x3_9": 9}.get(mode, 6)  # piece products of the generic split-operand GEMM

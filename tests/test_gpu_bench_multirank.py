@@ -1,0 +1,41 @@
+"""bench.py's N > 1 path THROUGH THE HIP KERNELS on a box with one GPU: two ranks share cuda:0 (TFGNN_BENCH_SINGLE_DEVICE=1,
+gloo collectives).  Covers what the 8-GPU driver run exercises - self-spawn, graph sharding of the molecule batch
+(parallel.shard_batch -> per-rank Graph / GNN / pooling step), replicas for the single-graph workloads, the weighted
+gradient all-reduce, the metric collectives - short of RCCL itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra):
+    env = dict(os.environ, TFGNN_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-alt-mode", *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_shard_the_molecule_batch_through_the_hip_path():
+    one = _bench(["--workload", "qm9-tiny", "--no-roofline"])
+    two = _bench(["--gpus", "2", "--workload", "qm9-tiny", "--no-roofline", "--allreduce-grads"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert sum(two["config"]["edges_per_rank"]) == one["config"]["edges_per_rank"][0]  # the same batch, split by graph
+    assert two["value"] > 0 and one["value"] > 0
+    assert "all-reduce" in two["config"]["collectives_per_step"]
+
+
+def test_two_replica_ranks_for_the_single_graph_workload():
+    r = _bench(["--gpus", "2", "--workload", "tiny"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["edges_per_rank"] == [40000.0, 40000.0]
+    assert r["roofline"]["bound"] in ("hbm", "mfma") and 0 < r["roofline"]["frac"] <= 1.0

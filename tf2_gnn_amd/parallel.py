@@ -112,6 +112,13 @@ def shard_batch(
     )
 
 
+def _collective_device(dist, device):
+    """device tensors for RCCL, host tensors for gloo (the CPU tests and the single-GPU multi-rank smoke test)"""
+    if dist is not None and dist.get_backend() == "gloo":
+        return "cpu"
+    return device or "cpu"
+
+
 def barrier(dist) -> None:
     if torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -125,7 +132,7 @@ def reduce_max(value: float, dist, device=None) -> float:
     """MAX over ranks of a host scalar (step time)."""
     if dist is None:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=_collective_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -133,7 +140,7 @@ def reduce_max(value: float, dist, device=None) -> float:
 def all_gather_scalars(values: Sequence[float], dist, device=None) -> np.ndarray:
     """all-gather of a few per-rank scalars (edge counts, loss sums, ...) -> [world, len(values)].
     This is the 'final metric reduction' of the north star: the only data any rank sends."""
-    mine = torch.tensor(list(values), dtype=torch.float64, device=device or "cpu")
+    mine = torch.tensor(list(values), dtype=torch.float64, device=_collective_device(dist, device))
     if dist is None:
         return mine.cpu().numpy()[None, :]
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
@@ -181,7 +188,12 @@ def allreduce_gradients(variables, dist, average: bool = True, bucket_bytes: int
         if weight is not None and start == 0:
             pieces.append(weight.to(pieces[0].device))
         flat = torch.cat(pieces)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and flat.is_cuda:  # single-GPU multi-rank smoke test: host round trip
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat = host.to(flat.device)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if weight is not None and start == 0:
             total = flat[-1].clone()
             flat = flat[:-1]
