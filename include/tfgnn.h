@@ -480,6 +480,13 @@ int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t
                         const float* d_fixed_inv_scale, void* stream);
 int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
                         float* d_inv_scale, void* stream);
+/* Both operand forms of `count` (<= 16) stacked kernels [L, D, H] of one shape in a single launch - the per-step weight
+ * preparation of a layer stack (after an optimizer update every kernel has to be split again; 2 x layers latency-bound
+ * launches otherwise): h_cols_sp[i] receives tfgnn_sp_split_cols of the [L D, H] view (rows = H, cols = L D),
+ * h_rows_sp[i] tfgnn_sp_split_rows of [W_0 | ... | W_{L-1}] (rows = D, cols = L H), each with one scale per row.  The
+ * pointer arrays are HOST arrays of device pointers. */
+int tfgnn_sp_split_weights(int count, const float* const* h_src, int64_t L, int64_t D, int64_t H, void* const* h_cols_sp,
+                           float* const* h_cols_inv_scale, void* const* h_rows_sp, float* const* h_rows_inv_scale, void* stream);
 int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
                      int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                      int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,

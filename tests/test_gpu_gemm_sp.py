@@ -355,3 +355,30 @@ def test_gemm_tn_row_count_not_a_multiple_of_the_tile(dev, K, M, N):
     dW = torch.zeros((N, M), device=dev)
     ops.sp_gemm_tn(ops.sp_split_rows(X.to(dev)), ops.sp_split_rows(G.to(dev)), out=dW, scatter=(M, 0, 1, M))
     assert torch.equal(dW.cpu().t(), out)
+
+
+def test_batched_weight_split_equals_the_two_single_splits(dev):
+    """tfgnn_sp_split_weights: both operand forms of several [L, D, H] kernel stacks in one launch, bit-equal to
+    tfgnn_sp_split_cols / tfgnn_sp_split_rows, and found by sp_weight_operand without another split."""
+    from tf2_gnn_amd import ops
+
+    L, D, H = 4, 320, 320
+    g = torch.Generator().manual_seed(3)
+    stacks = [(torch.randn((L, D, H), generator=g) * (0.05 * (i + 1))).to(dev) for i in range(5)]
+    stacks[2][1, 7] = 0.0
+    ops.clear_weight_operand_cache()
+    ops.sp_split_weights(stacks)
+
+    def fail():
+        raise AssertionError("the batched split should have filled the cache")
+
+    for W in stacks:
+        c = ops.sp_weight_operand(W, "cols", fail)
+        r = ops.sp_weight_operand(W, "rows", fail)
+        c_ref = ops.sp_split_cols(W.view(L * D, H))
+        r_ref = ops.sp_split_rows(W[0], segments=(H, D * H, L * H))
+        assert torch.equal(c.data, c_ref.data) and torch.equal(c.inv_scale.view(-1), c_ref.inv_scale.view(-1))
+        assert torch.equal(r.data, r_ref.data) and torch.equal(r.inv_scale.view(-1), r_ref.inv_scale.view(-1))
+    stacks[0].mul_(2.0)  # an optimizer update: the cached forms of this stack are stale
+    fresh = ops.sp_weight_operand(stacks[0], "cols", lambda: ops.sp_split_cols(stacks[0].view(L * D, H)))
+    assert torch.equal(fresh.data, ops.sp_split_cols(stacks[0].view(L * D, H)).data)

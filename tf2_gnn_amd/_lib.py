@@ -190,6 +190,7 @@ _SIGNATURES = [
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p],
     ),
+    ("tfgnn_sp_split_weights", c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     (
         "tfgnn_sp_gemm_nt_sp",
         c_int,

@@ -96,13 +96,13 @@ struct SpArgs {
 // (seg_len = C, seg_stride = 0: a plain row-major matrix; otherwise a row assembled from C / seg_len segments, e.g.
 // row d of [W_0[d,:] | W_1[d,:] | ...] from the stacked kernels [L, D, H]).  Two passes over the block (the second
 // one hits L1 / L2).
-__global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t seg_len,
-                                                            int64_t seg_stride, int64_t R, int64_t C, int sb,
-                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
-                                                            const float* __restrict__ fixed_inv) {
+__device__ __forceinline__ void sp_split_rows_body(const float* __restrict__ src, int64_t ld, int64_t seg_len,
+                                                   int64_t seg_stride, int64_t R, int64_t C, int sb,
+                                                   uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
+                                                   const float* __restrict__ fixed_inv, unsigned block) {
   const int lane = threadIdx.x & 63;
   const int nblk = (int)(C / sb);
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t item = (int64_t)block * 4 + (threadIdx.x >> 6);
   if (item >= R * nblk) return;
   const int64_t r = item / nblk;
   const int blk = (int)(item - r * nblk);
@@ -131,6 +131,13 @@ __global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restr
     const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
     sp_store4(drow, cc, v, s);
   }
+}
+
+__global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t seg_len,
+                                                            int64_t seg_stride, int64_t R, int64_t C, int sb,
+                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
+                                                            const float* __restrict__ fixed_inv) {
+  sp_split_rows_body(src, ld, seg_len, seg_stride, R, C, sb, dst, ld_dst, inv, fixed_inv, blockIdx.x);
 }
 
 // out[0] = max(out[0], scale * max |x|): the atomic maximum of non-negative floats through their bit patterns is
@@ -162,13 +169,14 @@ __global__ void sp_inv_scale_kernel(const float* bound, float* inv) {
 // [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  Workgroup (x, y): 16 dst rows, the
 // y-th slice of K; every workgroup takes the column maxima over ALL k itself (a weight matrix is L2 resident), so the
 // slices need no second launch.
-__global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
-                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv) {
+__device__ __forceinline__ void sp_split_cols_body(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
+                                                   uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
+                                                   unsigned bx, unsigned by, unsigned ny) {
   __shared__ float red[64][4];
   __shared__ float tile[16][65];
   __shared__ float sc[16];
   const int tid = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const int64_t n0 = (int64_t)bx * 16;
   const int kq = tid >> 2, nq = (tid & 3) * 4;  // this thread: k = kq + 64 i, columns n0 + nq .. +3
   const bool ok = n0 + nq < N;                  // N % 4 == 0
   float4 mx = {0.f, 0.f, 0.f, 0.f};
@@ -202,12 +210,12 @@ __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restr
     for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w * 4 + (tid >> 2)][tid & 3]);
     float iv;
     sc[tid] = sp_scale_for_max(m, &iv);
-    if (inv && blockIdx.y == 0 && n0 + tid < N) inv[n0 + tid] = iv;
+    if (inv && by == 0 && n0 + tid < N) inv[n0 + tid] = iv;
   }
   __syncthreads();
-  const int64_t kper = (((K + gridDim.y - 1) / gridDim.y) + 63) & ~63ll;
-  const int64_t kend = (blockIdx.y + 1) * kper < K ? (blockIdx.y + 1) * kper : K;
-  for (int64_t kb = blockIdx.y * kper; kb < kend; kb += 64) {
+  const int64_t kper = (((K + ny - 1) / ny) + 63) & ~63ll;
+  const int64_t kend = (by + 1) * kper < K ? (by + 1) * kper : K;
+  for (int64_t kb = by * kper; kb < kend; kb += 64) {
     const int64_t k = kb + kq;
     float4 v = {0.f, 0.f, 0.f, 0.f};
     if (ok && k < K) v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
@@ -220,6 +228,34 @@ __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restr
       sp_store4(dst + (n0 + rr) * ld_dst, kb + k4, o, sc[rr]);
     }
     __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
+                                                            uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv) {
+  sp_split_cols_body(src, ld, K, N, dst, ld_dst, inv, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Both operand forms of up to 16 stacked kernels [L, D, H] of the same shape in ONE launch (the per-step weight
+// preparation of a layer stack: 2 x layers small launches otherwise, each latency-bound): blockIdx.y = kernel stack;
+// workgroups [0, nc) do slice (x % ncx, x / ncx) of the transposed form [H, L D], the rest the stacked-rows form
+// [D, L H] (row d = [W_0[d, :] | W_1[d, :] | ...]).
+struct SpWeightJobs {
+  const float* src[16];
+  uint8_t* cols_sp[16];
+  float* cols_inv[16];
+  uint8_t* rows_sp[16];
+  float* rows_inv[16];
+  int64_t L, D, H;
+  unsigned ncx, ncy;
+};
+__global__ void __launch_bounds__(256) sp_split_weights_kernel(SpWeightJobs j) {
+  const unsigned w = blockIdx.y, nc = j.ncx * j.ncy;
+  if (blockIdx.x < nc) {
+    sp_split_cols_body(j.src[w], j.H, j.L * j.D, j.H, j.cols_sp[w], j.L * j.D * 4, j.cols_inv[w], blockIdx.x % j.ncx, blockIdx.x / j.ncx, j.ncy);
+  } else {
+    sp_split_rows_body(j.src[w], j.H, j.H, j.D * j.H, j.D, j.L * j.H, (int)(j.L * j.H), j.rows_sp[w], j.L * j.H * 4, j.rows_inv[w], nullptr,
+                       blockIdx.x - nc);
   }
 }
 
@@ -1176,6 +1212,29 @@ int tfgnn_sp_split_cols(const float* d_src, int64_t ld, int64_t K, int64_t N, vo
   TFGNN_REQUIRE(ld_sp_bytes >= K * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_cols: bad SP16 leading dimension / alignment");
   hipLaunchKernelGGL(sp_split_cols_kernel, dim3((unsigned)ceil_div(N, 16), (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, K / 128))), dim3(256), 0, (hipStream_t)stream, d_src, ld, K, N,
                      (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_split_weights(int count, const float* const* h_src, int64_t L, int64_t D, int64_t H, void* const* h_cols_sp,
+                           float* const* h_cols_inv_scale, void* const* h_rows_sp, float* const* h_rows_inv_scale, void* stream) {
+  TFGNN_REQUIRE(count >= 1 && count <= 16 && h_src && h_cols_sp && h_cols_inv_scale && h_rows_sp && h_rows_inv_scale,
+                "tfgnn_sp_split_weights: 1 .. 16 kernel stacks");
+  TFGNN_REQUIRE(L > 0 && D > 0 && H > 0 && (L * D) % 16 == 0 && (L * H) % 16 == 0 && H % 4 == 0,
+                "tfgnn_sp_split_weights: L D and L H must be multiples of 16, H a multiple of 4");
+  SpWeightJobs j{};
+  for (int i = 0; i < count; ++i) {
+    TFGNN_REQUIRE(h_src[i] && h_cols_sp[i] && h_cols_inv_scale[i] && h_rows_sp[i] && h_rows_inv_scale[i] &&
+                      (uintptr_t)h_src[i] % 16 == 0 && (uintptr_t)h_cols_sp[i] % 64 == 0 && (uintptr_t)h_rows_sp[i] % 64 == 0,
+                  "tfgnn_sp_split_weights: null or unaligned pointer");
+    j.src[i] = h_src[i]; j.cols_sp[i] = (uint8_t*)h_cols_sp[i]; j.cols_inv[i] = h_cols_inv_scale[i];
+    j.rows_sp[i] = (uint8_t*)h_rows_sp[i]; j.rows_inv[i] = h_rows_inv_scale[i];
+  }
+  j.L = L; j.D = D; j.H = H;
+  j.ncx = (unsigned)ceil_div(H, 16);
+  j.ncy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, L * D / 128));
+  const unsigned nr = (unsigned)ceil_div(D, 4);  // one wave per row of the stacked-rows form
+  hipLaunchKernelGGL(sp_split_weights_kernel, dim3(j.ncx * j.ncy + nr, (unsigned)count), dim3(256), 0, (hipStream_t)stream, j);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -234,6 +234,19 @@ class GNN:
         graph = get_graph(inputs.adjacency_lists, V)
         rate = float(self._params["layer_input_dropout_rate"])
         steps = []
+        import os
+
+        if training and ops.get_gemm_mode() == ops.GEMM_F16X2 and os.environ.get("TFGNN_BATCHED_WEIGHT_SPLIT", "0") == "1":
+            # Opt-in: both split forms of every layer's kernel stack in ONE launch at the start of the step instead of two
+            # small launches per layer.  Measured a LOSS (2.67 vs 2.62 ms per step): the batched launch is 59 us less
+            # split-kernel time, but every layer product then starts on a weight operand that is no longer in L2 and takes
+            # 15-17 us longer (80 -> 97 us forward, 95 -> 111 us dX) - splitting a kernel right before the product that
+            # re-reads it 235 times doubles as its prefetch.
+            stacks = [mp._edge_type_mlps.kernels[0] for mp in self._mp_layers
+                      if getattr(mp, "_edge_type_mlps", None) is not None and hasattr(mp, "_f16x2_eligible")
+                      and mp._path() == "A" and mp._f16x2_eligible(V, self._hidden_dim, graph.num_edge_types, self._hidden_dim)]
+            if len(stacks) > 1 and len({tuple(w.shape) for w in stacks}) == 1:
+                ops.sp_split_weights(stacks)
         cur, pre0 = self._dense(X, self._initial_projection_layer, self._init_act)
         ctx = {"X": X, "h0": cur, "pre0": pre0, "steps": steps}
         last = cur

@@ -957,11 +957,56 @@ def clear_weight_operand_cache() -> None:
     _sp_weight_cache.clear()
 
 
+def _weight_key(w: torch.Tensor, kind: str):
+    return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), kind)
+
+
+def sp_split_weights(stacks) -> None:
+    """Split the stacked kernels [L, D, H] of several layers (one shape) into both operand forms with ONE launch
+    (tfgnn_sp_split_weights) and put them where ``sp_weight_operand(W, "cols" | "rows", ...)`` finds them.  Stacks whose
+    current value is already split are skipped."""
+    import weakref
+
+    todo = []
+    for w in stacks:
+        hits = [_sp_weight_cache.get(_weight_key(w, kind)) for kind in ("cols", "rows")]
+        if not all(h is not None and h[0] == w._version and h[2]() is not None for h in hits):
+            todo.append(w)
+    if not todo:
+        return
+    lib = _lib.load()
+    L, D, H = todo[0].shape
+    for w in todo:
+        if tuple(w.shape) != (L, D, H) or not w.is_contiguous():
+            raise ValueError("sp_split_weights: contiguous [L, D, H] stacks of one shape")
+        _require_dev(w, torch.float32, "kernel stack")
+    for start in range(0, len(todo), 16):
+        group = todo[start : start + 16]
+        n = len(group)
+        dev = group[0].device
+        cols = [SplitOperand(torch.empty((H, L * D * 4), dtype=torch.uint8, device=dev), torch.empty((H, 1), dtype=torch.float32, device=dev),
+                             H, L * D, L * D) for _ in group]
+        rows = [SplitOperand(torch.empty((D, L * H * 4), dtype=torch.uint8, device=dev), torch.empty((D, 1), dtype=torch.float32, device=dev),
+                             D, L * H, L * H) for _ in group]
+
+        def ptrs(ts):
+            return (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+
+        _lib.check(lib.tfgnn_sp_split_weights(n, ptrs(group), L, D, H, ptrs([c.data for c in cols]), ptrs([c.inv_scale for c in cols]),
+                                              ptrs([r.data for r in rows]), ptrs([r.inv_scale for r in rows]), _stream()))
+        if len(_sp_weight_cache) > 256:
+            _sp_weight_cache.clear()
+        for w, c, r in zip(group, cols, rows):
+            base = w._base if w._base is not None else w
+            _sp_weight_cache[_weight_key(w, "cols")] = (w._version, c, weakref.ref(base))
+            _sp_weight_cache[_weight_key(w, "rows")] = (w._version, r, weakref.ref(base))
+
+
 def sp_weight_operand(w: torch.Tensor, kind: str, build) -> SplitOperand:
     """SP16 form of a weight tensor, built once per value: keyed on the tensor's storage and version (an in-place
     optimizer update bumps the version), so forward and backward passes of a step - and every step of an evaluation
     loop - share it.  ``build()`` makes the operand."""
-    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), kind)
+    key = _weight_key(w, kind)
     hit = _sp_weight_cache.get(key)
     if hit is not None and hit[0] == w._version and hit[2]() is not None:
         return hit[1]
