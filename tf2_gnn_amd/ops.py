@@ -68,6 +68,23 @@ def _rowmajor(t: torch.Tensor, what: str):
     return t, ld
 
 
+def _writes_out(fn):
+    """The kernels write caller-provided ``out`` tensors through raw pointers, which torch does not see: bump the tensor's
+    version counter so that everything keyed on (tensor, version) - the remembered split forms of ``sp_rows_of``, the
+    split weight operands, the Graph cache - notices the new contents."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        res = fn(*args, **kwargs)
+        out = kwargs.get("out")
+        if isinstance(out, torch.Tensor):
+            torch.autograd.graph.increment_version(out)
+        return res
+
+    return wrapper
+
+
 class _DevArray:
     """Zero-copy view of a device array owned by the C library (``__cuda_array_interface__``)."""
 
@@ -195,6 +212,7 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+@_writes_out
 def gather_reduce(
     rowptr: torch.Tensor,
     col: torch.Tensor,
@@ -234,6 +252,7 @@ def gather_reduce(
  VIEW_BY_SRC_TYPED_COMPACT) = range(6)
 
 
+@_writes_out
 def graph_gather(
     graph: "Graph",
     view: int,
@@ -280,6 +299,7 @@ def graph_gather(
     return out
 
 
+@_writes_out
 def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> torch.Tensor:
     """out = (a @ op(b)) * out_mul * act'(saved): an input-gradient product with the element-wise factors of the next
     backward step (dropout mask ``out_mul``, ``act_grad = (activation name, saved tensor)``) applied in the GEMM
@@ -352,6 +372,7 @@ def get_gemm_mode() -> int:
     return GEMM_F16X2 if _f16x2_on() else _lib.load().tfgnn_gemm_get_mode()
 
 
+@_writes_out
 def gemm(
     a: torch.Tensor,
     b: torch.Tensor,
@@ -401,6 +422,7 @@ def gemm(
     return out
 
 
+@_writes_out
 def activation_forward(act, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _require_dev(x, torch.float32, "x")
@@ -411,6 +433,7 @@ def activation_forward(act, x: torch.Tensor, out: Optional[torch.Tensor] = None)
     return out
 
 
+@_writes_out
 def activation_backward(act, dy: torch.Tensor, saved: torch.Tensor, out: Optional[torch.Tensor] = None):
     """dx = dy * act'(.), derivative evaluated from the saved output (saved input for gelu)."""
     lib = _lib.load()
@@ -633,6 +656,7 @@ def transpose_batched(x: torch.Tensor) -> torch.Tensor:
     return out[0] if squeeze else out
 
 
+@_writes_out
 def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=False, act=ACT_NONE, out=None):
     """out[rows g] = act(a[rows g] @ op(b_stack[g])) for row groups [off[g], off[g+1]).
     b_stack: [G, K, N] (or [G, N, K] with trans_b)."""
@@ -659,6 +683,7 @@ def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=Fals
     return out
 
 
+@_writes_out
 def gemm_grouped_k(a, b, group_off_dev, group_off_host, num_groups, out=None):
     """out[g] = a[rows g]^T @ b[rows g]  ->  [G, M, N]."""
     lib = _lib.load()
@@ -790,6 +815,7 @@ def sp_split_cols(w: torch.Tensor) -> SplitOperand:
     return SplitOperand(data, inv, N, K, K)
 
 
+@_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
                act_grad=None) -> torch.Tensor:
     """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt)."""
@@ -893,6 +919,7 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     return SplitOperand(data, inv, num_rows // R, R * width, width)
 
 
+@_writes_out
 def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
                scatter=None, accumulate: bool = False) -> torch.Tensor:
     """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn).  ``a`` carries one scale per (row, block),
