@@ -52,8 +52,8 @@ typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 // Probe builds (tools/sp_ablate.py) compile this file with -DSP_ABLATE=<bits> to leave parts of the main loop out:
-// 1 no DMA, 2 no fragment reads, 4 no MFMAs, 8 no barrier, 16 no stores, 32 no DMA of A, 64 no DMA of B.  The
-// library is built without it.
+// 1 no DMA, 2 no fragment reads, 4 no MFMAs, 8 no barrier, 16 no stores, 32 no DMA of A, 64 no DMA of B, 128 hardware ids,
+// 256 full-line DMA pattern (data lands wrongly), 512 no epilogue.  The library is built without it.
 #ifndef SP_ABLATE
 #define SP_ABLATE 0
 #endif
@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  if constexpr ((SP_ABLATE & 512) != 0) return;  // probe: no epilogue at all
   if constexpr (SP_ABLATE & 128) {  // probe: where did the waves of this workgroup run?  (HW_REG_HW_ID = 4)
     if (lane == 0) reinterpret_cast<unsigned*>(g.C)[blockIdx.x * 4 + wave] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
     return;

@@ -14,6 +14,12 @@ VARIANTS = {0: "full", 1: "no DMA", 2: "no fragment reads", 4: "no MFMA", 8: "no
             64: "no DMA of B", 1 | 2: "MFMA + barrier only", 4 | 2: "DMA + barrier only", 1 | 4: "fragment reads only", 1 | 2 | 8: "MFMA only, no barrier", 1 | 2 | 128: "hw ids", 256: "full, 128-B-line DMA pattern", 256 | 6: "DMA + barrier only, 128-B lines", 256 | 6 | 32: "DMA of B only, 128-B lines", 6 | 32: "DMA of B only", 6 | 64: "DMA of A only", 256 | 6 | 64: "DMA of A only, 128-B lines"}
 
 
+import os
+
+if os.environ.get("SP_ABLATE_VARIANTS"):
+    VARIANTS = {int(b): VARIANTS.get(int(b), f"bits {b}") for b in os.environ["SP_ABLATE_VARIANTS"].split(",")}
+
+
 def build():
     OUT.mkdir(exist_ok=True)
     objs = [str(p) for p in (ROOT / "tf2_gnn_amd" / "csrc" / "_obj").glob("*.o") if p.name != "gemm_sp.o"]
@@ -34,7 +40,7 @@ def run():
     from tf2_gnn_amd import ops
 
     dev = torch.device("cuda", 0)
-    M, N, K = 30000, 320, 1280
+    M, N, K = 30000, 320, int(os.environ.get("SP_K", "1280"))
     A = torch.randn((M, K), device=dev)
     Bt = torch.randn((N, K), device=dev) * 0.05
     a_op, b_op = ops.sp_split_rows(A), ops.sp_split_rows(Bt)
