@@ -524,6 +524,15 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
                      int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
                      int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
                      size_t workspace_bytes, void* stream);
+/* The three passes of tfgnn_sp_gemm_tn separately - phases is a mask of 1 (per-k factors from the two scale arrays), 2 (the
+ * product into the workspace), 4 (split reduction + scaling + scatter into d_C) - with the SAME arguments and workspace in
+ * every call: the factor pass only needs the scales and can run on another stream beside the product before it, the
+ * reduction beside whatever follows (the caller orders the streams; the workspace must live until the last phase). */
+int tfgnn_sp_gemm_tn_phase(int phases, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                           const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                           int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                           int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* Tensor-wide scales (d_fixed_inv_scale of the SP16 producers; tfgnn_sp_gemm_nt takes such an operand with a_scale_block < 0):
  * tfgnn_absmax gives *d_out = max(*d_out, scale * max |x|)

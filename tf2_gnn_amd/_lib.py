@@ -175,6 +175,12 @@ _SIGNATURES = [
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p],
     ),
+    (
+        "tfgnn_sp_gemm_tn_phase",
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p],
+    ),
     ("tfgnn_absmax", c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     ("tfgnn_sp_inv_scale_from_bound", c_int, [c_void_p, c_void_p, c_void_p]),
     ("tfgnn_sp_bytes", c_size_t, [c_int64, c_int64]),

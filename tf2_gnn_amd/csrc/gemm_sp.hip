@@ -1320,11 +1320,11 @@ size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t
   return factors + (size_t)sp_tn_splits(Mp, N, K, bn) * (size_t)Mp * (size_t)N * 4;
 }
 
-int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
-                     const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
-                     int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
-                     int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
-                     size_t workspace_bytes, void* stream) {
+static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                           const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                           int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                           int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                           size_t workspace_bytes, void* stream) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale, "tfgnn_sp_gemm_tn: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
   const int bn = sp_tile_width(N);
@@ -1353,9 +1353,11 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   hipStream_t s = (hipStream_t)stream;
   _Float16* F = (_Float16*)d_workspace;
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
-  hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * SP_TN_FCHUNKS), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
-                     kpad, ref);
-  TFGNN_LAUNCH_CHECK();
+  if (phases & 1) {
+    hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * SP_TN_FCHUNKS), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
+                       kpad, ref);
+    TFGNN_LAUNCH_CHECK();
+  }
   SpTnArgs g{};
   g.M = Mp; g.N = N; g.K = K;
   g.A = (const uint8_t*)d_A_sp + a_first_col * 4; g.lda = lda_bytes;
@@ -1381,17 +1383,41 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
     }                                                                                                              \
     hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeoTN<T>::LDS_BYTES, s, g);                    \
   } while (0)
-  if (bn == 320) SP_LAUNCH_TN(5);
-  else if (bn == 256) SP_LAUNCH_TN(4);
-  else SP_LAUNCH_TN(2);
+  if (phases & 2) {
+    if (bn == 320) SP_LAUNCH_TN(5);
+    else if (bn == 256) SP_LAUNCH_TN(4);
+    else SP_LAUNCH_TN(2);
+    TFGNN_LAUNCH_CHECK();
+  }
 #undef SP_LAUNCH_TN
-  TFGNN_LAUNCH_CHECK();
+  if (!(phases & 4)) return TFGNN_OK;
   const int64_t total = M * N;
   hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s,
                      (const float*)g.partial, splits_used, M, N, (const float*)ref, a_first_col, a_scale_block, d_C, group_rows,
                      stride_group, stride_row, stride_col, accumulate, Mp * N);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
+}
+
+int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                     const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                     int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                     int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                     size_t workspace_bytes, void* stream) {
+  return sp_gemm_tn_impl(7, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block, d_B_sp, ldb_bytes,
+                         b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate, d_workspace,
+                         workspace_bytes, stream);
+}
+
+int tfgnn_sp_gemm_tn_phase(int phases, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                           const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                           int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                           int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                           size_t workspace_bytes, void* stream) {
+  TFGNN_REQUIRE(phases >= 1 && phases <= 7, "tfgnn_sp_gemm_tn_phase: phases is a mask of 1 (factors), 2 (product), 4 (reduce)");
+  return sp_gemm_tn_impl(phases, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block, d_B_sp, ldb_bytes,
+                         b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate, d_workspace,
+                         workspace_bytes, stream);
 }
 
 int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream) {

@@ -331,6 +331,7 @@ class GNN:
         for layer_idx in range(self._num_layers - 1, -1, -1):
             st = ctx["steps"][layer_idx]
             mp = self._mp_layers[layer_idx]
+            mp._defer_aux_join = True  # joined once, at the end of this backward pass
             has_ln = self._use_inter_layer_layernorm
             has_ex = str(layer_idx) in self._global_exchange_layers
             if layer_idx % self._dense_every_num_layers == 0:
@@ -377,7 +378,9 @@ class GNN:
         gpre = g
         if self._init_act is not None and not g_is_pre:
             gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
-        return self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
+        res = self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
+        ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
+        return res
 
 
 def _act_name(fn):

@@ -376,7 +376,16 @@ class GNN_Edge_MLP(MessagePassing):
         L, H = g.num_edge_types, self._hidden_dim
         mlps = self._edge_type_mlps
         W = mlps.kernels[0]  # [L, D, H]
+        import os
+
         G_sp = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED, d_agg.contiguous(), edge_weight=ew_s, rows_per_operand_row=L)
+        # the weight gradient dW = X^T G is off the critical path of the backward pass: its two small passes (per-k factors,
+        # split reduction) run on the library's second stream beside the big kernels around them
+        overlap = os.environ.get("TFGNN_TN_OVERLAP", "0") == "1"
+        tn = None
+        if overlap:
+            dW = torch.empty_like(W)
+            tn = ops.SpGemmTnOverlapped(G_sp, ops.sp_rows_of(X), out=dW, scatter=(H, D * H, 1, H))  # factors: second stream
         Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H)))
         epi = getattr(self, "_out_epilogue", None)
         if epi is not None:
@@ -387,9 +396,15 @@ class GNN_Edge_MLP(MessagePassing):
             self._out_epilogue = None  # consumed
         else:
             dX = ops.sp_gemm_nt(G_sp, Wh_sp)
-        X_sp = ops.sp_rows_of(X)  # written by the dropout kernel when X came out of one
-        dW = torch.empty_like(W)
-        ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))  # element ((l, h), d) -> dW[l, d, h]
+        if tn is not None:
+            tn.product()
+            tn.finish()  # the reduction runs beside the next layer's gather; GNN.backward joins the second stream at its end
+            if not getattr(self, "_defer_aux_join", False):
+                ops.join_aux_stream()  # stand-alone layer call: the gradients are complete when backward() returns
+        else:
+            X_sp = ops.sp_rows_of(X)  # written by the dropout kernel when X came out of one
+            dW = torch.empty_like(W)
+            ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))  # element ((l, h), d) -> dW[l, d, h]
         mlps.grads = [dW]
         mlps.publish_grads()
         return dX

@@ -956,6 +956,80 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
     return out
 
 
+_aux_streams = {}
+_aux_pending = []
+
+
+def aux_stream(device) -> "torch.cuda.Stream":
+    """The library's second stream of a device: small passes that are off the critical path (the factor and reduction
+    passes of a weight-gradient product) run there beside the big kernels of the main stream."""
+    key = (device.type, device.index)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _aux_streams[key] = st
+    return st
+
+
+def join_aux_stream() -> None:
+    """Make the current stream wait for everything handed to the second stream (call before the results - weight
+    gradients - are read)."""
+    cur = torch.cuda.current_stream()
+    while _aux_pending:
+        cur.wait_event(_aux_pending.pop())
+
+
+class SpGemmTnOverlapped:
+    """sp_gemm_tn in three calls, the small passes on the second stream:
+         h = SpGemmTnOverlapped(a, b, out=..., scatter=...)   # factor pass: second stream, beside what the caller enqueues next
+         ...                                                   # e.g. the input-gradient product that precedes it
+         h.product()                                           # the product: current stream, after the factors
+         h.finish()                                            # reduction + scatter: second stream, beside what follows
+       ``join_aux_stream()`` before the result is read."""
+
+    def __init__(self, a: "SplitOperand", b: "SplitOperand", *, out: torch.Tensor, scatter=None, accumulate: bool = False):
+        if a.scale_block <= 0 or b.scale_block != b.cols or a.rows != b.rows:
+            raise ValueError("SpGemmTnOverlapped: operands as for sp_gemm_tn")
+        lib = _lib.load()
+        self.M, self.N, self.K = a.cols, b.cols, a.rows
+        if not out.is_contiguous() or out.numel() != self.M * self.N:
+            raise ValueError(f"out must be contiguous with {self.M * self.N} elements")
+        self.a, self.b, self.out, self.accumulate = a, b, out, accumulate
+        self.scatter = scatter if scatter is not None else (self.M, 0, self.N, 1)
+        ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(self.M, self.N, self.K, a.cols, a.scale_block)
+        self.ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=a.data.device)
+        self.main = torch.cuda.current_stream()
+        self.side = aux_stream(a.data.device)
+        for t in (self.ws, out, a.inv_scale, b.inv_scale):
+            t.record_stream(self.side)
+        self.side.wait_stream(self.main)  # the scales are written
+        with torch.cuda.stream(self.side):
+            self._phase(1)
+            self.ev_factors = self.side.record_event()
+
+    def _phase(self, phases: int):
+        a, b = self.a, self.b
+        off = (-self.ws.data_ptr()) % 256
+        gr, sg, sr, sc = self.scatter
+        _lib.check(_lib.load().tfgnn_sp_gemm_tn_phase(
+            phases, self.M, self.N, self.K, _ptr(a.data), a.data.stride(0), 0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
+            b.data.stride(0), 0, _ptr(b.inv_scale), _ptr(self.out), gr, sg, sr, sc, int(self.accumulate),
+            ctypes.c_void_p(self.ws.data_ptr() + off), self.ws.numel() - off, _stream()))
+
+    def product(self):
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ev_factors)
+        self._phase(2)
+        self.ev_product = cur.record_event()
+
+    def finish(self):
+        self.side.wait_event(self.ev_product)
+        with torch.cuda.stream(self.side):
+            self._phase(4)
+            _aux_pending.append(self.side.record_event())
+        torch.autograd.graph.increment_version(self.out)
+
+
 def tensor_inv_scale(bound: torch.Tensor) -> torch.Tensor:
     """2^-e with bound * 2^e in [2^14, 2^15) for a positive finite device scalar ``bound`` (>= the largest magnitude
     of the tensor that will be written with this scale): the fixed_inv_scale of the SP16 producers."""
