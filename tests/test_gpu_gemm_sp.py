@@ -382,3 +382,25 @@ def test_batched_weight_split_equals_the_two_single_splits(dev):
     stacks[0].mul_(2.0)  # an optimizer update: the cached forms of this stack are stale
     fresh = ops.sp_weight_operand(stacks[0], "cols", lambda: ops.sp_split_cols(stacks[0].view(L * D, H)))
     assert torch.equal(fresh.data, ops.sp_split_cols(stacks[0].view(L * D, H)).data)
+
+
+def test_gemm_tn_in_three_phases_on_two_streams_equals_the_single_call(dev):
+    """tfgnn_sp_gemm_tn_phase through ops.SpGemmTnOverlapped (factor pass and reduction on the library's second stream):
+    bit-identical to tfgnn_sp_gemm_tn."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    K, M, N = 5000, 1280, 320
+    G = (torch.randn((K, M), generator=g) * 1e-3).to(dev)
+    X = torch.randn((K, N), generator=g).to(dev)
+    gs, xs = ops.sp_split_rows(G, scale_block=320), ops.sp_split_rows(X)
+    ref = torch.empty((4, 320, 320), device=dev)
+    ops.sp_gemm_tn(gs, xs, out=ref, scatter=(320, 320 * 320, 1, 320))
+    out = torch.zeros_like(ref)
+    h = ops.SpGemmTnOverlapped(gs, xs, out=out, scatter=(320, 320 * 320, 1, 320))
+    filler = ops.sp_gemm_nt(gs, ops.sp_split_rows(torch.randn((320, M), device=dev)))  # something for the factor pass to run beside
+    h.product()
+    h.finish()
+    ops.join_aux_stream()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and bool(torch.isfinite(filler).all())
