@@ -358,7 +358,7 @@ class GNN_Edge_MLP(MessagePassing):
         act = None if gelu_split else fuse_act
         if ops.get_gemm_mode() != ops.GEMM_FP32:
             # the split-operand kernel stages K-contiguous operands fastest: hand it W^T ([H, L*Din], 1.6 MB copy)
-            Wt = ops.transpose_batched(W.view(L * Din, H))
+            Wt = ops.sp_weight_operand(W, "transposed", lambda: ops.transpose_batched(W.view(L * Din, H)))  # once per weight value
             pre = ops.gemm(A, Wt, trans_b=True, act=act)
         else:
             pre = ops.gemm(A, W.view(L * Din, H), act=act)
@@ -734,7 +734,7 @@ class GNN_Edge_MLP(MessagePassing):
             Din = W.shape[1]
             # horizontal stack [Din, L*H] of the L kernels: the backward pass becomes two large GEMMs
             #   dX = [G_0|...|G_{L-1}] @ [W_0|...|W_{L-1}]^T      dW_h = X^T @ [G_0|...|G_{L-1}]
-            Wh = ops.permute_021(W)  # [Din, L, H]
+            Wh = ops.sp_weight_operand(W, "stacked_rows", lambda: ops.permute_021(W))  # [Din, L, H], once per weight value
             G2 = G.view(V, L * H)
             if L > 0 and not self._use_target_state_as_input:
                 # dW^T = G^T X [L*H, D]: ten full 128-row output tiles instead of the 2.5 x 4 ragged ones of X^T G

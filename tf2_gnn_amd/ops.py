@@ -1103,8 +1103,9 @@ def sp_split_weights(stacks) -> None:
             _sp_weight_cache[_weight_key(w, "rows")] = (w._version, r, weakref.ref(base))
 
 
-def sp_weight_operand(w: torch.Tensor, kind: str, build) -> SplitOperand:
-    """SP16 form of a weight tensor, built once per value: keyed on the tensor's storage and version (an in-place
+def sp_weight_operand(w: torch.Tensor, kind: str, build):
+    """A derived form of a weight tensor (its SP16 operands; also the transposed / re-stacked fp32 copies the bf16x3 products
+    take), built once per value: keyed on the tensor's storage and version (an in-place
     optimizer update bumps the version), so forward and backward passes of a step - and every step of an evaluation
     loop - share it.  ``build()`` makes the operand."""
     key = _weight_key(w, kind)
