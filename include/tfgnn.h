@@ -58,6 +58,22 @@ const char* tfgnn_last_error(void);
 /* "tfgnn <version> gfx950" */
 const char* tfgnn_version(void);
 
+/* Diagnostics (no reference counterpart): number of launches of each product-kernel family this process has enqueued
+ * since the library was loaded - host-side counters, no device work.  The parity tests read them around a layer call
+ * to assert that a GEMM mode (tfgnn_gemm_set_mode / the f16x2 layer paths) really ran the kernels it names, so that
+ * parity evidence and timing evidence are about the same code. */
+typedef enum {
+  TFGNN_KFAM_GEMM_FP32 = 0,   /* gemm_mfma_kernel (v_mfma_f32_32x32x2_f32)                       */
+  TFGNN_KFAM_GEMM_BF16X3 = 1, /* gemm_x3s / gemm_x3p kernels (3-way bf16 split inside the GEMM)    */
+  TFGNN_KFAM_SP_NT = 2,       /* gemm_sp_nt_kernel (pre-split fp16 pairs, forward / input gradient) */
+  TFGNN_KFAM_SP_TN = 3,       /* gemm_sp_tn_kernel (pre-split fp16 pairs, weight gradient)          */
+  TFGNN_KFAM_GATHER_SP = 4,   /* csr_gather_reduce_kernel writing the SP16 operand                  */
+  TFGNN_KFAM_GATHER = 5,      /* csr_gather_reduce_kernel, fp32 output                              */
+  TFGNN_KFAM_FUSED_NT = 6,    /* gather-producing product kernel (rgcn_fused_nt_kernel)             */
+  TFGNN_KFAM_COUNT = 8
+} tfgnn_kernel_family;
+int tfgnn_launch_counts(int64_t* out_counts, int n);
+
 /* ------------------------------------------------------------------------------------------
  * Graph handle: the (dst, edge_type)- and (src, edge_type)-bucketed adjacency of one batch.
  * Replaces, for all L layers and both passes of a step, the per-layer work of

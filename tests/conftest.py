@@ -10,8 +10,43 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+GEMM_MODES = ("fp32", "bf16x3", "f16x2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line(
+        "markers",
+        "gemm_modes(*modes): run the test once per GEMM mode (default: fp32, bf16x3 and f16x2 - the library default, "
+        "bench.py's comparison mode and bench.py's headline mode) through the `gemm_mode` fixture",
+    )
+
+
+def pytest_generate_tests(metafunc):
+    """Tests (or whole modules, through `pytestmark`) marked `gemm_modes` run once per GEMM mode: the parity suite
+    has to hold in the mode bench.py is timed in, not only in the library default (VERDICT r2, weak #1)."""
+    marker = metafunc.definition.get_closest_marker("gemm_modes")
+    if marker is None or "gemm_mode" not in metafunc.fixturenames:
+        return
+    for m in metafunc.definition.iter_markers("parametrize"):  # the test names its own modes
+        names = m.args[0] if isinstance(m.args[0], (list, tuple)) else [n.strip() for n in m.args[0].split(",")]
+        if "gemm_mode" in names:
+            return
+    metafunc.parametrize("gemm_mode", list(marker.args) or list(GEMM_MODES), indirect=True)
+
+
+@pytest.fixture
+def gemm_mode(request):
+    """Selects tf2_gnn_amd's GEMM mode for one test (tfgnn_gemm_set_mode + the f16x2 layer paths), restores it after."""
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    from tf2_gnn_amd import ops
+
+    prev = ops.set_gemm_mode(mode)
+    yield mode
+    ops.set_gemm_mode(prev)
 
 
 @pytest.fixture(scope="session")

@@ -63,29 +63,87 @@ def mp_weights_from_layer(layer):
 
 
 _PARITY_LOG = {}
+_MODE_NAMES = {0: "fp32", 6: "bf16x3", 9: "bf16x3_9", 3: "f16x2"}
+
+
+def current_gemm_mode() -> str:
+    try:
+        from tf2_gnn_amd import ops
+
+        return _MODE_NAMES.get(ops.get_gemm_mode(), "?")
+    except Exception:  # no library (CPU-only run): nothing on the device was measured
+        return "cpu"
+
+
+def launch_counts():
+    """tfgnn_launch_counts as a dict (kernel family -> launches so far)."""
+    import ctypes
+
+    from tf2_gnn_amd import _lib
+
+    buf = (ctypes.c_int64 * 8)()
+    _lib.check(_lib.load().tfgnn_launch_counts(buf, 8))
+    names = ["gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "_"]
+    return dict(zip(names, list(buf)))
+
+
+class KernelsUsed:
+    """with KernelsUsed() as k: ...; k.delta["sp_nt"] = launches of that family inside the block."""
+
+    def __enter__(self):
+        self._before = launch_counts()
+        self.delta = {}
+        return self
+
+    def __exit__(self, *exc):
+        after = launch_counts()
+        self.delta = {k: after[k] - self._before[k] for k in after}
+        return False
 
 
 def record_parity(key: str, **numbers):
-    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r02.json (copied to profiles/ after a
-    run on the GPU box): the judge asked for the measured max scaled error of every parity test beside its bound."""
+    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r03.json (copied to profiles/ after a
+    run on the GPU box), keyed by GEMM MODE first: {mode: {check: {max error, bound, test id}}}.  A check that runs
+    several times in one mode (parametrised tests sharing a label) keeps its worst case."""
     import json
     import os
 
     if not key:
         return
-    _PARITY_LOG[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in numbers.items()}
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.json")
+    mode = current_gemm_mode()
+    entry = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in numbers.items()}
+    entry["test"] = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    slot = _PARITY_LOG.setdefault(mode, {})
+    err_keys = [k for k in entry if k.startswith("max_")]
+    old = slot.get(key)
+    if old is not None and err_keys and all(old.get(k, 0.0) >= entry[k] for k in err_keys):
+        old["count"] = old.get("count", 1) + 1
+    else:
+        entry["count"] = (old or {}).get("count", 0) + 1
+        slot[key] = entry
+    _PARITY_LOG["_n"] = _PARITY_LOG.get("_n", 0) + 1
+    if _PARITY_LOG["_n"] % 200 == 1:
+        _flush_parity_log()
+
+
+def _flush_parity_log():
+    import json
+    import os
+
+    if not _PARITY_LOG:
+        return
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        old = {}
-        if os.path.exists(path):
-            with open(path) as f:
-                old = json.load(f)
-        old.update(_PARITY_LOG)
         with open(path, "w") as f:
-            json.dump(old, f, indent=1, sort_keys=True)
+            json.dump({k: v for k, v in _PARITY_LOG.items() if k != "_n"}, f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_flush_parity_log)
 
 
 def assert_close(actual: torch.Tensor, expected: torch.Tensor, tol=1e-5, what=""):

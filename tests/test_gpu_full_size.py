@@ -95,7 +95,8 @@ def test_cfg2_gather_linearity_conservation_determinism(cfg2, dev):
     assert float(((got - expect).abs() / l1).max()) < 1e-6
 
 
-def test_cfg2_rgcn_layer_matches_oracle_on_sampled_targets(cfg2, dev):
+@pytest.mark.gemm_modes
+def test_cfg2_rgcn_layer_matches_oracle_on_sampled_targets(cfg2, dev, gemm_mode):
     """RGCN forward at V=30k, E=900k, 4 types, H=320 (BASELINE configs[1]) vs the oracle on 300 sampled
     target nodes (incl. the highest in-degree hub and isolated nodes)."""
     from tf2_gnn_amd.layers import MessagePassingInput
@@ -118,7 +119,8 @@ def test_cfg2_rgcn_layer_matches_oracle_on_sampled_targets(cfg2, dev):
     assert torch.all(out.cpu()[indeg == 0] == 0)
 
 
-def test_cfg2_rgcn_gnn_step_gradients_finite_and_reproducible(cfg2, dev):
+@pytest.mark.gemm_modes
+def test_cfg2_rgcn_gnn_step_gradients_finite_and_reproducible(cfg2, dev, gemm_mode):
     """the benchmarked step (PPI_RGCN.json model, fwd + bwd) twice: identical gradients, all finite."""
     from bench import ppi_rgcn_params
     from tf2_gnn_amd.layers import GNN, GNNInput
@@ -141,7 +143,8 @@ def test_cfg2_rgcn_gnn_step_gradients_finite_and_reproducible(cfg2, dev):
         assert bool(torch.isfinite(a).all())
 
 
-def test_cfg3_rgat_8_heads_h256(dev):
+@pytest.mark.gemm_modes
+def test_cfg3_rgat_8_heads_h256(dev, gemm_mode):
     """BASELINE configs[2]: RGAT, 8 heads, H=256 on the cfg-2 graph: attention is a distribution per
     (target, head); sampled targets match the oracle."""
     from tf2_gnn_amd import ops
@@ -180,8 +183,9 @@ def _qm9_shaped_batch(num_graphs, seed=0, D=128):
     return make_qm9_shaped_batch(num_graphs, seed=seed, feature_dim=D)
 
 
+@pytest.mark.gemm_modes
 @pytest.mark.parametrize("cls_name,over", [("GGNN", {"normalize_by_num_incoming": False}), ("GNN_Edge_MLP", {})])
-def test_cfg4_qm9_shaped_batch_sampled_graphs(dev, cls_name, over):
+def test_cfg4_qm9_shaped_batch_sampled_graphs(dev, gemm_mode, cls_name, over):
     """BASELINE configs[3]: 128k small molecules (V ~ 1.15M, ~3.4M edges incl. self loops), H=128, GGNN and
     GNN_Edge_MLP fwd+bwd + softmax pooling.  The batch is a disjoint union: the oracle on 150 sampled
     graphs reproduces their rows and their pooled representations."""
@@ -227,7 +231,8 @@ def test_cfg4_qm9_shaped_batch_sampled_graphs(dev, cls_name, over):
     g.close()
 
 
-def test_cfg5_rgin_40_edge_types_h512(dev):
+@pytest.mark.gemm_modes
+def test_cfg5_rgin_40_edge_types_h512(dev, gemm_mode):
     """BASELINE configs[4]: V=170k, E=1.2M, 40 edge types (Zipf), H=512, RGIN defaults (1 hidden layer per
     edge-type MLP): sampled targets match the oracle; ragged / empty edge types are fine."""
     from tf2_gnn_amd import ops
@@ -256,15 +261,6 @@ def test_cfg5_rgin_40_edge_types_h512(dev):
 
 # ---- backward at full size (the split-K weight gradient with K = 30 000 was never compared with anything) -------
 GEMM_MODES = ["fp32", "bf16x3", "f16x2"]
-
-
-@pytest.fixture
-def gemm_mode(request):
-    from tf2_gnn_amd import ops
-
-    prev = ops.set_gemm_mode(request.param)
-    yield request.param
-    ops.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("gemm_mode", GEMM_MODES, indirect=True)
@@ -329,3 +325,224 @@ def test_full_size_dense_weight_gradient_matches_fp64(dev, gemm_mode):
     print(f"[{gemm_mode}] dense dW: max |err| / max |dW| = {err:.2e}")
     record_parity(f"dense dW K=30000 vs fp64 [{gemm_mode}]", max_err_over_max_entry=err, bound=1e-5)
     assert err <= 1e-5
+
+
+# ---- full-size BACKWARD of configs[2..4] in every GEMM mode (VERDICT r2 missing #3) ------------------------------------
+# The fp64 reference of a full-size batch is evaluated ONCE per layer class (module-scoped fixtures: fp64 autograd
+# through the literal oracle on the host, tens of seconds at these sizes) and then compared with the HIP forward +
+# backward in each of the three GEMM modes; the weights are seeded, so every mode sees the same layer.
+def _host_threads(n=48):
+    """torch-CPU on the 256-thread GPU-box host is several times slower with all threads than with a few dozen."""
+    import os
+
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
+    return prev
+
+
+def _req(t, leaves):
+    t.requires_grad_(True)
+    leaves.append(t)
+    return t
+
+
+def _edge_mlp_family_leaves(w64, L):
+    leaves = []
+    for l in range(L):
+        w64["edge_mlps"][l] = [_req(k, leaves) for k in w64["edge_mlps"][l]]
+    if w64.get("aggr_mlp") is not None:
+        w64["aggr_mlp"] = [_req(k, leaves) for k in w64["aggr_mlp"]]
+    for key in ("gru_kernel", "gru_recurrent_kernel", "gru_bias"):
+        if key in w64:
+            w64[key] = _req(w64[key], leaves)
+    return leaves
+
+
+def _edge_mlp_family_pairs(layer, w64, L):
+    pairs = []
+    for l in range(L):
+        for j, v in enumerate(layer._edge_type_mlps.vars[l]):
+            pairs.append((v, w64["edge_mlps"][l][j]))
+    if w64.get("aggr_mlp") is not None:
+        pairs += list(zip(layer._aggregation_mlp_vars, w64["aggr_mlp"]))
+    if "gru_kernel" in w64:
+        ru = layer._recurrent_unit
+        pairs += [(ru["kernel"], w64["gru_kernel"]), (ru["recurrent_kernel"], w64["gru_recurrent_kernel"]),
+                  (ru["bias"], w64["gru_bias"])]
+    return pairs
+
+
+def _to64(w):
+    from tests.test_gpu_layers import _to64 as f
+
+    return f(w)
+
+
+def _compare_full_backward(tag, gemm_mode, out, dX, ref, layer_grads):
+    """out / dX: HIP results (device); ref: dict(out, dX fp64 on the host); layer_grads: [(name, HIP grad, fp64 grad)]."""
+    assert_close(out.cpu(), ref["out"].float(), tol=1e-5, what=f"{tag} forward (all rows)")
+    assert_close(dX.cpu(), ref["dX"].float(), tol=2e-5, what=f"{tag} dX (all rows)")
+    for name, got, want in layer_grads:
+        scale = max(float(want.abs().max()), 1e-30)
+        err = float((got.cpu().double() - want).abs().max()) / scale
+        record_parity(f"{tag} d{name} vs fp64", max_err_over_max_entry=err, bound=1e-5)
+        assert err <= 1e-5, (tag, gemm_mode, name, err)
+
+
+@pytest.fixture(scope="module")
+def cfg3_ref(dev):
+    """BASELINE configs[2] layer (RGAT, 8 heads, H = 256, V = 30k, E = 900k): HIP layer + fp64 autograd reference."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    V, E, L, H, K = 30000, 900000, 4, 256, 8
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=0)
+    set_seed(3)
+    layer, p = _build("RGAT", {"hidden_dim": H, "num_heads": K, "message_activation_function": "tanh"}, H, L)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(4))
+    prev = _host_threads()
+    try:
+        w64 = _to64(mp_weights_from_layer(layer))
+        for key in ("kernels", "attn"):
+            w64[key] = [t.requires_grad_(True) for t in w64[key]]
+        X64 = torch.from_numpy(feats).double().requires_grad_(True)
+        ref = orc.message_passing_call("rgat", p, w64, X64, [torch.from_numpy(a) for a in adjs])
+        grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + w64["kernels"] + w64["attn"])
+    finally:
+        torch.set_num_threads(prev)
+    g = ops.Graph(to_dev(adjs, dev), V)
+    yield dict(V=V, L=L, H=H, layer=layer, graph=g, X=torch.from_numpy(feats).to(dev), dOut=dOut.to(dev),
+               ref=dict(out=ref.detach(), dX=grads[0]), dW=grads[1:1 + L], dA=grads[1 + L:])
+    g.close()
+
+
+@pytest.mark.gemm_modes
+def test_cfg3_rgat_full_size_backward_matches_fp64(cfg3_ref, dev, gemm_mode):
+    """rgat.py:91-163 forward + backward at full size: every row of out and dX, every dW_l [256, 256] and
+    d alpha_l [8, 64] against fp64 autograd through the literal oracle."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    c = cfg3_ref
+    layer = c["layer"]
+    out = layer(MessagePassingInput(c["X"], c["graph"]), training=True)
+    dX = layer.backward(c["dOut"])
+    grads = []
+    for l in range(c["L"]):
+        grads.append((f"W_{l}", layer._edge_type_to_message_computation_layer[l].grad, c["dW"][l]))
+        grads.append((f"alpha_{l}", layer._edge_type_to_attention_parameters[l].grad, c["dA"][l]))
+    _compare_full_backward("cfg-3 RGAT full size", gemm_mode, out, dX, c["ref"], grads)
+
+
+def _chunked_graph_oracle(cls_name, p, layer, feats, adjs, offs, dOut, L, graphs_per_chunk=8000):
+    """fp64 autograd through the literal oracle over a batch of disjoint graphs, chunk by chunk (a batch is a disjoint
+    union, tf2_gnn/data/graph_dataset.py:202-222: outputs / input gradients of a chunk are its rows, weight gradients add)."""
+    G = offs.shape[0] - 1
+    V = feats.shape[0]
+    out = torch.empty((V, layer._hidden_dim), dtype=torch.float64)
+    dX = torch.empty((V, feats.shape[1]), dtype=torch.float64)
+    wsum = None
+    node_lo = offs[:-1]
+    for g0 in range(0, G, graphs_per_chunk):
+        g1 = min(G, g0 + graphs_per_chunk)
+        n0, n1 = int(offs[g0]), int(offs[g1])
+        sub = []
+        for a in adjs:
+            keep = (a[:, 1] >= n0) & (a[:, 1] < n1)  # edges never cross graphs
+            sub.append(torch.from_numpy((a[keep] - n0).astype(np.int64)))
+        w64 = _to64(mp_weights_from_layer(layer))
+        leaves = _edge_mlp_family_leaves(w64, L)
+        X64 = torch.from_numpy(feats[n0:n1]).double().requires_grad_(True)
+        ref = orc.message_passing_call(cls_name.lower(), p, w64, X64, sub)
+        grads = torch.autograd.grad((ref * dOut[n0:n1].double()).sum(), [X64] + leaves)
+        out[n0:n1] = ref.detach()
+        dX[n0:n1] = grads[0]
+        wsum = list(grads[1:]) if wsum is None else [a + b for a, b in zip(wsum, grads[1:])]
+    del node_lo
+    return out, dX, wsum
+
+
+@pytest.fixture(scope="module", params=[("GGNN", {"normalize_by_num_incoming": False}), ("GNN_Edge_MLP", {})],
+                ids=["GGNN", "GNN_Edge_MLP"])
+def cfg4_ref(request, dev):
+    """BASELINE configs[3] layers on the QM9-shaped batch (128k molecules, V ~ 1.15M, H = 128)."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    cls_name, over = request.param
+    G, H = 128000, 128
+    feats, adjs, n2g, offs = _qm9_shaped_batch(G, seed=0, D=H)
+    V, L = feats.shape[0], len(adjs)
+    set_seed(5)
+    layer, p = _build(cls_name, dict(over, hidden_dim=H), H, L)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(6))
+    prev = _host_threads()
+    try:
+        out, dX, wgrads = _chunked_graph_oracle(cls_name, p, layer, feats, adjs, offs, dOut, L)
+    finally:
+        torch.set_num_threads(prev)
+    g = ops.Graph(to_dev(adjs, dev), V)
+    yield dict(cls_name=cls_name, V=V, L=L, H=H, layer=layer, graph=g, X=torch.from_numpy(feats).to(dev), dOut=dOut.to(dev),
+               ref=dict(out=out, dX=dX), wgrads=wgrads)
+    g.close()
+
+
+@pytest.mark.gemm_modes
+def test_cfg4_qm9_full_size_backward_matches_fp64(cfg4_ref, dev, gemm_mode):
+    """ggnn.py:68-89 / gnn_edge_mlp.py:84-107 forward + backward over ALL 128k graphs: every row of out and dX, every
+    weight gradient (K = V = 1.15M row products) against fp64 autograd through the literal oracle."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    c = cfg4_ref
+    layer = c["layer"]
+    out = layer(MessagePassingInput(c["X"], c["graph"]), training=True)
+    dX = layer.backward(c["dOut"])
+    w64 = _to64(mp_weights_from_layer(layer))
+    pairs = _edge_mlp_family_pairs(layer, w64, c["L"])
+    assert len(pairs) == len(c["wgrads"]) == len(layer.trainable_variables)
+    grads = [(v.name, v.grad, r) for (v, _), r in zip(pairs, c["wgrads"])]
+    _compare_full_backward(f"cfg-4 {c['cls_name']} full size", gemm_mode, out, dX, c["ref"], grads)
+
+
+@pytest.fixture(scope="module")
+def cfg5_ref(dev):
+    """BASELINE configs[4] layer (RGIN, 40 Zipf edge types, H = 512, V = 170k, E = 1.2M)."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_zipf_typed_batch
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    V, E, L, H = 170000, 1200000, 40, 512
+    feats, adjs = make_zipf_typed_batch(V, E, L, H, seed=0)
+    set_seed(7)
+    layer, p = _build("RGIN", {"hidden_dim": H}, H, L)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(8))
+    prev = _host_threads()
+    try:
+        w64 = _to64(mp_weights_from_layer(layer))
+        leaves = _edge_mlp_family_leaves(w64, L)
+        X64 = torch.from_numpy(feats).double().requires_grad_(True)
+        ref = orc.message_passing_call("rgin", p, w64, X64, [torch.from_numpy(a) for a in adjs])
+        grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
+    finally:
+        torch.set_num_threads(prev)
+    g = ops.Graph(to_dev(adjs, dev), V)
+    yield dict(V=V, L=L, H=H, layer=layer, graph=g, X=torch.from_numpy(feats).to(dev), dOut=dOut.to(dev),
+               ref=dict(out=ref.detach(), dX=grads[0]), wgrads=list(grads[1:]))
+    g.close()
+
+
+@pytest.mark.gemm_modes
+def test_cfg5_rgin_full_size_backward_matches_fp64(cfg5_ref, dev, gemm_mode):
+    """rgin.py:88-106 forward + backward at full size (grouped products over the non-empty (source, type) rows):
+    every row of out and dX, all 80 kernel gradients [512, 512] against fp64 autograd through the literal oracle."""
+    from tf2_gnn_amd.layers import MessagePassingInput
+
+    c = cfg5_ref
+    layer = c["layer"]
+    out = layer(MessagePassingInput(c["X"], c["graph"]), training=True)
+    dX = layer.backward(c["dOut"])
+    w64 = _to64(mp_weights_from_layer(layer))
+    pairs = _edge_mlp_family_pairs(layer, w64, c["L"])
+    assert len(pairs) == len(c["wgrads"])
+    grads = [(v.name, v.grad, r) for (v, _), r in zip(pairs, c["wgrads"])]
+    _compare_full_backward("cfg-5 RGIN full size", gemm_mode, out, dX, c["ref"], grads)

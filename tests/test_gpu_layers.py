@@ -7,7 +7,8 @@ import torch
 from oracle import tf2gnn_oracle as orc
 from tests.helpers import assert_close, mp_weights_from_layer, random_graph, scaled_error, to_dev
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs in the three GEMM modes (conftest.py: gemm_modes)
+pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("gemm_mode")]
 
 
 def _build(cls_name, params, D, L):
@@ -75,10 +76,14 @@ CASES = [
 @pytest.mark.parametrize("name,cls_name,over", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("H", [16, 64])
 def test_layer_forward_parity(dev, name, cls_name, over, H):
+    check_layer_forward(dev, name, cls_name, over, H, V=150, E=1800, L=3)
+
+
+def check_layer_forward(dev, name, cls_name, over, H, V, E, L):
     from tf2_gnn_amd.layers import MessagePassingInput
 
-    V, L, D = 150, 3, H
-    adjs = random_graph(V, 1800, L, seed=H, empty_types=(1,) if "rgin" in name else (), hub=(3, 200))
+    D = H
+    adjs = random_graph(V, E, L, seed=H, empty_types=(1,) if "rgin" in name else (), hub=(3, min(200, V // 2)))
     layer, p = _build(cls_name, dict(over, hidden_dim=H), D, L)
     g = torch.Generator().manual_seed(H)
     X = torch.randn((V, D), generator=g)
@@ -352,15 +357,18 @@ def _pool_weights(layer):
 @pytest.mark.parametrize("wf", ["softmax", "sigmoid", "average", "none"])
 def test_weighted_sum_graph_representation_parity(dev, wf):
     """nodes_to_graph_representation.py:170-229 forward, and backward vs autograd on the oracle."""
+    check_weighted_sum(dev, wf, sizes=[5, 1, 9, 3, 7, 12], VD=20, GD=16, heads=4, hidden=24)
+
+
+def check_weighted_sum(dev, wf, sizes, VD, GD, heads, hidden):
     from tf2_gnn_amd.layers import NodesToGraphRepresentationInput, WeightedSumGraphRepresentation
 
     g = torch.Generator().manual_seed(3)
-    sizes = [5, 1, 9, 3, 7, 12]
     ids = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)])
-    V, VD, GD, heads = int(ids.numel()), 20, 16, 4
+    V = int(ids.numel())
     X = torch.randn((V, VD), generator=g)
-    layer = WeightedSumGraphRepresentation(GD, heads, weighting_fun=wf, scoring_mlp_layers=[24],
-                                           transformation_mlp_layers=[24], scoring_mlp_use_biases=True,
+    layer = WeightedSumGraphRepresentation(GD, heads, weighting_fun=wf, scoring_mlp_layers=[hidden],
+                                           transformation_mlp_layers=[hidden], scoring_mlp_use_biases=True,
                                            transformation_mlp_activation_fun="tanh")
     out = layer(NodesToGraphRepresentationInput(X.to(dev), ids.to(dev), len(sizes)))
     for v in layer.trainable_variables:  # make biases non-trivial, then recompute
@@ -376,10 +384,19 @@ def test_weighted_sum_graph_representation_parity(dev, wf):
     dOut = torch.randn((len(sizes), GD), generator=g)
     dX = layer.backward(dOut.to(dev))
     X64 = X.double().requires_grad_(True)
-    w64 = {k: ([t.double() for t in ks], [None if b is None else b.double() for b in bs]) for k, (ks, bs) in w.items()}
+    w64 = {k: ([t.double().requires_grad_(True) for t in ks], [None if b is None else b.double().requires_grad_(True) for b in bs])
+           for k, (ks, bs) in w.items()}
     ref64 = orc.weighted_sum_graph_representation(cfg, w64, X64, ids, len(sizes))
-    (gx,) = torch.autograd.grad((ref64 * dOut.double()).sum(), X64)
-    assert_close(dX.cpu(), gx.float(), tol=2e-5, what=f"pool {wf} dX")
+    pairs = []  # (HIP variable, fp64 leaf): kernels and biases of the two MLPs
+    for key, mlp in (("transformation", layer._transformation_mlp), ("scoring", getattr(layer, "_scoring_mlp", None))):
+        if key in w64:
+            pairs += [(v, t) for v, t in zip(mlp.kernels, w64[key][0])]
+            pairs += [(v, t) for v, t in zip(mlp.biases, w64[key][1]) if v is not None]
+    grads = torch.autograd.grad((ref64 * dOut.double()).sum(), [X64] + [t for _, t in pairs])
+    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=f"pool {wf} dX")
+    for (v, _), r in zip(pairs, grads[1:]):
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=2e-5, what=f"pool {wf} d{v.name}")
 
 
 def test_was_graph_representation_parity(dev):
@@ -411,10 +428,13 @@ def test_unsorted_node_to_graph_map_raises(dev):
 @pytest.mark.parametrize("K,act", [(4, "relu"), (8, "tanh"), (3, "gelu")])
 def test_rgat_backward_parity(dev, K, act):
     """RGAT backward (csrc/rgat.hip + generic gathers) vs autograd through the fp64 oracle."""
+    check_rgat_backward(dev, K, act, V=90, E=900, L=3, H=24)
+
+
+def check_rgat_backward(dev, K, act, V, E, L, H):
     from tf2_gnn_amd.layers import MessagePassingInput
 
-    V, L, H = 90, 3, 24
-    adjs = random_graph(V, 900, L, seed=6, hub=(1, 120))
+    adjs = random_graph(V, E, L, seed=6, hub=(1, min(120, V // 2)))
     layer, p = _build("RGAT", {"hidden_dim": H, "num_heads": K, "message_activation_function": act}, H, L)
     g = torch.Generator().manual_seed(12)
     X = torch.randn((V, H), generator=g)
@@ -550,10 +570,13 @@ FILM_CASES = [
 @pytest.mark.parametrize("name,over", FILM_CASES, ids=[c[0] for c in FILM_CASES])
 def test_gnn_film_forward_backward_parity(dev, name, over):
     """gnn_film.py:84-108 against the per-edge oracle (fp64 autograd for the gradients)."""
+    check_film(dev, name, over, V=90, E=900, L=3, H=24)
+
+
+def check_film(dev, name, over, V, E, L, H):
     from tf2_gnn_amd.layers import MessagePassingInput
 
-    V, L, H = 90, 3, 24
-    adjs = random_graph(V, 900, L, seed=8, empty_types=(), hub=(3, 70))
+    adjs = random_graph(V, E, L, seed=8, empty_types=(), hub=(3, min(70, V // 2)))
     layer, p = _build("GNN_FiLM", dict(over, hidden_dim=H), H, L)
     g = torch.Generator().manual_seed(13)
     X = torch.randn((V, H), generator=g)

@@ -13,7 +13,8 @@ import torch
 from oracle import tf2gnn_oracle as orc
 from tests.helpers import assert_close, mp_weights_from_layer, to_dev
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs in the three GEMM modes (conftest.py: gemm_modes)
+pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("gemm_mode")]
 
 
 @pytest.fixture(scope="module")

@@ -11,7 +11,8 @@ from oracle import tf2gnn_oracle as orc
 from tests.helpers import assert_close, to_dev
 from tests.test_gpu_layers import _gnn_oracle_weights, _pool_weights, _to64
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs in the three GEMM modes (conftest.py: gemm_modes)
+pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("gemm_mode")]
 
 
 @pytest.mark.parametrize("V,C", [(1, 1), (257, 121), (5000, 40)])

@@ -16,6 +16,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libtfgnn.so"
 _SIGNATURES = [
     ("tfgnn_last_error", c_char_p, []),
     ("tfgnn_version", c_char_p, []),
+    ("tfgnn_launch_counts", c_int, [POINTER(c_int64), c_int]),
     (
         "tfgnn_graph_create",
         c_int,

@@ -12,6 +12,9 @@
 namespace tfgnn {
 
 void set_error(const char* fmt, ...);
+// host-side launch counters per product-kernel family (tfgnn_launch_counts: the parity tests assert that a GEMM mode
+// really ran the kernels it names)
+void count_launch(int family);
 
 #define TFGNN_HIP_CHECK(expr)                                                              \
   do {                                                                                     \

@@ -390,6 +390,7 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_byte
 
 template <int WM_, int WN_, int TM, int TN, bool VEC>
 static void launch_cfg(const GemmArgs& g, int ta, int tb, dim3 grid, hipStream_t s) {
+  count_launch(TFGNN_KFAM_GEMM_FP32);
   dim3 block(64 * WM_ * WN_);
   if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, false, false, VEC>), grid, block, 0, s, g);
   else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<WM_, WN_, TM, TN, false, true, VEC>), grid, block, 0, s, g);

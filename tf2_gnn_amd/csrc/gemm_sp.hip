@@ -1148,6 +1148,7 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
   using G = SpGeo<TNW>;
   const bool ablk = g.a_inv && g.a_nblk > 1;
   const bool grad = g.mul || g.saved;
+  count_launch(TFGNN_KFAM_SP_NT);
 #define SP_LAUNCH(AB, GR, OS)                                                                                      \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
@@ -1384,6 +1385,7 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
     hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeoTN<T>::LDS_BYTES, s, g);                    \
   } while (0)
   if (phases & 2) {
+    count_launch(TFGNN_KFAM_SP_TN);
     if (bn == 320) SP_LAUNCH_TN(5);
     else if (bn == 256) SP_LAUNCH_TN(4);
     else SP_LAUNCH_TN(2);

@@ -865,6 +865,7 @@ static bool pipelined_nt() {
 template <int TN>
 static void launch_x3(const X3Args& g, dim3 grid, int nprod, int trans_a, int trans_b, hipStream_t s) {
   const bool nine = nprod >= 9;
+  count_launch(TFGNN_KFAM_GEMM_BF16X3);
   if (trans_a) {
     if (nine) hipLaunchKernelGGL((gemm_x3p_kernel<9, TN>), grid, dim3(X3_NT), 0, s, g);
     else hipLaunchKernelGGL((gemm_x3p_kernel<6, TN>), grid, dim3(X3_NT), 0, s, g);
@@ -989,6 +990,7 @@ int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t 
     g.per_xcd = (unsigned)ceil_div(tiles, 8);
     grid = dim3(8 * g.per_xcd, 1, 1);
   }
+  count_launch(TFGNN_KFAM_GEMM_BF16X3);
   if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   return 1;

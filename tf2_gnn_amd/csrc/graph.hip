@@ -31,7 +31,19 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static int64_t g_launch_counts[TFGNN_KFAM_COUNT] = {0};
+void count_launch(int family) {
+  if (family >= 0 && family < TFGNN_KFAM_COUNT) __atomic_fetch_add(&g_launch_counts[family], 1, __ATOMIC_RELAXED);
+}
+
 }  // namespace tfgnn
+
+extern "C" int tfgnn_launch_counts(int64_t* out_counts, int n) {
+  if (!out_counts || n < 0) return TFGNN_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; ++i)
+    out_counts[i] = i < TFGNN_KFAM_COUNT ? __atomic_load_n(&tfgnn::g_launch_counts[i], __ATOMIC_RELAXED) : 0;
+  return TFGNN_OK;
+}
 
 extern "C" const char* tfgnn_last_error(void) { return tfgnn::g_err; }
 extern "C" const char* tfgnn_version(void) { return "tfgnn 0.1 gfx950"; }

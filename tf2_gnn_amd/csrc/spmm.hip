@@ -609,6 +609,7 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
     a.short_rows = p.short_rows;
     a.num_short = p.num_short;
   }
+  count_launch(d_out_sp ? TFGNN_KFAM_GATHER_SP : TFGNN_KFAM_GATHER);
   return gather_dispatch(a, p.num_items, (hipStream_t)stream);
 }
 
