@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="N > 1: add the training-step exchange (one bucketed RCCL all-reduce of the weight gradients) to every "
                          "step; off by default - the fwd+bwd metric itself has no collective")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timings of the other BASELINE workloads that the default run reports under `other_configs`")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no device work: spawn / rendezvous (gloo) / sharding / collectives only - the CPU test of the N > 1 launch path")
     args = ap.parse_args()
@@ -383,6 +385,7 @@ def main():
         parallel.barrier(dist)
 
     ms_guess = [3.0]
+    per_rank_seconds = []
 
     def settle(max_batches=40, tol=0.03, min_batches=8):
         """Untimed extra warm-up: short batches of steps until two consecutive ones take the same time (clock ramp,
@@ -420,10 +423,13 @@ def main():
             g_.wait()
             g_.close()
         pending.clear()
+        # every rank's own time too (a straggler is visible in the scaling runs), then the MAX the metric is computed from
+        per_rank_seconds[:] = parallel.all_gather_scalars([dt], dist, dev)[:, 0].tolist()
         return parallel.reduce_max(dt, dist, dev)
 
     ops.set_gemm_mode(args.gemm_mode)
     elapsed = timed(args.warmup, args.steps)
+    ms_per_step_per_rank = [1000.0 * t / args.steps for t in per_rank_seconds]
     # final metric reduction: all-gather of the per-rank edge / node counts (north_star: the only collective)
     gathered = parallel.all_gather_scalars([float(E), float(V), float(G)], dist, dev)
     total_edges_per_step = float(gathered[:, 0].sum())
@@ -461,6 +467,7 @@ def main():
             "collectives_per_step": ("1 bucketed all-reduce of the weight gradients (--allreduce-grads)"
                                      if (args.allreduce_grads and world > 1) else "none (graph-sharded batches / replicas)"),
             "edges_per_rank": gathered[:, 0].tolist(),
+            "ms_per_step_per_rank": ms_per_step_per_rank,
         },
     }
     if not args.no_alt_mode:

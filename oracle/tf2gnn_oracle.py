@@ -26,16 +26,16 @@ SMALL_NUMBER = 1e-7  # tf2_gnn/utils/constants.py:2
 # tf.math.unsorted_segment_* [ext]  (used through tf2_gnn/utils/param_helpers.py:7-18)
 # --------------------------------------------------------------------------------------------
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int):
-    out = torch.zeros((num_segments,) + tuple(data.shape[1:]), dtype=data.dtype)
+    out = torch.zeros((num_segments,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
     if data.shape[0]:
         out.index_add_(0, segment_ids.long(), data)
     return out
 
 
 def _segment_counts(segment_ids: torch.Tensor, num_segments: int, dtype):
-    cnt = torch.zeros(num_segments, dtype=dtype)
+    cnt = torch.zeros(num_segments, dtype=dtype, device=segment_ids.device)
     if segment_ids.shape[0]:
-        cnt.index_add_(0, segment_ids.long(), torch.ones(segment_ids.shape[0], dtype=dtype))
+        cnt.index_add_(0, segment_ids.long(), torch.ones(segment_ids.shape[0], dtype=dtype, device=segment_ids.device))
     return cnt
 
 
@@ -56,7 +56,7 @@ def unsorted_segment_sqrt_n(data, segment_ids, num_segments):
 def unsorted_segment_max(data, segment_ids, num_segments):
     # [ext] tf.math.unsorted_segment_max: empty segments hold the lowest finite value of the dtype.
     lowest = torch.finfo(data.dtype).min
-    out = torch.full((num_segments,) + tuple(data.shape[1:]), lowest, dtype=data.dtype)
+    out = torch.full((num_segments,) + tuple(data.shape[1:]), lowest, dtype=data.dtype, device=data.device)
     if data.shape[0]:
         idx = segment_ids.long().reshape((-1,) + (1,) * (data.dim() - 1)).expand_as(data)
         out = out.scatter_reduce(0, idx, data, reduce="amax", include_self=True)
@@ -183,11 +183,11 @@ def calculate_type_to_num_incoming_edges(node_embeddings, adjacency_lists):
     rows = []
     for adj in adjacency_lists:
         targets = adj[:, 1].long()
-        cnt = torch.zeros(V, dtype=node_embeddings.dtype)
+        cnt = torch.zeros(V, dtype=node_embeddings.dtype, device=node_embeddings.device)
         if targets.shape[0]:
-            cnt.index_add_(0, targets, torch.ones(targets.shape[0], dtype=node_embeddings.dtype))
+            cnt.index_add_(0, targets, torch.ones(targets.shape[0], dtype=node_embeddings.dtype, device=node_embeddings.device))
         rows.append(cnt)
-    return torch.stack(rows) if rows else torch.zeros((0, V), dtype=node_embeddings.dtype)
+    return torch.stack(rows) if rows else torch.zeros((0, V), dtype=node_embeddings.dtype, device=node_embeddings.device)
 
 
 def _edge_mlp_message(params, mlp_kernels_l, src_states, tgt_states, num_incoming):
@@ -258,7 +258,7 @@ def message_passing_call(
                 m = film[:, :H_] * m + film[:, H_:]
         messages_per_type.append(m)
     targets = [adj[:, 1] for adj in adjacency_lists]
-    message_targets = torch.cat(targets, dim=0) if targets else torch.zeros(0, dtype=torch.int32)
+    message_targets = torch.cat(targets, dim=0) if targets else torch.zeros(0, dtype=torch.int32, device=X.device)
 
     if kind == "rgat":  # rgat.py:125-163
         K = params["num_heads"]
@@ -272,7 +272,7 @@ def message_passing_call(
 
     H = params["hidden_dim"]
     messages = (
-        torch.cat(messages_per_type, dim=0) if messages_per_type else torch.zeros((0, H), dtype=X.dtype)
+        torch.cat(messages_per_type, dim=0) if messages_per_type else torch.zeros((0, H), dtype=X.dtype, device=X.device)
     )
 
     if kind == "rgin":  # rgin.py:88-106 (ignores message_activation_before_aggregation)

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import tf2gnn_oracle as orc
-from tests.helpers import assert_close, mp_weights_from_layer, random_graph, scaled_error, to_dev
+from tests.helpers import (KINK_MARGIN, assert_close, kink_clearance, mp_weights_from_layer, random_graph, scaled_error,
+                           to_dev)
 
 # every test of this module runs in the three GEMM modes (conftest.py: gemm_modes)
 pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("gemm_mode")]
@@ -108,6 +109,19 @@ def check_layer_forward(dev, name, cls_name, over, H, V, E, L):
     assert err_hip <= max(1e-5, 2 * err_ref32), f"{name}: HIP vs fp64 {err_hip:.3e}, reference-order fp32 vs fp64 {err_ref32:.3e}"
 
 
+def draw_inputs_clear_of_kinks(ref_forward, V, H, seed):
+    """(X, dOut) ~ N(0,1) such that no relu / leaky_relu unit of the fp64 oracle forward ``ref_forward(X)`` lies within
+    KINK_MARGIN of its kink (tests/helpers.py): the gradient comparison is then between the same linear branches.  The
+    selection only looks at the oracle, never at HIP results."""
+    for attempt in range(60):
+        g = torch.Generator().manual_seed(seed + 1000 * attempt)
+        X = torch.randn((V, H), generator=g)
+        dOut = torch.randn((V, H), generator=g)
+        if kink_clearance(lambda: ref_forward(X)) >= KINK_MARGIN:
+            return X, dOut
+    raise AssertionError("no kink-free input found in 60 draws")
+
+
 def _to64(w):
     if isinstance(w, dict):
         return {k: _to64(v) for k, v in w.items()}
@@ -190,14 +204,14 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     from tf2_gnn_amd.layers import MessagePassingInput
 
     adjs = random_graph(V, E, L, seed=4, hub=(2, min(150, V // 2)))
+    adj_t = [torch.from_numpy(a) for a in adjs]
     layer, p = _build(cls_name, dict(over, hidden_dim=H), H, L)
-    g = torch.Generator().manual_seed(11)
-    X = torch.randn((V, H), generator=g)
-    dOut = torch.randn((V, H), generator=g)
+    w32 = mp_weights_from_layer(layer)
+    X, dOut = draw_inputs_clear_of_kinks(lambda x: orc.message_passing_call(cls_name, p, _to64(w32), x.double(), adj_t), V, H, 11)
     out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
     dX = layer.backward(dOut.to(dev))
 
-    w64 = _to64(mp_weights_from_layer(layer))
+    w64 = _to64(w32)
     leaves = []
 
     def req(t):
@@ -213,10 +227,16 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
         if k in w64:
             w64[k] = req(w64[k])
     X64 = X.double().requires_grad_(True)
-    ref = orc.message_passing_call(cls_name, p, w64, X64, [torch.from_numpy(a) for a in adjs])
-    assert_close(out.cpu(), ref.detach().float(), tol=1e-5, what=name + " fwd")
+    ref = orc.message_passing_call(cls_name, p, w64, X64, adj_t)
+    # the reference-order fp32 evaluation of the same step (forward + autograd): where ITS rounding error against fp64
+    # already exceeds the bound (un-normalised sums over a hub, 150+ terms with cancellation), the HIP path may not be
+    # worse than twice that (hard part 2)
+    X32 = X.clone().requires_grad_(True)
+    ref32 = orc.message_passing_call(cls_name, p, w32, X32, adj_t)
+    (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
+    assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, 2 * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
     grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
-    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=name + " dX")
+    assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, 2 * scaled_error(dX32, grads[0])), what=name + " dX")
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
     pairs = []
     for l in range(L):
@@ -436,12 +456,12 @@ def check_rgat_backward(dev, K, act, V, E, L, H):
 
     adjs = random_graph(V, E, L, seed=6, hub=(1, min(120, V // 2)))
     layer, p = _build("RGAT", {"hidden_dim": H, "num_heads": K, "message_activation_function": act}, H, L)
-    g = torch.Generator().manual_seed(12)
-    X = torch.randn((V, H), generator=g)
-    dOut = torch.randn((V, H), generator=g)
+    adj_t = [torch.from_numpy(a) for a in adjs]
+    w32 = mp_weights_from_layer(layer)
+    X, dOut = draw_inputs_clear_of_kinks(lambda x: orc.message_passing_call("rgat", p, _to64(w32), x.double(), adj_t), V, H, 12)
     out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
     dX = layer.backward(dOut.to(dev))
-    w64 = _to64(mp_weights_from_layer(layer))
+    w64 = _to64(w32)
     for key in ("kernels", "attn"):
         w64[key] = [t.requires_grad_(True) for t in w64[key]]
     X64 = X.double().requires_grad_(True)
@@ -578,24 +598,27 @@ def check_film(dev, name, over, V, E, L, H):
 
     adjs = random_graph(V, E, L, seed=8, empty_types=(), hub=(3, min(70, V // 2)))
     layer, p = _build("GNN_FiLM", dict(over, hidden_dim=H), H, L)
-    g = torch.Generator().manual_seed(13)
-    X = torch.randn((V, H), generator=g)
-    dOut = torch.randn((V, H), generator=g)
+    adj_t = [torch.from_numpy(a) for a in adjs]
+    w32 = mp_weights_from_layer(layer)
+    X, dOut = draw_inputs_clear_of_kinks(lambda x: orc.message_passing_call("gnn_film", p, _to64(w32), x.double(), adj_t), V, H, 13)
     out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
     dX = layer.backward(dOut.to(dev))
-    w64 = _to64(mp_weights_from_layer(layer))
+    w64 = _to64(w32)
     leaves = []
     for key in ("film_mlps", "edge_mlps"):
         for l in range(L):
             w64[key][l] = [k.requires_grad_(True) for k in w64[key][l]]
             leaves += w64[key][l]
     X64 = X.double().requires_grad_(True)
-    ref = orc.message_passing_call("gnn_film", p, w64, X64, [torch.from_numpy(a) for a in adjs])
-    assert_close(out.cpu(), ref.detach().float(), tol=1e-5, what=name + " fwd")
-    ref32 = orc.message_passing_call("gnn_film", p, mp_weights_from_layer(layer), X, [torch.from_numpy(a) for a in adjs])
-    assert_close(out.cpu(), ref32, tol=2e-5, what=name + " fwd vs reference-order fp32")
+    ref = orc.message_passing_call("gnn_film", p, w64, X64, adj_t)
+    # yardstick: the reference-order fp32 evaluation (forward + autograd) against the same fp64 result - un-normalised
+    # sums over the hub's 70 edges times gamma: where ITS rounding error exceeds the bound the HIP path may be at most twice that
+    X32 = X.clone().requires_grad_(True)
+    ref32 = orc.message_passing_call("gnn_film", p, w32, X32, adj_t)
+    (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
+    assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, 2 * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
     grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
-    assert_close(dX.cpu(), grads[0].float(), tol=2e-5, what=name + " dX")
+    assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, 2 * scaled_error(dX32, grads[0])), what=name + " dX")
     # variable order of the reference: all FiLM MLPs first, then the edge MLPs (gnn_film.py:72-82)
     hip_vars = [v for l in range(L) for v in layer._film_mlps.vars[l]] + [v for l in range(L) for v in layer._edge_type_mlps.vars[l]]
     assert [v.name for v in layer.trainable_variables] == [v.name for v in hip_vars]

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import tf2gnn_oracle as orc
-from tests.helpers import KernelsUsed, assert_close, random_graph, record_parity, scaled_error, to_dev
+from tests.helpers import ForcedKinks, KernelsUsed, assert_close, random_graph, record_parity, scaled_error, to_dev
 from tests.test_gpu_layers import (
     _gnn_oracle_weights,
     _to64,
@@ -32,8 +32,11 @@ from tests.test_gpu_layers import (
 pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("gemm_mode")]
 
 
-def _assert_kernel_families(mode, used, split_operand_path):
+def _assert_kernel_families(mode, used, split_operand_path, forward_only=False):
     """`used`: launches per kernel family during the test body."""
+    if forward_only and mode == "f16x2" and split_operand_path:
+        assert used["sp_nt"] >= 1 and used["gather_sp"] >= 1, used
+        return
     if mode == "fp32":
         assert used["gemm_fp32"] > 0 and used["gemm_bf16x3"] == 0 and used["sp_nt"] == 0 and used["sp_tn"] == 0, used
     elif mode == "bf16x3":
@@ -80,7 +83,7 @@ def test_wide_layer_forward_backward_parity_per_mode(dev, gemm_mode, name, cls_n
 def test_wide_layer_forward_parity_per_mode(dev, gemm_mode, name, cls_name, over, H):
     with KernelsUsed() as k:
         check_layer_forward(dev, name, cls_name, over, H, V=300, E=3600, L=4)
-    _assert_kernel_families(gemm_mode, k.delta, False if gemm_mode != "f16x2" else k.delta["sp_nt"] > 0)
+    _assert_kernel_families(gemm_mode, k.delta, gemm_mode == "f16x2" and k.delta["sp_nt"] > 0, forward_only=True)
 
 
 @pytest.mark.parametrize("H,K,act", [(256, 8, "tanh"), (128, 8, "relu"), (128, 4, "gelu")])
@@ -162,8 +165,15 @@ def test_benchmarked_rgcn_stack_training_step_matches_fp64_oracle(dev, gemm_mode
     leaves = []
     _visit_leaves(w64, leaves)
     X64 = X.double().requires_grad_(True)
-    ref64, ref_all = orc.gnn_internal_call(params, w64, X64, adj_t, dropout_masks=[m.double() for m in masks])
+    # 4 x V x 320 relu units: some lie within fp32 rounding of 0, where the gradient is discontinuous (tests/helpers.py,
+    # "activation kinks").  The fp64 reference is evaluated on the branch the HIP forward took: relu call i of the oracle is
+    # the message activation of layer i (tf2_gnn/layers/message_passing/message_passing.py:176-177).
+    relu_masks = [(mp._ctx["out"] > 0).cpu() for mp in gnn._mp_layers]
+    with ForcedKinks(lambda i, x: relu_masks[i]) as kinks:
+        ref64, ref_all = orc.gnn_internal_call(params, w64, X64, adj_t, dropout_masks=[m.double() for m in masks])
+    assert kinks.calls == 4 and kinks.flipped <= 1e-4 * kinks.units, (kinks.calls, kinks.flipped, kinks.units)
     tag = f"benchmarked stack V={V}"
+    record_parity(f"{tag} relu decisions differing from fp64", max_flipped_units=kinks.flipped, units=kinks.units, bound=1e-4 * kinks.units)
     assert len(all_reprs) == 5
     for i, (a, b) in enumerate(zip(all_reprs, ref_all)):
         assert_close(a.cpu(), b.detach().float(), tol=1e-5, what=f"{tag} representation {i}")

@@ -1,0 +1,61 @@
+"""Multi-GPU correctness THROUGH THE HIP PATH on a one-GPU box: two (and three, unequal shards)
+ranks on cuda:0 shard one molecule batch by graph, run forward + backward on their shard, exchange the weight gradients
+with `parallel.allreduce_gradients(local_count=...)` - and the result must equal the one-rank gradient of the whole batch
+to 1e-5 (of the largest entry), in the GEMM modes bench.py runs.  tests/multirank_grad_worker.py is the per-rank program."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, model, mode, tmp_path):
+    out = tmp_path / f"grads_{world}_{model}_{mode}.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_grad_worker.py"), str(out), model, mode]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return json.loads(out.read_text())
+
+
+@pytest.mark.parametrize("world,model,mode", [(2, "ggnn", "f16x2"), (2, "rgcn", "bf16x3"), (3, "gnn_edge_mlp", "f16x2")])
+def test_sharded_step_plus_weighted_allreduce_equals_the_one_rank_gradient(tmp_path, world, model, mode):
+    from tests.helpers import record_parity
+
+    r = _run(world, model, mode, tmp_path)
+    assert r["world"] == world and r["allreduce_calls"] >= 1 and r["num_variables"] > 4
+    assert len(set(r["graphs_per_rank"])) >= 1 and sum(r["graphs_per_rank"]) == 3000
+    assert abs(r["loss_sharded"] - r["loss_one_rank"]) <= 1e-5 * max(1.0, abs(r["loss_one_rank"]))
+    record_parity(f"{world}-rank sharded gradients vs one rank ({model}, {mode})",
+                  max_scaled_error=r["max_scaled_gradient_difference"], bound=1e-5)
+    assert r["max_scaled_gradient_difference"] <= 1e-5, r["per_variable"]
+
+
+def test_eight_ranks_on_one_device_rendezvous_and_run():
+    """bench.py --gpus 8 with all ranks on cuda:0: the self-spawn / rendezvous / port path of the 8-GPU driver run."""
+    env = dict(os.environ, TFGNN_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "qm9-tiny", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-alt-mode", "--no-roofline", "--no-other-configs", "--allreduce-grads"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 8 and len(r["config"]["edges_per_rank"]) == 8 and r["value"] > 0
+    assert len(r["config"]["ms_per_step_per_rank"]) == 8

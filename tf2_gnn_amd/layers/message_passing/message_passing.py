@@ -29,7 +29,14 @@ class MessagePassingInput(NamedTuple):
 
 
 class Variable:
-    """A named trainable tensor (stand-in for tf.Variable: ``.name``, ``.shape``, ``.value``)."""
+    """A named trainable tensor (stand-in for tf.Variable: ``.name``, ``.shape``, ``.value``).
+
+    Updating the value: ``assign(new)`` or in-place torch arithmetic on ``.value`` (``var.value.add_(...)``,
+    ``var.value.copy_(...)``) - both are seen by the library, which keeps derived forms of the weights (split fp16
+    operands, transposed copies) per weight VALUE.  Updates torch's version counter does not see are NOT supported without
+    telling the library: after ``var.value.data.add_(...)``, an optimizer kernel writing through ``data_ptr()``, or any
+    other out-of-band write call ``var.mark_updated()`` (ops.notify_weights_changed), otherwise the next forward / backward
+    pass may use the stale derived forms.  TFGNN_CHECK_WEIGHT_CACHE=1 makes the library verify this with checksums."""
 
     def __init__(self, name: str, value: torch.Tensor, trainable: bool = True):
         self.name = name
@@ -45,12 +52,20 @@ class Variable:
         """In-place update (tf.Variable.assign).  ``value`` tensors of several layers are VIEWS into one fused buffer (the
         per-type kernels of an edge-MLP stack, the RGAT kernels): an optimizer or a checkpoint loader must write through
         ``assign`` / ``value.copy_`` / in-place arithmetic - rebinding ``var.value`` to a new tensor detaches the variable
-        from the buffer the kernels read.  copy_ bumps the tensor version, which invalidates cached split operands."""
+        from the buffer the kernels read.  Cached derived forms of the buffer are dropped explicitly."""
         new = torch.as_tensor(value, dtype=self.value.dtype)
         if tuple(new.shape) != tuple(self.value.shape):
             raise ValueError(f"Shape mismatch for {self.name}: {tuple(self.value.shape)} vs {tuple(new.shape)}")
         with torch.no_grad():
             self.value.copy_(new.to(self.value.device))
+        self.mark_updated()
+        return self
+
+    def mark_updated(self) -> "Variable":
+        """The value was changed in place by something torch cannot see (``.data`` arithmetic, a raw-pointer kernel):
+        drop every derived form of this variable's buffer."""
+        if self.value.is_cuda:
+            ops.notify_weights_changed(self.value)
         return self
 
     def __repr__(self):

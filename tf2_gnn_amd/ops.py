@@ -74,10 +74,19 @@ def _writes_out(fn):
     split weight operands, the Graph cache - notices the new contents."""
     import functools
 
+    import inspect
+
+    try:
+        out_pos = list(inspect.signature(fn).parameters).index("out")
+    except ValueError:
+        out_pos = None
+
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         res = fn(*args, **kwargs)
         out = kwargs.get("out")
+        if out is None and out_pos is not None and len(args) > out_pos:  # ``out`` passed positionally
+            out = args[out_pos]
         if isinstance(out, torch.Tensor):
             torch.autograd.graph.increment_version(out)
         return res
@@ -1050,16 +1059,45 @@ def absmax(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 _sp_weight_cache: "dict" = {}
+_CHECK_WEIGHT_CACHE = [None]
 
 
 def clear_weight_operand_cache() -> None:
-    """Forget the split forms of the weights (what an optimizer step's in-place update does through the tensor version).
-    bench.py calls it once per step so that the per-step cost of splitting the updated weights is inside the timed region."""
+    """Forget the derived forms of the weights (split SP16 operands, transposed / re-stacked copies).  bench.py calls it
+    once per step so that the per-step cost of splitting the updated weights is inside the timed region."""
     _sp_weight_cache.clear()
+
+
+def notify_weights_changed(tensor: Optional[torch.Tensor] = None) -> None:
+    """Tell the library that weight values were changed by something torch's version counter does not see - an update
+    through ``tensor.data``, a raw-pointer optimizer kernel, another framework writing into the buffer.  Every derived form
+    of ``tensor`` (or of all weights) is dropped and rebuilt at its next use.  ``Variable.assign`` / ``Variable.mark_updated``
+    call this; in-place torch arithmetic on ``Variable.value`` itself is seen through the version counter as well."""
+    if tensor is None:
+        _sp_weight_cache.clear()
+        return
+    base = tensor._base if tensor._base is not None else tensor
+    lo = base.data_ptr()
+    hi = lo + base.numel() * base.element_size()
+    for key in [k for k in _sp_weight_cache if lo <= k[0] < hi]:
+        del _sp_weight_cache[key]
 
 
 def _weight_key(w: torch.Tensor, kind: str):
     return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), kind)
+
+
+def _weight_checksum(w: torch.Tensor):
+    """debug mode TFGNN_CHECK_WEIGHT_CACHE=1: a checksum of the weight beside every cached form; a hit whose weight no
+    longer has that checksum was updated behind the library's back (see notify_weights_changed) and raises."""
+    if _CHECK_WEIGHT_CACHE[0] is None:
+        import os
+
+        _CHECK_WEIGHT_CACHE[0] = os.environ.get("TFGNN_CHECK_WEIGHT_CACHE", "0") == "1"
+    if not _CHECK_WEIGHT_CACHE[0]:
+        return None
+    v = w.detach().double()
+    return (float(v.sum()), float(v.abs().sum()))
 
 
 def sp_split_weights(stacks) -> None:
@@ -1099,18 +1137,24 @@ def sp_split_weights(stacks) -> None:
             _sp_weight_cache.clear()
         for w, c, r in zip(group, cols, rows):
             base = w._base if w._base is not None else w
-            _sp_weight_cache[_weight_key(w, "cols")] = (w._version, c, weakref.ref(base))
-            _sp_weight_cache[_weight_key(w, "rows")] = (w._version, r, weakref.ref(base))
+            chk = _weight_checksum(w)
+            _sp_weight_cache[_weight_key(w, "cols")] = (w._version, c, weakref.ref(base), chk)
+            _sp_weight_cache[_weight_key(w, "rows")] = (w._version, r, weakref.ref(base), chk)
 
 
 def sp_weight_operand(w: torch.Tensor, kind: str, build):
     """A derived form of a weight tensor (its SP16 operands; also the transposed / re-stacked fp32 copies the bf16x3 products
-    take), built once per value: keyed on the tensor's storage and version (an in-place
-    optimizer update bumps the version), so forward and backward passes of a step - and every step of an evaluation
-    loop - share it.  ``build()`` makes the operand."""
+    take), built once per value: keyed on the tensor's storage and version (an in-place torch update bumps the version;
+    ``Variable.assign`` and ``notify_weights_changed`` drop the entry explicitly), so forward and backward passes of a step -
+    and every step of an evaluation loop - share it.  ``build()`` makes the operand.  Updates torch cannot see
+    (``var.value.data.add_(...)``, raw-pointer kernels) MUST be followed by ``Variable.mark_updated()`` /
+    ``notify_weights_changed``; TFGNN_CHECK_WEIGHT_CACHE=1 verifies every hit against a checksum of the weight."""
     key = _weight_key(w, kind)
     hit = _sp_weight_cache.get(key)
     if hit is not None and hit[0] == w._version and hit[2]() is not None:
+        if hit[3] is not None and hit[3] != _weight_checksum(w):
+            raise RuntimeError("a weight tensor changed without a version bump (update through .data or a raw pointer?): "
+                               "call Variable.mark_updated() / ops.notify_weights_changed() after such an update")
         return hit[1]
     import weakref
 
@@ -1118,5 +1162,5 @@ def sp_weight_operand(w: torch.Tensor, kind: str, build):
     if len(_sp_weight_cache) > 256:
         _sp_weight_cache.clear()
     base = w._base if w._base is not None else w  # views are temporaries: the entry lives as long as the parameter buffer
-    _sp_weight_cache[key] = (w._version, op, weakref.ref(base))
+    _sp_weight_cache[key] = (w._version, op, weakref.ref(base), _weight_checksum(w))
     return op
