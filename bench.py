@@ -131,71 +131,117 @@ def time_kernel(fn, iters=20, warmup=3):
 # --------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference's op sequence (oracle), SURVEY.md 8d protocol (warm-up, median) on a bounded sample
 # --------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, feats, adjs, params, budget_seconds=30.0):
-    """The oracle's RGCN step (per-edge gathers and matmuls, concat, scatter-add; torch-CPU fp32, autograd for the
-    backward) on all host cores: 1 warm-up run, then the median of as many timed runs (<= 5) as fit the budget, on an
-    edge sample sized so that a run takes a few seconds; scaled linearly to the full batch and stack."""
-    from oracle import tf2gnn_oracle as orc
-
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    H, NL, L = wl["hidden_dim"], wl["num_layers"], len(adjs)
-    g = torch.Generator().manual_seed(0)
-
+def _random_oracle_weights(model, params, D, H, L, NL, gen):
+    """Glorot-uniform weights in the oracle's layout for every model bench.py times (shapes as the HIP layers build them)."""
     def glorot(i, o):
         lim = (6.0 / (i + o)) ** 0.5
-        return ((torch.rand((i, o), generator=g) * 2 - 1) * lim).requires_grad_(True)
+        return ((torch.rand((i, o), generator=gen) * 2 - 1) * lim).requires_grad_(True)
 
-    weights = {
-        "initial_projection": glorot(feats.shape[1], H),
-        "mp": [{"edge_mlps": [[glorot(H, H)] for _ in range(L)]} for _ in range(NL)],
-        "dense": {0: glorot(H, H)},
-        "layernorm": [],
-    }
-    leaves = [weights["initial_projection"], weights["dense"][0]] + [w[0] for m in weights["mp"] for w in m["edge_mlps"]]
-    X = torch.from_numpy(feats)
+    leaves = []
+
+    def t(x):
+        leaves.append(x)
+        return x
+
+    mp = []
+    for _ in range(NL):
+        if model == "rgat":
+            K = params["num_heads"]
+            mp.append({"kernels": [t(glorot(H, H)) for _ in range(L)], "attn": [t(glorot(K, 2 * H // K)) for _ in range(L)]})
+            continue
+        din = 2 * H if params.get("use_target_state_as_input") else H
+        nh = int(params.get("num_edge_MLP_hidden_layers", 0))
+        sizes = [din] + [H] * nh + [H]
+        w = {"edge_mlps": [[t(glorot(sizes[k], sizes[k + 1])) for k in range(len(sizes) - 1)] for _ in range(L)], "aggr_mlp": None}
+        if model == "ggnn":
+            w["gru_kernel"], w["gru_recurrent_kernel"] = t(glorot(H, 3 * H)), t(glorot(H, 3 * H))
+            w["gru_bias"] = t(torch.zeros((2, 3 * H), requires_grad=True))
+        mp.append(w)
+    weights = {"initial_projection": t(glorot(D, H)), "mp": mp, "dense": {0: t(glorot(H, H))}, "layernorm": []}
+    return weights, leaves
+
+
+def cpu_baseline(wl, batch, params, budget_seconds=30.0):
+    """The oracle's training step of the workload's model - the reference's literal op sequence: materialised per-edge
+    gathers, per-edge matmuls, concat over edge types, scatter-add (torch-CPU fp32), autograd for the backward, plus the
+    WeightedSum pooling head for the molecule workloads - timed on the host: fastest thread count of a short sweep, one
+    warm-up, the median of up to 5 runs inside ``budget_seconds``, on a BOUNDED SAMPLE of the same batch (the whole batch
+    and the whole layer stack when that fits the budget; otherwise whole graphs of a molecule batch / a prefix of every
+    edge list of a single-graph batch, and fewer layers - scaled linearly, the per-edge cost dominates)."""
+    from oracle import tf2gnn_oracle as orc
+
+    feats, adjs, n2g, G = batch["feats"], batch["adjs"], batch["n2g"], int(batch["num_graphs"])
+    model = wl["model"]
+    cores_all = os.cpu_count() or 1
+    H, NL, L = wl["hidden_dim"], wl["num_layers"], len(adjs)
+    gen = torch.Generator().manual_seed(0)
+    weights, leaves = _random_oracle_weights(model, params, feats.shape[1], H, L, NL, gen)
+    pooled = bool(wl.get("sharded"))
+    if pooled:
+        def glorot(i, o):
+            lim = (6.0 / (i + o)) ** 0.5
+            return ((torch.rand((i, o), generator=gen) * 2 - 1) * lim).requires_grad_(True)
+        pool_w = {"scoring": ([glorot(H, H), glorot(H, 4)], None), "transformation": ([glorot(H, H), glorot(H, 32)], None)}
+        pool_cfg = {"graph_representation_size": 32, "num_heads": 4, "weighting_fun": "softmax",
+                    "scoring_mlp_activation_fun": "ReLU", "transformation_mlp_activation_fun": "ReLU"}
+        leaves = leaves + pool_w["scoring"][0] + pool_w["transformation"][0]
     E = sum(a.shape[0] for a in adjs)
 
+    def sample(frac):
+        """-> (X, adjacency lists, node_to_graph_map, graphs): whole graphs of a molecule batch, else an edge prefix"""
+        if pooled:
+            g_n = max(1, int(G * frac))
+            v_n = int(np.searchsorted(n2g, g_n, side="left"))
+            sub = [torch.from_numpy(a[a[:, 1] < v_n]) for a in adjs]  # edges never cross graphs
+            return torch.from_numpy(feats[:v_n]), sub, torch.from_numpy(n2g[:v_n]), g_n
+        return torch.from_numpy(feats), [torch.from_numpy(a[: max(1, int(a.shape[0] * frac))]) for a in adjs], None, 1
+
     def run(frac, layers):
-        adj_t = [torch.from_numpy(a[: max(1, int(a.shape[0] * frac))]) for a in adjs]
+        X, adj_t, ids, g_n = sample(frac)
         p = dict(params, num_layers=layers)
         t0 = time.perf_counter()
         out, _ = orc.gnn_internal_call(p, weights, X, adj_t)
-        torch.autograd.grad(out.sum(), leaves[:2] + leaves[2 : 2 + layers * L])
+        if pooled:
+            out = orc.weighted_sum_graph_representation(pool_cfg, pool_w, out, ids, g_n)
+        torch.autograd.grad(out.sum(), leaves, allow_unused=True)
         return time.perf_counter() - t0
 
-    # thread count: torch-CPU with every hardware thread of a 256-thread host is several times SLOWER on these per-edge ops than
-    # with a few dozen (measured: 11.6 s vs < 1 s for the same 1/16 sample) - take the fastest of a short sweep
-    run(1.0 / 16, 1)  # first-touch / thread-pool warm-up
+    # thread count: torch-CPU with every hardware thread of a 256-thread host is several times SLOWER on these per-edge ops
+    # than with a few dozen (measured: 11.6 s vs < 1 s for the same 1/16 sample) - take the fastest of a short sweep
+    torch.set_num_threads(min(16, cores_all))
+    cal = 1.0 / 64
+    run(cal, 1)  # first-touch / thread-pool warm-up
     sweep = {}
-    for nt in sorted({n for n in (8, 16, 32, 64, 128, cores) if n <= cores}):
+    for nt in sorted({n for n in (8, 16, 32, 64, 128, cores_all) if n <= cores_all}):
         torch.set_num_threads(nt)
-        sweep[nt] = min(run(1.0 / 16, 1), run(1.0 / 16, 1))
+        sweep[nt] = min(run(cal, 1), run(cal, 1))
         if sweep[nt] > 2.0 * min(sweep.values()):
             break
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    t_cal = sweep[threads]
-    # the sample: a prefix of every edge list sized for ~4 s per run (the whole batch if it fits)
-    frac = float(min(1.0, max(1.0 / 16, (4.0 / max(t_cal, 1e-3)) / 16)))
-    layers = 1
+    t_layer_full = sweep[threads] / cal  # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated
+    # the sample: whole stack on the whole batch if ~3 runs fit the budget, else fewer layers, then a fraction of the batch
+    per_run = budget_seconds / 3.5
+    layers = NL if t_layer_full * NL <= per_run else max(1, min(NL, int(per_run / max(t_layer_full, 1e-6))))
+    frac = float(min(1.0, max(cal, per_run / max(t_layer_full * layers, 1e-6))))
     t_used = run(frac, layers)  # warm-up at the sample size
     times = []
     while len(times) < 5 and (not times or t_used + times[-1] < budget_seconds):
         times.append(run(frac, layers))
         t_used += times[-1]
     t = float(np.median(times))
-    t_full = t / frac * NL / layers  # per-edge cost dominates (matmul + gather + scatter per edge), layers are alike
+    t_full = t / frac * NL / layers
+    what = ("whole graphs" if pooled else "a prefix of every edge list")
     return {
         "value": E / t_full,
         "unit": "edges/s",
         "cores": threads,
         "kind": "port",
         "thread_sweep_seconds": {str(k): v for k, v in sweep.items()},
-        "sample": f"{layers} of {NL} RGCN layers (+ projection / Dense) fwd+bwd on {frac:.3f} of the batch's edges, all nodes, {threads} threads "
-        f"(fastest of a sweep up to {cores}): 1 warm-up, "
-        f"median of {len(times)} runs = {t:.2f} s, scaled to the full batch and stack; torch-CPU fp32 restatement of the reference op "
-        "sequence (TensorFlow unavailable offline)",
+        "sample": f"{layers} of {NL} {model.upper()} layers (+ projection / Dense{' / WeightedSum pooling' if pooled else ''}) fwd+bwd on "
+        f"{frac:.3f} of the batch ({what}{', all nodes' if not pooled else ''}), {threads} threads (fastest of a sweep up to {cores_all}): "
+        f"1 warm-up, median of {len(times)} runs = {t:.2f} s, scaled to the full batch and stack; torch-CPU fp32 restatement of the "
+        "reference op sequence (TensorFlow unavailable offline)",
         "seconds_per_step": t_full,
     }
 
@@ -245,6 +291,7 @@ def main():
     ap.add_argument("--reuse-graph", action="store_true", help="bucket the edges once, outside the timed steps")
     ap.add_argument("--serial-bucketing", action="store_true", help="bucket each batch on the compute stream (no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="host time budget of the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-mode", default="f16x2", choices=["fp32", "bf16x3", "bf16x3_9", "f16x2"],
                     help="how the fp32 products run on the matrix cores (include/tfgnn.h): fp32 MFMA, exact bf16 operand splitting "
@@ -485,20 +532,64 @@ def main():
     if rank == 0 and not args.no_roofline:
         roofs = roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step)
         roofs.sort(key=lambda r: -r["share_of_step"])
+        result["roofline_blocks_share_of_step"] = float(sum(r["share_of_step"] for r in roofs))
         result["roofline"] = roofs[0]
         if len(roofs) > 1:
             result["roofline_secondary"] = roofs[1]
         if len(roofs) > 2:
             result["roofline_other"] = roofs[2:]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["model"] == "rgcn":
-        result["cpu_baseline"] = cpu_baseline(wl, feats, adjs, params)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl, batch, params, budget_seconds=args.cpu_baseline_seconds)
+
+    if rank == 0 and world == 1 and args.workload == "rmat30k" and not args.no_other_configs:
+        result["other_configs"] = other_configs(args)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+OTHER_CONFIGS = (("rgat", 10), ("qm9-ggnn", 3), ("qm9-edgemlp", 3), ("arxiv-rgin", 3))  # (workload, timed steps)
+
+
+def other_configs(args):
+    """The other BASELINE configs, timed briefly (a few steps each, own process: fresh allocator and weight caches) so that
+    the driver's line carries them next to the headline: ms/step, edges/s, the dominant kernel's roofline fraction and the
+    CPU baseline of the same model.  They are reported, not part of `value`."""
+    out = {}
+    for name, steps in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "1", "--no-alt-mode",
+               "--no-other-configs", "--gemm-mode", args.gemm_mode, "--cpu-baseline-seconds", "8"]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        if args.no_roofline:
+            cmd.append("--no-roofline")
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            if res.returncode != 0 or not line:
+                out[name] = {"error": (res.stderr or res.stdout)[-300:]}
+                continue
+            r = json.loads(line[-1])
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            out[name] = {"error": str(e)[:300]}
+            continue
+        entry = {"workload": r["config"]["workload"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
+                 "unit": r["unit"], "scaling": r["scaling"]}
+        for key in ("roofline", "roofline_secondary"):
+            if key in r:
+                b = r[key]
+                entry[key] = {k: b.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch",
+                                                    "launches_per_step", "share_of_step", "achieved_basis")}
+        if "roofline_blocks_share_of_step" in r:
+            entry["roofline_blocks_share_of_step"] = r["roofline_blocks_share_of_step"]
+        if "cpu_baseline" in r:
+            entry["cpu_baseline"] = {k: r["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        out[name] = entry
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------

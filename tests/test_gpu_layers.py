@@ -234,9 +234,11 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     X32 = X.clone().requires_grad_(True)
     ref32 = orc.message_passing_call(cls_name, p, w32, X32, adj_t)
     (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
-    assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, 2 * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
+    # un-normalised sums over the 150-edge hub reach |x| ~ 15 before the GRU / the next product: factor 3 there
+    slack = 3 if p.get("normalize_by_num_incoming", True) is False else 2
+    assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, slack * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
     grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
-    assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, 2 * scaled_error(dX32, grads[0])), what=name + " dX")
+    assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, slack * scaled_error(dX32, grads[0])), what=name + " dX")
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
     pairs = []
     for l in range(L):
@@ -907,8 +909,12 @@ def test_generic_backward_refuses_what_it_cannot_differentiate(dev):
     p["hidden_dim"] = 8
     layer = KernelOnly(p)
     adjs = random_graph(20, 60, 2, seed=1)
-    out = layer(MessagePassingInput(torch.randn((20, 8), device=dev), to_dev(adjs, dev)))
+    out = layer(MessagePassingInput(torch.randn((20, 8), device=dev), to_dev(adjs, dev)), training=True)
     with pytest.raises(NotImplementedError, match="autograd history"):
+        layer.backward(torch.ones_like(out))
+    # eval-mode forward passes record no tape (and leave the variables plain tensors): backward says so
+    out = layer(MessagePassingInput(torch.randn((20, 8), device=dev), to_dev(adjs, dev)), training=False)
+    with pytest.raises(RuntimeError, match="training"):
         layer.backward(torch.ones_like(out))
 
 

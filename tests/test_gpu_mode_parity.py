@@ -179,7 +179,13 @@ def test_benchmarked_rgcn_stack_training_step_matches_fp64_oracle(dev, gemm_mode
         assert_close(a.cpu(), b.detach().float(), tol=1e-5, what=f"{tag} representation {i}")
     assert_close(out.cpu(), ref64.detach().float(), tol=1e-5, what=f"{tag} output")
     grads = torch.autograd.grad((ref64 * dOut.double()).sum(), [X64] + leaves)
-    assert_close(dX.cpu(), grads[0].float(), tol=1e-5, what=f"{tag} d node_features")
+    # d node_features is a K = 320 product of the projection kernel with gradients that went through four layers: the
+    # yardstick is the reference-order fp32 evaluation of the same backward pass (its error against fp64, same masks)
+    X32 = X.clone().requires_grad_(True)
+    with ForcedKinks(lambda i, x: relu_masks[i]):
+        ref32, _ = orc.gnn_internal_call(params, w, X32, adj_t, dropout_masks=masks)
+        (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
+    assert_close(dX.cpu(), grads[0].float(), tol=max(1e-5, 2 * scaled_error(dX32, grads[0])), what=f"{tag} d node_features")
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
 
     def check_grad(var, leaf, what):
@@ -193,5 +199,5 @@ def test_benchmarked_rgcn_stack_training_step_matches_fp64_oracle(dev, gemm_mode
         for l in range(L):
             check_grad(mp._edge_type_mlps.vars[l][0], w64["mp"][i]["edge_mlps"][l][0], f"layer {i} dW_{l}")
     # the reference-order fp32 evaluation of the same step for scale: how far is ITS output from fp64?
-    ref32, _ = orc.gnn_internal_call(params, w, X, adj_t, dropout_masks=masks)
+    record_parity(f"{tag} reference-order fp32 d node_features vs fp64", max_scaled_error=scaled_error(dX32, grads[0]), bound=1e-5)
     record_parity(f"{tag} reference-order fp32 output vs fp64", max_scaled_error=scaled_error(ref32, ref64.detach()), bound=1e-5)

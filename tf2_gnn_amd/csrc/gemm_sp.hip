@@ -51,13 +51,6 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-// Probe builds (tools/sp_ablate.py) compile this file with -DSP_ABLATE=<bits> to leave parts of the main loop out:
-// 1 no DMA, 2 no fragment reads, 4 no MFMAs, 8 no barrier, 16 no stores, 32 no DMA of A, 64 no DMA of B, 128 hardware ids,
-// 256 full-line DMA pattern (data lands wrongly), 512 no epilogue.  The library is built without it.
-#ifndef SP_ABLATE
-#define SP_ABLATE 0
-#endif
-
 constexpr int SP_BM = 128;
 constexpr int SP_NT = 256;
 
@@ -332,7 +325,6 @@ struct SpLoop {
     // 35 of them at BN = 320 - runs out of SGPRs, parks the buffer descriptors in VGPRs and wraps every DMA in a
     // readfirstlane waterfall loop.  Here m0 is base + immediate: two SGPRs in all.
     unsigned so = (unsigned)(step < nsteps ? step : nsteps - 1) * 64u;
-    if constexpr ((SP_ABLATE & 256) != 0) so = (unsigned)(step % (nsteps / 2)) * 128u;  // probe: 8 rows x 128 B per DMA
     if constexpr (I < G::ND_A)
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(so) : "memory");
@@ -394,14 +386,9 @@ struct SpLoop {
   template <int S, int I, bool ABLK>
   __device__ __forceinline__ void step_items(int sbase) {
     if constexpr (I < NM) {
-      if constexpr (!(SP_ABLATE & 4)) mfma_one<I, (S & 1)>();
-      if constexpr (I < NR) {
-        if constexpr (!(SP_ABLATE & 2)) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
-      } else if constexpr (I < NR + G::ND) {
-        constexpr bool is_a = (I - NR) < G::ND_A;
-        if constexpr (!(SP_ABLATE & 1) && !((SP_ABLATE & 32) && is_a) && !((SP_ABLATE & 64) && !is_a))
-          dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
-      }
+      mfma_one<I, (S & 1)>();
+      if constexpr (I < NR) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
+      else if constexpr (I < NR + G::ND) dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
       if constexpr (ABLK && I == NM - 1) scale_frags<((S + 1) & 1)>(sbase + S + 1);  // after the last read was issued
       step_items<S, I + 1, ABLK>(sbase);
     }
@@ -409,9 +396,8 @@ struct SpLoop {
   template <int S, bool ABLK>
   __device__ __forceinline__ void step(int sbase) {
     step_items<S, 0, ABLK>(sbase);
-    if constexpr ((SP_ABLATE & (1 | 32 | 64)) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
-    if constexpr (!(SP_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    __builtin_amdgcn_s_barrier();
   }
   template <int S, bool ABLK>
   __device__ __forceinline__ void steps(int sbase) {  // one unrolled loop body: up to UNR steps (wave-uniform guard)
@@ -474,12 +460,6 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   for (int i = 0; i < G::ND_A; ++i) L.voff_a[i] = (unsigned)(((wave * G::ND_A + i) * 16 + drow) * g.lda + dq * 16);
 #pragma unroll
   for (int i = 0; i < G::ND_B; ++i) L.voff_b[i] = (unsigned)(((wave * G::ND_B + i) * 16 + drow) * g.ldb + dq * 16);
-  if constexpr ((SP_ABLATE & 256) != 0) {  // probe: full 128-byte lines, 8 rows per DMA instruction (data lands wrongly)
-#pragma unroll
-    for (int i = 0; i < G::ND_A; ++i) L.voff_a[i] = (unsigned)(((wave * G::ND_A + i) * 8 + (lane >> 3)) * g.lda + (lane & 7) * 16);
-#pragma unroll
-    for (int i = 0; i < G::ND_B; ++i) L.voff_b[i] = (unsigned)(((wave * G::ND_B + i) * 8 + (lane >> 3)) * g.ldb + (lane & 7) * 16);
-  }
 
   // ---- fragment addresses (one base register per stage and operand plane; tiles are immediate offsets) ---------
   const int fi = lane & 31, kg = lane >> 5;
@@ -536,11 +516,6 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  if constexpr ((SP_ABLATE & 512) != 0) return;  // probe: no epilogue at all
-  if constexpr (SP_ABLATE & 128) {  // probe: where did the waves of this workgroup run?  (HW_REG_HW_ID = 4)
-    if (lane == 0) reinterpret_cast<unsigned*>(g.C)[blockIdx.x * 4 + wave] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-    return;
-  }
   // ---- epilogue ------------------------------------------------------------------------------------------------
   // Scales, bias and activation are applied in the accumulator layout (their operands were fetched before the main
   // loop: column factors / bias per (lane, column tile), row factors by a lane exchange of a_rmax), then a 32-row
@@ -722,7 +697,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
           if (savp) { w.x *= sv[j].x; w.y *= sv[j].y; w.z *= sv[j].z; w.w *= sv[j].w; }
         }
         if (g.accumulate) { w.x += o[j].x; w.y += o[j].y; w.z += o[j].z; w.w += o[j].w; }
-        if (ok[j] && (!(SP_ABLATE & 16) || w.x == 12345.678f)) *reinterpret_cast<float4*>(cptr + coff[j]) = w;
+        if (ok[j]) *reinterpret_cast<float4*>(cptr + coff[j]) = w;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -328,6 +328,15 @@ class GNN:
             g = torch.zeros_like(ctx["steps"][-1].get("dense_out", ctx["h0"])) if self._num_layers else None
         g_is_pre = False  # g already carries the activation derivative of the op differentiated next
         g_last = None
+        try:
+            return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
+        finally:
+            # stand-alone layer.backward() calls after this pass join the second stream themselves again
+            for mp in self._mp_layers:
+                mp._defer_aux_join = False
+            ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
+
+    def _backward_walk(self, ctx, g, g_is_pre, g_last, extras, need_input_grad):
         for layer_idx in range(self._num_layers - 1, -1, -1):
             st = ctx["steps"][layer_idx]
             mp = self._mp_layers[layer_idx]
@@ -378,9 +387,7 @@ class GNN:
         gpre = g
         if self._init_act is not None and not g_is_pre:
             gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
-        res = self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
-        ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
-        return res
+        return self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
 
 
 def _act_name(fn):

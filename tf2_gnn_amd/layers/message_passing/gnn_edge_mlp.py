@@ -663,7 +663,7 @@ class GNN_Edge_MLP(MessagePassing):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
-        if "per_type" in ctx:  # the forward pass ran a user message function on the generic path
+        if ctx.get("generic"):  # the forward pass ran a user message function on the generic path
             return MessagePassing.backward(self, grad_output)
         d_agg = self._backward_finish(grad_output, ctx)
         return self._backward_messages(d_agg, ctx)
@@ -680,7 +680,7 @@ class GNN_Edge_MLP(MessagePassing):
         return act, (ctx["pre"] if act == "gelu" else ctx["out"])
 
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
-        if not self._plain_base_backward() or (self._ctx is not None and "per_type" in self._ctx):
+        if not self._plain_base_backward() or (self._ctx is not None and self._ctx.get("generic")):
             return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
         ctx = self._ctx
         if ctx is None:

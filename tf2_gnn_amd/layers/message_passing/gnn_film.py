@@ -199,7 +199,7 @@ class GNN_FiLM(GNN_Edge_MLP):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
-        if "per_type" in ctx:  # user message function on the generic path
+        if ctx.get("generic"):  # user message function on the generic path
             return MessagePassing.backward(self, grad_output)
         if ctx.get("per_edge"):
             return self._backward_per_edge(grad_output, ctx)

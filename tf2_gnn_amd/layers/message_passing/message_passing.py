@@ -243,8 +243,12 @@ class MessagePassing:
         if isinstance(adjacency_lists, ops.Graph):
             raise ValueError("the generic MessagePassing path needs the adjacency list tensors")
         num_nodes = node_embeddings.shape[0]
-        record = {"per_type": []}
-        self._generic_record = record
+        self._release_tape()  # a previous training-mode call whose backward never ran
+        # the autograd tape (per-edge states as leaves, variables with requires_grad) is only recorded when a backward
+        # pass can follow: training mode, or ``record_tape_in_eval = True`` on the layer (gradient checks in eval mode)
+        record_tape = bool(training) or bool(getattr(self, "record_tape_in_eval", False))
+        record = {"generic": True, "per_type": []} if record_tape else {"generic": True}
+        self._generic_record = record if record_tape else None
         try:
             messages_per_type = self._calculate_messages_per_type(adjacency_lists, node_embeddings, training)
         finally:
@@ -307,13 +311,33 @@ class MessagePassing:
             messages_per_type.append(m)
         return messages_per_type
 
+    def _release_tape(self):
+        """Drop the autograd tape of the generic path and make the variables plain tensors again (in-place optimizer
+        updates of a leaf that requires grad raise outside no_grad)."""
+        ctx = getattr(self, "_ctx", None)
+        if isinstance(ctx, dict) and "per_type" in ctx:
+            ctx.pop("per_type", None)
+            ctx.pop("messages", None)
+        for v in getattr(self, "_variables", []):
+            if v.trainable and v.value.requires_grad:
+                v.value.grad = None
+                v.value.requires_grad_(False)
+
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
         """Generic backward: d out / d messages through this library's activation / aggregation kernels, the user's
         ``_message_function`` through torch autograd, the two per-edge state gradients scattered back to the nodes by the
-        gather kernel.  Fills ``Variable.grad`` and returns d(node_embeddings)."""
+        gather kernel.  Fills ``Variable.grad`` and returns d(node_embeddings).  Needs a forward pass that recorded the
+        tape: ``training=True`` (or ``layer.record_tape_in_eval = True``)."""
         ctx = self._ctx
         if ctx is None or "per_type" not in ctx:
-            raise RuntimeError("backward called before a forward pass")
+            raise RuntimeError("backward called before a forward pass in training mode (the generic path records its "
+                               "autograd tape only when training=True or layer.record_tape_in_eval is set)")
+        try:
+            return self._generic_backward(ctx, grad_output)
+        finally:
+            self._release_tape()
+
+    def _generic_backward(self, ctx, grad_output: torch.Tensor) -> torch.Tensor:
         if type(self)._compute_new_node_embeddings is not MessagePassing._compute_new_node_embeddings:
             raise NotImplementedError(
                 f"{type(self).__name__} overrides _compute_new_node_embeddings; the generic backward covers the base class "
@@ -374,9 +398,7 @@ class MessagePassing:
         for v in self._variables:
             if v.trainable:
                 v.grad = v.value.grad if v.value.grad is not None else torch.zeros_like(v.value)
-                v.value.grad = None
-                v.value.requires_grad_(False)  # plain tensors again: optimizers update them in place
-        return dX
+        return dX  # backward() releases the tape and resets requires_grad
 
     # ---- hooks that let the layer stack fold element-wise backward steps into this layer's last GEMM ----------
     def activation_backward_spec(self):

@@ -68,8 +68,11 @@ def _get_name_to_variable_map(model) -> Dict[str, Any]:
 
 def save_model(save_file: str, model, dataset=None, extra_data_to_store: Optional[Dict[str, Any]] = None,
                store_weights_in_pkl: bool = True) -> None:
-    """model_utils.py:37-71.  Weight names carry the ":0" suffix of tf.Variable names so that the file reads back through
-    the reference's loader as well."""
+    """model_utils.py:37-71.  Weight names carry the ":0" suffix of tf.Variable names, so the "model_weights" dictionary is
+    what the reference's ``load_weights_verbosely`` matches by name.  The pickle as a whole is NOT loadable by the reference's
+    plain ``pickle.load``: ``model_class`` / ``dataset_class`` are stored as class objects like in the reference
+    (model_utils.py:42-46) and are tf2_gnn_amd classes here - a reference process needs tf2_gnn_amd importable, or reads
+    the weights with a tolerant unpickler like ``load_pickle`` below."""
     data_to_store = {
         "model_class": model.__class__,
         "model_params": getattr(model, "_params", {}),
@@ -238,6 +241,12 @@ def load_weights_verbosely(
         for n in var_name_to_weights.keys():
             if n not in used_saved:
                 print(f"I: Model does not use saved weights for {n}.")
+    # validate every shape BEFORE the first in-place write: a mismatch on variable k must not leave variables 0..k-1
+    # overwritten and the rest untouched (K.batch_set_value in the reference raises before assigning, model_utils.py:144-147)
+    for var, w in assignments:
+        if tuple(np.shape(w)) != tuple(var.value.shape):
+            raise ValueError(f"Shape mismatch for {var.name}: model has {tuple(var.value.shape)}, file has {tuple(np.shape(w))}; "
+                             "no weight was restored")
     for var, w in assignments:
         assign_variable(var, w)
     return restored

@@ -1,5 +1,8 @@
 """Where does the time of gemm_sp_nt_kernel go?  Builds probe variants of the library with parts of the main loop left
-out (-DSP_ABLATE=bits, see csrc/gemm_sp.hip) and times the forward shape with each.
+out and times the forward shape with each.  The shipped source (csrc/gemm_sp.hip) carries NO probe code: the
+instrumentation lives in tools/sp_ablate.patch and is applied to a temporary copy of the source here (-DSP_ABLATE=bits:
+1 no DMA, 2 no fragment reads, 4 no MFMAs, 8 no barrier, 16 no stores, 32 no DMA of A, 64 no DMA of B, 128 hardware ids,
+256 full-line DMA pattern (data lands wrongly), 512 no epilogue).
   python tools/sp_ablate.py build      (here: cross-compiles the variants into tools/_probe/)
   python tools/sp_ablate.py            (on the GPU box)"""
 import ctypes
@@ -23,11 +26,14 @@ if os.environ.get("SP_ABLATE_VARIANTS"):
 def build():
     OUT.mkdir(exist_ok=True)
     objs = [str(p) for p in (ROOT / "tf2_gnn_amd" / "csrc" / "_obj").glob("*.o") if p.name != "gemm_sp.o"]
+    src = OUT / "gemm_sp_instrumented.hip"  # the shipped kernel + the probe arms
+    src.write_text((ROOT / "tf2_gnn_amd" / "csrc" / "gemm_sp.hip").read_text())
+    subprocess.check_call(["patch", "-s", str(src), str(ROOT / "tools" / "sp_ablate.patch")])
     for bits in VARIANTS:
         obj = OUT / f"gemm_sp_{bits}.o"
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-pass-failed",
                                f"-DSP_ABLATE={bits}", f"-I{ROOT / 'include'}", f"-I{ROOT / 'tf2_gnn_amd' / 'csrc'}", "-c",
-                               str(ROOT / "tf2_gnn_amd" / "csrc" / "gemm_sp.hip"), "-o", str(obj)])
+                               str(src), "-o", str(obj)])
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, str(obj), "-o", str(OUT / f"libtfgnn_abl_{bits}.so")])
         obj.unlink()
         print("built", bits, VARIANTS[bits], flush=True)
