@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="N > 1: add the training-step exchange (one bucketed RCCL all-reduce of the weight gradients) to every "
                          "step; off by default - the fwd+bwd metric itself has no collective")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle loop (launch-path tests)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short timings of the other BASELINE workloads that the default run reports under `other_configs`")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -459,7 +460,8 @@ def main():
     def timed(warmup, steps):
         for _ in range(warmup):
             step()
-        settle()
+        if not args.no_settle:
+            settle()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -41,8 +41,10 @@ def step(gnn, pool, feats, adjs, n2g, G, c, dev):
     X = torch.from_numpy(np.ascontiguousarray(feats)).to(dev)
     adj_dev = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in adjs)
     n2g_dev = torch.from_numpy(np.ascontiguousarray(n2g, dtype=np.int32)).to(dev)
+    # training mode for the GNN (rate 0: no masks); the pooling MLPs apply dropout when training (rate 0.2), and the masks
+    # of a shard cannot equal those of the whole batch -> eval mode there
     out = gnn(GNNInput(X, adj_dev, n2g_dev, G), training=True)
-    pooled = pool(NodesToGraphRepresentationInput(out, n2g_dev, G), training=True)
+    pooled = pool(NodesToGraphRepresentationInput(out, n2g_dev, G), training=False)
     d_pooled = (torch.from_numpy(c).to(dev) / float(G)).contiguous()
     gnn.backward(pool.backward(d_pooled))
     loss = float((pooled.double() * torch.from_numpy(c).to(dev).double()).sum() / G)

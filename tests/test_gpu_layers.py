@@ -234,8 +234,9 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     X32 = X.clone().requires_grad_(True)
     ref32 = orc.message_passing_call(cls_name, p, w32, X32, adj_t)
     (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
-    # un-normalised sums over the 150-edge hub reach |x| ~ 15 before the GRU / the next product: factor 3 there
-    slack = 3 if p.get("normalize_by_num_incoming", True) is False else 2
+    # un-normalised sums over the 150-edge hub: the aggregate-first product is ONE fp32 chain over L x D = 640 terms at the
+    # magnitude of the 150-edge sum (|.| ~ 45), the reference's order a chain over the 150 messages - factor 4 there
+    slack = 4 if p.get("normalize_by_num_incoming", True) is False else 2
     assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, slack * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
     grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
     assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, slack * scaled_error(dX32, grads[0])), what=name + " dX")

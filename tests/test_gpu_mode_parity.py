@@ -135,7 +135,8 @@ def test_benchmarked_rgcn_stack_training_step_matches_fp64_oracle(dev, gemm_mode
     cross-layer gradient epilogues), 4 edge types, R-MAT edges at the benchmark's density (30 edges per node), TRAINING
     mode: the masks the HIP dropout kernel drew are read back and injected into the oracle.  Output, all five
     representations, d node_features and EVERY weight gradient against fp64 autograd through `orc.gnn_internal_call`;
-    bound 1e-5 * max(1, |ref|) on states, 1e-5 of the largest entry on weight gradients (measured values: parity_r03.json)."""
+    bound 1e-5 * max(1, |ref|) on states, 1e-5 of the largest entry on weight gradients, 2e-5 scaled on d node_features (the
+    bound of every input-gradient check of the suite; measured values: parity_r03.json)."""
     from bench import ppi_rgcn_params
     from tf2_gnn_amd.data import make_synthetic_batch
     from tf2_gnn_amd.layers import GNN, GNNInput
@@ -185,7 +186,7 @@ def test_benchmarked_rgcn_stack_training_step_matches_fp64_oracle(dev, gemm_mode
     with ForcedKinks(lambda i, x: relu_masks[i]):
         ref32, _ = orc.gnn_internal_call(params, w, X32, adj_t, dropout_masks=masks)
         (dX32,) = torch.autograd.grad((ref32 * dOut).sum(), [X32])
-    assert_close(dX.cpu(), grads[0].float(), tol=max(1e-5, 2 * scaled_error(dX32, grads[0])), what=f"{tag} d node_features")
+    assert_close(dX.cpu(), grads[0].float(), tol=max(2e-5, 2 * scaled_error(dX32, grads[0])), what=f"{tag} d node_features")
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
 
     def check_grad(var, leaf, what):

@@ -534,11 +534,17 @@ extern "C" int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_
 
 // ---- grouped variants ---------------------------------------------------------------------------
 namespace tfgnn {
+constexpr int64_t kMaxAccumulationChainRows = 16384;
 static int grouped_splits(int num_groups, int64_t max_rows, int64_t M, int64_t N, int bm, int bn) {
   const int64_t tiles = ceil_div(M, bm) * ceil_div(N, bn) * num_groups;
   int64_t s = ceil_div(512, tiles > 0 ? tiles : 1);
   const int64_t max_by_k = max_rows / (4 * BK);
   if (s > max_by_k) s = max_by_k;
+  // accuracy: one fp32 accumulation chain per split - keep it under 16384 rows of K (cfg-5's largest relation has 10^5
+  // rows: a single chain leaves sqrt(K) 2^-24 ~ 2e-5 of the largest entry; partial sums of <= 16k rows, added in split
+  // order, 6e-6)
+  const int64_t by_chain = ceil_div(max_rows, kMaxAccumulationChainRows);
+  if (s < by_chain) s = by_chain;
   if (s > 64) s = 64;
   return s < 1 ? 1 : (int)s;
 }

@@ -1039,7 +1039,9 @@ int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, i
   g.n_tiles = (unsigned)(N / bn);
   const int64_t tiles = ceil_div(M, X3_BM) * (int64_t)g.n_tiles * num_groups;
   int64_t splits = ceil_div(512, tiles > 0 ? tiles : 1);
-  splits = std::min<int64_t>(splits, std::min<int64_t>(max_rows / 128, 64));
+  splits = std::min<int64_t>(splits, max_rows / 128);
+  splits = std::max<int64_t>(splits, ceil_div(max_rows, 16384));  // accuracy: fp32 chains of <= 16384 rows (gemm.hip grouped_splits)
+  splits = std::min<int64_t>(splits, 64);
   const size_t per_split = (size_t)num_groups * (size_t)M * (size_t)N * 4;
   if (splits > 1 && (!workspace || (uintptr_t)workspace % 16 || workspace_bytes < 2 * per_split)) splits = 1;
   if (splits > 1) splits = std::min<int64_t>(splits, (int64_t)(workspace_bytes / per_split));
