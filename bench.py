@@ -479,6 +479,10 @@ def main():
     ops.set_gemm_mode(args.gemm_mode)
     elapsed = timed(args.warmup, args.steps)
     ms_per_step_per_rank = [1000.0 * t / args.steps for t in per_rank_seconds]
+    # the spread guard of the f16x2 products (tfgnn_sp_spread_flag) demotes the mode to bf16x3 when it trips: the timed steps
+    # must have run in the mode the line reports
+    mode_ids = {"fp32": ops.GEMM_FP32, "bf16x3": ops.GEMM_BF16X3, "bf16x3_9": ops.GEMM_BF16X3_EXACT, "f16x2": ops.GEMM_F16X2}
+    assert ops.get_gemm_mode() == mode_ids[args.gemm_mode], "the GEMM mode changed during the timed steps (spread guard tripped)"
     # final metric reduction: all-gather of the per-rank edge / node counts (north_star: the only collective)
     gathered = parallel.all_gather_scalars([float(E), float(V), float(G)], dist, dev)
     total_edges_per_step = float(gathered[:, 0].sum())

@@ -295,9 +295,10 @@ int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const 
                size_t workspace_bytes, void* stream);
 
 /* How tfgnn_gemm evaluates the fp32 product (process-wide; initial value from the environment variable
- * TFGNN_GEMM_MODE = fp32 | bf16x3 | bf16x3_9):
- *   TFGNN_GEMM_FP32          v_mfma_f32_32x32x2_f32 on the fp32 operands (default)
- *   TFGNN_GEMM_BF16X3        every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and
+ * TFGNN_GEMM_MODE = fp32 | bf16x3 | bf16x3_9 | f16x2; unset or f16x2: TFGNN_GEMM_BF16X3 - "f16x2" is the host mirror's name
+ * for handing the layers' hot products to the tfgnn_sp_* entry points, everything else runs as bf16x3):
+ *   TFGNN_GEMM_FP32          v_mfma_f32_32x32x2_f32 on the fp32 operands
+ *   TFGNN_GEMM_BF16X3        (default) every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and
  *                            the six largest piece products - each exact in fp32 - are accumulated in fp32 on
  *                            v_mfma_f32_32x32x16_bf16; dropped terms are < 2^-23 |a b| (csrc/gemm_x3.hip)
  *   TFGNN_GEMM_BF16X3_EXACT  all nine piece products: products exact, only the fp32 accumulation rounds
@@ -535,6 +536,13 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
  * n = d: group_rows = H, stride_group = D * H, stride_row = 1, stride_col = H).  d_workspace: 256-byte aligned,
  * tfgnn_sp_gemm_tn_workspace_bytes bytes. */
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block);
+/* Guard of the limit above: the factor pass of every tfgnn_sp_gemm_tn sets a library-wide flag (host-visible without a
+ * stream synchronisation; it trails the device by however far the stream is behind) when a NON-ZERO operand row lies more
+ * than 2^13 below the largest row scale of its column block - such a row keeps fewer than 22 bits relative to itself, its
+ * ABSOLUTE error stays <= 2^-25 of the largest row's elements, i.e. below the fp32 rounding of the sum.  Returns the flag
+ * (0 / 1), clears it when reset != 0.  The host mirror (tf2_gnn_amd.ops) routes the split-operand layer paths to the
+ * exact bf16x3 kernels from the next call on once the flag is seen. */
+int tfgnn_sp_spread_flag(int reset);
 int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
                      const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
                      int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,

@@ -17,6 +17,7 @@ _SIGNATURES = [
     ("tfgnn_last_error", c_char_p, []),
     ("tfgnn_version", c_char_p, []),
     ("tfgnn_launch_counts", c_int, [POINTER(c_int64), c_int]),
+    ("tfgnn_sp_spread_flag", c_int, [c_int]),
     (
         "tfgnn_graph_create",
         c_int,

@@ -770,7 +770,7 @@ struct SpTnArgs {
 constexpr int SP_TN_FCHUNKS = 16;
 __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
                                                              int64_t ld_b, int64_t K, _Float16* __restrict__ F, int64_t f_ld,
-                                                             float* __restrict__ ref) {
+                                                             float* __restrict__ ref, int* __restrict__ spread_flag) {
   __shared__ float red[16];
   const int b = blockIdx.x / SP_TN_FCHUNKS, chunk = blockIdx.x % SP_TN_FCHUNKS;
   float mx = 0.f;
@@ -797,8 +797,16 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
   const float r = 1.f / mx;  // powers of two: exact
   const int64_t per = ((f_ld + SP_TN_FCHUNKS - 1) / SP_TN_FCHUNKS + 7) & ~7ll;
   const int64_t kend = (chunk + 1) * per < f_ld ? (chunk + 1) * per : f_ld;
-  for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 1024)
-    F[(int64_t)b * f_ld + k] = k < K ? (_Float16)(inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f) * r) : (_Float16)0.f;
+  bool wide = false;
+  for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 1024) {
+    const float f = k < K ? inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f) * r : 0.f;
+    F[(int64_t)b * f_ld + k] = (_Float16)f;
+    // a NON-ZERO row more than 2^13 below the block's largest scale product (all-zero rows carry the smallest normal
+    // scale, 2^-126: their factor is 0 and they contribute nothing): its elements keep fewer than 22 bits relative to
+    // THEMSELVES (the absolute error stays <= 2^-25 of the largest row's elements) - reported, see tfgnn_sp_spread_flag
+    wide |= f < 1.220703125e-4f && f > 1e-30f;
+  }
+  if (spread_flag && __any(wide) && (threadIdx.x & 63) == 0) *spread_flag = 1;
 }
 
 template <int TNW>
@@ -1154,6 +1162,31 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
 
 static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
+// one int in host memory mapped into the device's address space: the factor pass of the weight-gradient product stores 1
+// there when an operand's row scales spread over more than 2^13 (plain store, no atomic: the value only ever becomes 1);
+// the host reads it without synchronising with any stream
+static int* g_spread_host = nullptr;
+static int* g_spread_dev = nullptr;
+static int* sp_spread_flag_device() {
+  if (!g_spread_host) {
+    int* h = nullptr;
+    if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    *h = 0;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipHostFree(h);
+      return nullptr;
+    }
+    g_spread_host = h;
+    g_spread_dev = (int*)d;
+  }
+  return g_spread_dev;
+}
+
 }  // namespace tfgnn
 
 using namespace tfgnn;
@@ -1161,6 +1194,13 @@ using namespace tfgnn;
 extern "C" {
 
 size_t tfgnn_sp_bytes(int64_t rows, int64_t cols) { return (size_t)rows * (size_t)cols * 4; }
+
+int tfgnn_sp_spread_flag(int reset) {
+  if (!g_spread_host) return 0;
+  const int v = __atomic_load_n(g_spread_host, __ATOMIC_RELAXED);
+  if (reset) __atomic_store_n(g_spread_host, 0, __ATOMIC_RELAXED);
+  return v;
+}
 
 int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
                         int scale_block, void* d_sp, int64_t ld_sp_bytes, float* d_inv_scale,
@@ -1331,7 +1371,7 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
   if (phases & 1) {
     hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * SP_TN_FCHUNKS), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
-                       kpad, ref);
+                       kpad, ref, sp_spread_flag_device());
     TFGNN_LAUNCH_CHECK();
   }
   SpTnArgs g{};

@@ -882,13 +882,14 @@ static void launch_x3(const X3Args& g, dim3 grid, int nprod, int trans_a, int tr
 }
 
 // 0 = off (fp32 MFMA), 6 / 9 = number of piece products.  Initialised from TFGNN_GEMM_MODE
-// (fp32 | bf16x3 | bf16x3_9), changed at run time by tfgnn_gemm_set_mode().
+// (fp32 | bf16x3 | bf16x3_9 | f16x2; default bf16x3 - the mode the whole parity suite runs in since round 3), changed at run
+// time by tfgnn_gemm_set_mode().
 static int mode_from_env() {
   const char* e = getenv("TFGNN_GEMM_MODE");
-  if (!e) return 0;
-  if (!strcmp(e, "bf16x3") || !strcmp(e, "bf16x3_6")) return 6;
+  if (!e || !*e) return 6;
+  if (!strcmp(e, "fp32")) return 0;
   if (!strcmp(e, "bf16x3_9")) return 9;
-  return 0;
+  return 6;  // bf16x3, bf16x3_6, f16x2 (the split-operand layer paths are the host mirror's choice)
 }
 static int g_x3_mode = -1;
 int gemm_x3_mode() {

@@ -351,16 +351,28 @@ def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> 
 
 GEMM_FP32, GEMM_BF16X3, GEMM_BF16X3_EXACT, GEMM_F16X2 = 0, 6, 9, 3
 _GEMM_MODE_NAMES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "bf16x3_9": GEMM_BF16X3_EXACT, "f16x2": GEMM_F16X2}
-_f16x2 = [None]  # None: not decided yet (environment TFGNN_GEMM_MODE=f16x2 switches it on)
+_f16x2 = [None]  # None: not decided yet (environment TFGNN_GEMM_MODE; unset = f16x2, the default since round 3)
+_spread_warned = [False]
 
 
 def _f16x2_on() -> bool:
     if _f16x2[0] is None:
         import os
 
-        _f16x2[0] = os.environ.get("TFGNN_GEMM_MODE", "") == "f16x2"
+        _f16x2[0] = os.environ.get("TFGNN_GEMM_MODE", "f16x2") in ("f16x2", "")
         if _f16x2[0]:
             _lib.check(_lib.load().tfgnn_gemm_set_mode(GEMM_BF16X3))
+    if _f16x2[0] and _lib.load().tfgnn_sp_spread_flag(0):
+        # the guard of the split-operand weight-gradient product (include/tfgnn.h, tfgnn_sp_spread_flag): an operand's row
+        # scales spread over more than 2^13 - from here on the layers take the exact bf16x3 kernels (sticky until
+        # set_gemm_mode("f16x2") is called again)
+        _f16x2[0] = False
+        if not _spread_warned[0]:
+            _spread_warned[0] = True
+            import warnings
+
+            warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread over more than 2^13 in magnitude; "
+                          "the f16x2 layer paths are switched to the exact bf16x3 kernels (ops.set_gemm_mode('f16x2') re-arms them)")
     return _f16x2[0]
 
 
@@ -368,10 +380,14 @@ def set_gemm_mode(mode) -> int:
     """Select how the Dense products are evaluated: "fp32" (fp32 MFMA), "bf16x3" (exact 3-way bf16 split of both operands,
     6 piece products), "bf16x3_9" (all 9) - include/tfgnn.h, tfgnn_gemm_set_mode - or "f16x2": the layers hand the hot
     products pre-split SP16 operands (tfgnn_sp_gemm_*: 2-way fp16 split, 3 piece products, the gather writes the
-    operand) and every other product runs as in "bf16x3".  Returns the previous mode id."""
+    operand) and every other product runs as in "bf16x3".  "f16x2" is the DEFAULT (environment TFGNN_GEMM_MODE overrides);
+    its spread guard (tfgnn_sp_spread_flag) demotes it to "bf16x3" when an operand's row scales spread over more than 2^13.
+    Returns the previous mode id."""
     lib = _lib.load()
     prev = get_gemm_mode()
     mode = _GEMM_MODE_NAMES.get(mode, mode)
+    if mode == GEMM_F16X2:
+        lib.tfgnn_sp_spread_flag(1)  # re-arm the spread guard
     _f16x2[0] = mode == GEMM_F16X2
     _lib.check(lib.tfgnn_gemm_set_mode(GEMM_BF16X3 if mode == GEMM_F16X2 else mode))
     return prev
