@@ -602,16 +602,22 @@ def other_configs(args):
 # rooflines: the dominant kernels of a workload, timed live (HIP events on the launch stream) at the workload's shapes
 # --------------------------------------------------------------------------------------------------------------------
 def _pmc_traffic(workload, name):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic_<workload>.json;
-    FETCH_SIZE corrected x2 as calibrated on gfx950, MI355X_MICROARCH.md), or None."""
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic_<workload>.json, derived by
+    tools/parse_pmc.py from the committed counter CSVs profiles/r03_pmc_{fetch,write}_<workload>_counter_collection.csv;
+    FETCH_SIZE corrected x2 as calibrated on gfx950 by the streaming kernel in the same pass, MI355X_MICROARCH.md), or None."""
     if name is None:
         return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_traffic_{workload}.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(name, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    root = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
+        path = os.path.join(root, "profiles", f"{tag}_pmc_traffic_{workload}.json")
+        try:
+            with open(path) as f:
+                v = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+            if v:
+                return v
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
@@ -703,7 +709,8 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         Wk = torch.randn((H, N), device=dev) * 0.05
         ms = time_kernel(lambda: ops.gemm(Hx, Wk))
         out.append(hbm_block(f"dense product [V, {H}] x [{H}, {N}] (skinny GEMM: bytes of A and C bound it, not the matrix cores)", ms,
-                             V * H * 4 + V * N * 4 + H * N * 4, (4 if model == "ggnn" else 6) * NL))
+                             V * H * 4 + V * N * 4 + H * N * 4, (4 if model == "ggnn" else 6) * NL,
+                             "gemm" if mode == "fp32" else "gemm_bf16x3_pipelined"))
     if model == "rgat":
         K = wl.get("num_heads", 8)
         Wc = torch.randn((H, L * H), device=dev) * 0.05
@@ -715,7 +722,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         agg = torch.empty((V, H), device=dev)
         ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=ew, out=agg))
         out.append(hbm_block(f"csr_gather_reduce_kernel<HEADS> (attention-weighted sum over all in-edges of a node, {K} heads)", ms,
-                             E * (4 * H + 4 * K + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, None,
+                             E * (4 * H + 4 * K + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, "gather_heads",
                              V * L * H * 4 + E * (4 * K + 4) + (V + 1) * 4 + V * H * 4))
     if model == "rgin":
         # per-relation 2-layer edge MLP over the non-empty (source, type) pairs: grouped GEMMs over compact rows
@@ -731,7 +738,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         agg = torch.empty((V, H), device=dev)
         ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Ac, col=colc, out=agg))
         out.append(hbm_block("csr_gather_reduce_kernel (messages of all edge types summed per target node)", ms,
-                             E * (4 * H + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, None, nz * H * 4 + E * 4 + (V + 1) * 4 + V * H * 4))
+                             E * (4 * H + 4) + (V + 1) * 4 + V * H * 4, 2 * NL, "gather", nz * H * 4 + E * 4 + (V + 1) * 4 + V * H * 4))
     ms_graph = time_kernel(lambda: ops.Graph(adj_dev, V).close(), iters=5, warmup=1)
     for r in out:
         r["ms_edge_bucketing_per_batch"] = ms_graph

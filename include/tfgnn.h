@@ -538,8 +538,10 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block);
 /* Guard of the limit above: the factor pass of every tfgnn_sp_gemm_tn sets a library-wide flag (host-visible without a
  * stream synchronisation; it trails the device by however far the stream is behind) when a NON-ZERO operand row lies more
- * than 2^13 below the largest row scale of its column block - such a row keeps fewer than 22 bits relative to itself, its
- * ABSOLUTE error stays <= 2^-25 of the largest row's elements, i.e. below the fp32 rounding of the sum.  Returns the flag
+ * than 2^20 below the largest row scale of its column block.  Between 2^-13 and 2^-20 a row keeps 35 - j bits relative to
+ * itself and its ABSOLUTE error stays <= 2^-39 of the largest rows' elements - far below the fp32 rounding of the sum (the
+ * measured error of the product against fp64, relative to sum |a||b|, as a function of the spread: tests/test_gpu_f16x2_mode.py,
+ * profiles/parity_r03.json); beyond 2^-20 fewer than 15 bits are left and at 2^-24 the row drops out.  Returns the flag
  * (0 / 1), clears it when reset != 0.  The host mirror (tf2_gnn_amd.ops) routes the split-operand layer paths to the
  * exact bf16x3 kernels from the next call on once the flag is seen. */
 int tfgnn_sp_spread_flag(int reset);

@@ -364,14 +364,14 @@ def _f16x2_on() -> bool:
             _lib.check(_lib.load().tfgnn_gemm_set_mode(GEMM_BF16X3))
     if _f16x2[0] and _lib.load().tfgnn_sp_spread_flag(0):
         # the guard of the split-operand weight-gradient product (include/tfgnn.h, tfgnn_sp_spread_flag): an operand's row
-        # scales spread over more than 2^13 - from here on the layers take the exact bf16x3 kernels (sticky until
+        # scales spread over more than 2^20 - from here on the layers take the exact bf16x3 kernels (sticky until
         # set_gemm_mode("f16x2") is called again)
         _f16x2[0] = False
         if not _spread_warned[0]:
             _spread_warned[0] = True
             import warnings
 
-            warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread over more than 2^13 in magnitude; "
+            warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread over more than 2^20 in magnitude; "
                           "the f16x2 layer paths are switched to the exact bf16x3 kernels (ops.set_gemm_mode('f16x2') re-arms them)")
     return _f16x2[0]
 
@@ -381,7 +381,7 @@ def set_gemm_mode(mode) -> int:
     6 piece products), "bf16x3_9" (all 9) - include/tfgnn.h, tfgnn_gemm_set_mode - or "f16x2": the layers hand the hot
     products pre-split SP16 operands (tfgnn_sp_gemm_*: 2-way fp16 split, 3 piece products, the gather writes the
     operand) and every other product runs as in "bf16x3".  "f16x2" is the DEFAULT (environment TFGNN_GEMM_MODE overrides);
-    its spread guard (tfgnn_sp_spread_flag) demotes it to "bf16x3" when an operand's row scales spread over more than 2^13.
+    its spread guard (tfgnn_sp_spread_flag) demotes it to "bf16x3" when an operand's row scales spread over more than 2^20.
     Returns the previous mode id."""
     lib = _lib.load()
     prev = get_gemm_mode()

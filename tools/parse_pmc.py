@@ -37,12 +37,19 @@ cal_w = pick(write, "act_forward_kernel") * 1024.0
 kf, kw = known / cal_f, known / cal_w
 res = {"calibration": {"known_bytes_each_way": known, "fetch_raw_bytes": cal_f, "write_raw_bytes": cal_w,
                        "fetch_factor": kf, "write_factor": kw}}
-for name, needle in (("gather", ("csr_gather_reduce_kernel", "false>")), ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel"),
-                     ("gather_sp", ("csr_gather_reduce_kernel", "true>")), ("gemm_sp_nt", "gemm_sp_nt_kernel"),
-                     ("gemm_sp_tn", "gemm_sp_tn_kernel")):
-    if pick(fetch, needle) is None:
+# traffic keys of bench.py's roofline blocks -> substrings of the kernel name
+NEEDLES = (
+    ("gather", ("csr_gather_reduce_kernel", ", 0, false>")), ("gather_sp", ("csr_gather_reduce_kernel", ", 0, true>")),
+    ("gather_heads", ("csr_gather_reduce_kernel", ", 1, false>")),
+    ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel"), ("gemm_bf16x3_pipelined", "gemm_x3p_kernel"),
+    ("gemm_sp_nt", "gemm_sp_nt_kernel"), ("gemm_sp_tn", "gemm_sp_tn_kernel"), ("gemm_skinny", "gemm_skinny"),
+)
+for name, needle in NEEDLES:
+    if pick(fetch, needle) is None or pick(write, needle) is None:
         continue
     f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0
-    res[name] = {"fetch_raw_bytes": f, "write_raw_bytes": w, "hbm_bytes_per_launch": f * kf + w * kw}
+    res[name] = {"kernel": [k for k in fetch if all(n in k for n in ((needle,) if isinstance(needle, str) else needle))][0][:160],
+                 "fetch_raw_bytes": f, "write_raw_bytes": w, "hbm_bytes_per_launch": f * kf + w * kw}
+res["all_kernels_raw_kib"] = {k[:120]: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(res, indent=1))
+print(json.dumps({k: v for k, v in res.items() if k != "all_kernels_raw_kib"}, indent=1))
