@@ -219,9 +219,12 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
             break
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    t_layer_full = sweep[threads] / cal  # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated
-    # the sample: whole stack on the whole batch if ~3 runs fit the budget, else fewer layers, then a fraction of the batch
-    per_run = budget_seconds / 3.5
+    # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated from a 1/8 sample (the 1/64 runs of the
+    # sweep are dominated by fixed costs)
+    t_layer_full = 8.0 * run(1.0 / 8, 1) if sweep[threads] / cal > 2.0 else sweep[threads] / cal
+    # the sample: whole stack on the whole batch if a warm-up and two timed runs fit the budget, else fewer layers, then a
+    # fraction of the batch
+    per_run = budget_seconds / 3.0
     layers = NL if t_layer_full * NL <= per_run else max(1, min(NL, int(per_run / max(t_layer_full, 1e-6))))
     frac = float(min(1.0, max(cal, per_run / max(t_layer_full * layers, 1e-6))))
     t_used = run(frac, layers)  # warm-up at the sample size
@@ -291,7 +294,7 @@ def main():
     ap.add_argument("--reuse-graph", action="store_true", help="bucket the edges once, outside the timed steps")
     ap.add_argument("--serial-bucketing", action="store_true", help="bucket each batch on the compute stream (no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="host time budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=36.0, help="host time budget of the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-mode", default="f16x2", choices=["fp32", "bf16x3", "bf16x3_9", "f16x2"],
                     help="how the fp32 products run on the matrix cores (include/tfgnn.h): fp32 MFMA, exact bf16 operand splitting "
