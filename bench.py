@@ -548,6 +548,16 @@ def main():
         if len(roofs) > 2:
             result["roofline_other"] = roofs[2:]
 
+    if rank == 0 and world == 1 and not args.no_roofline and args.workload != "rmat30k":
+        # the non-headline workloads spread their step over many kernels: the per-op breakdown of the REAL step (HIP events
+        # around every library op) says where the step goes and prices each op against its roof
+        ops.set_gemm_mode(args.gemm_mode)
+        result["step_breakdown"] = step_breakdown(step, ops)
+        for g_, _x in pending:
+            g_.wait()
+            g_.close()
+        pending.clear()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl, batch, params, budget_seconds=args.cpu_baseline_seconds)
 
@@ -595,10 +605,138 @@ def other_configs(args):
                                                     "launches_per_step", "share_of_step", "achieved_basis")}
         if "roofline_blocks_share_of_step" in r:
             entry["roofline_blocks_share_of_step"] = r["roofline_blocks_share_of_step"]
+        if "step_breakdown" in r:
+            sb = r["step_breakdown"]
+            entry["step_breakdown"] = {"ops_share_of_step": sb["ops_share_of_step"], "top_share_of_step": sb["top_share_of_step"],
+                                       "top": [{k: e[k] for k in ("op", "shapes", "launches_per_step", "ms_per_launch", "share_of_step", "bound", "frac")}
+                                               for e in sb["top"][:8]]}
         if "cpu_baseline" in r:
             entry["cpu_baseline"] = {k: r["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
         out[name] = entry
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# step breakdown: every library op of ONE real step between HIP events (launch stream), aggregated by (op, shapes)
+# --------------------------------------------------------------------------------------------------------------------
+_TIMED_OPS = ("gemm", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
+              "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
+              "activation_backward", "dropout_forward", "mul", "add_scale", "colsum", "layernorm_forward", "layernorm_backward",
+              "permute_021", "transpose_batched", "edge_aggregate_backward", "sp_split_rows", "sp_split_cols", "clip", "clip_backward")
+_PRODUCT_OPS = {"gemm", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
+
+
+def step_breakdown(step, ops, steps=2, top=12):
+    """Per-op time of the real step: every tf2_gnn_amd.ops call listed in _TIMED_OPS is bracketed by HIP events on the launch
+    stream for ``steps`` steps (after one untimed step), then aggregated by op name and tensor shapes.  For every entry:
+    launches per step, ms per launch, share of the step, the bytes it has to move (every tensor argument and result once:
+    compulsory bytes) and, for products, the fp32 flops - priced against the HBM roof or the matrix-core roof, whichever
+    takes longer at peak.  Nested library calls (gemm inside gemm_grad) are attributed to the outermost op.
+    -> (entries sorted by share, sum of shares)"""
+    records = []
+    depth = [0]
+    real = {}
+
+    def tensors_of(obj, out):
+        if isinstance(obj, torch.Tensor):
+            out.append(obj)
+        elif isinstance(obj, ops.SplitOperand):
+            out.append(obj.data)
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                tensors_of(o, out)
+        elif isinstance(obj, dict):
+            for o in obj.values():
+                tensors_of(o, out)
+
+    def wrap(name, fn):
+        def timed(*a, **k):
+            if depth[0]:
+                return fn(*a, **k)
+            depth[0] += 1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                res = fn(*a, **k)
+            finally:
+                depth[0] -= 1
+            e1.record()
+            ts = []
+            tensors_of((a, k, res), ts)
+            seen, nbytes, shapes = set(), 0, []
+            for t in ts:
+                if t.data_ptr() in seen:
+                    continue
+                seen.add(t.data_ptr())
+                nbytes += t.numel() * t.element_size()
+                if t.numel() * t.element_size() >= 1 << 16:
+                    shapes.append("x".join(map(str, t.shape)) + ("" if t.dtype == torch.float32 else f":{str(t.dtype).split('.')[-1]}"))
+            flops = 0.0
+            if name in _PRODUCT_OPS:
+                big = sorted((t for t in ts if t.dim() >= 2), key=lambda t: -t.numel())[:3]
+                if name in ("sp_gemm_nt", "sp_gemm_nt_split") and isinstance(a[0], ops.SplitOperand):
+                    flops = 2.0 * a[0].rows * a[0].cols * a[1].rows
+                elif name == "sp_gemm_tn" and isinstance(a[0], ops.SplitOperand):
+                    M = (k.get("a_cols") or (0, a[0].cols))[1]
+                    N = (k.get("b_cols") or (0, a[1].cols))[1]
+                    flops = 2.0 * a[0].rows * M * N
+                elif name == "gemm_gru":
+                    flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
+                elif name == "gemm_grouped_k":
+                    flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
+                elif len(big) >= 2 and isinstance(res, (torch.Tensor, tuple)):
+                    r = res[0] if isinstance(res, tuple) else res
+                    r = r if isinstance(r, torch.Tensor) else big[0]
+                    x, y = a[0], a[1]
+                    inner = x.shape[0] if k.get("trans_a") else x.shape[-1]
+                    flops = 2.0 * r.numel() * inner
+            records.append((name, " ".join(shapes[:4]), e0, e1, nbytes, flops))
+            return res
+        return timed
+
+    for name in _TIMED_OPS:
+        if hasattr(ops, name):
+            real[name] = getattr(ops, name)
+            setattr(ops, name, wrap(name, real[name]))
+    try:
+        step()
+        torch.cuda.synchronize()
+        records.clear()
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(steps):
+            step()
+        t1.record()
+        torch.cuda.synchronize()
+    finally:
+        for name, fn in real.items():
+            setattr(ops, name, fn)
+    total_ms = t0.elapsed_time(t1) / steps
+    agg = {}
+    for name, shapes, e0, e1, nbytes, flops in records:
+        a = agg.setdefault((name, shapes), [0, 0.0, nbytes, flops])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+    mode = ops.get_gemm_mode()
+    entries = []
+    for (name, shapes), (n, ms, nbytes, flops) in agg.items():
+        ms_launch = ms / n
+        executed = flops * (1 if mode == ops.GEMM_FP32 else (3 if name.startswith("sp_") else (9 if mode == ops.GEMM_BF16X3_EXACT else 6)))
+        peak_tf = MFMA_FP32_PEAK_TFLOPS if (mode == ops.GEMM_FP32 and not name.startswith("sp_")) else MFMA_16BIT_PEAK_TFLOPS
+        t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+        t_mfma = executed / (peak_tf * 1e12)
+        bound = "mfma" if t_mfma > t_hbm else "hbm"
+        achieved = (executed / (ms_launch * 1e-3) / 1e12) if bound == "mfma" else (nbytes / (ms_launch * 1e-3) / 1e9)
+        peak = peak_tf if bound == "mfma" else HBM_PEAK_GBS
+        entries.append({"op": name, "shapes": shapes, "launches_per_step": n / steps, "ms_per_launch": ms_launch,
+                        "share_of_step": ms / steps / total_ms, "bound": bound, "achieved": achieved, "peak": peak,
+                        "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak,
+                        "compulsory_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops})
+    entries.sort(key=lambda e: -e["share_of_step"])
+    covered = float(sum(e["share_of_step"] for e in entries))
+    return {"ms_per_step_under_events": total_ms, "ops_share_of_step": covered, "top": entries[:top],
+            "top_share_of_step": float(sum(e["share_of_step"] for e in entries[:top]))}
 
 
 # --------------------------------------------------------------------------------------------------------------------
