@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "graph.hpp"
 
 namespace tfgnn {
 
@@ -189,6 +190,157 @@ rgat_scores_backward_kernel(const float* __restrict__ ds_src, const float* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Row-centric softmax over all edges entering a node (round 3): ONE pass per CSR row of the node view instead of the five
+// launches above (edge scores, segment max, exp, segment sum, divide), and its backward (t = sum a da, dz) likewise.
+// A row's (edge, head) pairs are laid out lane = slot * K + head (K a power of two): an iteration covers T / K
+// consecutive edges, i.e. T consecutive floats of the [E, K] arrays.  Rows of at most long_threshold edges (the view's
+// short-row list, longest first) take one wave each; longer rows one 1024-thread workgroup (the first item of the row's
+// long-row plan; a 15 000-edge hub is 118 iterations per pass).  Every lane re-reads only what it wrote itself, the
+// reductions are fixed trees: deterministic.  The per-row max / sum orders differ from the generic gather's, results agree
+// to fp32 rounding.
+// ------------------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ float row_reduce(float v, bool is_max, int K, float* red /* [T / 64][64] */) {
+  for (int d = K; d < 64; d <<= 1) {
+    const float o = __shfl_xor(v, d, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  if (T > 64) {  // lanes with the same head sit at the same lane index of every wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    red[w * 64 + lane] = v;
+    __syncthreads();
+    float r = red[lane];
+#pragma unroll
+    for (int i = 1; i < T / 64; ++i) r = is_max ? fmaxf(r, red[i * 64 + lane]) : r + red[i * 64 + lane];
+    v = r;
+  }
+  return v;
+}
+
+struct RowSoftmaxArgs {
+  const int32_t* nodeptr;
+  const int32_t* coll;
+  const int32_t* rows;       // short rows (wave kernel) / item_row (workgroup kernel)
+  const int32_t* item_chunk; // workgroup kernel: only chunk 0 of a row works
+  int64_t num_rows;
+  const float* s_src;
+  const float* s_tgt;
+  int L, K;
+  float* att;       // forward: out [E, K]; backward: in
+  const float* da;  // backward
+  float* dz;        // backward
+};
+
+template <int T, bool BWD>
+__device__ __forceinline__ void row_softmax_body(const RowSoftmaxArgs& a, int64_t v, int tid, float* red) {
+  const int K = a.K;
+  const int epi = T / K;
+  const int slot = tid / K, k = tid & (K - 1);
+  const int32_t beg = a.nodeptr[v], end = a.nodeptr[v + 1];
+  const bool active = slot < epi;  // T / K * K == T for powers of two: always true; kept for clarity
+  const float* st = a.s_tgt + (int64_t)v * a.L * K + k;
+  if (!BWD) {
+    float m = -3.402823466e+38f;
+    if (active) {
+#pragma unroll 4
+      for (int32_t e = beg + slot; e < end; e += epi) {
+        const int32_t cl = a.coll[e];
+        const float sc = leaky(a.s_src[(int64_t)cl * K + k] + st[(cl % a.L) * K]);
+        a.att[(int64_t)e * K + k] = sc;
+        m = fmaxf(m, sc);
+      }
+    }
+    m = row_reduce<T>(m, true, K, red);
+    float den = 0.f;
+    if (active) {
+#pragma unroll 4
+      for (int32_t e = beg + slot; e < end; e += epi) {
+        const float p = expf(a.att[(int64_t)e * K + k] - m);
+        a.att[(int64_t)e * K + k] = p;
+        den += p;
+      }
+    }
+    den = row_reduce<T>(den, false, K, red);
+    if (active) {
+#pragma unroll 4
+      for (int32_t e = beg + slot; e < end; e += epi) a.att[(int64_t)e * K + k] = a.att[(int64_t)e * K + k] / den;
+    }
+  } else {
+    float t = 0.f;
+    if (active) {
+#pragma unroll 4
+      for (int32_t e = beg + slot; e < end; e += epi) t += a.att[(int64_t)e * K + k] * a.da[(int64_t)e * K + k];
+    }
+    t = row_reduce<T>(t, false, K, red);
+    if (active) {
+#pragma unroll 4
+      for (int32_t e = beg + slot; e < end; e += epi) {
+        const int32_t cl = a.coll[e];
+        const float z = a.s_src[(int64_t)cl * K + k] + st[(cl % a.L) * K];
+        const int64_t i = (int64_t)e * K + k;
+        a.dz[i] = a.att[i] * (a.da[i] - t) * (z > 0.f ? 1.f : 0.2f);
+      }
+    }
+  }
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) rgat_row_softmax_wave_kernel(RowSoftmaxArgs a) {
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= a.num_rows) return;
+  row_softmax_body<64, BWD>(a, a.rows[w], threadIdx.x & 63, nullptr);
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(1024) rgat_row_softmax_block_kernel(RowSoftmaxArgs a) {
+  __shared__ float red[16 * 64];
+  if (a.item_chunk[blockIdx.x] != 0) return;  // one workgroup per long row: the row's first item
+  row_softmax_body<1024, BWD>(a, a.rows[blockIdx.x], threadIdx.x, red);
+}
+
+// d alpha[l, k, :Hk] = sum_v ds_src[(v,l), k] Y[(v,l), k, :] ;  d alpha[l, k, Hk:] likewise with ds_tgt: the block diagonal of
+// ds^T Y - two [V, L K]^T x [V, L H] products computed 32x too much of it.  Stage 1: blockIdx.x owns a slice of the nodes,
+// a thread owns columns (l, f) and walks the slice (Y is read exactly once, coalesced); stage 2 adds the slices in order.
+__global__ void __launch_bounds__(256)
+rgat_alpha_grad_partial_kernel(const float* __restrict__ ds_src, const float* __restrict__ ds_tgt, const float* __restrict__ Y,
+                               int64_t V, int L, int K, int Hk, int64_t nodes_per_block, float* __restrict__ partial) {
+  const int H = K * Hk;
+  const int64_t LH = (int64_t)L * H;
+  const int64_t v0 = (int64_t)blockIdx.x * nodes_per_block;
+  const int64_t v1 = v0 + nodes_per_block < V ? v0 + nodes_per_block : V;
+  float* out = partial + (int64_t)blockIdx.x * 2 * LH;
+  for (int64_t p = threadIdx.x; p < LH; p += 256) {
+    const int l = (int)(p / H), f = (int)(p - (int64_t)l * H), k = f / Hk;
+    float as = 0.f, at = 0.f;
+#pragma unroll 4
+    for (int64_t v = v0; v < v1; ++v) {
+      const int64_t row = v * L + l;
+      const float y = Y[row * H + f];
+      as += ds_src[row * K + k] * y;
+      at += ds_tgt[row * K + k] * y;
+    }
+    out[p] = as;
+    out[LH + p] = at;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+rgat_alpha_grad_final_kernel(const float* __restrict__ partial, int nblocks, int L, int K, int Hk, float* __restrict__ d_alpha) {
+  const int H = K * Hk;
+  const int64_t LH = (int64_t)L * H;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * LH) return;
+  const int side = (int)(i / LH);
+  const int64_t p = i - side * LH;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * LH + i];
+  const int l = (int)(p / H), f = (int)(p - (int64_t)l * H), k = f / Hk, j = f - k * Hk;
+  d_alpha[(((int64_t)l * K + k) * 2 + side) * Hk + j] = s;
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 16384)); }
 
 // shapes the lane-group kernels take: H / 4 lanes per row inside one wave, Hk / 4 lanes per head, both powers of two
@@ -307,6 +459,77 @@ extern "C" int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_
   hipLaunchKernelGGL(rgat_scores_backward_kernel, dim3(grid_for(rows * hidden_dim)), dim3(256), 0,
                      (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, rows, num_edge_types, num_heads,
                      hidden_dim / num_heads, d_dY);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+static int rgat_row_softmax(const tfgnn_graph* g, const float* s_src, const float* s_tgt, int K, float* att, const float* da,
+                            float* dz, bool bwd, hipStream_t s) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  if (K <= 0 || K > MAX_HEADS || (K & (K - 1))) return TFGNN_ERR_UNSUPPORTED;  // lane = slot * K + head needs a power of two
+  if (g->E == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(s_src && s_tgt && att && (!bwd || (da && dz)), "NULL pointer");
+  const GraphView& gv = g->views[1];  // by target, all edge types of a node in one row
+  RowSoftmaxArgs a{};
+  a.nodeptr = gv.rowptr; a.coll = gv.col; a.s_src = s_src; a.s_tgt = s_tgt; a.L = g->L > 0 ? g->L : 1; a.K = K;
+  a.att = att; a.da = da; a.dz = dz;
+  if (gv.plan.num_short > 0) {
+    a.rows = gv.plan.short_rows; a.num_rows = gv.plan.num_short; a.item_chunk = nullptr;
+    const dim3 grid((unsigned)ceil_div(gv.plan.num_short, 4));
+    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_wave_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rgat_row_softmax_wave_kernel<false>, grid, dim3(256), 0, s, a);
+  }
+  if (gv.plan.num_items > 0) {
+    a.rows = gv.plan.item_row; a.num_rows = gv.plan.num_items; a.item_chunk = gv.plan.item_chunk;
+    const dim3 grid((unsigned)gv.plan.num_items);
+    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_block_kernel<true>, grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(rgat_row_softmax_block_kernel<false>, grid, dim3(1024), 0, s, a);
+  }
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_attention_forward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, int num_heads,
+                                            float* d_att, void* stream) {
+  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, d_att, nullptr, nullptr, false, (hipStream_t)stream);
+}
+
+extern "C" int tfgnn_rgat_attention_backward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, const float* d_att,
+                                             const float* d_da, int num_heads, float* d_dz, void* stream) {
+  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, const_cast<float*>(d_att), d_da, d_dz, true, (hipStream_t)stream);
+}
+
+static int alpha_grad_blocks(int64_t V) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, tfgnn::ceil_div(V, 16))); }
+
+extern "C" size_t tfgnn_rgat_alpha_grad_workspace_bytes(int64_t num_nodes, int num_edge_types, int hidden_dim) {
+  if (num_nodes <= 0 || num_edge_types <= 0 || hidden_dim <= 0) return 0;
+  return (size_t)alpha_grad_blocks(num_nodes) * 2 * (size_t)num_edge_types * (size_t)hidden_dim * 4;
+}
+
+extern "C" int tfgnn_rgat_alpha_grad(const float* d_ds_src, const float* d_ds_tgt, const float* d_Y, int64_t num_nodes,
+                                     int num_edge_types, int num_heads, int hidden_dim, float* d_alpha_grad, void* d_workspace,
+                                     size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0, "bad sizes");
+  int rc = check_heads(num_heads, hidden_dim);
+  if (rc) return rc;
+  if (num_edge_types == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_alpha_grad, "NULL pointer");
+  const int64_t LH = (int64_t)num_edge_types * hidden_dim;
+  if (num_nodes == 0) {
+    TFGNN_HIP_CHECK(hipMemsetAsync(d_alpha_grad, 0, (size_t)2 * LH * 4, (hipStream_t)stream));
+    return TFGNN_OK;
+  }
+  TFGNN_REQUIRE(d_ds_src && d_ds_tgt && d_Y, "NULL pointer");
+  const int nb = alpha_grad_blocks(num_nodes);
+  TFGNN_REQUIRE(d_workspace && workspace_bytes >= (size_t)nb * 2 * LH * 4, "workspace too small: need %zu bytes",
+                (size_t)nb * 2 * LH * 4);
+  const int64_t per = ceil_div(num_nodes, nb);
+  hipLaunchKernelGGL(rgat_alpha_grad_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_ds_src, d_ds_tgt, d_Y, num_nodes,
+                     num_edge_types, num_heads, hidden_dim / num_heads, per, (float*)d_workspace);
+  hipLaunchKernelGGL(rgat_alpha_grad_final_kernel, dim3((unsigned)ceil_div(2 * LH, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)d_workspace, nb, num_edge_types, num_heads, hidden_dim / num_heads, d_alpha_grad);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -135,6 +135,13 @@ class RGAT(MessagePassing):
         att = torch.empty((E, K), dtype=torch.float32, device=dev)
         if E == 0:
             return att
+        # one pass per CSR row (csrc/rgat.hip, tfgnn_rgat_attention_forward) when the head count is a power of two; the
+        # piecewise form below otherwise
+        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._stream())
+        if rc == 0:
+            return att
+        if rc != -4:
+            _lib.check(rc)
         coll, tgt = g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST)
         ident = self._ident(g, E)[:E]
         scores = torch.empty((E, K), dtype=torch.float32, device=dev)
@@ -182,29 +189,33 @@ class RGAT(MessagePassing):
                 ops._ptr(d_agg), E, K, H, ops._ptr(da), ops._stream(),
             )
         )
-        t = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, ops.mul(att, da), col=ident_e[:E])  # [V, K] sum of a * da
         dz = torch.empty((E, K), dtype=torch.float32, device=dev)
-        _lib.check(
-            lib.tfgnn_rgat_edge_softmax_backward(
-                ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(s_src),
-                ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), ops._ptr(t), E, L, K, ops._ptr(dz), ops._stream(),
+        rc = lib.tfgnn_rgat_attention_backward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), K, ops._ptr(dz),
+                                               ops._stream())
+        if rc == -4:  # head count not a power of two: the piecewise form
+            t = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, ops.mul(att, da), col=ident_e[:E])  # [V, K] sum of a * da
+            _lib.check(
+                lib.tfgnn_rgat_edge_softmax_backward(
+                    ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(s_src),
+                    ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), ops._ptr(t), E, L, K, ops._ptr(dz), ops._stream(),
+                )
             )
-        )
+        else:
+            _lib.check(rc)
         # (3) logits are s_src[(src,l)] + s_tgt[(tgt,l)]: segment sums of dz over both bucketings
         ds_tgt = ops.graph_gather(g, ops.VIEW_BY_DST_TYPED, dz, col=ident_e[:E])  # [V*L, K]
         ds_src = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dz, col=s2d)  # [V*L, K]
         # (4) through the inner products with alpha
         #     d alpha[l,k,:Hk] = sum_v ds_src[(v,l),k] * Y[(v,l),k,:]   (block diagonal of a small GEMM)
-        Hk = H // K
-        Yv = Y.view(V, L * H)
-        full_s = ops.gemm(ds_src.view(V, L * K), Yv, trans_a=True)  # [L*K, L*H]
-        full_t = ops.gemm(ds_tgt.view(V, L * K), Yv, trans_a=True)
+        #     (tfgnn_rgat_alpha_grad: Y is read once; the two [V, L K]^T x [V, L H] products it replaces computed the whole
+        #      [L K, L H] matrix for its block diagonal)
         d_attn = torch.empty_like(self._attn)
-        idx = torch.arange(L * K, device=dev)
-        blocks_s = full_s.view(L * K, L * K, Hk)[idx, idx]  # [(l,k), Hk]
-        blocks_t = full_t.view(L * K, L * K, Hk)[idx, idx]
-        d_attn[:, :, :Hk].copy_(blocks_s.view(L, K, Hk))
-        d_attn[:, :, Hk:].copy_(blocks_t.view(L, K, Hk))
+        ws_bytes = lib.tfgnn_rgat_alpha_grad_workspace_bytes(V, L, H)
+        ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
+        _lib.check(
+            lib.tfgnn_rgat_alpha_grad(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(Y), V, L, K, H, ops._ptr(d_attn), ops._ptr(ws),
+                                      ws.numel() if ws is not None else 0, ops._stream())
+        )
         _lib.check(
             lib.tfgnn_rgat_scores_backward(
                 ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
