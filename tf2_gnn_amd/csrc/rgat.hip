@@ -196,8 +196,8 @@ rgat_scores_backward_kernel(const float* __restrict__ ds_src, const float* __res
 // launches above (edge scores, segment max, exp, segment sum, divide), and its backward (t = sum a da, dz) likewise.
 // A row's (edge, head) pairs are laid out lane = slot * K + head (K a power of two): an iteration covers T / K
 // consecutive edges, i.e. T consecutive floats of the [E, K] arrays.  Rows of at most long_threshold edges (the view's
-// short-row list, longest first) take one wave each; longer rows one 1024-thread workgroup (the first item of the row's
-// long-row plan; a 15 000-edge hub is 118 iterations per pass).  Every lane re-reads only what it wrote itself, the
+// short-row list, longest first) take one wave each; rows that are ONE item of the long-row plan (up to item_chunk edges) one
+// 256-thread workgroup; rows cut into several items one 1024-thread workgroup (a 15 000-edge hub is 118 iterations per pass).  Every lane re-reads only what it wrote itself, the
 // reductions are fixed trees: deterministic.  The per-row max / sum orders differ from the generic gather's, results agree
 // to fp32 rounding.
 // ------------------------------------------------------------------------------------------------------
@@ -223,8 +223,8 @@ __device__ __forceinline__ float row_reduce(float v, bool is_max, int K, float* 
 struct RowSoftmaxArgs {
   const int32_t* nodeptr;
   const int32_t* coll;
-  const int32_t* rows;       // short rows (wave kernel) / item_row (workgroup kernel)
-  const int32_t* item_chunk; // workgroup kernel: only chunk 0 of a row works
+  const int32_t* rows;       // short rows (wave kernel) / item_row (workgroup kernel) / multi_row (hub kernel)
+  const int32_t* item_chunk; // workgroup kernel: the items' scratch slots (< 0: the item is a whole row)
   int64_t num_rows;
   const float* s_src;
   const float* s_tgt;
@@ -294,10 +294,18 @@ __global__ void __launch_bounds__(256) rgat_row_softmax_wave_kernel(RowSoftmaxAr
   row_softmax_body<64, BWD>(a, a.rows[w], threadIdx.x & 63, nullptr);
 }
 
+// rows of long_threshold + 1 .. item_chunk edges: the items that ARE a whole row (item_slot < 0), 256 threads each
 template <bool BWD>
-__global__ void __launch_bounds__(1024) rgat_row_softmax_block_kernel(RowSoftmaxArgs a) {
+__global__ void __launch_bounds__(256) rgat_row_softmax_block_kernel(RowSoftmaxArgs a) {
+  __shared__ float red[4 * 64];
+  if (a.item_chunk[blockIdx.x] >= 0) return;  // (item_slot passed as item_chunk) items of multi-item rows: next kernel
+  row_softmax_body<256, BWD>(a, a.rows[blockIdx.x], threadIdx.x, red);
+}
+
+// rows cut into several items (more than item_chunk edges, up to the 15 000 of an R-MAT hub): 1024 threads each
+template <bool BWD>
+__global__ void __launch_bounds__(1024) rgat_row_softmax_hub_kernel(RowSoftmaxArgs a) {
   __shared__ float red[16 * 64];
-  if (a.item_chunk[blockIdx.x] != 0) return;  // one workgroup per long row: the row's first item
   row_softmax_body<1024, BWD>(a, a.rows[blockIdx.x], threadIdx.x, red);
 }
 
@@ -327,18 +335,33 @@ rgat_alpha_grad_partial_kernel(const float* __restrict__ ds_src, const float* __
   }
 }
 
+// 32 outputs per workgroup, 8 lanes per output: each lane adds a CONTIGUOUS run of the node slices (fixed order), the 8 runs
+// are then added in order through LDS - deterministic, and 64 workgroups instead of the 8 of a thread-per-output form
 __global__ void __launch_bounds__(256)
 rgat_alpha_grad_final_kernel(const float* __restrict__ partial, int nblocks, int L, int K, int Hk, float* __restrict__ d_alpha) {
+  __shared__ float red[8][32];
   const int H = K * Hk;
   const int64_t LH = (int64_t)L * H;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * LH) return;
-  const int side = (int)(i / LH);
-  const int64_t p = i - side * LH;
+  const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + o;
+  const int per = (nblocks + 7) / 8;
+  const int b0 = part * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * LH + i];
-  const int l = (int)(p / H), f = (int)(p - (int64_t)l * H), k = f / Hk, j = f - k * Hk;
-  d_alpha[(((int64_t)l * K + k) * 2 + side) * Hk + j] = s;
+  if (i < 2 * LH) {
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) s += partial[(int64_t)b * 2 * LH + i];
+  }
+  red[part][o] = s;
+  __syncthreads();
+  if (part == 0 && i < 2 * LH) {
+    float t = red[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q][o];
+    const int side = (int)(i / LH);
+    const int64_t p = i - side * LH;
+    const int l = (int)(p / H), f = (int)(p - (int64_t)l * H), k = f / Hk, j = f - k * Hk;
+    d_alpha[(((int64_t)l * K + k) * 2 + side) * Hk + j] = t;
+  }
 }
 
 static unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 16384)); }
@@ -481,10 +504,16 @@ static int rgat_row_softmax(const tfgnn_graph* g, const float* s_src, const floa
     else hipLaunchKernelGGL(rgat_row_softmax_wave_kernel<false>, grid, dim3(256), 0, s, a);
   }
   if (gv.plan.num_items > 0) {
-    a.rows = gv.plan.item_row; a.num_rows = gv.plan.num_items; a.item_chunk = gv.plan.item_chunk;
+    a.rows = gv.plan.item_row; a.num_rows = gv.plan.num_items; a.item_chunk = gv.plan.item_slot;
     const dim3 grid((unsigned)gv.plan.num_items);
-    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_block_kernel<true>, grid, dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL(rgat_row_softmax_block_kernel<false>, grid, dim3(1024), 0, s, a);
+    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_block_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rgat_row_softmax_block_kernel<false>, grid, dim3(256), 0, s, a);
+  }
+  if (gv.plan.num_multi > 0) {
+    a.rows = gv.plan.multi_row; a.num_rows = gv.plan.num_multi; a.item_chunk = nullptr;
+    const dim3 grid((unsigned)gv.plan.num_multi);
+    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_hub_kernel<true>, grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(rgat_row_softmax_hub_kernel<false>, grid, dim3(1024), 0, s, a);
   }
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
@@ -528,7 +557,7 @@ extern "C" int tfgnn_rgat_alpha_grad(const float* d_ds_src, const float* d_ds_tg
   const int64_t per = ceil_div(num_nodes, nb);
   hipLaunchKernelGGL(rgat_alpha_grad_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_ds_src, d_ds_tgt, d_Y, num_nodes,
                      num_edge_types, num_heads, hidden_dim / num_heads, per, (float*)d_workspace);
-  hipLaunchKernelGGL(rgat_alpha_grad_final_kernel, dim3((unsigned)ceil_div(2 * LH, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rgat_alpha_grad_final_kernel, dim3((unsigned)ceil_div(2 * LH, 32)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)d_workspace, nb, num_edge_types, num_heads, hidden_dim / num_heads, d_alpha_grad);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
