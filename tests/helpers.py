@@ -210,6 +210,21 @@ class ForcedKinks(torch.overrides.TorchFunctionMode):
                 if func is F.leaky_relu:
                     slope = args[1] if len(args) > 1 else kwargs.get("negative_slope", 0.01)
                 return torch.where(mask, x, slope * x)
+        if func is torch.Tensor.scatter_reduce and (kwargs.get("reduce") == "amax" or (len(args) > 4 and args[4] == "amax")):
+            # max aggregation (tf.math.unsorted_segment_max): a segment whose two largest entries are within fp32 rounding of
+            # each other has its gradient routed to a different edge by an fp32 and an fp64 forward pass - the same kind of
+            # kink.  Exact ties (duplicate edges of a multigraph: identical messages) are consistent in both and ignored.
+            out = func(*args, **kwargs)
+            base, dim, index, src = args[0], args[1], args[2], args[3]
+            if src.numel():
+                winner = out.gather(dim, index)
+                rest = torch.where(src == winner, torch.full_like(src, float("-inf")), src)
+                second = torch.full_like(base, float("-inf")).scatter_reduce(dim, index, rest, reduce="amax", include_self=True)
+                gap = (out - second) / out.abs().clamp(min=1.0)
+                ok = torch.isfinite(second) & torch.isfinite(out)
+                if bool(ok.any()):
+                    self.clearance = min(self.clearance, float(gap[ok].min()))
+            return out
         return func(*args, **kwargs)
 
 

@@ -9,6 +9,8 @@ sampled-subgraph oracles: the CPU oracle cannot run the whole batch in seconds, 
   * attention weights are a distribution per (target, head);
   * the bucketing is a permutation of the edge list; results are bit-reproducible run to run.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,8 @@ def _build(cls_name, params, D, L):
     cls = getattr(mp, cls_name)
     p = cls.get_default_hyperparameters()
     p.update(params)
+    # the weights of a test do not depend on which tests ran before it (the initialiser's generator is global)
+    mp.set_seed(zlib.crc32(repr((cls_name, sorted(p.items(), key=lambda kv: kv[0]), D, L)).encode()) & 0x7FFFFFFF)
     layer = cls(p)
     layer.build(mp.MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
     return layer, p

@@ -1,5 +1,7 @@
 """Parity of the HIP layers (through the C ABI) with the CPU oracle on identical inputs.
 Tolerance: fp32 node states within 1e-5 (north_star), scaled: |a-b| <= 1e-5 * max(1, |b|)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +20,8 @@ def _build(cls_name, params, D, L):
     cls = getattr(mp, cls_name)
     p = cls.get_default_hyperparameters()
     p.update(params)
+    # the weights of a test do not depend on which tests ran before it (the initialiser's generator is global)
+    mp.set_seed(zlib.crc32(repr((cls_name, sorted(p.items(), key=lambda kv: kv[0]), D, L)).encode()) & 0x7FFFFFFF)
     layer = cls(p)
     layer.build(mp.MessagePassingInput((None, D), tuple((None, 2) for _ in range(L))))
     return layer, p

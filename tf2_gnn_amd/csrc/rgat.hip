@@ -146,12 +146,28 @@ rgat_edge_dot_vec_kernel(const int32_t* __restrict__ coll, const int32_t* __rest
   const int H = K * Hk, lpe = H >> 2, lph = Hk >> 2;
   const int per_block = 256 / lpe;
   const int l = threadIdx.x % lpe;
-  for (int64_t e = (int64_t)blockIdx.x * per_block + threadIdx.x / lpe; e < E; e += (int64_t)gridDim.x * per_block) {
-    const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)coll[e] * H + 4 * l);
-    const float4 g = *reinterpret_cast<const float4*>(d_agg + (int64_t)tgt[e] * H + 4 * l);
-    float sum = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
-    for (int d = lph >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if (l % lph == 0) da[e * K + l / lph] = sum;
+  constexpr int UNR = 4;  // consecutive edges per lane group and iteration: 8 row loads in flight (one edge at a time ran at
+                          // half the rate: 138 -> us at cfg-3); consecutive by-dst edges mostly share the d_agg row
+  for (int64_t e0 = ((int64_t)blockIdx.x * per_block + threadIdx.x / lpe) * UNR; e0 < E; e0 += (int64_t)gridDim.x * per_block * UNR) {
+    int32_t c[UNR], t[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t e = e0 + u < E ? e0 + u : E - 1;
+      c[u] = coll[e];
+      t[u] = tgt[e];
+    }
+    float4 y[UNR], g[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      y[u] = *reinterpret_cast<const float4*>(Y + (int64_t)c[u] * H + 4 * l);
+      g[u] = *reinterpret_cast<const float4*>(d_agg + (int64_t)t[u] * H + 4 * l);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float sum = y[u].x * g[u].x + y[u].y * g[u].y + y[u].z * g[u].z + y[u].w * g[u].w;
+      for (int d = lph >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+      if (l % lph == 0 && e0 + u < E) da[(e0 + u) * K + l / lph] = sum;
+    }
   }
 }
 
@@ -237,52 +253,53 @@ struct RowSoftmaxArgs {
 template <int T, bool BWD>
 __device__ __forceinline__ void row_softmax_body(const RowSoftmaxArgs& a, int64_t v, int tid, float* red) {
   const int K = a.K;
-  const int epi = T / K;
+  const int epi = T / K;  // edges per iteration: lane = slot * K + head
   const int slot = tid / K, k = tid & (K - 1);
   const int32_t beg = a.nodeptr[v], end = a.nodeptr[v + 1];
-  const bool active = slot < epi;  // T / K * K == T for powers of two: always true; kept for clarity
-  const float* st = a.s_tgt + (int64_t)v * a.L * K + k;
+  // restrict-qualified locals: without them every store to att / dz orders the next iteration's loads behind it
+  const int32_t* __restrict__ coll = a.coll;
+  const float* __restrict__ s_src = a.s_src;
+  const float* __restrict__ st = a.s_tgt + (int64_t)v * a.L * K + k;
+  const int L = a.L;
   if (!BWD) {
-    float m = -3.402823466e+38f;
-    if (active) {
+    float* __restrict__ att = a.att;
+    // pass 1: scores (two scalar gathers per edge) with a running (max, sum of exp) per lane - online softmax - so that
+    // the row is walked twice, not three times; the scores are parked in att
+    float m = -3.402823466e+38f, d = 0.f;
 #pragma unroll 4
-      for (int32_t e = beg + slot; e < end; e += epi) {
-        const int32_t cl = a.coll[e];
-        const float sc = leaky(a.s_src[(int64_t)cl * K + k] + st[(cl % a.L) * K]);
-        a.att[(int64_t)e * K + k] = sc;
-        m = fmaxf(m, sc);
-      }
+    for (int32_t e = beg + slot; e < end; e += epi) {
+      const int32_t cl = coll[e];
+      const float sc = leaky(s_src[(int64_t)cl * K + k] + st[(cl % L) * K]);
+      att[(int64_t)e * K + k] = sc;
+      const float mn = fmaxf(m, sc);
+      d = d * expf(m - mn) + expf(sc - mn);
+      m = mn;
     }
-    m = row_reduce<T>(m, true, K, red);
-    float den = 0.f;
-    if (active) {
+    const float M = row_reduce<T>(m, true, K, red);
+    const float D = row_reduce<T>(d * expf(m - M), false, K, red);  // lanes without an edge: d = 0
+    // pass 2: a = exp(score - max) / sum  (exp(log_softmax) of rgat.py:147-151)
 #pragma unroll 4
-      for (int32_t e = beg + slot; e < end; e += epi) {
-        const float p = expf(a.att[(int64_t)e * K + k] - m);
-        a.att[(int64_t)e * K + k] = p;
-        den += p;
-      }
-    }
-    den = row_reduce<T>(den, false, K, red);
-    if (active) {
-#pragma unroll 4
-      for (int32_t e = beg + slot; e < end; e += epi) a.att[(int64_t)e * K + k] = a.att[(int64_t)e * K + k] / den;
+    for (int32_t e = beg + slot; e < end; e += epi) {
+      const int64_t i = (int64_t)e * K + k;
+      att[i] = expf(att[i] - M) / D;
     }
   } else {
+    const float* __restrict__ att = a.att;
+    const float* __restrict__ da = a.da;
+    float* __restrict__ dz = a.dz;
     float t = 0.f;
-    if (active) {
 #pragma unroll 4
-      for (int32_t e = beg + slot; e < end; e += epi) t += a.att[(int64_t)e * K + k] * a.da[(int64_t)e * K + k];
+    for (int32_t e = beg + slot; e < end; e += epi) {
+      const int64_t i = (int64_t)e * K + k;
+      t += att[i] * da[i];
     }
     t = row_reduce<T>(t, false, K, red);
-    if (active) {
 #pragma unroll 4
-      for (int32_t e = beg + slot; e < end; e += epi) {
-        const int32_t cl = a.coll[e];
-        const float z = a.s_src[(int64_t)cl * K + k] + st[(cl % a.L) * K];
-        const int64_t i = (int64_t)e * K + k;
-        a.dz[i] = a.att[i] * (a.da[i] - t) * (z > 0.f ? 1.f : 0.2f);
-      }
+    for (int32_t e = beg + slot; e < end; e += epi) {
+      const int32_t cl = coll[e];
+      const float z = s_src[(int64_t)cl * K + k] + st[(cl % L) * K];
+      const int64_t i = (int64_t)e * K + k;
+      dz[i] = att[i] * (da[i] - t) * (z > 0.f ? 1.f : 0.2f);
     }
   }
 }
@@ -361,6 +378,26 @@ rgat_alpha_grad_final_kernel(const float* __restrict__ partial, int nblocks, int
     const int64_t p = i - side * LH;
     const int l = (int)(p / H), f = (int)(p - (int64_t)l * H), k = f / Hk, j = f - k * Hk;
     d_alpha[(((int64_t)l * K + k) * 2 + side) * Hk + j] = t;
+  }
+}
+
+// float4 form (Hk % 4 == 0): a thread owns four consecutive features of one head
+__global__ void __launch_bounds__(256)
+rgat_scores_backward_vec_kernel(const float* __restrict__ ds_src, const float* __restrict__ ds_tgt, const float* __restrict__ alpha,
+                                int64_t rows, int L, int K, int Hk, float* __restrict__ dY) {
+  const int H4 = (K * Hk) >> 2, Hk4 = Hk >> 2;
+  const int64_t total = rows * H4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / H4;
+    const int f4 = (int)(i - row * H4);
+    const int k = f4 / Hk4, j = (f4 - k * Hk4) * 4;
+    const float* a = alpha + ((int64_t)(row % L) * K + k) * 2 * Hk;
+    const float4 as = *reinterpret_cast<const float4*>(a + j);
+    const float4 at = *reinterpret_cast<const float4*>(a + Hk + j);
+    const float s = ds_src[row * K + k], t = ds_tgt[row * K + k];
+    float4 d = reinterpret_cast<float4*>(dY)[i];
+    d.x += s * as.x + t * at.x; d.y += s * as.y + t * at.y; d.z += s * as.z + t * at.z; d.w += s * as.w + t * at.w;
+    reinterpret_cast<float4*>(dY)[i] = d;
   }
 }
 
@@ -443,7 +480,7 @@ extern "C" int tfgnn_rgat_edge_dot(const int32_t* d_coll_by_dst, const int32_t* 
   TFGNN_REQUIRE(d_coll_by_dst && d_target_by_dst && d_Y && d_dagg && d_da, "NULL pointer");
   if (rgat_vec_shape(num_heads, hidden_dim) && ((uintptr_t)d_Y | (uintptr_t)d_dagg) % 16 == 0) {
     const int per_block = 256 / (hidden_dim / 4);
-    hipLaunchKernelGGL(rgat_edge_dot_vec_kernel, dim3(grid_for(ceil_div(num_edges, per_block) * 256)), dim3(256), 0,
+    hipLaunchKernelGGL(rgat_edge_dot_vec_kernel, dim3(grid_for(ceil_div(num_edges, per_block * 4) * 256)), dim3(256), 0,
                        (hipStream_t)stream, d_coll_by_dst, d_target_by_dst, d_Y, d_dagg, num_edges, num_heads,
                        hidden_dim / num_heads, d_da);
   } else {
@@ -479,9 +516,14 @@ extern "C" int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_
   const int64_t rows = num_nodes * num_edge_types;
   if (rows == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_ds_src && d_ds_tgt && d_alpha && d_dY, "NULL pointer");
-  hipLaunchKernelGGL(rgat_scores_backward_kernel, dim3(grid_for(rows * hidden_dim)), dim3(256), 0,
-                     (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, rows, num_edge_types, num_heads,
-                     hidden_dim / num_heads, d_dY);
+  if ((hidden_dim / num_heads) % 4 == 0 && ((uintptr_t)d_dY | (uintptr_t)d_alpha) % 16 == 0) {
+    hipLaunchKernelGGL(rgat_scores_backward_vec_kernel, dim3(grid_for(rows * hidden_dim / 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_ds_src, d_ds_tgt, d_alpha, rows, num_edge_types, num_heads, hidden_dim / num_heads, d_dY);
+  } else {
+    hipLaunchKernelGGL(rgat_scores_backward_kernel, dim3(grid_for(rows * hidden_dim)), dim3(256), 0,
+                       (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, rows, num_edge_types, num_heads,
+                       hidden_dim / num_heads, d_dY);
+  }
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
