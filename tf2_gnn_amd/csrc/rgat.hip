@@ -261,45 +261,88 @@ __device__ __forceinline__ void row_softmax_body(const RowSoftmaxArgs& a, int64_
   const float* __restrict__ s_src = a.s_src;
   const float* __restrict__ st = a.s_tgt + (int64_t)v * a.L * K + k;
   const int L = a.L;
+  constexpr int U = 8;  // edges per lane and step, loads issued together: a 15 000-edge hub row is 118 dependent
+                        // (index -> score) steps per pass otherwise, the tail of the whole launch (122 us at cfg-3)
   if (!BWD) {
     float* __restrict__ att = a.att;
     // pass 1: scores (two scalar gathers per edge) with a running (max, sum of exp) per lane - online softmax - so that
     // the row is walked twice, not three times; the scores are parked in att
     float m = -3.402823466e+38f, d = 0.f;
-#pragma unroll 4
-    for (int32_t e = beg + slot; e < end; e += epi) {
-      const int32_t cl = coll[e];
-      const float sc = leaky(s_src[(int64_t)cl * K + k] + st[(cl % L) * K]);
-      att[(int64_t)e * K + k] = sc;
-      const float mn = fmaxf(m, sc);
-      d = d * expf(m - mn) + expf(sc - mn);
-      m = mn;
+    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
+      int32_t cl[U];
+      float sc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        cl[u] = coll[e < end ? e : end - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) sc[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        if (e < end) {
+          const float v_ = leaky(sc[u]);
+          att[(int64_t)e * K + k] = v_;
+          const float mn = fmaxf(m, v_);
+          d = d * expf(m - mn) + expf(v_ - mn);
+          m = mn;
+        }
+      }
     }
     const float M = row_reduce<T>(m, true, K, red);
     const float D = row_reduce<T>(d * expf(m - M), false, K, red);  // lanes without an edge: d = 0
     // pass 2: a = exp(score - max) / sum  (exp(log_softmax) of rgat.py:147-151)
-#pragma unroll 4
-    for (int32_t e = beg + slot; e < end; e += epi) {
-      const int64_t i = (int64_t)e * K + k;
-      att[i] = expf(att[i] - M) / D;
+    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
+      float x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        x[u] = att[(int64_t)(e < end ? e : end - 1) * K + k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        if (e < end) att[(int64_t)e * K + k] = expf(x[u] - M) / D;
+      }
     }
   } else {
     const float* __restrict__ att = a.att;
     const float* __restrict__ da = a.da;
     float* __restrict__ dz = a.dz;
     float t = 0.f;
-#pragma unroll 4
-    for (int32_t e = beg + slot; e < end; e += epi) {
-      const int64_t i = (int64_t)e * K + k;
-      t += att[i] * da[i];
+    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
+      float x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        const int64_t i = (int64_t)(e < end ? e : end - 1) * K + k;
+        x[u] = att[i];
+        y[u] = da[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * epi < end) t += x[u] * y[u];
     }
     t = row_reduce<T>(t, false, K, red);
-#pragma unroll 4
-    for (int32_t e = beg + slot; e < end; e += epi) {
-      const int32_t cl = coll[e];
-      const float z = s_src[(int64_t)cl * K + k] + st[(cl % L) * K];
-      const int64_t i = (int64_t)e * K + k;
-      dz[i] = att[i] * (da[i] - t) * (z > 0.f ? 1.f : 0.2f);
+    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
+      int32_t cl[U];
+      float x[U], y[U], z[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        const int32_t ee = e < end ? e : end - 1;
+        cl[u] = coll[ee];
+        x[u] = att[(int64_t)ee * K + k];
+        y[u] = da[(int64_t)ee * K + k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) z[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = e0 + u * epi;
+        if (e < end) dz[(int64_t)e * K + k] = x[u] * (y[u] - t) * (z[u] > 0.f ? 1.f : 0.2f);
+      }
     }
   }
 }
