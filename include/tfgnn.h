@@ -417,16 +417,21 @@ int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, con
                                int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
                                float* d_dY, void* stream);
 
-/* Round 3: the per-target softmax of rgat.py:142-151 in ONE pass per CSR row of the node view (all incoming edges of a node,
- * every type) instead of edge scores + segment max + exp + segment sum + divide, and its gradient likewise:
- *   forward:  att[e, k] = softmax over the in-edges e of v of leaky_relu(s_src[(src_e, l_e), k] + s_tgt[(v, l_e), k])   [E, K], by-dst order
+/* Round 3: the per-target softmax of rgat.py:142-151 row by row over the node view (all incoming edges of a node, every
+ * type) instead of edge scores + segment max + exp + segment sum + divide, and its gradient likewise:
+ *   forward:  att[e, k] = softmax over the in-edges e of v of leaky_relu(s_src[(src_e, l_e), k] + s_tgt[(v, l_e), k])   [E, K], by-dst order;
+ *             d_att_by_src (nullable): the same weights in the by-source edge order (for the backward pass's weighted gather)
  *   backward: dz[e, k]  = att (da - sum_{e' into v} att da) leaky_relu'(z)                  (the gradient w.r.t. the logits)
  * num_heads must be a power of two <= 64 (TFGNN_ERR_UNSUPPORTED otherwise: callers keep the piecewise kernels above).
- * Rows up to the view's long-row threshold take one wave, longer rows one 1024-thread workgroup; fixed reduction trees. */
+ * Short rows take one wave, single-item rows of the long-row plan one workgroup, hub rows one workgroup PER ITEM with an
+ * in-order combine of the items' (max, sum) pairs in between (d_workspace: tfgnn_rgat_attention_workspace_bytes); online
+ * softmax, fixed reduction trees and orders: deterministic. */
+size_t tfgnn_rgat_attention_workspace_bytes(const tfgnn_graph* graph, int num_heads);
 int tfgnn_rgat_attention_forward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, int num_heads,
-                                 float* d_att, void* stream);
+                                 float* d_att, float* d_att_by_src, void* d_workspace, size_t workspace_bytes, void* stream);
 int tfgnn_rgat_attention_backward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, const float* d_att,
-                                  const float* d_da, int num_heads, float* d_dz, void* stream);
+                                  const float* d_da, int num_heads, float* d_dz, void* d_workspace, size_t workspace_bytes,
+                                  void* stream);
 /* d alpha_l[k, :H/K] = sum_v ds_src[(v,l), k] Y[(v,l), k, :],  d alpha_l[k, H/K:] = sum_v ds_tgt[(v,l), k] Y[(v,l), k, :]
  * (gradient of the einsum of rgat.py:115-121 w.r.t. the attention parameters): d_alpha_grad [L, K, 2 H/K]; two-stage
  * reduction in a fixed order (workspace: tfgnn_rgat_alpha_grad_workspace_bytes). */

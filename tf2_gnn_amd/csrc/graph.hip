@@ -438,10 +438,13 @@ __global__ void unpack_kernel(const uint64_t* __restrict__ comp, const uint32_t*
 }
 
 __global__ void src2dst_kernel(const int32_t* __restrict__ eid_s, const int32_t* __restrict__ eid_to_pos_d,
-                               int64_t E, int32_t* __restrict__ src2dst) {
+                               int64_t E, int32_t* __restrict__ src2dst, int32_t* __restrict__ dst2src) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
-       p += (int64_t)gridDim.x * blockDim.x)
-    src2dst[p] = eid_to_pos_d[eid_s[p]];
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t q = eid_to_pos_d[eid_s[p]];
+    src2dst[p] = q;
+    dst2src[q] = (int32_t)p;  // the inverse permutation (RGAT writes its attention weights in both edge orders)
+  }
 }
 
 }  // namespace tfgnn
@@ -581,7 +584,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const size_t o_col_d = plan.take(E * 4), o_eid_d = plan.take(E * 4), o_coll_d = plan.take(E * 4);
   const size_t o_col_s = plan.take(E * 4), o_eid_s = plan.take(E * 4), o_coll_s = plan.take(E * 4);
   const size_t o_nodeptr_d = plan.take((V + 1) * 4), o_nodeptr_s = plan.take((V + 1) * 4);
-  const size_t o_src2dst = plan.take(E * 4);
+  const size_t o_src2dst = plan.take(E * 4), o_dst2src = plan.take(E * 4);
   const size_t o_tgt_d = plan.take(E * 4);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
@@ -672,6 +675,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   g->nodeptr_d = (int32_t*)(slab + o_nodeptr_d);
   g->nodeptr_s = (int32_t*)(slab + o_nodeptr_s);
   g->src2dst = (int32_t*)(slab + o_src2dst);
+  g->dst2src = (int32_t*)(slab + o_dst2src);
   g->tgt_d = (int32_t*)(slab + o_tgt_d);
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
@@ -796,7 +800,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
                        g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr,
                        (int32_t*)nullptr);
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
-                       g->src2dst);
+                       g->src2dst, g->dst2src);
   }
   // non-empty buckets in type-major order, for both bucketings
   {

@@ -60,7 +60,7 @@ struct tfgnn_graph {
   void* slab = nullptr;
   int32_t *rowptr_d = nullptr, *col_d = nullptr, *eid_d = nullptr, *coll_d = nullptr;
   int32_t *rowptr_s = nullptr, *col_s = nullptr, *eid_s = nullptr, *coll_s = nullptr;
-  int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *tgt_d = nullptr;
+  int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *dst2src = nullptr, *tgt_d = nullptr;
   float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
   tfgnn::GraphView views[4];  // tfgnn_graph_view order
   tfgnn::CompactBuckets compact[2];  // 0: by target, 1: by source

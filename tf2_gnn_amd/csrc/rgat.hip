@@ -208,14 +208,19 @@ rgat_scores_backward_kernel(const float* __restrict__ ds_src, const float* __res
 
 
 // ------------------------------------------------------------------------------------------------------
-// Row-centric softmax over all edges entering a node (round 3): ONE pass per CSR row of the node view instead of the five
-// launches above (edge scores, segment max, exp, segment sum, divide), and its backward (t = sum a da, dz) likewise.
-// A row's (edge, head) pairs are laid out lane = slot * K + head (K a power of two): an iteration covers T / K
-// consecutive edges, i.e. T consecutive floats of the [E, K] arrays.  Rows of at most long_threshold edges (the view's
-// short-row list, longest first) take one wave each; rows that are ONE item of the long-row plan (up to item_chunk edges) one
-// 256-thread workgroup; rows cut into several items one 1024-thread workgroup (a 15 000-edge hub is 118 iterations per pass).  Every lane re-reads only what it wrote itself, the
-// reductions are fixed trees: deterministic.  The per-row max / sum orders differ from the generic gather's, results agree
-// to fp32 rounding.
+// Row-centric softmax over all edges entering a node (round 3): the five launches above (edge scores, segment max, exp,
+// segment sum, divide) in one pass structure over the CSR rows of the node view, and its backward (t = sum a da, dz) likewise.
+// A row's (edge, head) pairs are laid out lane = slot * K + head (K a power of two): a step covers T / K consecutive edges,
+// i.e. T consecutive floats of the [E, K] arrays, U steps in flight per lane.  Work units follow the view's long-row plan:
+//   * rows of at most long_threshold edges (short-row list, longest first): one wave each, both passes;
+//   * rows that are ONE item of the plan (up to item_chunk edges): one 256-thread workgroup, both passes;
+//   * rows cut into several items (a 15 000-edge R-MAT hub: 30 items): every item is a workgroup - pass 1 leaves the item's
+//     online-softmax pair (max, sum of exp) [backward: its partial sum] in a scratch slot, a tiny kernel combines the slots
+//     of a row IN ITEM ORDER and writes the row's (max, sum) back into each of them, pass 2 normalises item by item.  A hub
+//     is thus as parallel as the rest of the batch (one 1024-thread workgroup per hub was the tail: 85 us of 130).
+// Every lane re-reads only what it wrote itself, the reductions are fixed trees / fixed orders: deterministic.  The order of
+// the max / sum differs from the generic gather's; results agree to fp32 rounding.  Forward also writes the weights in the
+// by-source edge order (att_s[dst2src[e]]) for the backward pass's weighted gather.
 // ------------------------------------------------------------------------------------------------------
 template <int T>
 __device__ __forceinline__ float row_reduce(float v, bool is_max, int K, float* red /* [T / 64][64] */) {
@@ -239,97 +244,117 @@ __device__ __forceinline__ float row_reduce(float v, bool is_max, int K, float* 
 struct RowSoftmaxArgs {
   const int32_t* nodeptr;
   const int32_t* coll;
-  const int32_t* rows;       // short rows (wave kernel) / item_row (workgroup kernel) / multi_row (hub kernel)
-  const int32_t* item_chunk; // workgroup kernel: the items' scratch slots (< 0: the item is a whole row)
+  const int32_t* dst2src;    // nullable: by-dst edge position -> by-src position
+  const int32_t* rows;       // short rows (wave kernel) / item_row (item kernels)
+  const int32_t* item_chunk;
+  const int32_t* item_slot;  // < 0: the item is a whole row
   int64_t num_rows;
+  int chunk_edges;
   const float* s_src;
   const float* s_tgt;
   int L, K;
   float* att;       // forward: out [E, K]; backward: in
+  float* att_s;     // forward, nullable: the same weights in by-src edge order
   const float* da;  // backward
   float* dz;        // backward
+  float* part;      // [num_partials][K][2] scratch of the multi-item rows
 };
 
-template <int T, bool BWD>
-__device__ __forceinline__ void row_softmax_body(const RowSoftmaxArgs& a, int64_t v, int tid, float* red) {
-  const int K = a.K;
-  const int epi = T / K;  // edges per iteration: lane = slot * K + head
-  const int slot = tid / K, k = tid & (K - 1);
-  const int32_t beg = a.nodeptr[v], end = a.nodeptr[v + 1];
-  // restrict-qualified locals: without them every store to att / dz orders the next iteration's loads behind it
+constexpr int RS_U = 8;  // edges per lane and step, loads issued together
+
+// pass 1 over edges [beg, end) of node v: forward -> scores parked in att, running (max, sum of exp) in (m, d);
+// backward -> t += att * da
+template <bool BWD>
+__device__ __forceinline__ void row_pass1(const RowSoftmaxArgs& a, int64_t v, int32_t beg, int32_t end, int slot, int k, int epi,
+                                          float& m, float& d) {
+  const int K = a.K, L = a.L;
   const int32_t* __restrict__ coll = a.coll;
   const float* __restrict__ s_src = a.s_src;
-  const float* __restrict__ st = a.s_tgt + (int64_t)v * a.L * K + k;
-  const int L = a.L;
-  constexpr int U = 8;  // edges per lane and step, loads issued together: a 15 000-edge hub row is 118 dependent
-                        // (index -> score) steps per pass otherwise, the tail of the whole launch (122 us at cfg-3)
+  const float* __restrict__ st = a.s_tgt + (int64_t)v * L * K + k;
   if (!BWD) {
     float* __restrict__ att = a.att;
-    // pass 1: scores (two scalar gathers per edge) with a running (max, sum of exp) per lane - online softmax - so that
-    // the row is walked twice, not three times; the scores are parked in att
-    float m = -3.402823466e+38f, d = 0.f;
-    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
-      int32_t cl[U];
-      float sc[U];
+    for (int32_t e0 = beg + slot; e0 < end; e0 += RS_U * epi) {
+      int32_t cl[RS_U];
+      float sc[RS_U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < RS_U; ++u) {
         const int32_t e = e0 + u * epi;
         cl[u] = coll[e < end ? e : end - 1];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) sc[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
+      for (int u = 0; u < RS_U; ++u) sc[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < RS_U; ++u) {
         const int32_t e = e0 + u * epi;
         if (e < end) {
-          const float v_ = leaky(sc[u]);
-          att[(int64_t)e * K + k] = v_;
-          const float mn = fmaxf(m, v_);
-          d = d * expf(m - mn) + expf(v_ - mn);
+          const float x = leaky(sc[u]);
+          att[(int64_t)e * K + k] = x;
+          const float mn = fmaxf(m, x);
+          d = d * expf(m - mn) + expf(x - mn);
           m = mn;
         }
-      }
-    }
-    const float M = row_reduce<T>(m, true, K, red);
-    const float D = row_reduce<T>(d * expf(m - M), false, K, red);  // lanes without an edge: d = 0
-    // pass 2: a = exp(score - max) / sum  (exp(log_softmax) of rgat.py:147-151)
-    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
-      float x[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int32_t e = e0 + u * epi;
-        x[u] = att[(int64_t)(e < end ? e : end - 1) * K + k];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int32_t e = e0 + u * epi;
-        if (e < end) att[(int64_t)e * K + k] = expf(x[u] - M) / D;
       }
     }
   } else {
     const float* __restrict__ att = a.att;
     const float* __restrict__ da = a.da;
-    float* __restrict__ dz = a.dz;
-    float t = 0.f;
-    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
-      float x[U], y[U];
+    for (int32_t e0 = beg + slot; e0 < end; e0 += RS_U * epi) {
+      float x[RS_U], y[RS_U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < RS_U; ++u) {
         const int32_t e = e0 + u * epi;
         const int64_t i = (int64_t)(e < end ? e : end - 1) * K + k;
         x[u] = att[i];
         y[u] = da[i];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (e0 + u * epi < end) t += x[u] * y[u];
+      for (int u = 0; u < RS_U; ++u)
+        if (e0 + u * epi < end) d += x[u] * y[u];
     }
-    t = row_reduce<T>(t, false, K, red);
-    for (int32_t e0 = beg + slot; e0 < end; e0 += U * epi) {
-      int32_t cl[U];
-      float x[U], y[U], z[U];
+  }
+}
+
+// pass 2: forward -> att = exp(score - M) / D (+ by-src copy); backward -> dz = att (da - D) leaky'(z)   (D = t)
+template <bool BWD>
+__device__ __forceinline__ void row_pass2(const RowSoftmaxArgs& a, int64_t v, int32_t beg, int32_t end, int slot, int k, int epi,
+                                          float M, float D) {
+  const int K = a.K, L = a.L;
+  if (!BWD) {
+    float* __restrict__ att = a.att;
+    float* __restrict__ att_s = a.att_s;
+    const int32_t* __restrict__ d2s = a.dst2src;
+    for (int32_t e0 = beg + slot; e0 < end; e0 += RS_U * epi) {
+      float x[RS_U];
+      int32_t q[RS_U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < RS_U; ++u) {
+        const int32_t e = e0 + u * epi;
+        const int32_t ee = e < end ? e : end - 1;
+        x[u] = att[(int64_t)ee * K + k];
+        q[u] = att_s ? d2s[ee] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < RS_U; ++u) {
+        const int32_t e = e0 + u * epi;
+        if (e < end) {
+          const float w = expf(x[u] - M) / D;
+          att[(int64_t)e * K + k] = w;
+          if (att_s) att_s[(int64_t)q[u] * K + k] = w;
+        }
+      }
+    }
+  } else {
+    const int32_t* __restrict__ coll = a.coll;
+    const float* __restrict__ s_src = a.s_src;
+    const float* __restrict__ st = a.s_tgt + (int64_t)v * L * K + k;
+    const float* __restrict__ att = a.att;
+    const float* __restrict__ da = a.da;
+    float* __restrict__ dz = a.dz;
+    for (int32_t e0 = beg + slot; e0 < end; e0 += RS_U * epi) {
+      int32_t cl[RS_U];
+      float x[RS_U], y[RS_U], z[RS_U];
+#pragma unroll
+      for (int u = 0; u < RS_U; ++u) {
         const int32_t e = e0 + u * epi;
         const int32_t ee = e < end ? e : end - 1;
         cl[u] = coll[ee];
@@ -337,13 +362,30 @@ __device__ __forceinline__ void row_softmax_body(const RowSoftmaxArgs& a, int64_
         y[u] = da[(int64_t)ee * K + k];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) z[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
+      for (int u = 0; u < RS_U; ++u) z[u] = s_src[(int64_t)cl[u] * K + k] + st[(cl[u] % L) * K];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < RS_U; ++u) {
         const int32_t e = e0 + u * epi;
-        if (e < end) dz[(int64_t)e * K + k] = x[u] * (y[u] - t) * (z[u] > 0.f ? 1.f : 0.2f);
+        if (e < end) dz[(int64_t)e * K + k] = x[u] * (y[u] - D) * (z[u] > 0.f ? 1.f : 0.2f);
       }
     }
+  }
+}
+
+// a whole row with T threads: both passes
+template <int T, bool BWD>
+__device__ __forceinline__ void row_softmax_whole(const RowSoftmaxArgs& a, int64_t v, int tid, float* red) {
+  const int K = a.K, epi = T / K, slot = tid / K, k = tid & (K - 1);
+  const int32_t beg = a.nodeptr[v], end = a.nodeptr[v + 1];
+  float m = -3.402823466e+38f, d = 0.f;
+  row_pass1<BWD>(a, v, beg, end, slot, k, epi, m, d);
+  if (!BWD) {
+    const float M = row_reduce<T>(m, true, K, red);
+    const float D = row_reduce<T>(d * expf(m - M), false, K, red);  // lanes without an edge: d = 0
+    row_pass2<false>(a, v, beg, end, slot, k, epi, M, D);
+  } else {
+    const float t = row_reduce<T>(d, false, K, red);
+    row_pass2<true>(a, v, beg, end, slot, k, epi, 0.f, t);
   }
 }
 
@@ -351,22 +393,67 @@ template <bool BWD>
 __global__ void __launch_bounds__(256) rgat_row_softmax_wave_kernel(RowSoftmaxArgs a) {
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= a.num_rows) return;
-  row_softmax_body<64, BWD>(a, a.rows[w], threadIdx.x & 63, nullptr);
+  row_softmax_whole<64, BWD>(a, a.rows[w], threadIdx.x & 63, nullptr);
 }
 
-// rows of long_threshold + 1 .. item_chunk edges: the items that ARE a whole row (item_slot < 0), 256 threads each
-template <bool BWD>
-__global__ void __launch_bounds__(256) rgat_row_softmax_block_kernel(RowSoftmaxArgs a) {
+// one workgroup per item of the long-row plan.  PHASE 1: whole-row items do both passes; items of multi-item rows pass 1 and
+// leave their pair in part[slot].  PHASE 2 (after the combine kernel): items of multi-item rows normalise.
+template <bool BWD, int PHASE>
+__global__ void __launch_bounds__(256) rgat_row_softmax_item_kernel(RowSoftmaxArgs a) {
   __shared__ float red[4 * 64];
-  if (a.item_chunk[blockIdx.x] >= 0) return;  // (item_slot passed as item_chunk) items of multi-item rows: next kernel
-  row_softmax_body<256, BWD>(a, a.rows[blockIdx.x], threadIdx.x, red);
+  const int item = blockIdx.x;
+  const int32_t sl = a.item_slot[item];
+  const int64_t v = a.rows[item];
+  if (sl < 0) {
+    if (PHASE == 1) row_softmax_whole<256, BWD>(a, v, threadIdx.x, red);
+    return;
+  }
+  const int K = a.K, epi = 256 / K, slot = threadIdx.x / K, k = threadIdx.x & (K - 1);
+  const int32_t rbeg = a.nodeptr[v], rend = a.nodeptr[v + 1];
+  const int32_t beg = rbeg + a.item_chunk[item] * a.chunk_edges;
+  const int32_t end = beg + a.chunk_edges < rend ? beg + a.chunk_edges : rend;
+  float* pr = a.part + ((int64_t)sl * K + k) * 2;
+  if (PHASE == 1) {
+    float m = -3.402823466e+38f, d = 0.f;
+    row_pass1<BWD>(a, v, beg, end, slot, k, epi, m, d);
+    if (!BWD) {
+      const float M = row_reduce<256>(m, true, K, red);
+      const float D = row_reduce<256>(d * expf(m - M), false, K, red);
+      if (slot == 0) { pr[0] = M; pr[1] = D; }
+    } else {
+      const float t = row_reduce<256>(d, false, K, red);
+      if (slot == 0) pr[0] = t;
+    }
+  } else {
+    row_pass2<BWD>(a, v, beg, end, slot, k, epi, pr[0], BWD ? pr[0] : pr[1]);
+  }
 }
 
-// rows cut into several items (more than item_chunk edges, up to the 15 000 of an R-MAT hub): 1024 threads each
+// one wave per multi-item row: lane k combines the row's item pairs in item order and writes the result back to every slot
 template <bool BWD>
-__global__ void __launch_bounds__(1024) rgat_row_softmax_hub_kernel(RowSoftmaxArgs a) {
-  __shared__ float red[16 * 64];
-  row_softmax_body<1024, BWD>(a, a.rows[blockIdx.x], threadIdx.x, red);
+__global__ void __launch_bounds__(64) rgat_row_softmax_combine_kernel(const int32_t* __restrict__ multi_base,
+                                                                     const int32_t* __restrict__ multi_n, int K, float* __restrict__ part) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  const int32_t base = multi_base[blockIdx.x], n = multi_n[blockIdx.x];
+  if (!BWD) {
+    float M = -3.402823466e+38f;
+    for (int i = 0; i < n; ++i) M = fmaxf(M, part[((int64_t)(base + i) * K + k) * 2]);
+    float D = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float* p = part + ((int64_t)(base + i) * K + k) * 2;
+      D += p[1] * expf(p[0] - M);
+    }
+    for (int i = 0; i < n; ++i) {
+      float* p = part + ((int64_t)(base + i) * K + k) * 2;
+      p[0] = M;
+      p[1] = D;
+    }
+  } else {
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) t += part[((int64_t)(base + i) * K + k) * 2];
+    for (int i = 0; i < n; ++i) part[((int64_t)(base + i) * K + k) * 2] = t;
+  }
 }
 
 // d alpha[l, k, :Hk] = sum_v ds_src[(v,l), k] Y[(v,l), k, :] ;  d alpha[l, k, Hk:] likewise with ds_tgt: the block diagonal of
@@ -571,47 +658,61 @@ extern "C" int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_
   return TFGNN_OK;
 }
 
-static int rgat_row_softmax(const tfgnn_graph* g, const float* s_src, const float* s_tgt, int K, float* att, const float* da,
-                            float* dz, bool bwd, hipStream_t s) {
+static int rgat_row_softmax(const tfgnn_graph* g, const float* s_src, const float* s_tgt, int K, float* att, float* att_s,
+                            const float* da, float* dz, bool bwd, void* workspace, size_t workspace_bytes, hipStream_t s) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   if (K <= 0 || K > MAX_HEADS || (K & (K - 1))) return TFGNN_ERR_UNSUPPORTED;  // lane = slot * K + head needs a power of two
   if (g->E == 0) return TFGNN_OK;
   TFGNN_REQUIRE(s_src && s_tgt && att && (!bwd || (da && dz)), "NULL pointer");
   const GraphView& gv = g->views[1];  // by target, all edge types of a node in one row
+  const CsrPlan& pl = gv.plan;
+  const size_t need = (size_t)pl.num_partials * K * 2 * 4;
+  TFGNN_REQUIRE(pl.num_partials == 0 || (workspace && workspace_bytes >= need), "workspace too small: need %zu bytes", need);
   RowSoftmaxArgs a{};
-  a.nodeptr = gv.rowptr; a.coll = gv.col; a.s_src = s_src; a.s_tgt = s_tgt; a.L = g->L > 0 ? g->L : 1; a.K = K;
-  a.att = att; a.da = da; a.dz = dz;
-  if (gv.plan.num_short > 0) {
-    a.rows = gv.plan.short_rows; a.num_rows = gv.plan.num_short; a.item_chunk = nullptr;
-    const dim3 grid((unsigned)ceil_div(gv.plan.num_short, 4));
+  a.nodeptr = gv.rowptr; a.coll = gv.col; a.dst2src = g->dst2src; a.s_src = s_src; a.s_tgt = s_tgt; a.L = g->L > 0 ? g->L : 1; a.K = K;
+  a.att = att; a.att_s = att_s; a.da = da; a.dz = dz; a.part = (float*)workspace; a.chunk_edges = pl.item_chunk_edges;
+  if (pl.num_short > 0) {
+    a.rows = pl.short_rows; a.num_rows = pl.num_short;
+    const dim3 grid((unsigned)ceil_div(pl.num_short, 4));
     if (bwd) hipLaunchKernelGGL(rgat_row_softmax_wave_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(rgat_row_softmax_wave_kernel<false>, grid, dim3(256), 0, s, a);
   }
-  if (gv.plan.num_items > 0) {
-    a.rows = gv.plan.item_row; a.num_rows = gv.plan.num_items; a.item_chunk = gv.plan.item_slot;
-    const dim3 grid((unsigned)gv.plan.num_items);
-    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_block_kernel<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(rgat_row_softmax_block_kernel<false>, grid, dim3(256), 0, s, a);
-  }
-  if (gv.plan.num_multi > 0) {
-    a.rows = gv.plan.multi_row; a.num_rows = gv.plan.num_multi; a.item_chunk = nullptr;
-    const dim3 grid((unsigned)gv.plan.num_multi);
-    if (bwd) hipLaunchKernelGGL(rgat_row_softmax_hub_kernel<true>, grid, dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL(rgat_row_softmax_hub_kernel<false>, grid, dim3(1024), 0, s, a);
+  if (pl.num_items > 0) {
+    a.rows = pl.item_row; a.num_rows = pl.num_items; a.item_chunk = pl.item_chunk; a.item_slot = pl.item_slot;
+    const dim3 grid((unsigned)pl.num_items);
+    if (bwd) hipLaunchKernelGGL((rgat_row_softmax_item_kernel<true, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rgat_row_softmax_item_kernel<false, 1>), grid, dim3(256), 0, s, a);
+    if (pl.num_multi > 0) {
+      if (bwd) {
+        hipLaunchKernelGGL(rgat_row_softmax_combine_kernel<true>, dim3((unsigned)pl.num_multi), dim3(64), 0, s, pl.multi_base, pl.multi_n, K, a.part);
+        hipLaunchKernelGGL((rgat_row_softmax_item_kernel<true, 2>), grid, dim3(256), 0, s, a);
+      } else {
+        hipLaunchKernelGGL(rgat_row_softmax_combine_kernel<false>, dim3((unsigned)pl.num_multi), dim3(64), 0, s, pl.multi_base, pl.multi_n, K, a.part);
+        hipLaunchKernelGGL((rgat_row_softmax_item_kernel<false, 2>), grid, dim3(256), 0, s, a);
+      }
+    }
   }
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
 
+extern "C" size_t tfgnn_rgat_attention_workspace_bytes(const tfgnn_graph* graph, int num_heads) {
+  if (!graph || num_heads <= 0) return 0;
+  return (size_t)graph->views[1].plan.num_partials * (size_t)num_heads * 2 * 4;
+}
+
 extern "C" int tfgnn_rgat_attention_forward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, int num_heads,
-                                            float* d_att, void* stream) {
-  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, d_att, nullptr, nullptr, false, (hipStream_t)stream);
+                                            float* d_att, float* d_att_by_src, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, d_att, d_att_by_src, nullptr, nullptr, false, d_workspace, workspace_bytes,
+                          (hipStream_t)stream);
 }
 
 extern "C" int tfgnn_rgat_attention_backward(const tfgnn_graph* graph, const float* d_s_src, const float* d_s_tgt, const float* d_att,
-                                             const float* d_da, int num_heads, float* d_dz, void* stream) {
-  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, const_cast<float*>(d_att), d_da, d_dz, true, (hipStream_t)stream);
+                                             const float* d_da, int num_heads, float* d_dz, void* d_workspace, size_t workspace_bytes,
+                                             void* stream) {
+  return rgat_row_softmax(graph, d_s_src, d_s_tgt, num_heads, const_cast<float*>(d_att), nullptr, d_da, d_dz, true, d_workspace,
+                          workspace_bytes, (hipStream_t)stream);
 }
 
 static int alpha_grad_blocks(int64_t V) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, tfgnn::ceil_div(V, 16))); }

@@ -101,7 +101,7 @@ class RGAT(MessagePassing):
                 ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
             )
         )
-        att = self._edge_attention(g, s_src, s_tgt, K)
+        att = self._edge_attention(g, s_src, s_tgt, K, training)
         act = self._activation_name
         fused = None if act == "gelu" else act
         if L == 0 or g.num_edges == 0:
@@ -110,7 +110,9 @@ class RGAT(MessagePassing):
                 out = ops.activation_forward(fused, out)
         else:
             out = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=att, post_act=fused)
-        ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act}
+        ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act,
+               "att_by_src": getattr(self, "_att_by_src", None) if g.num_edges else None}
+        self._att_by_src = None
         if act == "gelu":
             ctx["pre"] = out
             out = ops.activation_forward("gelu", out)
@@ -126,7 +128,7 @@ class RGAT(MessagePassing):
             g._cache["ident_e"] = ident
         return ident
 
-    def _edge_attention(self, g, s_src, s_tgt, K):
+    def _edge_attention(self, g, s_src, s_tgt, K, training=True):
         """a[e,k]: per head, softmax over all edges entering the target (rgat.py:142-151).  Edge-parallel
         kernels + two generic segment reductions over the node view (identity columns)."""
         lib = _lib.load()
@@ -137,9 +139,14 @@ class RGAT(MessagePassing):
             return att
         # one pass per CSR row (csrc/rgat.hip, tfgnn_rgat_attention_forward) when the head count is a power of two; the
         # piecewise form below otherwise
-        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._stream())
+        self._att_by_src = torch.empty((E, K), dtype=torch.float32, device=dev) if training else None
+        ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
+        ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
+        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(self._att_by_src),
+                                              ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
         if rc == 0:
             return att
+        self._att_by_src = None
         if rc != -4:
             _lib.check(rc)
         coll, tgt = g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST)
@@ -179,7 +186,9 @@ class RGAT(MessagePassing):
         s2d = g.array(ops.G_SRC2DST_POS)
         ident_e = self._ident(g, E)
         # (1) dY[(u,l),k,:] = sum over out-edges e of (u,l): a_ek * d_agg[tgt_e, k, :]
-        att_s = ops.gather_reduce(ident_e[: E + 1], s2d, att)  # attention re-ordered to the by-src edge order
+        att_s = ctx.get("att_by_src")  # written by the forward row kernels in training mode
+        if att_s is None:
+            att_s = ops.gather_reduce(ident_e[: E + 1], s2d, att)  # attention re-ordered to the by-src edge order
         dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]
         # (2) gradient w.r.t. the attention values, softmax + leaky_relu backward
         da = torch.empty((E, K), dtype=torch.float32, device=dev)
@@ -190,8 +199,10 @@ class RGAT(MessagePassing):
             )
         )
         dz = torch.empty((E, K), dtype=torch.float32, device=dev)
+        ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
+        ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
         rc = lib.tfgnn_rgat_attention_backward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), K, ops._ptr(dz),
-                                               ops._stream())
+                                               ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
         if rc == -4:  # head count not a power of two: the piecewise form
             t = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, ops.mul(att, da), col=ident_e[:E])  # [V, K] sum of a * da
             _lib.check(
