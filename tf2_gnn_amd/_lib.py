@@ -92,6 +92,13 @@ _SIGNATURES = [
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     ),
+    ("tfgnn_gru_gates_backward_sp_workspace_bytes", c_size_t, [c_int64, c_int]),
+    (
+        "tfgnn_gru_gates_backward_sp",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+         c_void_p, c_size_t, c_void_p],
+    ),
     ("tfgnn_colsum_workspace_bytes", c_size_t, [c_int64, c_int]),
     ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("tfgnn_add_scale", c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),

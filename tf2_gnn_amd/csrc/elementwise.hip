@@ -107,6 +107,85 @@ gru_gates_backward_kernel(const float* __restrict__ dh_new, const float* __restr
   }
 }
 
+// The same gate gradients written as the SPLIT OPERANDS of the f16x2 products that consume them (csrc/gemm_sp.hip: dmx, dmh
+// [V, 3H] as SP16 rows with one power-of-two scale per row), the bias gradients (column sums of dmx and dmh) folded in as
+// per-wave partial sums: no fp32 dmx / dmh is ever written or re-read.  One wave per row, lane j owns units j, j + 64, ...
+// (H % 64 == 0); a wave walks rows w, w + W, ... in order and keeps the six column sums of each of its units in registers
+// -> partial[w][6H] (x gates z, r, c then h gates z, r, c), added over w in order by colsum_final_kernel.
+template <int UPL>  // units per lane = H / 64
+__global__ void __launch_bounds__(256)
+gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __restrict__ gates, const float* __restrict__ mh,
+                             const float* __restrict__ h, uint8_t* __restrict__ dmx_sp, float* __restrict__ dmx_inv,
+                             uint8_t* __restrict__ dmh_sp, float* __restrict__ dmh_inv, float* __restrict__ dh_direct,
+                             float* __restrict__ partial, int64_t V) {
+  constexpr int H = 64 * UPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), W = (int64_t)gridDim.x * 4;
+  float cs[6][UPL];
+#pragma unroll
+  for (int g = 0; g < 6; ++g)
+#pragma unroll
+    for (int u = 0; u < UPL; ++u) cs[g][u] = 0.f;
+  for (int64_t v = w; v < V; v += W) {
+    const float* pg = gates + v * 3 * H;
+    const float* pm = mh + v * 3 * H + 2 * H;
+    float x[3][UPL], y[UPL];  // dmx gates; dmh differs in the candidate gate only
+    float mxx = 0.f, mxh = 0.f;
+#pragma unroll
+    for (int u = 0; u < UPL; ++u) {
+      const int j = lane + 64 * u;
+      const float z = pg[j], r = pg[H + j], c = pg[2 * H + j];
+      const float hh = pm[j];
+      const float g = dh_new[v * H + j];
+      const float dc = g * (1.f - z);
+      const float dz = g * (h[v * H + j] - c);
+      const float dpc = dc * (1.f - c * c);
+      const float dpz = dz * z * (1.f - z);
+      const float dpr = dpc * hh * r * (1.f - r);
+      x[0][u] = dpz; x[1][u] = dpr; x[2][u] = dpc; y[u] = dpc * r;
+      dh_direct[v * H + j] = g * z;
+      cs[0][u] += dpz; cs[1][u] += dpr; cs[2][u] += dpc;
+      cs[3][u] += dpz; cs[4][u] += dpr; cs[5][u] += dpc * r;
+      const float m2 = fmaxf(fabsf(dpz), fabsf(dpr));
+      mxx = fmaxf(mxx, fmaxf(m2, fabsf(dpc)));
+      mxh = fmaxf(mxh, fmaxf(m2, fabsf(dpc * r)));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64));
+      mxh = fmaxf(mxh, __shfl_xor(mxh, o, 64));
+    }
+    float ivx, ivh;
+    const float sx = sp_scale_for_max(mxx, &ivx), sh = sp_scale_for_max(mxh, &ivh);
+    if (lane == 0) {
+      dmx_inv[v] = ivx;
+      dmh_inv[v] = ivh;
+    }
+    uint8_t* rx = dmx_sp + v * (int64_t)(3 * H * 4);
+    uint8_t* rh = dmh_sp + v * (int64_t)(3 * H * 4);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int u = 0; u < UPL; ++u) {
+        const int c = g * H + lane + 64 * u;  // column of the [V, 3H] operand: granule c / 16, position c % 16
+        _Float16 hi, lo;
+        sp_split(x[g][u] * sx, hi, lo);
+        _Float16* px = reinterpret_cast<_Float16*>(rx + (c >> 4) * 64) + (c & 15);
+        px[0] = hi;
+        px[16] = lo;
+        sp_split((g == 2 ? y[u] : x[g][u]) * sh, hi, lo);
+        _Float16* ph = reinterpret_cast<_Float16*>(rh + (c >> 4) * 64) + (c & 15);
+        ph[0] = hi;
+        ph[16] = lo;
+      }
+  }
+  float* out = partial + w * 6 * H;
+#pragma unroll
+  for (int g = 0; g < 6; ++g)
+#pragma unroll
+    for (int u = 0; u < UPL; ++u) out[g * H + lane + 64 * u] = cs[g][u];
+}
+
 // out[n] = sum_m in[m, n]   (bias gradients).  Two deterministic stages: gridDim.y row slabs each
 // reduce to partial[slab, n] (4 waves x 64 columns per workgroup), then the slabs are summed in order.
 __global__ void __launch_bounds__(256)
@@ -386,6 +465,54 @@ extern "C" int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_ga
   TFGNN_REQUIRE(d_dh_new && d_gates && d_mh && d_h && d_dmx && d_dmh && d_dh_direct, "NULL pointer");
   hipLaunchKernelGGL(gru_gates_backward_kernel, dim3(ew_blocks(V * H)), dim3(256), 0, (hipStream_t)stream, d_dh_new,
                      d_gates, d_mh, d_h, d_dmx, d_dmh, d_dh_direct, V, H);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+static int gates_sp_waves(int64_t V) { return (int)(4 * std::max<int64_t>(1, std::min<int64_t>(512, (V + 255) / 256))); }
+
+extern "C" size_t tfgnn_gru_gates_backward_sp_workspace_bytes(int64_t V, int H) {
+  if (V <= 0 || H <= 0) return 0;
+  return (size_t)gates_sp_waves(V) * 6 * (size_t)H * 4;
+}
+
+extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
+                                           void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
+                                           float* d_dh_direct, float* d_bias_grad, int64_t V, int H, void* d_workspace,
+                                           size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
+  if (H % 64 != 0 || H > 512) return TFGNN_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (V == 0) {
+    if (d_bias_grad) TFGNN_HIP_CHECK(hipMemsetAsync(d_bias_grad, 0, (size_t)6 * H * 4, s));
+    return TFGNN_OK;
+  }
+  TFGNN_REQUIRE(d_dh_new && d_gates && d_mh && d_h && d_dmx_sp && d_dmx_inv_scale && d_dmh_sp && d_dmh_inv_scale && d_dh_direct &&
+                    d_bias_grad, "NULL pointer");
+  TFGNN_REQUIRE(((uintptr_t)d_dmx_sp | (uintptr_t)d_dmh_sp) % 64 == 0, "SP16 operands must be 64-byte aligned");
+  const int waves = gates_sp_waves(V);
+  TFGNN_REQUIRE(d_workspace && workspace_bytes >= (size_t)waves * 6 * H * 4, "workspace too small: need %zu bytes",
+                (size_t)waves * 6 * H * 4);
+  float* partial = (float*)d_workspace;
+  const dim3 grid(waves / 4), block(256);
+#define GATES_SP(U)                                                                                                     \
+  hipLaunchKernelGGL(gru_gates_backward_sp_kernel<U>, grid, block, 0, s, d_dh_new, d_gates, d_mh, d_h, (uint8_t*)d_dmx_sp, \
+                     d_dmx_inv_scale, (uint8_t*)d_dmh_sp, d_dmh_inv_scale, d_dh_direct, partial, V)
+  switch (H / 64) {
+    case 1: GATES_SP(1); break;
+    case 2: GATES_SP(2); break;
+    case 3: GATES_SP(3); break;
+    case 4: GATES_SP(4); break;
+    case 5: GATES_SP(5); break;
+    case 6: GATES_SP(6); break;
+    case 7: GATES_SP(7); break;
+    default: GATES_SP(8); break;
+  }
+#undef GATES_SP
+  TFGNN_LAUNCH_CHECK();
+  // bias gradients [2, 3H]: the six column sums, waves added in order
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(6 * H, 64)), dim3(256), 0, s, partial, waves, 6 * H, d_bias_grad);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -262,7 +262,7 @@ class GNN:
                     cur = ops.add_scale(cur, last, 0.5)
                 last = tmp
             # a Dense right behind this layer takes its input as a split operand: let the layer's product write it
-            mp_layer._want_split_output = (
+            mp_layer._want_split_output = bool(getattr(mp_layer, "_always_split_output", False)) or (
                 layer_idx % self._dense_every_num_layers == 0 and str(layer_idx) not in self._global_exchange_layers
                 and not self._use_inter_layer_layernorm and self._dense_f16x2(self._hidden_dim, self._hidden_dim)
             )

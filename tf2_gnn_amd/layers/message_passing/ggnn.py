@@ -57,6 +57,10 @@ class GGNN(GNN_Edge_MLP):
     def _uses_base_aggregation(self) -> bool:
         return False
 
+    # f16x2: the aggregate [V, H] is the K operand of the GRU kernel's gradient product - let the forward product's epilogue
+    # write its split form (tfgnn_sp_gemm_nt_sp) instead of splitting it in a pass of its own
+    _always_split_output = True
+
     def _post_activation_name(self):
         return None  # ggnn.py:80-89: aggregated messages go straight into the GRU
 
@@ -79,11 +83,35 @@ class GGNN(GNN_Edge_MLP):
             raise RuntimeError("backward called before a forward pass")
         ru = self._recurrent_unit
         X = ctx["X"]
+        if ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2:
+            dX = self._backward_f16x2(grad_output, ctx, X)
+            if dX is not None:
+                return dX
         dmx, dmh, dh_direct = ops.gru_gates_backward(grad_output, ctx["gates"], ctx["mh"], X)
         ru["kernel"].grad = ops.gemm(ctx["agg"], dmx, trans_a=True)
         ru["recurrent_kernel"].grad = ops.gemm(X, dmh, trans_a=True)
         ru["bias"].grad = torch.stack([ops.colsum(dmx), ops.colsum(dmh)], dim=0)
         d_agg = ops.gemm(dmx, ru["kernel"].value, trans_b=True)
         dX_state = ops.gemm(dmh, ru["recurrent_kernel"].value, trans_b=True, out=dh_direct, accumulate=True)
+        dX_msgs = self._backward_messages(d_agg, ctx)
+        return ops.add_scale(dX_msgs, dX_state, 1.0)
+
+    def _backward_f16x2(self, grad_output, ctx, X):
+        """The GRU part of the backward pass on split operands (round 3): the gate-gradient kernel writes dmx / dmh only as
+        SP16 operands (with the bias gradients folded in), the two kernel gradients are tfgnn_sp_gemm_tn products (K = V
+        rows), the two input gradients tfgnn_sp_gemm_nt products - no fp32 [V, 3H] tensor is written or re-read, and the
+        products run 3 piece products instead of 6.  None when the width has no such kernel."""
+        res = ops.gru_gates_backward_sp(grad_output, ctx["gates"], ctx["mh"], X)
+        if res is None:
+            return None
+        dmx_sp, dmh_sp, dh_direct, bias_grad = res
+        ru = self._recurrent_unit
+        Wk, Wr = ru["kernel"].value, ru["recurrent_kernel"].value  # [H, 3H]: rows are the N = H outputs, K = 3H contiguous
+        ru["kernel"].grad = ops.sp_gemm_tn(ops.sp_rows_of(ctx["agg"]), dmx_sp)  # agg^T dmx  [H, 3H]
+        ru["recurrent_kernel"].grad = ops.sp_gemm_tn(ops.sp_rows_of(X), dmh_sp)  # h^T dmh
+        ru["bias"].grad = bias_grad
+        d_agg = ops.sp_gemm_nt(dmx_sp, ops.sp_weight_operand(Wk, "rows", lambda: ops.sp_split_rows(Wk)))
+        dX_state = ops.sp_gemm_nt(dmh_sp, ops.sp_weight_operand(Wr, "rows", lambda: ops.sp_split_rows(Wr)), out=dh_direct,
+                                  accumulate=True)
         dX_msgs = self._backward_messages(d_agg, ctx)
         return ops.add_scale(dX_msgs, dX_state, 1.0)

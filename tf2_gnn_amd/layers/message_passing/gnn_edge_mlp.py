@@ -336,7 +336,8 @@ class GNN_Edge_MLP(MessagePassing):
             A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L)
             Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H)))
             gelu_split = fuse_act == "gelu"
-            if getattr(self, "_want_split_output", False) and not gelu_split and H in (128, 256, 320):
+            want_split = getattr(self, "_want_split_output", False) or getattr(self, "_always_split_output", False)
+            if want_split and not gelu_split and H in (128, 256, 320):
                 pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act)  # the consumer finds the split form with sp_rows_of
             else:
                 pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)

@@ -535,6 +535,33 @@ def gru_gates_backward(dh_new, gates, mh, h):
     return dmx, dmh, dh_direct
 
 
+def gru_gates_backward_sp(dh_new, gates, mh, h):
+    """gru_gates_backward with dmx / dmh written ONLY as SP16 split operands (one scale per row) and the bias gradients
+    [2, 3H] folded in (tfgnn_gru_gates_backward_sp) -> (dmx_sp, dmh_sp, dh_direct, bias_grad), or None when the library has
+    no such kernel for this width (H % 64 != 0 or H > 512)."""
+    lib = _lib.load()
+    V, H = h.shape
+    if H % 64 != 0 or H > 512:
+        return None
+    dh_new = dh_new.contiguous()
+    dev = h.device
+    dmx = SplitOperand(torch.empty((V, 3 * H * 4), dtype=torch.uint8, device=dev), torch.empty((V, 1), dtype=torch.float32, device=dev),
+                       V, 3 * H, 3 * H)
+    dmh = SplitOperand(torch.empty((V, 3 * H * 4), dtype=torch.uint8, device=dev), torch.empty((V, 1), dtype=torch.float32, device=dev),
+                       V, 3 * H, 3 * H)
+    dh_direct = torch.empty_like(h)
+    bias_grad = torch.empty((2, 3 * H), dtype=torch.float32, device=dev)
+    ws_bytes = lib.tfgnn_gru_gates_backward_sp_workspace_bytes(V, H)
+    ws = _workspace(dev, ws_bytes) if ws_bytes else None
+    rc = lib.tfgnn_gru_gates_backward_sp(_ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx.data), _ptr(dmx.inv_scale),
+                                         _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct), _ptr(bias_grad), V, H, _ptr(ws),
+                                         ws.numel() if ws is not None else 0, _stream())
+    if rc == -4:
+        return None
+    _lib.check(rc)
+    return dmx, dmh, dh_direct, bias_grad
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x, ld = _rowmajor(x, "x")
