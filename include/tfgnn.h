@@ -371,13 +371,14 @@ int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const 
 /* The same gate gradients for the f16x2 products that consume them (round 3): dmx and dmh [V, 3H] are written ONLY as SP16
  * split operands (one scale per row, d_*_inv_scale [V]) - the operands of tfgnn_sp_gemm_tn (kernel gradients agg^T dmx,
  * h^T dmh) and tfgnn_sp_gemm_nt (d agg = dmx kernel^T, d h += dmh recurrent^T) - and the bias gradients [2, 3H] (column sums
- * of dmx, dmh: fixed-order two-stage reduction) come out of the same pass.  H % 64 == 0, H <= 512 (TFGNN_ERR_UNSUPPORTED
- * otherwise); workspace: tfgnn_gru_gates_backward_sp_workspace_bytes. */
+ * of dmx, dmh: fixed-order two-stage reduction) come out of the same pass.  d_out_mul (nullable, [V, H]): an element-wise
+ * factor of the state gradient (the dropout mask of the layer's input) applied to d_dh_direct = dh_new * z on the way out.
+ * H % 64 == 0, H <= 512 (TFGNN_ERR_UNSUPPORTED otherwise); workspace: tfgnn_gru_gates_backward_sp_workspace_bytes. */
 size_t tfgnn_gru_gates_backward_sp_workspace_bytes(int64_t V, int H);
 int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
                                 void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
-                                float* d_dh_direct, float* d_bias_grad, int64_t V, int H, void* d_workspace,
-                                size_t workspace_bytes, void* stream);
+                                float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
+                                void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* tf.maximum(x, lower) then tf.minimum(., upper) (nodes_to_graph_representation.py:194-197; pass -inf / +inf for an absent
  * bound) and its gradient: dx = dy where lower <= x <= upper, else 0 (TensorFlow's MaximumMinimumGrad). */

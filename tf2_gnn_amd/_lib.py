@@ -96,8 +96,8 @@ _SIGNATURES = [
     (
         "tfgnn_gru_gates_backward_sp",
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
-         c_void_p, c_size_t, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+         c_int, c_void_p, c_size_t, c_void_p],
     ),
     ("tfgnn_colsum_workspace_bytes", c_size_t, [c_int64, c_int]),
     ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

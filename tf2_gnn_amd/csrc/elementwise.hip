@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256)
 gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __restrict__ gates, const float* __restrict__ mh,
                              const float* __restrict__ h, uint8_t* __restrict__ dmx_sp, float* __restrict__ dmx_inv,
                              uint8_t* __restrict__ dmh_sp, float* __restrict__ dmh_inv, float* __restrict__ dh_direct,
-                             float* __restrict__ partial, int64_t V) {
+                             const float* __restrict__ out_mul, float* __restrict__ partial, int64_t V) {
   constexpr int H = 64 * UPL;
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), W = (int64_t)gridDim.x * 4;
@@ -143,7 +143,7 @@ gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __re
       const float dpz = dz * z * (1.f - z);
       const float dpr = dpc * hh * r * (1.f - r);
       x[0][u] = dpz; x[1][u] = dpr; x[2][u] = dpc; y[u] = dpc * r;
-      dh_direct[v * H + j] = g * z;
+      dh_direct[v * H + j] = out_mul ? g * z * out_mul[v * H + j] : g * z;
       cs[0][u] += dpz; cs[1][u] += dpr; cs[2][u] += dpc;
       cs[3][u] += dpz; cs[4][u] += dpr; cs[5][u] += dpc * r;
       const float m2 = fmaxf(fabsf(dpz), fabsf(dpr));
@@ -478,8 +478,8 @@ extern "C" size_t tfgnn_gru_gates_backward_sp_workspace_bytes(int64_t V, int H) 
 
 extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
                                            void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
-                                           float* d_dh_direct, float* d_bias_grad, int64_t V, int H, void* d_workspace,
-                                           size_t workspace_bytes, void* stream) {
+                                           float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
+                                           void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
   if (H % 64 != 0 || H > 512) return TFGNN_ERR_UNSUPPORTED;
@@ -498,7 +498,7 @@ extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d
   const dim3 grid(waves / 4), block(256);
 #define GATES_SP(U)                                                                                                     \
   hipLaunchKernelGGL(gru_gates_backward_sp_kernel<U>, grid, block, 0, s, d_dh_new, d_gates, d_mh, d_h, (uint8_t*)d_dmx_sp, \
-                     d_dmx_inv_scale, (uint8_t*)d_dmh_sp, d_dmh_inv_scale, d_dh_direct, partial, V)
+                     d_dmx_inv_scale, (uint8_t*)d_dmh_sp, d_dmh_inv_scale, d_dh_direct, d_out_mul, partial, V)
   switch (H / 64) {
     case 1: GATES_SP(1); break;
     case 2: GATES_SP(2); break;

@@ -767,12 +767,15 @@ struct SpTnArgs {
 // their own factors would double that range but costs 40 more VALU instructions per step (measured 115 vs 92 us).
 // SP_TN_FCHUNKS workgroups per block: each one takes the maximum over ALL k itself (the scales are 4 bytes per row, L2
 // resident; loads issued eight at a time) and writes its own slice of the factors - no second launch, no atomics.
-constexpr int SP_TN_FCHUNKS = 16;
+constexpr int SP_TN_FCHUNKS = 16;  // for K up to 128k rows; more for longer operands (sp_tn_fchunks)
+static int sp_tn_fchunks(int64_t K) {  // 16 workgroups walked the 1.15M row scales of a QM9-sized operand in 225 us
+  return (int)std::max<int64_t>(SP_TN_FCHUNKS, std::min<int64_t>(128, (K + 8191) / 8192));
+}
 __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
                                                              int64_t ld_b, int64_t K, _Float16* __restrict__ F, int64_t f_ld,
-                                                             float* __restrict__ ref, int* __restrict__ spread_flag) {
+                                                             float* __restrict__ ref, int* __restrict__ spread_flag, int nchunks) {
   __shared__ float red[16];
-  const int b = blockIdx.x / SP_TN_FCHUNKS, chunk = blockIdx.x % SP_TN_FCHUNKS;
+  const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   float mx = 0.f;
   for (int64_t k0 = threadIdx.x; k0 < K; k0 += 8 * 1024) {
     float va[8], vb[8];
@@ -795,7 +798,7 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
   if (mx == 0.f) mx = 1.f;
   if (threadIdx.x == 0 && chunk == 0) ref[b] = mx;
   const float r = 1.f / mx;  // powers of two: exact
-  const int64_t per = ((f_ld + SP_TN_FCHUNKS - 1) / SP_TN_FCHUNKS + 7) & ~7ll;
+  const int64_t per = ((f_ld + nchunks - 1) / nchunks + 7) & ~7ll;
   const int64_t kend = (chunk + 1) * per < f_ld ? (chunk + 1) * per : f_ld;
   bool wide = false;
   for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 1024) {
@@ -1373,8 +1376,9 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   _Float16* F = (_Float16*)d_workspace;
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
   if (phases & 1) {
-    hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * SP_TN_FCHUNKS), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
-                       kpad, ref, sp_spread_flag_device());
+    const int fch = sp_tn_fchunks(K);
+    hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * fch), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
+                       kpad, ref, sp_spread_flag_device(), fch);
     TFGNN_LAUNCH_CHECK();
   }
   SpTnArgs g{};

@@ -96,12 +96,25 @@ class GGNN(GNN_Edge_MLP):
         dX_msgs = self._backward_messages(d_agg, ctx)
         return ops.add_scale(dX_msgs, dX_state, 1.0)
 
-    def _backward_f16x2(self, grad_output, ctx, X):
+    def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
+        """f16x2: the dropout mask of this layer's input (``out_mul``) rides in the epilogues of the three input-gradient
+        terms instead of a pass of its own over [V, H]; anything else takes the generic form."""
+        ctx = self._ctx
+        if (not grad_is_pre_activation and out_act_grad is None and ctx is not None and ctx.get("f16x2")
+                and ops.get_gemm_mode() == ops.GEMM_F16X2):
+            dX = self._backward_f16x2(grad_output, ctx, ctx["X"], out_mul=out_mul)
+            if dX is not None:
+                return dX
+        return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+
+    def _backward_f16x2(self, grad_output, ctx, X, out_mul=None):
         """The GRU part of the backward pass on split operands (round 3): the gate-gradient kernel writes dmx / dmh only as
         SP16 operands (with the bias gradients folded in), the two kernel gradients are tfgnn_sp_gemm_tn products (K = V
         rows), the two input gradients tfgnn_sp_gemm_nt products - no fp32 [V, 3H] tensor is written or re-read, and the
-        products run 3 piece products instead of 6.  None when the width has no such kernel."""
-        res = ops.gru_gates_backward_sp(grad_output, ctx["gates"], ctx["mh"], X)
+        products run 3 piece products instead of 6.  The three terms of d(node_embeddings) - dh_new * z, dmh recurrent^T and the
+        message path's G W^T - accumulate in ONE buffer through the products' epilogues (with ``out_mul`` applied to each).
+        None when the width has no such kernel."""
+        res = ops.gru_gates_backward_sp(grad_output, ctx["gates"], ctx["mh"], X, out_mul=out_mul)
         if res is None:
             return None
         dmx_sp, dmh_sp, dh_direct, bias_grad = res
@@ -111,7 +124,16 @@ class GGNN(GNN_Edge_MLP):
         ru["recurrent_kernel"].grad = ops.sp_gemm_tn(ops.sp_rows_of(X), dmh_sp)  # h^T dmh
         ru["bias"].grad = bias_grad
         d_agg = ops.sp_gemm_nt(dmx_sp, ops.sp_weight_operand(Wk, "rows", lambda: ops.sp_split_rows(Wk)))
-        dX_state = ops.sp_gemm_nt(dmh_sp, ops.sp_weight_operand(Wr, "rows", lambda: ops.sp_split_rows(Wr)), out=dh_direct,
-                                  accumulate=True)
-        dX_msgs = self._backward_messages(d_agg, ctx)
-        return ops.add_scale(dX_msgs, dX_state, 1.0)
+        dX = ops.sp_gemm_nt(dmh_sp, ops.sp_weight_operand(Wr, "rows", lambda: ops.sp_split_rows(Wr)), out=dh_direct,
+                            accumulate=True, out_mul=out_mul)
+        # the message path adds its term into the same buffer (GNN_Edge_MLP._backward_A_f16x2 consumes the request)
+        self._dx_accumulate = (dX, out_mul)
+        try:
+            dX_msgs = self._backward_messages(d_agg, ctx)
+            if self._dx_accumulate is None:
+                return dX_msgs  # == dX, accumulated in place
+        finally:
+            self._dx_accumulate = None
+        if out_mul is not None:
+            dX_msgs = ops.mul(dX_msgs, out_mul)
+        return ops.add_scale(dX_msgs, dX, 1.0)

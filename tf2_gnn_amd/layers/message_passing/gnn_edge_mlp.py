@@ -389,7 +389,12 @@ class GNN_Edge_MLP(MessagePassing):
             tn = ops.SpGemmTnOverlapped(G_sp, ops.sp_rows_of(X), out=dW, scatter=(H, D * H, 1, H))  # factors: second stream
         Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H)))
         epi = getattr(self, "_out_epilogue", None)
-        if epi is not None:
+        acc = getattr(self, "_dx_accumulate", None)
+        if acc is not None:
+            # a subclass (GGNN) already holds other terms of d(node_embeddings): add this one in the product's epilogue
+            dX = ops.sp_gemm_nt(G_sp, Wh_sp, out=acc[0], accumulate=True, out_mul=acc[1])
+            self._dx_accumulate = None  # consumed
+        elif epi is not None:
             if getattr(self, "_want_split_input_grad", False) and D in (128, 256, 320):
                 dX, _ = ops.sp_gemm_nt_split(G_sp, Wh_sp, out_mul=epi[0], act_grad=epi[1])
             else:

@@ -535,10 +535,10 @@ def gru_gates_backward(dh_new, gates, mh, h):
     return dmx, dmh, dh_direct
 
 
-def gru_gates_backward_sp(dh_new, gates, mh, h):
+def gru_gates_backward_sp(dh_new, gates, mh, h, out_mul=None):
     """gru_gates_backward with dmx / dmh written ONLY as SP16 split operands (one scale per row) and the bias gradients
     [2, 3H] folded in (tfgnn_gru_gates_backward_sp) -> (dmx_sp, dmh_sp, dh_direct, bias_grad), or None when the library has
-    no such kernel for this width (H % 64 != 0 or H > 512)."""
+    no such kernel for this width (H % 64 != 0 or H > 512).  ``out_mul`` [V, H]: factor of dh_direct (a dropout mask)."""
     lib = _lib.load()
     V, H = h.shape
     if H % 64 != 0 or H > 512:
@@ -554,7 +554,8 @@ def gru_gates_backward_sp(dh_new, gates, mh, h):
     ws_bytes = lib.tfgnn_gru_gates_backward_sp_workspace_bytes(V, H)
     ws = _workspace(dev, ws_bytes) if ws_bytes else None
     rc = lib.tfgnn_gru_gates_backward_sp(_ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx.data), _ptr(dmx.inv_scale),
-                                         _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct), _ptr(bias_grad), V, H, _ptr(ws),
+                                         _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct),
+                                         _ptr(out_mul.contiguous() if out_mul is not None else None), _ptr(bias_grad), V, H, _ptr(ws),
                                          ws.numel() if ws is not None else 0, _stream())
     if rc == -4:
         return None
