@@ -767,16 +767,41 @@ struct SpTnArgs {
 // their own factors would double that range but costs 40 more VALU instructions per step (measured 115 vs 92 us).
 // SP_TN_FCHUNKS workgroups per block: each one takes the maximum over ALL k itself (the scales are 4 bytes per row, L2
 // resident; loads issued eight at a time) and writes its own slice of the factors - no second launch, no atomics.
-constexpr int SP_TN_FCHUNKS = 16;  // for K up to 128k rows; more for longer operands (sp_tn_fchunks)
-static int sp_tn_fchunks(int64_t K) {  // 16 workgroups walked the 1.15M row scales of a QM9-sized operand in 225 us
-  return (int)std::max<int64_t>(SP_TN_FCHUNKS, std::min<int64_t>(128, (K + 8191) / 8192));
+constexpr int SP_TN_FCHUNKS = 16;  // K up to 128k rows: every workgroup takes the maximum over all k itself (one launch)
+// Longer operands (QM9-sized batches: 1.15M rows - 16 workgroups walking all of them took 225 us, 128 of them 359 us): the
+// maxima of SP_TN_MAXCHUNKS slices first (sp_tn_slice_max_kernel), then the factor pass reads those instead of all k
+constexpr int SP_TN_MAXCHUNKS = 128;
+static int sp_tn_fchunks(int64_t K) { return K > 131072 ? SP_TN_MAXCHUNKS : SP_TN_FCHUNKS; }
+
+__global__ void __launch_bounds__(1024) sp_tn_slice_max_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
+                                                               int64_t ld_b, int64_t K, float* __restrict__ slice_max, int nchunks) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  const int64_t per = (K + nchunks - 1) / nchunks;
+  const int64_t k1 = (chunk + 1) * per < K ? (chunk + 1) * per : K;
+  float mx = 0.f;
+  for (int64_t k = chunk * per + threadIdx.x; k < k1; k += 1024) mx = fmaxf(mx, inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+    slice_max[blockIdx.x] = m;
+  }
 }
 __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __restrict__ inv_a, int64_t ld_a, const float* __restrict__ inv_b,
                                                              int64_t ld_b, int64_t K, _Float16* __restrict__ F, int64_t f_ld,
-                                                             float* __restrict__ ref, int* __restrict__ spread_flag, int nchunks) {
+                                                             float* __restrict__ ref, int* __restrict__ spread_flag, int nchunks,
+                                                             const float* __restrict__ slice_max) {
   __shared__ float red[16];
   const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   float mx = 0.f;
+  if (slice_max) {  // the slices' maxima were taken by sp_tn_slice_max_kernel
+    for (int i = threadIdx.x; i < nchunks; i += 1024) mx = fmaxf(mx, slice_max[b * nchunks + i]);
+  } else
   for (int64_t k0 = threadIdx.x; k0 < K; k0 += 8 * 1024) {
     float va[8], vb[8];
 #pragma unroll
@@ -1338,7 +1363,7 @@ size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t
   if (!bn || M <= 0 || a_scale_block <= 0) return 0;
   const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
   const int64_t nblk = ceil_div(a_total_cols, a_scale_block), kpad = (K + 15) & ~15ll;
-  const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * 4 + 255) & ~(size_t)255);
+  const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * (1 + SP_TN_MAXCHUNKS) * 4 + 255) & ~(size_t)255);
   return factors + (size_t)sp_tn_splits(Mp, N, K, bn) * (size_t)Mp * (size_t)N * 4;
 }
 
@@ -1368,7 +1393,7 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
                 "tfgnn_sp_gemm_tn: 32-column scale blocks need a block-aligned first column (at most 4 blocks per 128-column tile)");
   const int splits = sp_tn_splits(Mp, N, K, bn);
   const int64_t nblk = a_total_cols / a_scale_block, kpad = (K + 15) & ~15ll;
-  const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * 4 + 255) & ~(size_t)255;
+  const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * (1 + SP_TN_MAXCHUNKS) * 4 + 255) & ~(size_t)255;
   const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)Mp * (size_t)N * 4;
   TFGNN_REQUIRE(d_workspace && workspace_bytes >= need && (uintptr_t)d_workspace % 256 == 0,
                 "tfgnn_sp_gemm_tn: workspace too small or unaligned (need %zu bytes)", need);
@@ -1377,8 +1402,14 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
   if (phases & 1) {
     const int fch = sp_tn_fchunks(K);
+    float* slice_max = nullptr;
+    if (fch > SP_TN_FCHUNKS) {  // two stages; the slice maxima live behind the reference scales (r_bytes reserves nblk * SP_TN_MAXCHUNKS floats for them)
+      slice_max = ref + nblk;
+      hipLaunchKernelGGL(sp_tn_slice_max_kernel, dim3((unsigned)nblk * fch), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K,
+                         slice_max, fch);
+    }
     hipLaunchKernelGGL(sp_tn_factors_kernel, dim3((unsigned)nblk * fch), dim3(1024), 0, s, d_a_inv_scale, nblk, d_b_inv_scale, (int64_t)1, K, F,
-                       kpad, ref, sp_spread_flag_device(), fch);
+                       kpad, ref, sp_spread_flag_device(), fch, (const float*)slice_max);
     TFGNN_LAUNCH_CHECK();
   }
   SpTnArgs g{};
