@@ -26,7 +26,10 @@ the script re-executes itself under ``python -m torch.distributed.run --nnodes=1
     gradients, parallel.allreduce_gradients).
 
 Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant kernel of the workload, timed live with HIP events on
-the launch stream; ``cpu_baseline`` times the CPU oracle (the reference's op sequence, torch-CPU) on rank 0 at N == 1.
+the launch stream; ``cpu_baseline`` times the CPU oracle (the reference's op sequence, torch-CPU, the workload's own model)
+on rank 0 at N == 1 on a bounded sample; the non-headline workloads also carry ``step_breakdown`` - every library op of the
+real step between HIP events, priced against its roof; the default run (rmat30k, N == 1) times the other four BASELINE
+workloads briefly in processes of their own and reports them under ``other_configs`` (--no-other-configs skips that).
 """
 from __future__ import annotations
 
@@ -52,7 +55,8 @@ GEMM_MODE_NOTES = {
     "f16x2": "f16x2: the layers' products on pre-split operands - every fp32 value scaled by a power of two per row and split "
     "into two fp16 pieces by round-to-nearest (22+ significand bits), 3 piece products (each exact in fp32), fp32 accumulate "
     "on v_mfma_f32_32x32x16_f16, the gather writes the split operand; fp32 in/out; error vs fp64 measured at or below the "
-    "fp32-MFMA kernel's (profiles/parity_r02.json, tools/mfma_acc_probe.hip); products without a split producer run as bf16x3",
+    "fp32-MFMA kernel's (profiles/parity_r03.json - every parity check of the suite in this mode, tools/mfma_acc_probe.hip); "
+    "products without a split producer run as bf16x3; the library default since round 3",
 }
 
 # BASELINE.json configs -> workloads.  ``sharded``: one global batch split by graph over the ranks (strong scaling);
