@@ -223,9 +223,9 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
             break
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated from a 1/8 sample (the 1/64 runs of the
-    # sweep are dominated by fixed costs)
-    t_layer_full = 8.0 * run(1.0 / 8, 1) if sweep[threads] / cal > 2.0 else sweep[threads] / cal
+    # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated from HALF the batch (the 1/64 runs of the
+    # sweep are dominated by fixed costs: they over-estimate a full layer several times)
+    t_layer_full = 2.0 * run(1.0 / 2, 1) if sweep[threads] / cal > 1.0 else sweep[threads] / cal
     # the sample: whole stack on the whole batch if a warm-up and two timed runs fit the budget, else fewer layers, then a
     # fraction of the batch
     per_run = budget_seconds / 3.0

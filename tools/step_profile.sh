@@ -4,7 +4,7 @@ set -u
 TAG=${1:-r02c}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-mode --no-roofline > $O/bench.json 2> $O/err.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-mode --no-roofline --no-other-configs > $O/bench.json 2> $O/err.log
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
 python - <<PY
