@@ -810,7 +810,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         rs = g.array(ops.G_INVDEG_BY_DST) if model == "rgcn" else None
         gather_bytes = E * (4 * H + 4) + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4  # one source row per edge
         gather_compulsory = V * H * 4 + E * 4 + (V * L + 1) * 4 + V * L * 4 + V * L * H * 4  # every source row once
-        f16 = mode == "f16x2" and model == "rgcn"
+        f16 = mode == "f16x2" and model in ("rgcn", "ggnn")  # the layers whose gather writes the split operand
         if f16:
             ms = time_kernel(lambda: ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=rs, rows_per_operand_row=L))
             name = "csr_gather_reduce_kernel<SP16> (aggregate source rows per (node, type) bucket, written as the split fp16 operand)"
