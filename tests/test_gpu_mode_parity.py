@@ -35,7 +35,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.gemm_modes, pytest.mark.usefixtures("
 def _assert_kernel_families(mode, used, split_operand_path, forward_only=False):
     """`used`: launches per kernel family during the test body."""
     if forward_only and mode == "f16x2" and split_operand_path:
-        assert used["sp_nt"] >= 1 and used["gather_sp"] >= 1, used
+        assert used["sp_nt"] >= 1, used  # (+ the SP16-writing gather for the edge-MLP family; RGAT's operand is X itself)
         return
     if mode == "fp32":
         assert used["gemm_fp32"] > 0 and used["gemm_bf16x3"] == 0 and used["sp_nt"] == 0 and used["sp_tn"] == 0, used
@@ -91,7 +91,10 @@ def test_wide_rgat_backward_parity_per_mode(dev, gemm_mode, H, K, act):
     """BASELINE configs[2]'s layer (8 heads, H = 256) at 300 nodes: forward, dX, dW_l, d alpha_l vs fp64 autograd."""
     with KernelsUsed() as k:
         check_rgat_backward(dev, K, act, V=300, E=3200, L=4, H=H)
-    _assert_kernel_families(gemm_mode, k.delta, False)
+    if gemm_mode == "f16x2":  # Y = X W and dX on gemm_sp_nt, dW on gemm_sp_tn (round 3)
+        assert k.delta["sp_nt"] >= 2 and k.delta["sp_tn"] >= 1, k.delta
+    else:
+        _assert_kernel_families(gemm_mode, k.delta, False)
 
 
 @pytest.mark.parametrize("name,over", [

@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "graph.hpp"
+#include "sp16.hpp"
 
 namespace tfgnn {
 
@@ -531,6 +532,48 @@ rgat_scores_backward_vec_kernel(const float* __restrict__ ds_src, const float* _
   }
 }
 
+// The same update with the result written ONLY as the split operand of the f16x2 products that consume it (dX = dY W^T on
+// tfgnn_sp_gemm_nt, dW = X^T dY on tfgnn_sp_gemm_tn): one wave per node row of C = L H columns (C <= 2048, Hk % 4 == 0), one
+// power-of-two scale per row.
+__global__ void __launch_bounds__(256)
+rgat_scores_backward_sp_kernel(const float* __restrict__ ds_src, const float* __restrict__ ds_tgt, const float* __restrict__ alpha,
+                               const float* __restrict__ dY, int64_t V, int L, int K, int Hk, uint8_t* __restrict__ out_sp,
+                               float* __restrict__ inv) {
+  const int H = K * Hk, C = L * H, lane = threadIdx.x & 63;
+  constexpr int MAXI = 8;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < V; v += (int64_t)gridDim.x * 4) {
+    float4 d[MAXI];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < C) {
+        const int l = c / H, f = c - l * H, k = f / Hk, j = f - k * Hk;
+        const int64_t row = v * L + l;
+        const float* a = alpha + ((int64_t)l * K + k) * 2 * Hk;
+        const float4 as = *reinterpret_cast<const float4*>(a + j);
+        const float4 at = *reinterpret_cast<const float4*>(a + Hk + j);
+        const float s = ds_src[row * K + k], t = ds_tgt[row * K + k];
+        float4 x = *reinterpret_cast<const float4*>(dY + v * C + c);
+        x.x += s * as.x + t * at.x; x.y += s * as.y + t * at.y; x.z += s * as.z + t * at.z; x.w += s * as.w + t * at.w;
+        d[i] = x;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float iv;
+    const float sc = sp_scale_for_max(mx, &iv);
+    if (lane == 0) inv[v] = iv;
+    uint8_t* drow = out_sp + v * (int64_t)C * 4;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < C) sp_store4(drow, c, d[i], sc);
+    }
+  }
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 16384)); }
 
 // shapes the lane-group kernels take: H / 4 lanes per row inside one wave, Hk / 4 lanes per head, both powers of two
@@ -745,6 +788,25 @@ extern "C" int tfgnn_rgat_alpha_grad(const float* d_ds_src, const float* d_ds_tg
                      num_edge_types, num_heads, hidden_dim / num_heads, per, (float*)d_workspace);
   hipLaunchKernelGGL(rgat_alpha_grad_final_kernel, dim3((unsigned)ceil_div(2 * LH, 32)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)d_workspace, nb, num_edge_types, num_heads, hidden_dim / num_heads, d_alpha_grad);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha, const float* d_dY,
+                                             int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim, void* d_dY_sp,
+                                             float* d_inv_scale, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0, "bad sizes");
+  int rc = check_heads(num_heads, hidden_dim);
+  if (rc) return rc;
+  const int64_t C = (int64_t)num_edge_types * hidden_dim;
+  if ((hidden_dim / num_heads) % 4 != 0 || C > 2048 || C % 16 != 0) return TFGNN_ERR_UNSUPPORTED;
+  if (num_nodes == 0 || C == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_ds_src && d_ds_tgt && d_alpha && d_dY && d_dY_sp && d_inv_scale, "NULL pointer");
+  TFGNN_REQUIRE(((uintptr_t)d_dY | (uintptr_t)d_alpha) % 16 == 0 && (uintptr_t)d_dY_sp % 64 == 0, "unaligned operand");
+  hipLaunchKernelGGL(rgat_scores_backward_sp_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_nodes, 4), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, d_dY, num_nodes, num_edge_types, num_heads,
+                     hidden_dim / num_heads, (uint8_t*)d_dY_sp, d_inv_scale);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

@@ -93,7 +93,13 @@ class RGAT(MessagePassing):
             raise ValueError(f"layer was built for {self._num_edge_types} edge types, got {L}")
         lib = _lib.load()
         dev = X.device
-        Y = ops.gemm(X, self._kernels)  # [V, L*H] == rows (v, l) of width H
+        f16 = self._f16x2_eligible(V, X.shape[1], L, H)
+        if f16:
+            # f16x2: Y = X [W_0 | ... | W_{L-1}] on split operands (X's split form comes from the dropout kernel in a GNN stack)
+            Wn = ops.sp_weight_operand(self._kernels, "cols", lambda: ops.sp_split_cols(self._kernels))
+            Y = ops.sp_gemm_nt(ops.sp_rows_of(X), Wn)
+        else:
+            Y = ops.gemm(X, self._kernels)  # [V, L*H] == rows (v, l) of width H
         s_src = torch.empty((V * L, K), dtype=torch.float32, device=dev)
         s_tgt = torch.empty((V * L, K), dtype=torch.float32, device=dev)
         _lib.check(
@@ -110,7 +116,7 @@ class RGAT(MessagePassing):
                 out = ops.activation_forward(fused, out)
         else:
             out = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=att, post_act=fused)
-        ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act,
+        ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act, "f16x2": f16,
                "att_by_src": getattr(self, "_att_by_src", None) if g.num_edges else None}
         self._att_by_src = None
         if act == "gelu":
@@ -119,6 +125,14 @@ class RGAT(MessagePassing):
         ctx["out"] = out
         self._ctx = ctx
         return out
+
+    def _f16x2_eligible(self, V, D, L, H) -> bool:
+        """the three products of the layer (Y = X W, dX = dY W^T, dW = X^T dY) on split operands: widths the kernels tile"""
+        def tiles(n):
+            return n % 128 == 0 or n % 320 == 0
+
+        return (ops.get_gemm_mode() == ops.GEMM_F16X2 and V > 0 and L > 0 and D % 16 == 0 and 32 <= D <= 512 and tiles(D)
+                and tiles(L * H) and L * H <= 2048 and (H // self._num_heads) % 4 == 0)
 
     @staticmethod
     def _ident(g, n):
@@ -227,15 +241,29 @@ class RGAT(MessagePassing):
             lib.tfgnn_rgat_alpha_grad(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(Y), V, L, K, H, ops._ptr(d_attn), ops._ptr(ws),
                                       ws.numel() if ws is not None else 0, ops._stream())
         )
-        _lib.check(
-            lib.tfgnn_rgat_scores_backward(
-                ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
+        d_kernels = dX = None
+        if ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2:
+            # the score terms are added while dY is written as the split operand of the two products below (no fp32 dY pass)
+            dY_sp = ops.SplitOperand(torch.empty((V, L * H * 4), dtype=torch.uint8, device=dev),
+                                     torch.empty((V, 1), dtype=torch.float32, device=dev), V, L * H, L * H)
+            rc = lib.tfgnn_rgat_scores_backward_sp(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), ops._ptr(dY), V, L, K, H,
+                                                   ops._ptr(dY_sp.data), ops._ptr(dY_sp.inv_scale), ops._stream())
+            if rc == 0:
+                d_kernels = ops.sp_gemm_tn(ops.sp_rows_of(X), dY_sp)  # X^T dY  [D, L*H]
+                Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels))
+                dX = ops.sp_gemm_nt(dY_sp, Wr)
+            elif rc != -4:
+                _lib.check(rc)
+        if dX is None:
+            _lib.check(
+                lib.tfgnn_rgat_scores_backward(
+                    ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
+                )
             )
-        )
-        # (5) Y = X @ W
-        dYv = dY.view(V, L * H)
-        d_kernels = ops.gemm(X, dYv, trans_a=True)  # [D, L*H]
-        dX = ops.gemm(dYv, self._kernels, trans_b=True)
+            # (5) Y = X @ W
+            dYv = dY.view(V, L * H)
+            d_kernels = ops.gemm(X, dYv, trans_a=True)  # [D, L*H]
+            dX = ops.gemm(dYv, self._kernels, trans_b=True)
         for i in range(L):
             self._edge_type_to_message_computation_layer[i].grad = d_kernels[:, i * H : (i + 1) * H]
             self._edge_type_to_attention_parameters[i].grad = d_attn[i]
