@@ -427,12 +427,13 @@ int tfgnn_rgat_edge_softmax_backward(const int32_t* d_coll_by_dst, const int32_t
 int tfgnn_rgat_scores_backward(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha,
                                int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
                                float* d_dY, void* stream);
-/* As above, the result dY' = dY + (score terms) written ONLY as an SP16 split operand (rows = nodes, L * H columns, one scale
- * per row): the operand of dX = dY' W^T (tfgnn_sp_gemm_nt) and dW = X^T dY' (tfgnn_sp_gemm_tn) in mode f16x2.  d_dY is read,
- * not written.  (H / K) % 4 == 0, L * H <= 2048 and a multiple of 16 (TFGNN_ERR_UNSUPPORTED otherwise). */
-int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha, const float* d_dY,
-                                  int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim, void* d_dY_sp,
-                                  float* d_inv_scale, void* stream);
+/* As above, the result dY' = dY + (score terms) written as an SP16 split operand (rows = nodes, L * H columns, one scale per
+ * row) - the operand of dX = dY' W^T (tfgnn_sp_gemm_nt) in mode f16x2 - and, when update_fp32 != 0, back into d_dY as well
+ * (the weight gradient X^T dY' stays on tfgnn_gemm: the rows of dY' carry attention weights and spread over more than the
+ * 2^20 tfgnn_sp_gemm_tn's guard allows).  (H / K) % 4 == 0, L * H <= 2048 and a multiple of 16 (TFGNN_ERR_UNSUPPORTED otherwise). */
+int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha, float* d_dY,
+                                  int update_fp32, int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
+                                  void* d_dY_sp, float* d_inv_scale, void* stream);
 
 /* Round 3: the per-target softmax of rgat.py:142-151 row by row over the node view (all incoming edges of a node, every
  * type) instead of edge scores + segment max + exp + segment sum + divide, and its gradient likewise:

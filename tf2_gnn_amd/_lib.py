@@ -112,7 +112,7 @@ _SIGNATURES = [
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
     ),
     ("tfgnn_rgat_scores_backward", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    ("tfgnn_rgat_scores_backward_sp", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("tfgnn_rgat_scores_backward_sp", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("tfgnn_rgat_attention_workspace_bytes", c_size_t, [c_void_p, c_int]),
     ("tfgnn_rgat_attention_forward", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("tfgnn_rgat_attention_backward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

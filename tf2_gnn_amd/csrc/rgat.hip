@@ -532,13 +532,14 @@ rgat_scores_backward_vec_kernel(const float* __restrict__ ds_src, const float* _
   }
 }
 
-// The same update with the result written ONLY as the split operand of the f16x2 products that consume it (dX = dY W^T on
-// tfgnn_sp_gemm_nt, dW = X^T dY on tfgnn_sp_gemm_tn): one wave per node row of C = L H columns (C <= 2048, Hk % 4 == 0), one
-// power-of-two scale per row.
+// The same update with the result ALSO written as the split operand of the f16x2 product that consumes it (dX = dY W^T on
+// tfgnn_sp_gemm_nt): one wave per node row of C = L H columns (C <= 2048, Hk % 4 == 0), one power-of-two scale per row.  The
+// weight gradient X^T dY stays on the exact bf16x3 kernel: dY's rows carry the attention weights of their edges (1e-9 for an
+// edge into a 15 000-edge hub) and spread over far more than the 2^20 the split-operand TN product's guard allows.
 __global__ void __launch_bounds__(256)
 rgat_scores_backward_sp_kernel(const float* __restrict__ ds_src, const float* __restrict__ ds_tgt, const float* __restrict__ alpha,
-                               const float* __restrict__ dY, int64_t V, int L, int K, int Hk, uint8_t* __restrict__ out_sp,
-                               float* __restrict__ inv) {
+                               float* __restrict__ dY, int write_fp32, int64_t V, int L, int K, int Hk,
+                               uint8_t* __restrict__ out_sp, float* __restrict__ inv) {
   const int H = K * Hk, C = L * H, lane = threadIdx.x & 63;
   constexpr int MAXI = 8;
   for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < V; v += (int64_t)gridDim.x * 4) {
@@ -557,6 +558,7 @@ rgat_scores_backward_sp_kernel(const float* __restrict__ ds_src, const float* __
         float4 x = *reinterpret_cast<const float4*>(dY + v * C + c);
         x.x += s * as.x + t * at.x; x.y += s * as.y + t * at.y; x.z += s * as.z + t * at.z; x.w += s * as.w + t * at.w;
         d[i] = x;
+        if (write_fp32) *reinterpret_cast<float4*>(dY + v * C + c) = x;
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
       }
     }
@@ -792,9 +794,9 @@ extern "C" int tfgnn_rgat_alpha_grad(const float* d_ds_src, const float* d_ds_tg
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha, const float* d_dY,
-                                             int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim, void* d_dY_sp,
-                                             float* d_inv_scale, void* stream) {
+extern "C" int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float* d_ds_tgt, const float* d_alpha, float* d_dY,
+                                             int update_fp32, int64_t num_nodes, int num_edge_types, int num_heads, int hidden_dim,
+                                             void* d_dY_sp, float* d_inv_scale, void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(num_nodes >= 0 && num_edge_types >= 0, "bad sizes");
   int rc = check_heads(num_heads, hidden_dim);
@@ -805,7 +807,7 @@ extern "C" int tfgnn_rgat_scores_backward_sp(const float* d_ds_src, const float*
   TFGNN_REQUIRE(d_ds_src && d_ds_tgt && d_alpha && d_dY && d_dY_sp && d_inv_scale, "NULL pointer");
   TFGNN_REQUIRE(((uintptr_t)d_dY | (uintptr_t)d_alpha) % 16 == 0 && (uintptr_t)d_dY_sp % 64 == 0, "unaligned operand");
   hipLaunchKernelGGL(rgat_scores_backward_sp_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(num_nodes, 4), 8192)), dim3(256), 0,
-                     (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, d_dY, num_nodes, num_edge_types, num_heads,
+                     (hipStream_t)stream, d_ds_src, d_ds_tgt, d_alpha, d_dY, update_fp32, num_nodes, num_edge_types, num_heads,
                      hidden_dim / num_heads, (uint8_t*)d_dY_sp, d_inv_scale);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;

@@ -243,13 +243,15 @@ class RGAT(MessagePassing):
         )
         d_kernels = dX = None
         if ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2:
-            # the score terms are added while dY is written as the split operand of the two products below (no fp32 dY pass)
+            # the score terms are added while dY is ALSO written as the split operand of dX = dY W^T.  The weight gradient stays
+            # on the exact bf16x3 kernel: dY's rows carry attention weights (1e-9 into a hub) - beyond the spread guard of the
+            # split-operand TN product (measured: it trips on the first step of the rgat workload)
             dY_sp = ops.SplitOperand(torch.empty((V, L * H * 4), dtype=torch.uint8, device=dev),
                                      torch.empty((V, 1), dtype=torch.float32, device=dev), V, L * H, L * H)
-            rc = lib.tfgnn_rgat_scores_backward_sp(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), ops._ptr(dY), V, L, K, H,
+            rc = lib.tfgnn_rgat_scores_backward_sp(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), ops._ptr(dY), 1, V, L, K, H,
                                                    ops._ptr(dY_sp.data), ops._ptr(dY_sp.inv_scale), ops._stream())
             if rc == 0:
-                d_kernels = ops.sp_gemm_tn(ops.sp_rows_of(X), dY_sp)  # X^T dY  [D, L*H]
+                d_kernels = ops.gemm(X, dY.view(V, L * H), trans_a=True)  # X^T dY  [D, L*H]
                 Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels))
                 dX = ops.sp_gemm_nt(dY_sp, Wr)
             elif rc != -4:
