@@ -107,7 +107,7 @@ class RGAT(MessagePassing):
                 ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
             )
         )
-        att = self._edge_attention(g, s_src, s_tgt, K, training)
+        att, att_by_src = self._edge_attention(g, s_src, s_tgt, K, training)
         act = self._activation_name
         fused = None if act == "gelu" else act
         if L == 0 or g.num_edges == 0:
@@ -117,8 +117,7 @@ class RGAT(MessagePassing):
         else:
             out = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Y.view(V * L, H), edge_weight=att, post_act=fused)
         ctx = {"graph": g, "X": X, "Y": Y, "s_src": s_src, "s_tgt": s_tgt, "att": att, "fused_act": act, "f16x2": f16,
-               "att_by_src": getattr(self, "_att_by_src", None) if g.num_edges else None}
-        self._att_by_src = None
+               "att_by_src": att_by_src}
         if act == "gelu":
             ctx["pre"] = out
             out = ops.activation_forward("gelu", out)
@@ -143,24 +142,23 @@ class RGAT(MessagePassing):
         return ident
 
     def _edge_attention(self, g, s_src, s_tgt, K, training=True):
-        """a[e,k]: per head, softmax over all edges entering the target (rgat.py:142-151).  Edge-parallel
-        kernels + two generic segment reductions over the node view (identity columns)."""
+        """a[e,k]: per head, softmax over all edges entering the target (rgat.py:142-151) -> (a in by-target edge order,
+        the same weights in by-source order or None).  One pass structure per CSR row (csrc/rgat.hip,
+        tfgnn_rgat_attention_forward) when the head count is a power of two; otherwise edge-parallel kernels + two generic
+        segment reductions over the node view (identity columns)."""
         lib = _lib.load()
         E, V, L = g.num_edges, g.num_nodes, g.num_edge_types
         dev = s_src.device
         att = torch.empty((E, K), dtype=torch.float32, device=dev)
         if E == 0:
-            return att
-        # one pass per CSR row (csrc/rgat.hip, tfgnn_rgat_attention_forward) when the head count is a power of two; the
-        # piecewise form below otherwise
-        self._att_by_src = torch.empty((E, K), dtype=torch.float32, device=dev) if training else None
+            return att, None
+        att_by_src = torch.empty((E, K), dtype=torch.float32, device=dev) if training else None
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
-        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(self._att_by_src),
+        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(att_by_src),
                                               ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
         if rc == 0:
-            return att
-        self._att_by_src = None
+            return att, att_by_src
         if rc != -4:
             _lib.check(rc)
         coll, tgt = g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST)
@@ -174,7 +172,7 @@ class RGAT(MessagePassing):
         den = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, scores, col=ident)  # [V, K]
         _lib.check(lib.tfgnn_rgat_edge_node_op(ops._ptr(scores), ops._ptr(tgt), ops._ptr(den), E, K, 1, ops._ptr(att),
                                                ops._stream()))
-        return att
+        return att, None
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(out) -> d(loss)/d(node_embeddings); fills the kernel / attention gradients."""

@@ -47,7 +47,15 @@ res["ii_gather_us"] = 1e3 * time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_
 res["ii_max_abs_diff_vs_shipped"] = float((out2 - ref_out).abs().max())
 
 # ---- producer-side probe -------------------------------------------------------------------------------------------
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_probe", "libfusedprobe.so"))
+_so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_probe", "libfusedprobe.so")
+if not os.path.exists(_so):  # tools/_probe/ is not tracked: build the probe kernel from tools/fused_probe.hip
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.dirname(_so), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           f"-I{root}/tf2_gnn_amd/csrc", f"-I{root}/include", f"{root}/tools/fused_probe.hip", "-o", _so])
+lib = ctypes.CDLL(_so)
 rowptr = g.array(ops.G_ROWPTR_BY_DST)
 col = g.array(ops.G_COL_BY_DST)
 lens = (rowptr[1:] - rowptr[:-1]).view(V, L)
