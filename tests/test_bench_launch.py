@@ -38,3 +38,20 @@ def test_gpus_2_replicas_for_single_graph_workloads():
 def test_single_rank_needs_no_launcher():
     r = _run(["--workload", "tiny"])
     assert r["n_gpus"] == 1
+
+
+def test_cpu_baseline_runs_for_every_workload_model():
+    """bench.py's cpu_baseline leg (the oracle's training step of the workload's own model on a bounded sample) on tiny
+    shapes of every model the default run reports: no device involved."""
+    import bench
+
+    for model in ("rgcn", "rgat", "ggnn", "gnn_edge_mlp", "rgin"):
+        if model in ("ggnn", "gnn_edge_mlp"):
+            wl = dict(model=model, num_graphs=60, feature_dim=16, hidden_dim=16, num_layers=2, sharded=True)
+        else:
+            wl = dict(model=model, num_nodes=200, num_edges=1500, num_edge_types=3, feature_dim=16, hidden_dim=16, num_layers=2,
+                      num_heads=4)
+        batch = bench.build_batch(wl, 0, 1)
+        params = bench.model_params(model, 16, 2, wl.get("num_heads"))
+        r = bench.cpu_baseline(wl, batch, params, budget_seconds=1.0)
+        assert r["value"] > 0 and r["kind"] == "port" and r["cores"] >= 1 and model.upper() in r["sample"], (model, r)
