@@ -69,7 +69,9 @@ typedef enum {
   TFGNN_KFAM_SP_TN = 3,       /* gemm_sp_tn_kernel (pre-split fp16 pairs, weight gradient)          */
   TFGNN_KFAM_GATHER_SP = 4,   /* csr_gather_reduce_kernel writing the SP16 operand                  */
   TFGNN_KFAM_GATHER = 5,      /* csr_gather_reduce_kernel, fp32 output                              */
-  TFGNN_KFAM_FUSED_NT = 6,    /* gather-producing product kernel (rgcn_fused_nt_kernel)             */
+  TFGNN_KFAM_FUSED_NT = 6,    /* reserved (the gather-producing product was measured and not shipped) */
+  TFGNN_KFAM_GEMM_STREAM = 7, /* gemm_x3k_kernel: bf16x3 products with the weight block resident in LDS (short K,
+                                 very many rows); every such launch also counts as TFGNN_KFAM_GEMM_BF16X3 */
   TFGNN_KFAM_COUNT = 8
 } tfgnn_kernel_family;
 int tfgnn_launch_counts(int64_t* out_counts, int n);

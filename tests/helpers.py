@@ -84,7 +84,7 @@ def launch_counts():
 
     buf = (ctypes.c_int64 * 8)()
     _lib.check(_lib.load().tfgnn_launch_counts(buf, 8))
-    names = ["gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "_"]
+    names = ["gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream"]
     return dict(zip(names, list(buf)))
 
 

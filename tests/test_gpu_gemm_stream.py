@@ -1,0 +1,115 @@
+"""The two QM9-sized product routes of the bf16x3 path (csrc/gemm_x3.hip): the streaming kernel with the weight block
+resident in LDS (short K, very many rows: Dense / edge-MLP / GRU-input products of configs[3]) and the long-K split of
+skinny weight gradients (1 - 8 output tiles under ~10^6 rows).  Every case against the fp64 product, and the kernel
+family counters show that the route under test really ran."""
+import pytest
+import torch
+
+from tests.helpers import KernelsUsed, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["bf16x3", "bf16x3_9"])
+def x3_mode(request):
+    from tf2_gnn_amd import ops
+
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(prev)
+
+
+STREAM_CASES = [
+    # M, K, N, trans_b, epilogue, (pad_a, pad_b, pad_c)
+    (65536, 128, 128, False, "none", (0, 0, 0)),
+    (65536 + 37, 128, 128, True, "bias_relu", (0, 0, 0)),
+    (70001, 64, 384, False, "bias_tanh", (4, 0, 8)),
+    (70001, 96, 128, True, "accumulate", (0, 4, 4)),
+    (100003, 128, 640, True, "none", (8, 0, 0)),
+    (65540, 128, 256, False, "grad_relu", (0, 0, 0)),
+    (65540, 64, 128, True, "grad_mask_tanh", (0, 0, 4)),
+    (131072 + 5, 32 * 3, 1280, False, "bias_relu", (0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{'nt' if c[3] else 'nn'}-{c[4]}")
+def test_streaming_kernel_against_fp64(dev, x3_mode, case):
+    from tf2_gnn_amd import ops
+
+    M, K, N, tb, epi, (pad_a, pad_b, pad_c) = case
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N)
+    A_full = torch.randn((M, K + pad_a), generator=g)
+    b_shape = (N, K) if tb else (K, N)
+    B_full = torch.randn((b_shape[0], b_shape[1] + pad_b), generator=g) * 0.2
+    C_full = torch.randn((M, N + pad_c), generator=g)
+    A, B = A_full[:, :K], B_full[:, : b_shape[1]]
+    Ad, Bd, Cd = A_full.to(dev)[:, :K], B_full.to(dev)[:, : b_shape[1]], C_full.to(dev)
+    out_view = Cd[:, :N]
+    ref = A.double() @ (B.double().t() if tb else B.double())
+    with KernelsUsed() as k:
+        if epi in ("none", "accumulate"):
+            ops.gemm(Ad, Bd, trans_b=tb, out=out_view, accumulate=epi == "accumulate")
+            if epi == "accumulate":
+                ref = ref + C_full[:, :N].double()
+            res = out_view
+        elif epi in ("bias_relu", "bias_tanh"):
+            bias = torch.randn(N, generator=g)
+            act = epi.split("_")[1]
+            ops.gemm(Ad, Bd, trans_b=tb, bias=bias.to(dev), act=act, out=out_view)
+            ref = ref + bias.double()
+            ref = torch.relu(ref) if act == "relu" else torch.tanh(ref)
+            res = out_view
+        else:
+            saved = torch.randn((M, N), generator=g)
+            mask = (torch.rand((M, N), generator=g) > 0.2).float() * 1.25 if "mask" in epi else None
+            act = "relu" if "relu" in epi else "tanh"
+            res = ops.gemm_grad(Ad, Bd, trans_b=tb, out=out_view, out_mul=None if mask is None else mask.to(dev),
+                                act_grad=(act, saved.to(dev)))
+            dact = (saved > 0).double() if act == "relu" else 1.0 - saved.double() ** 2
+            ref = ref * dact * (1.0 if mask is None else mask.double())
+    assert k.delta["gemm_stream"] == 1, k.delta
+    assert res.data_ptr() == out_view.data_ptr()
+    scale = max(1.0, 0.2 * float(K) ** 0.5)
+    assert_close(res.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"streaming {x3_mode} {case}")
+    if pad_c:
+        assert torch.equal(Cd[:, N:].cpu(), C_full[:, N:])
+
+
+def test_streaming_kernel_special_values_stay_in_their_rows(dev, x3_mode):
+    """inf / nan rows stay in their rows, zero rows give exact zeros."""
+    from tf2_gnn_amd import ops
+
+    M, K, N = 65536 + 64, 128, 128
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn((M, K), generator=g)
+    A[7, 3] = float("inf")
+    A[M - 1, 100] = float("nan")
+    A[12345] = 0.0
+    B = torch.randn((K, N), generator=g).abs() + 0.1  # positive: inf * b stays +inf, no inf - inf
+    out = ops.gemm(A.to(dev), B.to(dev)).cpu()
+    # inf * b is +inf in fp32; the split evaluation also multiplies inf by b's lower pieces, and where such a piece is exactly
+    # zero inf * 0 = nan joins the sum (tests/test_gpu_bf16x3_mode.py): non-finite everywhere, +inf almost everywhere
+    assert (~torch.isfinite(out[7])).all()
+    assert (out[7][torch.isinf(out[7])] > 0).all() and float(torch.isnan(out[7]).float().mean()) < 0.2
+    assert torch.isnan(out[M - 1]).all()
+    assert torch.equal(out[12345], torch.zeros(N))
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[7] = keep[M - 1] = False
+    assert torch.isfinite(out[keep]).all()
+
+
+@pytest.mark.parametrize("K,M,N", [(150001, 128, 128), (140000, 128, 640), (200003, 256, 128)])
+def test_long_k_weight_gradient_split(dev, x3_mode, K, M, N):
+    """dW = X^T G with a 1 - 4 tile output under K >= 2^17 rows runs up to 512 splits and the sliced reduction."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(K + M)
+    X = torch.randn((K, M), generator=g)
+    G = torch.randn((K, N), generator=g) * 0.05
+    out = ops.gemm(X.to(dev), G.to(dev), trans_a=True)
+    ref = X.double().t() @ G.double()
+    scale = 0.05 * float(K) ** 0.5
+    assert_close(out.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"long-K split {x3_mode} {(K, M, N)}")
+    again = ops.gemm(X.to(dev), G.to(dev), trans_a=True)
+    assert torch.equal(out, again)  # fixed summation order

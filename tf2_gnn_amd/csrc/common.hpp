@@ -1,10 +1,12 @@
 // Shared helpers for the tfgnn HIP library (gfx950 only).
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "tfgnn.h"
@@ -45,6 +47,21 @@ void count_launch(int family);
   } while (0)
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Split-K count of a product whose output grid has `tiles` workgroups (before the limits of K and of the workspace):
+// one round of workgroups on the 256 CUs, at most 64 splits - more only add rounds on the hot-path shapes (12 tiles x 43
+// splits ran as 3 rounds of 22 K tiles, x 21 as one round of 45).  Skinny outputs under a very long K (QM9-sized weight
+// gradients: 1 - 8 tiles, K ~ 10^6 rows) are the exception: 64 workgroups leave three quarters of the chip idle, so
+// they get two workgroups per CU with chunks of at least 512 rows.
+static inline int64_t splitk_want(int64_t tiles, int64_t K) {
+  if (tiles < 1) tiles = 1;
+  static const bool long_k = [] { const char* e = getenv("TFGNN_LONG_K_SPLITS"); return !e || atoi(e) != 0; }();  // 0: A/B probe
+  if (long_k && tiles <= 8 && K >= 131072) {
+    const int64_t want = std::min<int64_t>(512 / tiles, K / 512);
+    return std::min<int64_t>(want, 512);
+  }
+  return std::max<int64_t>(1, std::min<int64_t>(256 / tiles, 64));
+}
 
 constexpr float kSmallNumber = 1e-7f;  // tf2_gnn/utils/constants.py:2
 constexpr float kFloatLowest = -3.402823466e+38f;

@@ -373,11 +373,9 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_byte
   if (tiles < 192 && K >= 1024) {
     // one wave of workgroups on the 256 CUs: more splits only add rounds (12 output tiles x 43 splits ran
     // as 3 rounds of 22 K-tiles; x 21 splits is one round of 45)
-    int64_t want = 256 / tiles;
-    if (want < 1) want = 1;
+    const int64_t want = splitk_want(tiles, K);
     int64_t max_by_k = K / (4 * BK);
     int64_t s = want < max_by_k ? want : max_by_k;
-    if (s > 64) s = 64;
     int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4 + 1));
     if (s > max_by_ws) s = max_by_ws;
     if (s > 1) {

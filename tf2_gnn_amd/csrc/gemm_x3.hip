@@ -850,6 +850,57 @@ __global__ void __launch_bounds__(256) x3_splitk_reduce_kernel(X3Args g) {
   }
 }
 
+// The same sum for many splits (skinny outputs under a long K run up to 512 of them, splitk_want): a block owns 64
+// consecutive elements, 16 lanes x float4 wide, and its 16 lane rows walk the splits 16 apart; the 16 slice sums are
+// added in slice order through LDS.  Fixed order, so results repeat bit for bit.
+__global__ void __launch_bounds__(256) x3_splitk_reduce_sliced_kernel(X3Args g) {
+  __shared__ float4 acc[16][16];
+  const int64_t total = g.M * g.N;  // a multiple of 64 (launch site)
+  const float* part = g.partial + (int64_t)blockIdx.y * g.splits * total;
+  g.C += (int64_t)blockIdx.y * g.strideC;
+  const int q = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + q * 4;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = slice; z < g.splits; z += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * total + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    acc[slice][q] = s;
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+      for (int t = 1; t < 16; ++t) {
+        const float4 v = acc[t][q];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t row = i / g.N, col = i - row * g.N;  // N % 4 == 0: the four elements share a row
+      float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float r = o[e];
+        if (g.bias) r += g.bias[col + e];
+        r = act_apply(g.act, r);
+        if (g.mul) r *= g.mul[row * g.ld_mul + col + e];
+        if (g.saved) r *= act_grad(g.dact, g.saved[row * g.ld_saved + col + e]);
+        float* c = g.C + row * g.ldc + col + e;
+        if (g.accumulate) r += *c;
+        *c = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static void launch_x3_splitk_reduce(const X3Args& g, unsigned groups, hipStream_t s) {
+  const int64_t total = g.M * g.N;
+  if (g.splits > 64 && total % 64 == 0 && g.N % 4 == 0)
+    hipLaunchKernelGGL(x3_splitk_reduce_sliced_kernel, dim3((unsigned)std::min<int64_t>(total / 64, 8192), groups), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(x3_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096), groups), dim3(256), 0, s, g);
+}
+
 // Layouts: NN / NT (A K-contiguous) -> specialised kernel (NT 140 vs 160 us, NN 68 vs 72 us for the pipelined one
 // on the hot-path shapes); TN (both K-major: weight gradients) -> pipelined kernel (with two K-major operands four
 // producer waves cannot keep up with the register transposes: 185 vs 207 us).
@@ -879,6 +930,295 @@ static void launch_x3(const X3Args& g, dim3 grid, int nprod, int trans_a, int tr
     if (nine) hipLaunchKernelGGL((gemm_x3s_kernel<true, 9, TN>), grid, dim3(X3_NT), 0, s, g);
     else hipLaunchKernelGGL((gemm_x3s_kernel<true, 6, TN>), grid, dim3(X3_NT), 0, s, g);
   }
+}
+
+// =====================================================================================================
+// Streaming kernel for short-K products over very many rows (QM9-sized batches: [10^6, 128] x [128, 128 n], the Dense
+// layers, the per-edge MLP layers and the GRU inputs of configs[3]).  On these shapes a tiled kernel spends its time
+// re-staging and re-splitting the SAME weight tile for every 128 rows (K = 128 is 8 k-steps: prologue and epilogue
+// never overlap anything).  Here the weight block is the resident operand: a workgroup of eight waves splits its 128
+// columns of B once into three bf16 planes in LDS (K x 128 x 3 x 2 B <= 102 KB) and then only streams rows.  Every
+// wave owns whole 32-row tiles - no barrier after the fill: a lane loads its row's fp32 values straight from global
+// memory in MFMA operand order (lane (row i, half kg) takes k in [kg K/2, (kg + 1) K/2), 8 per k-step; a sum over k
+// does not care about the order as long as B is read with the same map), splits them in registers, reads the B
+// pieces as ds_read_b128 (rows padded by 16 B: conflict-free) and keeps the next tile's loads in flight under the 24 K/16
+// MFMAs of the current one (16 KB per wave, 128 KB per CU).  The accumulators leave through a wave-private LDS patch as
+// 16-byte stores.  Column blocks of one row range run as neighbouring workgroups of the
+// SAME XCD, so the rows cross the fabric once and are re-read from that XCD's L2.
+constexpr int XK_COLS = 128, XK_NT = 512, XK_WAVES = 8;
+typedef __attribute__((address_space(3))) void x3k_lds_void;
+template <int OFF>
+__device__ __forceinline__ void x3k_request(uint4v (&dst)[3], const unsigned (&addr)[3]) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(addr[0]), "n"(OFF) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(addr[1]), "n"(OFF) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(addr[2]), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void x3k_wait_all_but_3(uint4v (&b)[3]) {  // the three reads of the group BEFORE the last request
+  asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2])::"memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void x3k_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    x3k_static_for<I + 1, N>(f);
+  }
+}
+constexpr int XK_PS = 36;  // row stride (floats) of a wave's 32 x 32 epilogue patch
+
+template <int NPROD, int KS, bool EXTRAS>
+__global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor, int ncb, int spx) {
+  constexpr int K = KS * 16, ROWB = 2 * K + 16, PLANE_B = XK_COLS * ROWB;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  // workgroup id -> (XCD, slot); the ncb column blocks of a row stream sit in neighbouring slots of one XCD
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned cb = slot % (unsigned)ncb, stream_local = slot / (unsigned)ncb;
+  if ((int)stream_local >= spx) return;
+  const int stream = (int)(stream_local * 8 + xcd), nstreams = spx * 8;
+  const int64_t n0 = (int64_t)cb * XK_COLS;
+
+  // ---- fill: B[:, n0 .. n0 + 127] -> planes[p][n][k] (bf16, k natural order) ---------------------------------
+  if (!b_kmajor) {  // B given as [N, K] (K-contiguous)
+    for (int idx = tid; idx < XK_COLS * (K / 4); idx += XK_NT) {
+      const int n = idx / (K / 4), kq = idx - n * (K / 4);
+      const float4 v = *reinterpret_cast<const float4*>(g.B + (n0 + n) * g.ldb + kq * 4);
+      split_store4(v.x, v.y, v.z, v.w, reinterpret_cast<unsigned short*>(lds + n * ROWB + kq * 8), PLANE_B / 2);
+    }
+  } else {  // B given as [K, N]
+    for (int idx = tid; idx < K * (XK_COLS / 4); idx += XK_NT) {
+      const int k = idx / (XK_COLS / 4), nq = idx - k * (XK_COLS / 4);
+      const float4 v = *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n0 + nq * 4);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned h, m, l;
+        split3(e[q], h, m, l);
+        unsigned short* d = reinterpret_cast<unsigned short*>(lds + (nq * 4 + q) * ROWB + k * 2);
+        d[0] = (unsigned short)(h >> 16);
+        d[PLANE_B / 2] = (unsigned short)(m >> 16);
+        d[PLANE_B] = (unsigned short)(l >> 16);
+      }
+    }
+  }
+  if (g.bias && tid < XK_COLS) reinterpret_cast<float*>(lds + 3 * PLANE_B)[XK_WAVES * 32 * XK_PS + tid] = g.bias[n0 + tid];
+  __syncthreads();
+
+  const int ntiles = (int)((g.M + 31) / 32);  // M * lda < 2^30 (launch site): rows, tiles and blocks fit 32 bits
+  const int nblocks = (ntiles + XK_WAVES - 1) / XK_WAVES;
+  // byte offset of this lane's half row (32 bits: the launch site requires M * lda * 4 < 2^32).  The streamed operand is read
+  // through a raw buffer descriptor: one address register per lane and tile, the 16 loads differ in the immediate offset
+  const int Mi = (int)g.M;
+  const unsigned a_row_bytes = (unsigned)g.lda * 4u, a_lane_bytes = (unsigned)kg * (K / 2) * 4u;
+  auto row_off = [&](int tile) {
+    int row = tile * 32 + li;
+    if (row >= Mi) row = Mi - 1;
+    return __umul24((unsigned)row, a_row_bytes) + a_lane_bytes;  // v_mad_u32_u24 (M, 4 lda < 2^24: launch site)
+  };
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)(unsigned)(g.M * g.lda * 4), 0x00020000);
+  auto a_load = [&](unsigned off, int i) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + i * 16, 0, 0));
+  };
+  // B piece addresses: one LDS byte address per plane (+ col tile * 32 * ROWB + step * 16 as the immediate offset).  The reads
+  // are written as asm so that they are issued ONE GROUP (6 - 9 MFMAs) AHEAD of their use; left to the compiler every read
+  // sits right in front of its MFMAs and the LDS latency is paid 4 K/16 times per tile (the multiply side alone took 198 us
+  // of a 320 us kernel, twice the time of its MFMAs).  The chain of requests runs on across tiles: B does not depend on the
+  // tile.  A request's registers reach the MFMAs through the "+v" operands of the wait, so neither can move above it.
+  unsigned b_addr[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
+  uint4v bq[2][3];
+  auto b_request = [&](auto group_c) {  // group = step * 4 + column tile
+    constexpr int grp = decltype(group_c)::value % (4 * KS);
+    x3k_request<(grp & 3) * 32 * ROWB + (grp >> 2) * 16>(bq[grp & 1], b_addr);
+  };
+  float* patch = reinterpret_cast<float*>(lds + 3 * PLANE_B) + wave * 32 * XK_PS;
+  const float* lds_bias = reinterpret_cast<const float*>(lds + 3 * PLANE_B) + XK_WAVES * 32 * XK_PS;  // [128], filled above
+  float4 araw[2 * KS];
+  int blk = stream;
+  {
+    const int t0 = blk * XK_WAVES + wave;
+    const unsigned ao = row_off(t0 < ntiles ? t0 : ntiles - 1);
+#pragma unroll
+    for (int j = 0; j < 2 * KS; ++j) araw[j] = a_load(ao, j);
+  }
+  b_request(std::integral_constant<int, 0>{});
+  for (; blk < nblocks; blk += nstreams) {
+    const int tile = blk * XK_WAVES + wave;
+    int next = (blk + nstreams) * XK_WAVES + wave;
+    if (next >= ntiles) next = ntiles - 1;  // nothing left: a harmless re-load
+    const unsigned no = row_off(next);
+    floatx16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    x3k_static_for<0, KS>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      const float4 x0 = araw[2 * j], x1 = araw[2 * j + 1];
+      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(xs[e], h[e], m[e], l[e]);
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, uint4v{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])});
+      const bf16x8 am = __builtin_bit_cast(bf16x8, uint4v{pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7])});
+      const bf16x8 al = __builtin_bit_cast(bf16x8, uint4v{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])});
+      x3k_static_for<0, 4>([&](auto c_c) {
+        constexpr int c = decltype(c_c)::value, cur = c & 1;
+        b_request(std::integral_constant<int, j * 4 + c + 1>{});
+        x3k_wait_all_but_3(bq[cur]);
+        acc[c] = mfma_group<NPROD>(acc[c], ah, am, al, __builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, bq[cur][1]),
+                                   __builtin_bit_cast(bf16x8, bq[cur][2]));
+      });
+      // the next tile's values, one burst of whole 128-byte lines per lane every four steps (with two loads per step a line
+      // stays half-read for four steps while the other seven waves push it out of the 32 KB L1)
+      if ((j & 3) == 3 || j == KS - 1) {
+#pragma unroll
+        for (int i = 2 * (j & ~3); i <= 2 * j + 1; ++i) araw[i] = a_load(no, i);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: hoisting every split to the top spills 370 registers
+    });
+    if (tile >= ntiles) continue;
+    // ---- epilogue, straight from the accumulator layout: register r of lane (li, kg) is element
+    // (row (r & 3) + 8 (r >> 2) + 4 kg, column li) of its 32 x 32 block ------------------------------------------
+    if (g.bias) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float bias = lds_bias[c * 32 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] += bias;
+      }
+    }
+    // one wave-uniform dispatch per tile on the activation (a switch per element is a taken branch per element)
+    auto act_all = [&](auto act_c) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = act_apply(decltype(act_c)::value, acc[c][r]);
+    };
+    switch (g.act) {
+      case TFGNN_ACT_RELU: act_all(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+      case TFGNN_ACT_TANH: act_all(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+      case TFGNN_ACT_LEAKY_RELU: act_all(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+      case TFGNN_ACT_ELU: act_all(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+      case TFGNN_ACT_SELU: act_all(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+      case TFGNN_ACT_GELU: act_all(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+      case TFGNN_ACT_SIGMOID: act_all(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+      default: break;
+    }
+    // a 32 x 32 block at a time through the wave's LDS patch, so that a lane stores 16 contiguous bytes: dword stores
+    // straight from the accumulator layout are store-issue bound (355 us for [1.15 M, 128] x [128, 128], 0.4 of HBM)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * XK_PS + li] = acc[c][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      const int64_t col = n0 + c * 32 + (lane & 7) * 4;
+      float4 v[4];
+      bool ok[4];
+      int64_t rowq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pr = (lane >> 3) + 8 * q;
+        rowq[q] = tile * 32 + pr;
+        ok[q] = rowq[q] < g.M;
+        if (!ok[q]) rowq[q] = g.M - 1;
+        v[q] = *reinterpret_cast<const float4*>(patch + pr * XK_PS + (lane & 7) * 4);
+      }
+      if constexpr (EXTRAS) {
+        if (g.mul) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 m = *reinterpret_cast<const float4*>(g.mul + rowq[q] * g.ld_mul + col);
+            v[q].x *= m.x; v[q].y *= m.y; v[q].z *= m.z; v[q].w *= m.w;
+          }
+        }
+        if (g.saved) {
+          float4 sv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const float4*>(g.saved + rowq[q] * g.ld_saved + col);
+          auto dact_all = [&](auto act_c) {
+            constexpr int A = decltype(act_c)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q].x *= act_grad(A, sv[q].x); v[q].y *= act_grad(A, sv[q].y);
+              v[q].z *= act_grad(A, sv[q].z); v[q].w *= act_grad(A, sv[q].w);
+            }
+          };
+          switch (g.dact) {
+            case TFGNN_ACT_RELU: dact_all(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+            case TFGNN_ACT_TANH: dact_all(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+            case TFGNN_ACT_LEAKY_RELU: dact_all(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+            case TFGNN_ACT_ELU: dact_all(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+            case TFGNN_ACT_SELU: dact_all(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+            case TFGNN_ACT_GELU: dact_all(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+            case TFGNN_ACT_SIGMOID: dact_all(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+            default: dact_all(std::integral_constant<int, TFGNN_ACT_NONE>{}); break;
+          }
+        }
+        if (g.accumulate) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 c4 = *reinterpret_cast<const float4*>(g.C + rowq[q] * g.ldc + col);
+            v[q].x += c4.x; v[q].y += c4.y; v[q].z += c4.z; v[q].w += c4.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) *reinterpret_cast<float4*>(g.C + rowq[q] * g.ldc + col) = v[q];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int NPROD, bool EXTRAS>
+static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int spx, dim3 grid, hipStream_t s) {
+  const size_t lds_bytes = (size_t)3 * XK_COLS * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + XK_COLS * 4;
+#define TFGNN_X3K_CASE(KSV)                                                                                                     \
+  case KSV: {                                                                                                                   \
+    static const bool raised = [] {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)gemm_x3k_kernel<NPROD, KSV, EXTRAS>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                3 * XK_COLS * (2 * KSV * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + XK_COLS * 4);                                  \
+      return true;                                                                                                              \
+    }();                                                                                                                        \
+    (void)raised;                                                                                                               \
+    hipLaunchKernelGGL((gemm_x3k_kernel<NPROD, KSV, EXTRAS>), grid, dim3(XK_NT), lds_bytes, s, g, b_kmajor, ncb, spx);          \
+  } break;
+  switch (ks) {
+    TFGNN_X3K_CASE(2)
+    TFGNN_X3K_CASE(4)
+    TFGNN_X3K_CASE(6)
+    TFGNN_X3K_CASE(8)
+    default: break;
+  }
+#undef TFGNN_X3K_CASE
+}
+
+// 1 = the streaming kernel took the product (NN / NT, K in {32, 64, 96, 128}, N a multiple of 128, many rows)
+static int gemm_x3k_try(int nprod, int trans_b, const X3Args& g, hipStream_t s) {
+  static const int64_t min_rows = [] { const char* e = getenv("TFGNN_X3_STREAM_MIN_ROWS"); return e ? atoll(e) : 65536ll; }();
+  if (min_rows <= 0 || g.M < min_rows || g.N % XK_COLS || g.K % 32 || g.K < 32 || g.K > 128) return 0;
+  if (g.M * g.lda >= (1ll << 30) || g.M >= (1 << 24) || g.lda >= (1 << 22)) return 0;  // 32-bit byte offsets, 24-bit factors
+  const int ncb = (int)(g.N / XK_COLS);
+  if (ncb > 32) return 0;
+  const int spx = 32 / ncb;  // row streams per XCD (32 CUs each)
+  count_launch(TFGNN_KFAM_GEMM_BF16X3);
+  count_launch(TFGNN_KFAM_GEMM_STREAM);
+  dim3 grid((unsigned)(8 * spx * ncb));
+  const bool extras = g.mul || g.saved || g.accumulate;  // the plain forward kernels carry none of that code
+  const int ks = (int)(g.K / 16), bkm = trans_b ? 0 : 1;
+  if (nprod >= 9) {
+    if (extras) launch_x3k_ks<9, true>(g, ks, bkm, ncb, spx, grid, s);
+    else launch_x3k_ks<9, false>(g, ks, bkm, ncb, spx, grid, s);
+  } else {
+    if (extras) launch_x3k_ks<6, true>(g, ks, bkm, ncb, spx, grid, s);
+    else launch_x3k_ks<6, false>(g, ks, bkm, ncb, spx, grid, s);
+  }
+  return 1;
 }
 
 // 0 = off (fp32 MFMA), 6 / 9 = number of piece products.  Initialised from TFGNN_GEMM_MODE
@@ -932,15 +1272,22 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   g.bias = bias; g.act = act; g.accumulate = accumulate;
   g.mul = mul; g.ld_mul = ld_mul; g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
   g.group_mode = 0; g.group_off = nullptr; g.strideB = 0; g.strideC = 0;
+  g.splits = 1; g.partial = nullptr;
+  if (!trans_a && gemm_x3k_try(nprod, trans_b, g, s)) {
+    if (hipGetLastError() != hipSuccess) {
+      set_error("bf16x3 streaming GEMM launch failed");
+      *status = TFGNN_ERR_HIP;
+    }
+    return 1;
+  }
   g.n_tiles = (unsigned)(N / bn);
   const int64_t tiles = ceil_div(M, 128) * (int64_t)g.n_tiles;
   g.splits = 1;
   g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
   if (tiles < 192 && K >= 1024 && workspace) {
-    int64_t want = 256 / tiles;
+    int64_t want = splitk_want(tiles, K);
     const int64_t max_by_k = K / 128;
     if (want > max_by_k) want = max_by_k;
-    if (want > 64) want = 64;
     const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4 + 1));
     if (want > max_by_ws) want = max_by_ws;
     if (want > 1 && (uintptr_t)workspace % 16 == 0) {
@@ -964,8 +1311,7 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     return 1;
   }
   if (g.splits > 1) {
-    const int64_t total = M * N;
-    hipLaunchKernelGGL(x3_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0, s, g);
+    launch_x3_splitk_reduce(g, 1, s);
   }
   return 1;
 }

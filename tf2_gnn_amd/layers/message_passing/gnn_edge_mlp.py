@@ -43,6 +43,14 @@ def mlp_hidden_sizes(out_size: int, hidden_layers) -> List[int]:
     return list(hidden_layers)
 
 
+def _relu_input_grad(d_out, W, layer_input, out):
+    """out = (d_out @ W^T) * relu'(layer_input), the gradient w.r.t. the pre-activation of the layer below, with the
+    factor applied in the product's epilogue when the active kernel has one (one pass over [rows, width] less)."""
+    res = ops.gemm_grad(d_out, W, trans_b=True, out=out, act_grad=("relu", layer_input))
+    if res.data_ptr() != out.data_ptr():  # unfused route: the factor was applied out of place
+        out.copy_(res)
+
+
 class StackedEdgeMLPs:
     """L bias-free MLPs (one per edge type) stored layer-wise as [L, in, out] tensors so that the
     per-type kernels of one layer are contiguous ([L*in, out] is the vertical stack)."""
@@ -448,12 +456,13 @@ class GNN_Edge_MLP(MessagePassing):
                 inp = X if j == 0 else inp_all[:, l, :]
                 ops.gemm(inp, dcur[:, l, :], trans_a=True, out=grads[j][l])
                 if j > 0:
-                    ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dprev[:, l, :])
+                    # hidden layers use relu ([ext] dpu_utils MLP default activation): its derivative rides in the
+                    # epilogue of the product where the active kernel has one
+                    _relu_input_grad(dcur[:, l, :], W[l], inp, dprev[:, l, :])
                 else:
                     ops.gemm(dcur[:, l, :], W[l], trans_b=True, out=dX, accumulate=accumulate or l > 0)
             if j > 0:
-                # hidden layers use relu ([ext] dpu_utils MLP default activation)
-                dcur = ops.activation_backward("relu", dprev, inp_all)
+                dcur = dprev
         mlps.grads = grads
         if L == 0 and not accumulate:
             dX.zero_()
@@ -646,9 +655,9 @@ class GNN_Edge_MLP(MessagePassing):
                 if off[l + 1] > off[l]:
                     sl = slice(off[l], off[l + 1])
                     ops.gemm(inp[sl], dcur[sl], trans_a=True, out=gW[l])
-                    ops.gemm(dcur[sl], W[l], trans_b=True, out=dprev[sl])
+                    _relu_input_grad(dcur[sl], W[l], inp[sl], dprev[sl])  # hidden layers are relu (dpu_utils MLP)
             grads[j] = gW
-            dcur = ops.activation_backward("relu", dprev, inp)  # hidden layers are relu (dpu_utils MLP)
+            dcur = dprev
         # first layer: z0[e] = relu(P[(src,l)] + Q[(tgt,l)]); dcur is d(P+Q) per edge
         H0 = mlps.kernels[0].shape[2]
         dP = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dcur, col=g.array(ops.G_EID_BY_SRC)).view(V, L * H0)
