@@ -30,6 +30,11 @@ STREAM_CASES = [
     (65540, 128, 256, False, "grad_relu", (0, 0, 0)),
     (65540, 64, 128, True, "grad_mask_tanh", (0, 0, 4)),
     (131072 + 5, 32 * 3, 1280, False, "bias_relu", (0, 0, 0)),
+    # several row blocks per workgroup at every K (256 row streams at N = 128, 80 at N = 384)
+    (300001, 128, 128, False, "bias_relu", (0, 0, 0)),
+    (300001, 128, 384, True, "grad_relu", (0, 0, 0)),
+    (200003, 64, 128, True, "none", (0, 0, 0)),
+    (200003, 96, 128, False, "accumulate", (0, 0, 0)),
 ]
 
 

@@ -956,6 +956,9 @@ __device__ __forceinline__ void x3k_request(uint4v (&dst)[3], const unsigned (&a
 __device__ __forceinline__ void x3k_wait_all_but_3(uint4v (&b)[3]) {  // the three reads of the group BEFORE the last request
   asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2])::"memory");
 }
+__device__ __forceinline__ void x3k_wait_all(uint4v (&b)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2])::"memory");
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void x3k_static_for(F&& f) {
   if constexpr (I < N) {
@@ -1024,8 +1027,8 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   // B piece addresses: one LDS byte address per plane (+ col tile * 32 * ROWB + step * 16 as the immediate offset).  The reads
   // are written as asm so that they are issued ONE GROUP (6 - 9 MFMAs) AHEAD of their use; left to the compiler every read
   // sits right in front of its MFMAs and the LDS latency is paid 4 K/16 times per tile (the multiply side alone took 198 us
-  // of a 320 us kernel, twice the time of its MFMAs).  The chain of requests runs on across tiles: B does not depend on the
-  // tile.  A request's registers reach the MFMAs through the "+v" operands of the wait, so neither can move above it.
+  // of a 320 us kernel, twice the time of its MFMAs).  A request's registers reach the MFMAs through the "+v" operands of the
+  // wait, so neither can move above it.
   unsigned b_addr[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
@@ -1044,7 +1047,6 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
 #pragma unroll
     for (int j = 0; j < 2 * KS; ++j) araw[j] = a_load(ao, j);
   }
-  b_request(std::integral_constant<int, 0>{});
   for (; blk < nblocks; blk += nstreams) {
     const int tile = blk * XK_WAVES + wave;
     int next = (blk + nstreams) * XK_WAVES + wave;
@@ -1055,6 +1057,9 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    // requests are pending only inside the step code below (VALU + MFMA, no spill code: the compiler does not know that the
+    // registers of an asm read are still in flight - around the epilogue it spilled them and saved the OLD contents)
+    b_request(std::integral_constant<int, 0>{});
     x3k_static_for<0, KS>([&](auto j_c) {
       constexpr int j = decltype(j_c)::value;
       const float4 x0 = araw[2 * j], x1 = araw[2 * j + 1];
@@ -1067,8 +1072,12 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
       const bf16x8 al = __builtin_bit_cast(bf16x8, uint4v{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])});
       x3k_static_for<0, 4>([&](auto c_c) {
         constexpr int c = decltype(c_c)::value, cur = c & 1;
-        b_request(std::integral_constant<int, j * 4 + c + 1>{});
-        x3k_wait_all_but_3(bq[cur]);
+        if constexpr (j * 4 + c + 1 < 4 * KS) {
+          b_request(std::integral_constant<int, j * 4 + c + 1>{});
+          x3k_wait_all_but_3(bq[cur]);
+        } else {
+          x3k_wait_all(bq[cur]);  // last group of the tile: nothing stays pending across the epilogue
+        }
         acc[c] = mfma_group<NPROD>(acc[c], ah, am, al, __builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, bq[cur][1]),
                                    __builtin_bit_cast(bf16x8, bq[cur][2]));
       });
