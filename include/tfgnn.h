@@ -324,6 +324,18 @@ int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int
                              const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved,
                              int64_t ld_saved, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* The Dense layer over GATHERED rows: C[m, :] = act( (C[m, :] if accumulate == 2) + A[row_index[m], :] @ op(B) + bias )
+ * (+ C[m, :] if accumulate == 1), A [a_rows, lda] fp32, row_index [M] int32 in [0, a_rows).
+ * Replaces tf.nn.embedding_lookup(node_embeddings, sources / targets) followed by the first Dense layer of an edge MLP
+ * (gnn_edge_mlp.py:84-100 with message_passing.py:195-206): the per-edge input [x_src || x_tgt] W = x_src W_s + x_tgt W_t is
+ * two calls (the second with accumulate = 2 and the MLP's activation) and the [E, 2D] concatenation is never written.
+ * Only the streaming bf16x3 kernel reads rows through an index (K in {64, 96, 128}, N % 128 == 0, M >= 65536, 16-byte aligned
+ * operands, a_rows * lda < 2^30); otherwise TFGNN_ERR_UNSUPPORTED and the caller gathers (tfgnn_gather_reduce with an
+ * identity row pointer) and multiplies (tfgnn_gemm) - what the Python mirror does. */
+int tfgnn_gemm_gathered(int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, int64_t a_rows,
+                        const int32_t* d_row_index, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                        const float* d_bias, int act, int accumulate, void* stream);
+
 /* Grouped forms of the Dense layer for the per-relation multiply over NON-EMPTY buckets only (rows of
  * the stacked operand are grouped by edge type: group g owns rows [d_group_offsets[g],
  * d_group_offsets[g+1]), TFGNN_G_NZ_OFF_*; max_group_rows bounds the launch grid):

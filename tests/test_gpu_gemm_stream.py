@@ -118,3 +118,42 @@ def test_long_k_weight_gradient_split(dev, x3_mode, K, M, N):
     assert_close(out.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"long-K split {x3_mode} {(K, M, N)}")
     again = ops.gemm(X.to(dev), G.to(dev), trans_a=True)
     assert torch.equal(out, again)  # fixed summation order
+
+
+@pytest.mark.parametrize("M,V,K,N,tb", [(70000, 20000, 128, 128, False), (150001, 9000, 64, 256, True), (5000, 3000, 128, 128, False),
+                                        (70000, 20000, 72, 128, False)])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "after", "before_relu", "before_tanh_bias"])
+def test_gathered_rows_product(dev, x3_mode, M, V, K, N, tb, epi):
+    """tfgnn_gemm_gathered = embedding_lookup + Dense: rows of A read through an index inside the streaming kernel, or (small /
+    odd shapes) a row gather followed by tfgnn_gemm; both accumulate orders."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn((V, K), generator=g)
+    idx = torch.randint(0, V, (M,), generator=g, dtype=torch.int64)
+    idx[0], idx[-1] = V - 1, 0
+    B = torch.randn((N, K) if tb else (K, N), generator=g) * 0.2
+    C0 = torch.randn((M, N), generator=g)
+    bias = torch.randn(N, generator=g) if "bias" in epi else None
+    ref = X.double()[idx] @ (B.double().t() if tb else B.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    act = "relu" if "relu" in epi else ("tanh" if "tanh" in epi else None)
+    f = {"relu": torch.relu, "tanh": torch.tanh, None: lambda t: t}[act]
+    if epi.startswith("before"):
+        ref = f(ref + C0.double())
+        acc = "before"
+    elif epi == "after":
+        ref = f(ref) + C0.double()
+        acc = "after"
+    else:
+        ref = f(ref)
+        acc = None
+    out = C0.to(dev) if acc else None
+    streaming = M >= 65536 and K in (64, 96, 128)
+    with KernelsUsed() as k:
+        res = ops.gemm_gathered(X.to(dev), idx.to(torch.int32).to(dev), B.to(dev), trans_b=tb, bias=None if bias is None else bias.to(dev),
+                                act=act, out=out, accumulate=acc)
+    assert k.delta["gemm_stream"] == (1 if streaming else 0), k.delta
+    scale = max(1.0, 0.2 * float(K) ** 0.5)
+    assert_close(res.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"gathered product {x3_mode} {(M, V, K, N, tb, epi)}")

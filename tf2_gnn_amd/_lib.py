@@ -57,6 +57,12 @@ _SIGNATURES = [
         [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
          c_int, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
     ),
+    (
+        "tfgnn_gemm_gathered",
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+         c_int, c_int, c_void_p],
+    ),
     ("tfgnn_gemm_set_mode", c_int, [c_int]),
     ("tfgnn_gemm_get_mode", c_int, []),
     (

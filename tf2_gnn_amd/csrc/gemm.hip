@@ -412,6 +412,9 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
                 void* workspace, size_t workspace_bytes, hipStream_t s, int* status, const float* mul = nullptr,
                 int64_t ld_mul = 0, const float* saved = nullptr, int64_t ld_saved = 0, int dact = 0);
 
+int gemm_x3_gathered_try(int nprod, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t a_rows,
+                         const int32_t* index, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                         int accumulate, hipStream_t s, int* status);
 int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t lda, const float* Bt, const float* bias,
                 const float* mh, const float* h, float* h_new, float* gates, hipStream_t s);
 
@@ -450,6 +453,24 @@ extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int
   if (gemm_x3_try(nprod, trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, nullptr, TFGNN_ACT_NONE, 0, d_workspace,
                   d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status, d_mul, ld_mul, d_saved, ld_saved,
                   act_of_saved))
+    return status;
+  return TFGNN_ERR_UNSUPPORTED;
+}
+
+extern "C" int tfgnn_gemm_gathered(int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, int64_t a_rows,
+                                   const int32_t* d_row_index, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                                   const float* d_bias, int act, int accumulate, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(M >= 0 && N >= 0 && K >= 0 && a_rows >= 0, "negative GEMM size");
+  TFGNN_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate is 0 (no), 1 (after the activation) or 2 (before it)");
+  if (M == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_C && d_A && d_B && d_row_index, "NULL operand");
+  TFGNN_REQUIRE(lda >= K && ldb >= (trans_b ? K : N) && ldc >= N, "bad leading dimension");
+  const int nprod = gemm_x3_mode();
+  if (!nprod) return TFGNN_ERR_UNSUPPORTED;
+  int status = TFGNN_OK;
+  if (gemm_x3_gathered_try(nprod, trans_b, M, N, K, d_A, lda, a_rows, d_row_index, d_B, ldb, d_C, ldc, d_bias, act, accumulate,
+                           (hipStream_t)stream, &status))
     return status;
   return TFGNN_ERR_UNSUPPORTED;
 }

@@ -68,6 +68,9 @@ struct X3Args {
   const float* gru_h;    // [M, H]: previous state
   float* gru_gates;      // [M, 3H] z | r | c for the backward pass, or NULL
   int gru_H;
+  // streaming kernel only (tfgnn_gemm_gathered): row m of the product reads row a_index[m] of A ([a_rows, lda]); NULL = row m
+  const int32_t* a_index;
+  int64_t a_rows;
 };
 
 __device__ __forceinline__ float4 grad_epilogue(const X3Args& g, float4 v, int64_t row, int64_t col) {
@@ -1014,13 +1017,15 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   // through a raw buffer descriptor: one address register per lane and tile, the 16 loads differ in the immediate offset
   const int Mi = (int)g.M;
   const unsigned a_row_bytes = (unsigned)g.lda * 4u, a_lane_bytes = (unsigned)kg * (K / 2) * 4u;
+  const int32_t* __restrict__ a_index = g.a_index;
   auto row_off = [&](int tile) {
     int row = tile * 32 + li;
     if (row >= Mi) row = Mi - 1;
-    return __umul24((unsigned)row, a_row_bytes) + a_lane_bytes;  // v_mad_u32_u24 (M, 4 lda < 2^24: launch site)
+    if (a_index) row = a_index[row];  // gathered rows (per-edge products over node states): a lane's row is its own anyway
+    return __umul24((unsigned)row, a_row_bytes) + a_lane_bytes;  // v_mad_u32_u24 (rows, 4 lda < 2^24: launch site)
   };
   const __amdgpu_buffer_rsrc_t a_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)(unsigned)(g.M * g.lda * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)(unsigned)((g.a_index ? g.a_rows : g.M) * g.lda * 4), 0x00020000);
   auto a_load = [&](unsigned off, int i) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + i * 16, 0, 0));
   };
@@ -1107,7 +1112,9 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = act_apply(decltype(act_c)::value, acc[c][r]);
     };
-    switch (g.act) {
+    // accumulate == 2: C = act(C + A B + bias) - the activation then waits for the old values (after the patch)
+    const bool act_late = EXTRAS && g.accumulate == 2;
+    switch (act_late ? TFGNN_ACT_NONE : g.act) {
       case TFGNN_ACT_RELU: act_all(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
       case TFGNN_ACT_TANH: act_all(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
       case TFGNN_ACT_LEAKY_RELU: act_all(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
@@ -1175,6 +1182,26 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
             v[q].x += c4.x; v[q].y += c4.y; v[q].z += c4.z; v[q].w += c4.w;
           }
         }
+        if (act_late) {
+          auto late = [&](auto act_c) {
+            constexpr int A = decltype(act_c)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q].x = act_apply(A, v[q].x); v[q].y = act_apply(A, v[q].y);
+              v[q].z = act_apply(A, v[q].z); v[q].w = act_apply(A, v[q].w);
+            }
+          };
+          switch (g.act) {
+            case TFGNN_ACT_RELU: late(std::integral_constant<int, TFGNN_ACT_RELU>{}); break;
+            case TFGNN_ACT_TANH: late(std::integral_constant<int, TFGNN_ACT_TANH>{}); break;
+            case TFGNN_ACT_LEAKY_RELU: late(std::integral_constant<int, TFGNN_ACT_LEAKY_RELU>{}); break;
+            case TFGNN_ACT_ELU: late(std::integral_constant<int, TFGNN_ACT_ELU>{}); break;
+            case TFGNN_ACT_SELU: late(std::integral_constant<int, TFGNN_ACT_SELU>{}); break;
+            case TFGNN_ACT_GELU: late(std::integral_constant<int, TFGNN_ACT_GELU>{}); break;
+            case TFGNN_ACT_SIGMOID: late(std::integral_constant<int, TFGNN_ACT_SIGMOID>{}); break;
+            default: break;
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -1211,7 +1238,8 @@ static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int sp
 static int gemm_x3k_try(int nprod, int trans_b, const X3Args& g, hipStream_t s) {
   static const int64_t min_rows = [] { const char* e = getenv("TFGNN_X3_STREAM_MIN_ROWS"); return e ? atoll(e) : 65536ll; }();
   if (min_rows <= 0 || g.M < min_rows || g.N % XK_COLS || g.K % 32 || g.K < 32 || g.K > 128) return 0;
-  if (g.M * g.lda >= (1ll << 30) || g.M >= (1 << 24) || g.lda >= (1 << 22)) return 0;  // 32-bit byte offsets, 24-bit factors
+  const int64_t src_rows = g.a_index ? g.a_rows : g.M;
+  if (src_rows * g.lda >= (1ll << 30) || src_rows >= (1 << 24) || g.M >= (1ll << 31) - 64 || g.lda >= (1 << 22)) return 0;  // 32-bit byte offsets, 24-bit factors
   const int ncb = (int)(g.N / XK_COLS);
   if (ncb > 32) return 0;
   const int spx = 32 / ncb;  // row streams per XCD (32 CUs each)
@@ -1282,6 +1310,7 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   g.mul = mul; g.ld_mul = ld_mul; g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
   g.group_mode = 0; g.group_off = nullptr; g.strideB = 0; g.strideC = 0;
   g.splits = 1; g.partial = nullptr;
+  g.a_index = nullptr; g.a_rows = 0;
   if (!trans_a && gemm_x3k_try(nprod, trans_b, g, s)) {
     if (hipGetLastError() != hipSuccess) {
       set_error("bf16x3 streaming GEMM launch failed");
@@ -1321,6 +1350,25 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
   }
   if (g.splits > 1) {
     launch_x3_splitk_reduce(g, 1, s);
+  }
+  return 1;
+}
+
+// C[m] = act?( (C[m] if accumulate) + A[index[m]] @ op(B) + bias ) on the streaming kernel; accumulate: 0 no, 1 after the
+// activation, 2 before it.  1 = taken, 0 = shape not covered (caller gathers and multiplies separately).
+int gemm_x3_gathered_try(int nprod, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t a_rows,
+                         const int32_t* index, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                         int accumulate, hipStream_t s, int* status) {
+  *status = TFGNN_OK;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || lda % 4 || ldb % 4 || ldc % 4) return 0;
+  X3Args g{};
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.act = act; g.accumulate = accumulate; g.splits = 1;
+  g.a_index = index; g.a_rows = a_rows;
+  if (!gemm_x3k_try(nprod, trans_b, g, s)) return 0;
+  if (hipGetLastError() != hipSuccess) {
+    set_error("bf16x3 streaming GEMM launch failed");
+    *status = TFGNN_ERR_HIP;
   }
   return 1;
 }

@@ -568,31 +568,64 @@ class GNN_Edge_MLP(MessagePassing):
         L, E = g.num_edge_types, g.num_edges
         mlps = self._edge_type_mlps
         src_l, tgt_l, tgt_node, _, off, _ = self._original_order(g, ew_d)
-        Wh = ops.permute_021(mlps.kernels[0])  # [2D, L, H0]
         H0 = mlps.kernels[0].shape[2]
+        first_act = "relu" if mlps.num_layers > 1 else None
+        if self._first_layer_per_edge(g, D, H0, off):
+            # few edges per (node, type) pair (molecules: E < V L): the first layer runs once per EDGE on rows of X read
+            # through the edge's source / target index - x_u W_s, then act(. + x_v W_t) - instead of once per (node, type)
+            # pair followed by a pass that adds the two gathered rows
+            src_node = g._cache.get("orig_src_node")
+            if src_node is None:
+                src_node = torch.div(src_l, L, rounding_mode="floor").to(torch.int32)
+                g._cache["orig_src_node"] = src_node
+            W0 = mlps.kernels[0]  # [L, 2D, H0]
+            Z = torch.empty((E, H0), dtype=torch.float32, device=X.device)
+            for l in range(L):
+                if off[l + 1] > off[l]:
+                    sl = slice(off[l], off[l + 1])
+                    ops.gemm_gathered(X, src_node[sl], W0[l, :D], out=Z[sl])
+                    ops.gemm_gathered(X, tgt_node[sl], W0[l, D:], out=Z[sl], act=first_act, accumulate="before")
+            return self._edge_hidden_layers_C(Z, off, L)
+        Wh = ops.permute_021(mlps.kernels[0])  # [2D, L, H0]
         P = ops.gemm(X, Wh[:D].view(D, L * H0))  # x_u W_s for every (node, type)
         Q = ops.gemm(X, Wh[D:].view(D, L * H0))  # x_v W_t
         Z = torch.empty((E, H0), dtype=torch.float32, device=X.device)
         # a single Dense layer has no activation (dpu_utils MLP [ext]: the final layer is linear)
-        first_act = "relu" if mlps.num_layers > 1 else None
         _lib.check(
             _lib.load().tfgnn_edge_pair_combine(
                 ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(P), ops._ptr(Q), E, H0, ops.act_id(first_act), ops._ptr(Z),
                 ops._stream(),
             )
         )
+        return self._edge_hidden_layers_C(Z, off, L)
+
+    def _edge_hidden_layers_C(self, Z, off, L):
+        """layers 1 .. of the per-edge MLPs on the first layer's activations Z [E, H0] (edge-list order) -> (outputs, acts)."""
+        mlps = self._edge_type_mlps
+        E = Z.shape[0]
         acts = [Z]
         cur = Z
         for j in range(1, mlps.num_layers):
             W = mlps.kernels[j]
             last = j == mlps.num_layers - 1
-            nxt = torch.empty((E, W.shape[2]), dtype=torch.float32, device=X.device)
+            nxt = torch.empty((E, W.shape[2]), dtype=torch.float32, device=Z.device)
             for l in range(L):
                 if off[l + 1] > off[l]:
                     ops.gemm(cur[off[l] : off[l + 1]], W[l], act=None if last else "relu", out=nxt[off[l] : off[l + 1]])
             acts.append(nxt)
             cur = nxt
         return cur, acts
+
+    # rows per product below which the streaming kernel does not take a gathered product (include/tfgnn.h tfgnn_gemm_gathered)
+    PER_EDGE_MIN_ROWS = 65536
+
+    def _first_layer_per_edge(self, g, D, H0, off) -> bool:
+        if ops.get_gemm_mode() == ops.GEMM_FP32 or D not in (64, 96, 128) or H0 % 128 != 0:
+            return False
+        L, E, V = g.num_edge_types, g.num_edges, g.num_nodes
+        if E == 0 or E >= V * L or V * D >= (1 << 30):
+            return False
+        return all(off[l + 1] - off[l] == 0 or off[l + 1] - off[l] >= self.PER_EDGE_MIN_ROWS for l in range(L))
 
     def _aggregate_nothing(self, V, X, fuse_act, ctx):
         """aggregation over zero edges: zeros (sum-like) / the float minimum (max), then the activation."""

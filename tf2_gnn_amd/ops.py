@@ -447,6 +447,71 @@ def gemm(
     return out
 
 
+_ident_ptrs = {}
+
+
+def _identity_rowptr(device, n: int) -> torch.Tensor:
+    """[0, 1, ..., n] int32 (rows of one element each: turns tfgnn_csr_gather_reduce into a plain row gather)."""
+    key = str(device)
+    t = _ident_ptrs.get(key)
+    if t is None or t.numel() < n + 1:
+        t = torch.arange(max(n + 1, 1 << 16), dtype=torch.int32, device=device)
+        _ident_ptrs[key] = t
+    return t[: n + 1]
+
+
+def gemm_gathered(a: torch.Tensor, row_index: torch.Tensor, b: torch.Tensor, *, trans_b: bool = False,
+                  bias: Optional[torch.Tensor] = None, act=ACT_NONE, out: Optional[torch.Tensor] = None,
+                  accumulate: Optional[str] = None) -> torch.Tensor:
+    """out[m] = act(a[row_index[m]] @ op(b) + bias)  (tfgnn_gemm_gathered: tf.nn.embedding_lookup + Dense, the gathered rows are
+    never written).  ``accumulate``: None, "after" (out += act(..)) or "before" (out = act(out + ..), the second half of a
+    product over concatenated inputs).  Shapes the streaming kernel does not take run as a row gather + gemm."""
+    lib = _lib.load()
+    _require_dev(a, torch.float32, "a")
+    _require_dev(b, torch.float32, "b")
+    _require_dev(row_index, torch.int32, "row_index")
+    if accumulate not in (None, "after", "before"):
+        raise ValueError('accumulate is None, "after" or "before"')
+    a2, lda = _rowmajor(a, "a")
+    b2, ldb = _rowmajor(b, "b")
+    K = a2.shape[1]
+    Kb, N = (b2.shape[1], b2.shape[0]) if trans_b else (b2.shape[0], b2.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm_gathered: inner dimensions differ ({K} vs {Kb})")
+    M = row_index.numel()
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    out2, ldc = _rowmajor(out, "out")
+    if out2 is not out or tuple(out.shape) != (M, N):
+        raise ValueError(f"out must be [{M},{N}] with unit inner stride")
+    if bias is not None:
+        _require_dev(bias, torch.float32, "bias")
+        bias = bias.contiguous()
+    if M == 0:
+        return out
+    row_index = row_index.contiguous()
+    rc = lib.tfgnn_gemm_gathered(
+        int(trans_b), M, N, K, _ptr(a2), lda, a2.shape[0], _ptr(row_index), _ptr(b2), ldb, _ptr(out), ldc, _ptr(bias),
+        act_id(act), {None: 0, "after": 1, "before": 2}[accumulate], _stream(),
+    )
+    if rc == 0:
+        return out
+    if rc != -4:  # TFGNN_ERR_UNSUPPORTED: the caller-side route below
+        _lib.check(rc)
+    rows = gather_reduce(_identity_rowptr(a.device, M), row_index, a2)
+    if accumulate == "before":
+        gemm(rows, b2, trans_b=trans_b, bias=bias, out=out, accumulate=True)
+        if act_id(act) != act_id(ACT_NONE):
+            if out.is_contiguous():
+                activation_forward(act, out, out=out)
+            else:
+                out.copy_(activation_forward(act, out))
+        return out
+    return gemm(rows, b2, trans_b=trans_b, bias=bias, act=act, out=out, accumulate=accumulate == "after")
+
+
 @_writes_out
 def activation_forward(act, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
