@@ -623,11 +623,11 @@ def other_configs(args):
 # --------------------------------------------------------------------------------------------------------------------
 # step breakdown: every library op of ONE real step between HIP events (launch stream), aggregated by (op, shapes)
 # --------------------------------------------------------------------------------------------------------------------
-_TIMED_OPS = ("gemm", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
+_TIMED_OPS = ("gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
               "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
               "activation_backward", "dropout_forward", "mul", "add_scale", "colsum", "layernorm_forward", "layernorm_backward",
               "permute_021", "transpose_batched", "edge_aggregate_backward", "sp_split_rows", "sp_split_cols", "clip", "clip_backward")
-_PRODUCT_OPS = {"gemm", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
+_PRODUCT_OPS = {"gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
 
 
 def step_breakdown(step, ops, steps=2, top=12):
