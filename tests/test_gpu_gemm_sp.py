@@ -404,3 +404,23 @@ def test_gemm_tn_in_three_phases_on_two_streams_equals_the_single_call(dev):
     ops.join_aux_stream()
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and bool(torch.isfinite(filler).all())
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_narrow_row_split_equals_the_general_kernel(dev, C):
+    """rows of 64 / 128 / 256 columns take a one-pass kernel from 4096 rows on: same bytes and scales as the general kernel
+    (run here on chunks below that size), padded source rows, special values included."""
+    from tf2_gnn_amd import ops
+
+    R = 9001
+    g = torch.Generator().manual_seed(C)
+    full = torch.randn((R, C + 8), generator=g) * torch.exp(torch.randn((R, 1), generator=g) * 4)
+    full[5] = 0.0
+    full[6, 3] = float("inf")
+    full[7, 9] = float("nan")
+    x = full.to(dev)[:, :C]
+    whole = ops.sp_split_rows(x)
+    for r0 in range(0, R, 4000):
+        part = ops.sp_split_rows(x[r0 : r0 + 4000])
+        assert torch.equal(whole.data[r0 : r0 + 4000], part.data)
+        assert torch.equal(whole.inv_scale[r0 : r0 + 4000].view(-1), part.inv_scale.view(-1))

@@ -133,6 +133,27 @@ __global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restr
   sp_split_rows_body(src, ld, seg_len, seg_stride, R, C, sb, dst, ld_dst, inv, fixed_inv, blockIdx.x);
 }
 
+// Plain row-major rows of 64 / 128 / 256 columns with one scale per row (node states, gate gradients: [10^6, 128]): C / 4 lanes
+// per row, one float4 per lane held in registers between the row maximum and the store - one pass and full waves, where the
+// general kernel above spends a half-empty wave and two passes per row (0.50 -> ~0.2 ms for [1.15 M, 128]).  Same scale
+// function and store: bit-identical output.
+template <int LPR>
+__global__ void __launch_bounds__(256) sp_split_rows_narrow_kernel(const float* __restrict__ src, int64_t ld, int64_t R,
+                                                                   uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv) {
+  constexpr int RPB = 256 / LPR;  // rows per workgroup and round
+  const int sub = threadIdx.x % LPR;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < R; r += (int64_t)gridDim.x * RPB) {
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + sub * 4);
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+    for (int o = LPR / 2; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float iv;
+    const float sc = sp_scale_for_max(mx, &iv);
+    if (inv && sub == 0) inv[r] = iv;
+    sp_store4(dst + r * ld_dst, sub * 4, v, sc);
+  }
+}
+
 // out[0] = max(out[0], scale * max |x|): the atomic maximum of non-negative floats through their bit patterns is
 // independent of the order -> reproducible.  out must start at 0.
 __global__ void __launch_bounds__(256) sp_absmax_kernel(const float* __restrict__ x, int64_t n, float scale, float* out) {
@@ -1245,6 +1266,17 @@ int tfgnn_sp_split_rows(const float* d_src, int64_t ld, int64_t seg_len, int64_t
                 "tfgnn_sp_split_rows: source must be 16-byte aligned with segment length / strides multiples of 4");
   TFGNN_REQUIRE(ld_sp_bytes >= cols * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_rows: bad SP16 leading dimension / alignment");
   if (rows == 0) return TFGNN_OK;
+  if (!d_fixed_inv_scale && scale_block == cols && (seg_len <= 0 || seg_len >= cols) && rows >= 4096 &&
+      (cols == 64 || cols == 128 || cols == 256)) {
+    const unsigned rpb = (unsigned)(256 / (cols / 4));
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(rows, rpb), 256 * 32);
+    hipStream_t s = (hipStream_t)stream;
+    if (cols == 64) hipLaunchKernelGGL(sp_split_rows_narrow_kernel<16>, dim3(grid), dim3(256), 0, s, d_src, ld, rows, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
+    else if (cols == 128) hipLaunchKernelGGL(sp_split_rows_narrow_kernel<32>, dim3(grid), dim3(256), 0, s, d_src, ld, rows, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
+    else hipLaunchKernelGGL(sp_split_rows_narrow_kernel<64>, dim3(grid), dim3(256), 0, s, d_src, ld, rows, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale);
+    TFGNN_LAUNCH_CHECK();
+    return TFGNN_OK;
+  }
   const int64_t items = rows * (cols / scale_block);
   hipLaunchKernelGGL(sp_split_rows_kernel, dim3((unsigned)ceil_div(items, 4)), dim3(256), 0, (hipStream_t)stream, d_src, ld,
                      seg_len, seg_stride, rows, cols, scale_block, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale, d_fixed_inv_scale);
