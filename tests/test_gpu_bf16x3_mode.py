@@ -46,7 +46,9 @@ def test_modes_agree_on_the_benchmarked_layer(dev, cfg2):
     assert float((out3 - out32).abs().max()) <= 2e-6 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("V,K,H", [(1000, 128, 128), (4097, 640, 64), (300, 72, 192)])
+# the last three run on the streaming kernel (V >= 65536, K in {64, 96, 128}: three column tiles z | r | h per 32 units)
+@pytest.mark.parametrize("V,K,H", [(1000, 128, 128), (4097, 640, 64), (300, 72, 192), (70001, 128, 128), (150003, 64, 64),
+                                   (300001, 96, 192)])
 def test_gemm_gru_matches_unfused(dev, V, K, H):
     """tfgnn_gemm_gru (matmul + GRUCell gate math in one kernel) against tfgnn_gemm + tfgnn_gru_gates_forward in the same
     mode: h' and the saved gates agree to fp32 rounding; and against an fp64 evaluation of the cell."""
@@ -61,8 +63,12 @@ def test_gemm_gru_matches_unfused(dev, V, K, H):
         rk = (torch.randn((H, 3 * H), generator=g) * 0.1).to(dev)
         bias = torch.randn((2, 3 * H), generator=g).to(dev)
         mh = ops.gemm(h, rk, bias=bias[1])
-        fused = ops.gemm_gru(x, kernel, bias[0], mh, h)
+        from tests.helpers import KernelsUsed
+
+        with KernelsUsed() as used:
+            fused = ops.gemm_gru(x, kernel, bias[0], mh, h)
         assert fused is not None
+        assert used.delta["gemm_stream"] == (1 if V >= 65536 and K in (64, 96, 128) else 0), used.delta
         mx = ops.gemm(x, kernel, bias=bias[0])
         h_ref, gates_ref = ops.gru_gates_forward(mx, mh, h)
         # (the unfused product may run on another tile width or, for N = 192, on the fp32-MFMA kernel: fp32 rounding apart)

@@ -971,9 +971,14 @@ __device__ __forceinline__ void x3k_static_for(F&& f) {
 }
 constexpr int XK_PS = 36;  // row stride (floats) of a wave's 32 x 32 epilogue patch
 
-template <int NPROD, int KS, bool EXTRAS>
+// MODE: 0 plain epilogue (bias, activation), 1 + gradient factors / accumulate, 2 GRU gate math (three column tiles: z | r | h
+// of 32 units per workgroup; B in the regrouped layout of tfgnn_gemm_gru)
+constexpr int XK_PLAIN = 0, XK_EXTRAS = 1, XK_GRU = 2;
+template <int NPROD, int KS, int MODE>
 __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor, int ncb, int spx) {
-  constexpr int K = KS * 16, ROWB = 2 * K + 16, PLANE_B = XK_COLS * ROWB;
+  constexpr bool EXTRAS = MODE == XK_EXTRAS;
+  constexpr int CT = MODE == XK_GRU ? 3 : 4, COLS = CT * 32;  // column tiles / columns per workgroup
+  constexpr int K = KS * 16, ROWB = 2 * K + 16, PLANE_B = COLS * ROWB;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -983,18 +988,24 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   const unsigned cb = slot % (unsigned)ncb, stream_local = slot / (unsigned)ncb;
   if ((int)stream_local >= spx) return;
   const int stream = (int)(stream_local * 8 + xcd), nstreams = spx * 8;
-  const int64_t n0 = (int64_t)cb * XK_COLS;
+  const int64_t n0 = (int64_t)cb * COLS;
+  // row of B (K-contiguous form) behind column n of this workgroup; GRU: unit block cb = half (cb & 1) of the 64 units of
+  // the 192-row group cb / 2, rows [z 64 | r 64 | h 64]
+  auto b_row = [&](int n) -> int64_t {
+    if constexpr (MODE == XK_GRU) return (int64_t)(cb >> 1) * 192 + (n >> 5) * 64 + (cb & 1) * 32 + (n & 31);
+    else return n0 + n;
+  };
 
   // ---- fill: B[:, n0 .. n0 + 127] -> planes[p][n][k] (bf16, k natural order) ---------------------------------
   if (!b_kmajor) {  // B given as [N, K] (K-contiguous)
-    for (int idx = tid; idx < XK_COLS * (K / 4); idx += XK_NT) {
+    for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
       const int n = idx / (K / 4), kq = idx - n * (K / 4);
-      const float4 v = *reinterpret_cast<const float4*>(g.B + (n0 + n) * g.ldb + kq * 4);
+      const float4 v = *reinterpret_cast<const float4*>(g.B + b_row(n) * g.ldb + kq * 4);
       split_store4(v.x, v.y, v.z, v.w, reinterpret_cast<unsigned short*>(lds + n * ROWB + kq * 8), PLANE_B / 2);
     }
   } else {  // B given as [K, N]
-    for (int idx = tid; idx < K * (XK_COLS / 4); idx += XK_NT) {
-      const int k = idx / (XK_COLS / 4), nq = idx - k * (XK_COLS / 4);
+    for (int idx = tid; idx < K * (COLS / 4); idx += XK_NT) {  // (not reached in GRU mode: its B is K-contiguous)
+      const int k = idx / (COLS / 4), nq = idx - k * (COLS / 4);
       const float4 v = *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n0 + nq * 4);
       const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1008,7 +1019,7 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
       }
     }
   }
-  if (g.bias && tid < XK_COLS) reinterpret_cast<float*>(lds + 3 * PLANE_B)[XK_WAVES * 32 * XK_PS + tid] = g.bias[n0 + tid];
+  if (g.bias && tid < COLS) reinterpret_cast<float*>(lds + 3 * PLANE_B)[XK_WAVES * 32 * XK_PS + tid] = g.bias[b_row(tid)];
   __syncthreads();
 
   const int ntiles = (int)((g.M + 31) / 32);  // M * lda < 2^30 (launch site): rows, tiles and blocks fit 32 bits
@@ -1038,9 +1049,9 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
 #pragma unroll
   for (int p = 0; p < 3; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
   uint4v bq[2][3];
-  auto b_request = [&](auto group_c) {  // group = step * 4 + column tile
-    constexpr int grp = decltype(group_c)::value % (4 * KS);
-    x3k_request<(grp & 3) * 32 * ROWB + (grp >> 2) * 16>(bq[grp & 1], b_addr);
+  auto b_request = [&](auto group_c) {  // group = step * CT + column tile
+    constexpr int grp = decltype(group_c)::value;
+    x3k_request<(grp % CT) * 32 * ROWB + (grp / CT) * 16>(bq[grp & 1], b_addr);
   };
   float* patch = reinterpret_cast<float*>(lds + 3 * PLANE_B) + wave * 32 * XK_PS;
   const float* lds_bias = reinterpret_cast<const float*>(lds + 3 * PLANE_B) + XK_WAVES * 32 * XK_PS;  // [128], filled above
@@ -1057,9 +1068,9 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
     int next = (blk + nstreams) * XK_WAVES + wave;
     if (next >= ntiles) next = ntiles - 1;  // nothing left: a harmless re-load
     const unsigned no = row_off(next);
-    floatx16 acc[4];
+    floatx16 acc[CT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     // requests are pending only inside the step code below (VALU + MFMA, no spill code: the compiler does not know that the
@@ -1075,10 +1086,10 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
       const bf16x8 ah = __builtin_bit_cast(bf16x8, uint4v{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])});
       const bf16x8 am = __builtin_bit_cast(bf16x8, uint4v{pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7])});
       const bf16x8 al = __builtin_bit_cast(bf16x8, uint4v{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])});
-      x3k_static_for<0, 4>([&](auto c_c) {
-        constexpr int c = decltype(c_c)::value, cur = c & 1;
-        if constexpr (j * 4 + c + 1 < 4 * KS) {
-          b_request(std::integral_constant<int, j * 4 + c + 1>{});
+      x3k_static_for<0, CT>([&](auto c_c) {
+        constexpr int c = decltype(c_c)::value, cur = (j * CT + c) & 1;
+        if constexpr (j * CT + c + 1 < CT * KS) {
+          b_request(std::integral_constant<int, j * CT + c + 1>{});
           x3k_wait_all_but_3(bq[cur]);
         } else {
           x3k_wait_all(bq[cur]);  // last group of the tile: nothing stays pending across the epilogue
@@ -1099,16 +1110,62 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
     // (row (r & 3) + 8 (r >> 2) + 4 kg, column li) of its 32 x 32 block ------------------------------------------
     if (g.bias) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < CT; ++c) {
         const float bias = lds_bias[c * 32 + li];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] += bias;
       }
     }
+    if constexpr (MODE == XK_GRU) {
+      // GRU gate math ([ext] GRUCell, reset_after: ggnn.py:84-87): the three tiles are mx_z, mx_r, mx_h of the SAME 32 units;
+      // each goes through the patch so that a lane ends up with four units of one row of all three
+      float4 xg[3][4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * XK_PS + li] = acc[c][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          xg[c][q] = *reinterpret_cast<const float4*>(patch + ((lane >> 3) + 8 * q) * XK_PS + (lane & 7) * 4);
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int H = g.gru_H;
+      const int64_t unit = (int64_t)cb * 32 + (lane & 7) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = (int64_t)tile * 32 + (lane >> 3) + 8 * q;
+        if (row < g.M) {
+          const float* pm = g.gru_mh + row * 3 * H + unit;
+          const float4 hz = *reinterpret_cast<const float4*>(pm);
+          const float4 hr = *reinterpret_cast<const float4*>(pm + H);
+          const float4 hc = *reinterpret_cast<const float4*>(pm + 2 * H);
+          const float4 hv = *reinterpret_cast<const float4*>(g.gru_h + row * H + unit);
+          const float4 xz = xg[0][q], xr = xg[1][q], xh = xg[2][q];
+          float4 z, r, c, o;
+#define X3K_GRU1(e)                                  \
+          z.e = 1.f / (1.f + expf(-(xz.e + hz.e)));  \
+          r.e = 1.f / (1.f + expf(-(xr.e + hr.e)));  \
+          c.e = tanhf(xh.e + r.e * hc.e);            \
+          o.e = z.e * hv.e + (1.f - z.e) * c.e;
+          X3K_GRU1(x) X3K_GRU1(y) X3K_GRU1(z) X3K_GRU1(w)
+#undef X3K_GRU1
+          *reinterpret_cast<float4*>(g.C + row * g.ldc + unit) = o;
+          if (g.gru_gates) {
+            float* pg = g.gru_gates + row * 3 * H + unit;
+            *reinterpret_cast<float4*>(pg) = z;
+            *reinterpret_cast<float4*>(pg + H) = r;
+            *reinterpret_cast<float4*>(pg + 2 * H) = c;
+          }
+        }
+      }
+      continue;
+    }
     // one wave-uniform dispatch per tile on the activation (a switch per element is a taken branch per element)
     auto act_all = [&](auto act_c) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = act_apply(decltype(act_c)::value, acc[c][r]);
     };
@@ -1127,7 +1184,7 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
     // a 32 x 32 block at a time through the wave's LDS patch, so that a lane stores 16 contiguous bytes: dword stores
     // straight from the accumulator layout are store-issue bound (355 us for [1.15 M, 128] x [128, 128], 0.4 of HBM)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * XK_PS + li] = acc[c][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -1211,18 +1268,19 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   }
 }
 
-template <int NPROD, bool EXTRAS>
+template <int NPROD, int MODE>
 static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int spx, dim3 grid, hipStream_t s) {
-  const size_t lds_bytes = (size_t)3 * XK_COLS * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + XK_COLS * 4;
-#define TFGNN_X3K_CASE(KSV)                                                                                                     \
-  case KSV: {                                                                                                                   \
-    static const bool raised = [] {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_x3k_kernel<NPROD, KSV, EXTRAS>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                3 * XK_COLS * (2 * KSV * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + XK_COLS * 4);                                  \
-      return true;                                                                                                              \
-    }();                                                                                                                        \
-    (void)raised;                                                                                                               \
-    hipLaunchKernelGGL((gemm_x3k_kernel<NPROD, KSV, EXTRAS>), grid, dim3(XK_NT), lds_bytes, s, g, b_kmajor, ncb, spx);          \
+  constexpr int COLS = MODE == XK_GRU ? 96 : 128;
+  const size_t lds_bytes = (size_t)3 * COLS * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4;
+#define TFGNN_X3K_CASE(KSV)                                                                                                   \
+  case KSV: {                                                                                                                 \
+    static const bool raised = [] {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm_x3k_kernel<NPROD, KSV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                3 * COLS * (2 * KSV * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4);                       \
+      return true;                                                                                                            \
+    }();                                                                                                                      \
+    (void)raised;                                                                                                             \
+    hipLaunchKernelGGL((gemm_x3k_kernel<NPROD, KSV, MODE>), grid, dim3(XK_NT), lds_bytes, s, g, b_kmajor, ncb, spx);          \
   } break;
   switch (ks) {
     TFGNN_X3K_CASE(2)
@@ -1234,12 +1292,21 @@ static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int sp
 #undef TFGNN_X3K_CASE
 }
 
+static int64_t x3k_min_rows() {
+  static const int64_t min_rows = [] { const char* e = getenv("TFGNN_X3_STREAM_MIN_ROWS"); return e ? atoll(e) : 65536ll; }();
+  return min_rows;
+}
+// shape limits shared by the forms of the streaming kernel: K in {32, 64, 96, 128}, many rows, 32-bit byte offsets and 24-bit
+// factors for the streamed operand
+static bool x3k_shape_ok(const X3Args& g) {
+  if (x3k_min_rows() <= 0 || g.M < x3k_min_rows() || g.K % 32 || g.K < 32 || g.K > 128) return false;
+  const int64_t src_rows = g.a_index ? g.a_rows : g.M;
+  return src_rows * g.lda < (1ll << 30) && src_rows < (1 << 24) && g.M < (1ll << 31) - 64 && g.lda < (1 << 22);
+}
+
 // 1 = the streaming kernel took the product (NN / NT, K in {32, 64, 96, 128}, N a multiple of 128, many rows)
 static int gemm_x3k_try(int nprod, int trans_b, const X3Args& g, hipStream_t s) {
-  static const int64_t min_rows = [] { const char* e = getenv("TFGNN_X3_STREAM_MIN_ROWS"); return e ? atoll(e) : 65536ll; }();
-  if (min_rows <= 0 || g.M < min_rows || g.N % XK_COLS || g.K % 32 || g.K < 32 || g.K > 128) return 0;
-  const int64_t src_rows = g.a_index ? g.a_rows : g.M;
-  if (src_rows * g.lda >= (1ll << 30) || src_rows >= (1 << 24) || g.M >= (1ll << 31) - 64 || g.lda >= (1 << 22)) return 0;  // 32-bit byte offsets, 24-bit factors
+  if (!x3k_shape_ok(g) || g.N % XK_COLS) return 0;
   const int ncb = (int)(g.N / XK_COLS);
   if (ncb > 32) return 0;
   const int spx = 32 / ncb;  // row streams per XCD (32 CUs each)
@@ -1249,12 +1316,26 @@ static int gemm_x3k_try(int nprod, int trans_b, const X3Args& g, hipStream_t s) 
   const bool extras = g.mul || g.saved || g.accumulate;  // the plain forward kernels carry none of that code
   const int ks = (int)(g.K / 16), bkm = trans_b ? 0 : 1;
   if (nprod >= 9) {
-    if (extras) launch_x3k_ks<9, true>(g, ks, bkm, ncb, spx, grid, s);
-    else launch_x3k_ks<9, false>(g, ks, bkm, ncb, spx, grid, s);
+    if (extras) launch_x3k_ks<9, XK_EXTRAS>(g, ks, bkm, ncb, spx, grid, s);
+    else launch_x3k_ks<9, XK_PLAIN>(g, ks, bkm, ncb, spx, grid, s);
   } else {
-    if (extras) launch_x3k_ks<6, true>(g, ks, bkm, ncb, spx, grid, s);
-    else launch_x3k_ks<6, false>(g, ks, bkm, ncb, spx, grid, s);
+    if (extras) launch_x3k_ks<6, XK_EXTRAS>(g, ks, bkm, ncb, spx, grid, s);
+    else launch_x3k_ks<6, XK_PLAIN>(g, ks, bkm, ncb, spx, grid, s);
   }
+  return 1;
+}
+
+// the GRU form (g filled by gemm_x3_gru: B = the regrouped kernel [3H, K], C = h' [M, H]): one workgroup per 32 units
+static int gemm_x3k_gru_try(int nprod, const X3Args& g, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("TFGNN_X3_STREAM_GRU"); return !e || atoi(e) != 0; }();  // 0: A/B probe
+  const int H = g.gru_H;
+  if (!on || !x3k_shape_ok(g) || H % 64 || H / 32 > 32 || g.ldc % 4) return 0;
+  const int ncb = H / 32, spx = 32 / ncb;
+  count_launch(TFGNN_KFAM_GEMM_BF16X3);
+  count_launch(TFGNN_KFAM_GEMM_STREAM);
+  dim3 grid((unsigned)(8 * spx * ncb));
+  if (nprod >= 9) launch_x3k_ks<9, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
+  else launch_x3k_ks<6, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
   return 1;
 }
 
@@ -1386,6 +1467,7 @@ int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t 
   g.bias = bias; g.act = TFGNN_ACT_NONE; g.splits = 1; g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
   g.n_tiles = (unsigned)(3 * H / 192);
   g.gru_mh = mh; g.gru_h = h; g.gru_gates = gates; g.gru_H = H;
+  if (gemm_x3k_gru_try(nprod, g, s)) return 1;  // QM9-sized batches: the weight block stays in LDS, rows stream
   const int64_t tiles = ceil_div(M, X3_BM) * g.n_tiles;
   if (tiles > 0x3fffffff) return 0;
   dim3 grid((unsigned)tiles, 1, 1);
