@@ -853,9 +853,10 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         N = 3 * H if model == "ggnn" else H
         Wk = torch.randn((H, N), device=dev) * 0.05
         ms = time_kernel(lambda: ops.gemm(Hx, Wk))
-        out.append(hbm_block(f"dense product [V, {H}] x [{H}, {N}] (skinny GEMM: bytes of A and C bound it, not the matrix cores)", ms,
+        out.append(hbm_block(f"dense product [V, {H}] x [{H}, {N}] (gemm_x3k_kernel: weight block resident in LDS, rows streamed; "
+                             "bytes of A and C bound it, not the matrix cores)", ms,
                              V * H * 4 + V * N * 4 + H * N * 4, (4 if model == "ggnn" else 6) * NL,
-                             "gemm" if mode == "fp32" else "gemm_bf16x3_pipelined"))
+                             "gemm" if mode == "fp32" else "gemm_stream"))
     if model == "rgat":
         K = wl.get("num_heads", 8)
         Wc = torch.randn((H, L * H), device=dev) * 0.05

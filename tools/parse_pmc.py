@@ -42,7 +42,7 @@ NEEDLES = (
     ("gather", ("csr_gather_reduce_kernel", ", 0, false>")), ("gather_sp", ("csr_gather_reduce_kernel", ", 0, true>")),
     ("gather_heads", ("csr_gather_reduce_kernel", ", 1, false>")),
     ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel"), ("gemm_bf16x3_pipelined", "gemm_x3p_kernel"),
-    ("gemm_sp_nt", "gemm_sp_nt_kernel"), ("gemm_sp_tn", "gemm_sp_tn_kernel"), ("gemm_skinny", "gemm_skinny"),
+    ("gemm_sp_nt", "gemm_sp_nt_kernel"), ("gemm_sp_tn", "gemm_sp_tn_kernel"), ("gemm_stream", "gemm_x3k_kernel"),
 )
 for name, needle in NEEDLES:
     if pick(fetch, needle) is None or pick(write, needle) is None:
