@@ -54,12 +54,7 @@ def messages_per_edge(layer, g, D, H) -> bool:
     L, E, V = g.num_edge_types, g.num_edges, g.num_nodes
     if E == 0 or E >= V * L or V * D >= (1 << 30) or layer._aggregation_name == "max" or layer._pre_activation():
         return False
-    counts = g._cache.get("edges_per_type")
-    if counts is None:
-        rowptr = g.array(ops.G_ROWPTR_BY_DST)
-        counts = (rowptr[1:] - rowptr[:-1]).view(V, L).sum(dim=0).tolist()
-        g._cache["edges_per_type"] = counts
-    return all(c == 0 or c >= PER_EDGE_MIN_ROWS for c in counts)
+    return all(c == 0 or c >= PER_EDGE_MIN_ROWS for c in g.edges_per_type)
 
 
 def _relu_input_grad(d_out, W, layer_input, out):
@@ -585,9 +580,7 @@ class GNN_Edge_MLP(MessagePassing):
                     g._h, ops._ptr(ew_d), ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(tgt_node), ops._ptr(w), ops._stream()
                 )
             )
-            # edges of type l occupy [off[l], off[l+1]) in this order: row lengths of the by-dst buckets
-            rowptr = g.array(ops.G_ROWPTR_BY_DST)
-            counts = (rowptr[1:] - rowptr[:-1]).view(g.num_nodes, g.num_edge_types).sum(dim=0).tolist()
+            counts = g.edges_per_type  # edges of type l occupy [off[l], off[l+1]) in this order (host-side sizes: no sync)
             off = [0]
             for c in counts:
                 off.append(off[-1] + int(c))

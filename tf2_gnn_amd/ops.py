@@ -150,6 +150,7 @@ class Graph:
         self.num_nodes = int(num_nodes)
         self.num_edge_types = L
         self.num_edges = int(sum(a.shape[0] for a in adjs))
+        self.edges_per_type = tuple(int(a.shape[0]) for a in adjs)  # host-side: known without touching the device
         self.device = adjs[0].device if adjs else torch.device("cuda")
         self._cache = {}
         if wait:
