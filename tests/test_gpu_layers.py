@@ -979,3 +979,36 @@ def test_overriding_message_function_where_the_aggregation_is_not_the_base_class
         layer = Mine(p)
         with pytest.raises(NotImplementedError, match="override call"):
             layer(MessagePassingInput(torch.zeros((10, 8), device=dev), to_dev(random_graph(10, 20, 2, seed=0), dev)))
+
+
+PER_EDGE_CASES = [
+    ("ggnn", "GGNN", {}),
+    ("ggnn_nonorm", "GGNN", {"normalize_by_num_incoming": False}),
+    ("rgcn_tanh_mean", "RGCN", {"message_activation_function": "tanh", "aggregation_function": "mean"}),
+    ("rgcn_sqrt_n_nonorm_gelu", "RGCN", {"aggregation_function": "sqrt_n", "normalize_by_num_incoming": False,
+                                         "message_activation_function": "gelu"}),
+    # (tanh: with fewer edges than buckets some nodes have no in-edge, and relu(0) sits exactly on its kink)
+    ("edge_mlp_default_tanh", "GNN_Edge_MLP", {"message_activation_function": "tanh"}),
+    ("edge_mlp_2hidden_norm_mean", "GNN_Edge_MLP", {"num_edge_MLP_hidden_layers": 2, "normalize_by_num_incoming": True,
+                                                    "aggregation_function": "mean", "message_activation_function": "tanh"}),
+]
+
+
+@pytest.mark.parametrize("name,cls_name,over", PER_EDGE_CASES, ids=[c[0] for c in PER_EDGE_CASES])
+def test_one_message_per_edge_formulation(dev, monkeypatch, name, cls_name, over):
+    """Graphs with fewer edges than (node, type) buckets take the per-edge formulation (rows of X read through the edge's source /
+    target index, tfgnn_gemm_gathered) once every edge type is large enough for the streaming kernel; here the size threshold is
+    lowered so that the layer logic - index arrays, normalisation, aggregation, the unchanged backward pass - is held against the
+    fp64 oracle on a small graph (the products themselves then take the gather + gemm route of ops.gemm_gathered)."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers.message_passing import gnn_edge_mlp
+
+    monkeypatch.setattr(gnn_edge_mlp, "PER_EDGE_MIN_ROWS", 1)
+    calls = []
+    real = ops.gemm_gathered
+    monkeypatch.setattr(ops, "gemm_gathered", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    check_layer_backward(dev, "per-edge " + name, cls_name, over, V=400, E=900, L=3, H=128)
+    if ops.get_gemm_mode() != ops.GEMM_FP32:
+        assert calls, "the per-edge formulation did not run"
+    else:
+        assert not calls
