@@ -312,7 +312,8 @@ int tfgnn_gemm_set_mode(int mode);
 int tfgnn_gemm_get_mode(void);
 
 /* The input-gradient product with the element-wise factors of the NEXT backward step applied on the way out:
- *   C[M,N] = (op(A) @ op(B)) * mul * act'(saved)
+ *   C[M,N] = (op(A) @ op(B)) * mul * act'(saved)      (+ C[M,N] if accumulate: a second term of the same gradient,
+ *                                                       e.g. the target half of an edge MLP's concatenated input)
  * mul    = the dropout mask of tf.nn.dropout on the layer input (gnn.py:285-288), NULL = absent;
  * saved  = what tfgnn_activation_backward takes for `act_of_saved` (the activation's output, or its input for
  *          gelu) of the layer below (message_passing.py:176-177 / Dense activation gnn.py:324-327), NULL = absent.
@@ -322,7 +323,7 @@ int tfgnn_gemm_get_mode(void);
 int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
                              int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                              const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved,
-                             int64_t ld_saved, void* d_workspace, size_t workspace_bytes, void* stream);
+                             int64_t ld_saved, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* The Dense layer over GATHERED rows: C[m, :] = act( (C[m, :] if accumulate == 2) + A[row_index[m], :] @ op(B) + bias )
  * (+ C[m, :] if accumulate == 1), A [a_rows, lda] fp32, row_index [M] int32 in [0, a_rows).

@@ -35,6 +35,7 @@ STREAM_CASES = [
     (300001, 128, 384, True, "grad_relu", (0, 0, 0)),
     (200003, 64, 128, True, "none", (0, 0, 0)),
     (200003, 96, 128, False, "accumulate", (0, 0, 0)),
+    (70001, 128, 128, True, "grad_mask_relu_accumulate", (0, 0, 0)),
 ]
 
 
@@ -70,9 +71,11 @@ def test_streaming_kernel_against_fp64(dev, x3_mode, case):
             mask = (torch.rand((M, N), generator=g) > 0.2).float() * 1.25 if "mask" in epi else None
             act = "relu" if "relu" in epi else "tanh"
             res = ops.gemm_grad(Ad, Bd, trans_b=tb, out=out_view, out_mul=None if mask is None else mask.to(dev),
-                                act_grad=(act, saved.to(dev)))
+                                act_grad=(act, saved.to(dev)), accumulate="accumulate" in epi)
             dact = (saved > 0).double() if act == "relu" else 1.0 - saved.double() ** 2
             ref = ref * dact * (1.0 if mask is None else mask.double())
+            if "accumulate" in epi:
+                ref = ref + C_full[:, :N].double()
     assert k.delta["gemm_stream"] == 1, k.delta
     assert res.data_ptr() == out_view.data_ptr()
     scale = max(1.0, 0.2 * float(K) ** 0.5)

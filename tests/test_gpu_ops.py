@@ -161,6 +161,13 @@ def test_gemm_grad_epilogue(dev, gemm_mode, mode, act, with_mask):
     out2 = ops.gemm_grad(A.to(dev), B.to(dev), trans_b=True, out=buf, out_mul=None if mask is None else mask.to(dev),
                          act_grad=None if act is None else (act, saved.to(dev)))
     assert torch.equal(out2, out)
+    # accumulating form: a second term of the same gradient added into the first one's result
+    C0 = torch.randn((M, N), generator=g)
+    buf3 = C0.to(dev)
+    out3 = ops.gemm_grad(A.to(dev), B.to(dev), trans_b=True, out=buf3, accumulate=True, out_mul=None if mask is None else mask.to(dev),
+                         act_grad=None if act is None else (act, saved.to(dev)))
+    assert out3.data_ptr() == buf3.data_ptr()
+    assert_close(out3.cpu() / scale, ((ref + C0.double()) / scale).float(), tol=2e-6, what=f"gemm_grad accumulate {mode} {act} mask={with_mask}")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3"])

@@ -55,7 +55,7 @@ _SIGNATURES = [
         "tfgnn_gemm_grad_epilogue",
         c_int,
         [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-         c_int, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
+         c_int, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p],
     ),
     (
         "tfgnn_gemm_gathered",

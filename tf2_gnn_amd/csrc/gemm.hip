@@ -440,7 +440,8 @@ extern "C" int tfgnn_gemm_get_mode(void) { return tfgnn::gemm_x3_mode(); }
 extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
                                         int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                                         const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved,
-                                        int64_t ld_saved, void* d_workspace, size_t workspace_bytes, void* stream) {
+                                        int64_t ld_saved, int accumulate, void* d_workspace, size_t workspace_bytes,
+                                        void* stream) {
   using namespace tfgnn;
   TFGNN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative GEMM size");
   if (M == 0 || N == 0) return TFGNN_OK;
@@ -450,8 +451,8 @@ extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int
   const int nprod = gemm_x3_mode();
   if (!nprod) return TFGNN_ERR_UNSUPPORTED;
   int status = TFGNN_OK;
-  if (gemm_x3_try(nprod, trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, nullptr, TFGNN_ACT_NONE, 0, d_workspace,
-                  d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status, d_mul, ld_mul, d_saved, ld_saved,
+  if (gemm_x3_try(nprod, trans_a, trans_b, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, nullptr, TFGNN_ACT_NONE, accumulate ? 1 : 0,
+                  d_workspace, d_workspace ? workspace_bytes : 0, (hipStream_t)stream, &status, d_mul, ld_mul, d_saved, ld_saved,
                   act_of_saved))
     return status;
   return TFGNN_ERR_UNSUPPORTED;

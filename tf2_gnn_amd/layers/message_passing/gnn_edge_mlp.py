@@ -724,8 +724,16 @@ class GNN_Edge_MLP(MessagePassing):
         dWh = torch.empty_like(Wh)
         ops.gemm(X, dP, trans_a=True, out=dWh[:D].view(D, L * H0))
         ops.gemm(X, dQ, trans_a=True, out=dWh[D:].view(D, L * H0))
-        dX = ops.gemm(dP, Wh[:D].view(D, L * H0), trans_b=True)
-        ops.gemm(dQ, Wh[D:].view(D, L * H0), trans_b=True, out=dX, accumulate=True)
+        epi = getattr(self, "_out_epilogue", None)
+        if epi is not None:
+            # the factors of the next backward step (dropout mask, activation derivative of the layer below) distribute over
+            # the two terms: both products apply them in their epilogues, the second one adds into the first's result
+            dX = ops.gemm_grad(dP, Wh[:D].view(D, L * H0), trans_b=True, out_mul=epi[0], act_grad=epi[1])
+            dX = ops.gemm_grad(dQ, Wh[D:].view(D, L * H0), trans_b=True, out=dX, accumulate=True, out_mul=epi[0], act_grad=epi[1])
+            self._out_epilogue = None  # consumed
+        else:
+            dX = ops.gemm(dP, Wh[:D].view(D, L * H0), trans_b=True)
+            ops.gemm(dQ, Wh[D:].view(D, L * H0), trans_b=True, out=dX, accumulate=True)
         grads[0] = ops.permute_021(dWh)
         mlps.grads = grads
         mlps.publish_grads()

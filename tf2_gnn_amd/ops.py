@@ -310,14 +310,16 @@ def graph_gather(
 
 
 @_writes_out
-def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> torch.Tensor:
-    """out = (a @ op(b)) * out_mul * act'(saved): an input-gradient product with the element-wise factors of the next
-    backward step (dropout mask ``out_mul``, ``act_grad = (activation name, saved tensor)``) applied in the GEMM
-    epilogue when the active kernel has one (tfgnn_gemm_grad_epilogue), by separate kernels otherwise.
+def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None, accumulate=False) -> torch.Tensor:
+    """out = (a @ op(b)) * out_mul * act'(saved) (+ out if ``accumulate``): an input-gradient product with the element-wise
+    factors of the next backward step (dropout mask ``out_mul``, ``act_grad = (activation name, saved tensor)``) applied in the
+    GEMM epilogue when the active kernel has one (tfgnn_gemm_grad_epilogue), by separate kernels otherwise.
     Use the RETURN value: on the unfused route the factors are applied out of place and ``out`` only holds the raw
-    product."""
+    product (with ``accumulate`` the result is added into ``out`` and ``out`` is returned)."""
+    if accumulate and out is None:
+        raise ValueError("accumulate=True needs out")
     if out_mul is None and act_grad is None:
-        return gemm(a, b, trans_b=trans_b, out=out)
+        return gemm(a, b, trans_b=trans_b, out=out, accumulate=accumulate)
     lib = _lib.load()
     a2, lda = _rowmajor(a, "a")
     b2, ldb = _rowmajor(b, "b")
@@ -336,17 +338,20 @@ def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None) -> 
         rc = lib.tfgnn_gemm_grad_epilogue(
             0, int(trans_b), M, N, K, _ptr(a2), lda, _ptr(b2), ldb, _ptr(res), ldc, _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
-            saved.stride(0) if saved is not None else 0, _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+            saved.stride(0) if saved is not None else 0, int(accumulate), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
         )
         if rc == 0:
             return res
         if rc != -4:  # TFGNN_ERR_UNSUPPORTED: no fused epilogue for this mode / shape
             _lib.check(rc)
-    res = gemm(a, b, trans_b=trans_b, out=out)
+    res = gemm(a, b, trans_b=trans_b, out=None if accumulate else out)
     if out_mul is not None:
         res = mul(res, out_mul)
     if act_grad is not None:
         res = activation_backward(act_name, res, saved)
+    if accumulate:
+        out.copy_(add_scale(out, res, 1.0))
+        return out
     return res
 
 
