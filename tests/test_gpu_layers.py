@@ -282,6 +282,9 @@ def _gnn_oracle_weights(gnn):
         ("rgcn", {"dense_every_num_layers": 2, "residual_every_num_layers": 2, "use_inter_layer_layernorm": True}),
         ("ggnn", {"dense_every_num_layers": 3, "residual_every_num_layers": 1}),
         ("rgin", {"dense_every_num_layers": 1, "residual_every_num_layers": 2, "use_inter_layer_layernorm": True}),
+        # per-edge MLP with target states (path C): both input-gradient products carry the next step's factors
+        ("gnn_edge_mlp", {"dense_every_num_layers": 10000, "residual_every_num_layers": 10000}),
+        ("gnn_edge_mlp", {"dense_every_num_layers": 2, "residual_every_num_layers": 2}),
     ],
 )
 def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
@@ -302,9 +305,20 @@ def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
     w = _gnn_oracle_weights(gnn)
     ref, ref_all = orc.gnn_internal_call(params, w, X, [torch.from_numpy(a) for a in adjs])
     assert len(all_reprs) == params["num_layers"] + 1
-    for a, b in zip(all_reprs, ref_all):
-        assert_close(a.cpu(), b, tol=2e-5, what="all_node_representations")
-    assert_close(out.cpu(), ref, tol=2e-5, what=f"gnn {mp_style}")
+    if mp_style == "gnn_edge_mlp":
+        # four un-normalised per-edge MLP layers: states reach |x| ~ 10^2 and two fp32 evaluation orders differ by more than the
+        # elementwise bound; the fp64 oracle is the arbiter, the yardstick the magnitude of a node's state vector, and the HIP
+        # path may not be worse than twice the reference-order fp32 evaluation (as in check_layer_forward)
+        ref64f, ref_all64 = orc.gnn_internal_call(params, _to64(w), X.double(), [torch.from_numpy(a) for a in adjs])
+        for a, b32, b64 in zip(list(all_reprs) + [out], list(ref_all) + [ref], list(ref_all64) + [ref64f]):
+            scale = b64.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+            err_hip = float(((a.cpu().double() - b64).abs() / scale).max())
+            err_ref32 = float(((b32.double() - b64).abs() / scale).max())
+            assert err_hip <= max(2e-5, 2 * err_ref32), f"gnn {mp_style}: HIP vs fp64 {err_hip:.3e}, reference-order fp32 {err_ref32:.3e}"
+    else:
+        for a, b in zip(all_reprs, ref_all):
+            assert_close(a.cpu(), b, tol=2e-5, what="all_node_representations")
+        assert_close(out.cpu(), ref, tol=2e-5, what=f"gnn {mp_style}")
 
     # backward vs autograd through the fp64 oracle
     w64 = _to64(w)
