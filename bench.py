@@ -377,6 +377,7 @@ def main():
         dOut = torch.randn((G, 32), generator=torch.Generator().manual_seed(0)).to(dev)
     else:
         dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(0)).to(dev)
+    edges_per_type = [int(a.shape[0]) for a in adj_dev]
     graph = ops.Graph(adj_dev, V) if args.reuse_graph else None
     # Input pipeline: every step buckets one batch's edges (ops.Graph).  Like the reference, whose batches are prepared by
     # a background thread + tf.data prefetch while the previous step trains (data/graph_dataset.py:292-295,
@@ -399,14 +400,14 @@ def main():
         if side is None:
             if f16_features:
                 ops.split_rows_remembered(x)
-            return ops.Graph(adj_dev, V), x
+            return ops.Graph(adj_dev, V, parts=gnn.graph_parts(V, edges_per_type)), x
         # the preparation may start once the steps enqueued so far are done (the step before last used this copy of the
         # features); it then runs under the step that is enqueued next
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if f16_features:
                 ops.split_rows_remembered(x)
-            return ops.Graph(adj_dev, V, wait=False), x
+            return ops.Graph(adj_dev, V, wait=False, parts=gnn.graph_parts(V, edges_per_type)), x  # only the tables this stack reads
 
     def step():
         # a training step ends with an in-place weight update, which invalidates the split forms of the weights the f16x2

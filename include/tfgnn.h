@@ -103,6 +103,24 @@ int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes, const int32_
 int tfgnn_graph_wait(tfgnn_graph* graph);
 int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stream);
 
+/* What a batch's handle holds beyond the two sorted edge orders (row pointers, columns, edge ids, degrees: always built).
+ * A layer stack that only runs the aggregate-first RGCN / GGNN path needs the typed plans alone; everything else costs
+ * preparation kernels per batch for arrays nobody reads.  tfgnn_graph_create / _async build everything (as before);
+ * tfgnn_graph_create_parts_async builds the requested parts; tfgnn_graph_ensure adds missing ones later on `stream`
+ * (it blocks the host: the sizes of a part come back from the device).  Entry points that need a part the handle does
+ * not have fail with TFGNN_ERR_INVALID_ARGUMENT and name the part - they never read unbuilt arrays. */
+typedef enum {
+  TFGNN_GRAPH_PART_PLAN_TYPED = 1, /* long-row plans + length-ordered short rows of the views BY_DST_TYPED / BY_SRC_TYPED */
+  TFGNN_GRAPH_PART_PLAN_NODE = 2,  /* ... of the views BY_DST_NODE / BY_SRC_NODE (RGAT, per-edge messages)                */
+  TFGNN_GRAPH_PART_COMPACT = 4,    /* non-empty (node, type) buckets, type-major: TFGNN_G_NZ_* and the COMPACT views        */
+  TFGNN_GRAPH_PART_EDGE_MAPS = 8,  /* TFGNN_G_SRC2DST_POS and its inverse (RGAT: attention weights in both edge orders)     */
+  TFGNN_GRAPH_PARTS_ALL = 15
+} tfgnn_graph_part;
+int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                                   const int64_t* num_edges, unsigned parts, void* stream, tfgnn_graph** out_graph);
+int tfgnn_graph_ensure(tfgnn_graph* graph, unsigned parts, void* stream);
+unsigned tfgnn_graph_parts(const tfgnn_graph* graph);
+
 typedef enum {
   TFGNN_G_ROWPTR_BY_DST = 0, /* int32 [V*L+1]                                                  */
   TFGNN_G_COL_BY_DST = 1,    /* int32 [E]  source node of each bucketed edge                  */
@@ -296,18 +314,26 @@ int tfgnn_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const 
                const float* d_bias, int act, int accumulate, void* d_workspace,
                size_t workspace_bytes, void* stream);
 
-/* How tfgnn_gemm evaluates the fp32 product (process-wide; initial value from the environment variable
- * TFGNN_GEMM_MODE = fp32 | bf16x3 | bf16x3_9 | f16x2; unset or f16x2: TFGNN_GEMM_BF16X3 - "f16x2" is the host mirror's name
- * for handing the layers' hot products to the tfgnn_sp_* entry points, everything else runs as bf16x3):
+/* How the fp32 products are evaluated (process-wide; initial value from the environment variable
+ * TFGNN_GEMM_MODE = fp32 | bf16x3 | bf16x3_9 | f16x2; unset = f16x2, the mode bench.py is timed in):
  *   TFGNN_GEMM_FP32          v_mfma_f32_32x32x2_f32 on the fp32 operands
- *   TFGNN_GEMM_BF16X3        (default) every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and
+ *   TFGNN_GEMM_BF16X3        every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and
  *                            the six largest piece products - each exact in fp32 - are accumulated in fp32 on
  *                            v_mfma_f32_32x32x16_bf16; dropped terms are < 2^-23 |a b| (csrc/gemm_x3.hip)
  *   TFGNN_GEMM_BF16X3_EXACT  all nine piece products: products exact, only the fp32 accumulation rounds
+ *   TFGNN_GEMM_F16X2         (default) the products whose operands come out of a kernel that can write them SPLIT (the gather,
+ *                            a product's epilogue, the dropout pass) go to the tfgnn_sp_* entry points - operands as two
+ *                            rounded fp16 pieces with a power-of-two block scale, 3 piece products ("Split fp16 operands"
+ *                            below); the tfgnn_gemm* entry points themselves run as TFGNN_GEMM_BF16X3.  The choice of entry
+ *                            point is the binder's: take the tfgnn_sp_* route while tfgnn_gemm_get_mode() returns
+ *                            TFGNN_GEMM_F16X2.  The spread guard of the split weight-gradient product
+ *                            (tfgnn_sp_spread_flag) demotes the mode inside the library: once it has tripped,
+ *                            tfgnn_gemm_get_mode() returns TFGNN_GEMM_BF16X3 until tfgnn_gemm_set_mode(TFGNN_GEMM_F16X2)
+ *                            re-arms it (which waits for the device, so that no factor pass in flight can trip it again).
  * Inputs, outputs and accumulators are fp32 in every mode.  The split modes cover N % 128 == 0 (tiles of 320, 256
  * or 128 columns; NN, NT, TN layouts, K >= 64, 16-byte aligned operands); other shapes run the fp32 kernel
  * whatever the mode. */
-enum { TFGNN_GEMM_FP32 = 0, TFGNN_GEMM_BF16X3 = 6, TFGNN_GEMM_BF16X3_EXACT = 9 };
+enum { TFGNN_GEMM_FP32 = 0, TFGNN_GEMM_F16X2 = 3, TFGNN_GEMM_BF16X3 = 6, TFGNN_GEMM_BF16X3_EXACT = 9 };
 int tfgnn_gemm_set_mode(int mode);
 int tfgnn_gemm_get_mode(void);
 
@@ -502,7 +528,9 @@ int tfgnn_segment_softmax_backward(const float* d_w, const float* d_dw, int head
 
 /* Layer-input dropout of the GNN stack (gnn.py:285-288; [ext] tf.nn.dropout scales kept units by
  * 1/(1-rate)).  d_mask receives 0 or 1/(1-rate) per element; the gradient is tfgnn_mul(dy, mask).
- * The stream of random numbers is this library's own (counter-based), not TensorFlow's. */
+ * The stream of random numbers is this library's own (counter-based: element i of a call is a pure function of (seed, i)),
+ * not TensorFlow's.  d_mask may be NULL (not stored); d_y == NULL (then d_x is ignored) only (re)generates the mask of
+ * (seed, rate) - what tfgnn_sp_gemm_nt_dropout applies in its epilogue. */
 int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask, int64_t n, float rate,
                           uint64_t seed, void* stream);
 /* The same dropout (same random numbers: element (r, c) draws that of flat index r * cols + c) that also writes its result
@@ -575,6 +603,21 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
                         int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
                         const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                         float* d_out_inv_scale, void* stream);
+/* The superset: tfgnn_sp_gemm_nt / _sp (d_out_sp may be NULL) with the layer-input dropout of the NEXT op in the epilogue
+ * (gnn.py:285-288 - the producer of a layer's input drops it, so the stand-alone pass over [V, H], its mask tensor and the
+ * split pass disappear): the result, after bias / activation / the gradient factors, is multiplied by the mask
+ * tfgnn_dropout_forward draws for (dropout_seed, dropout_rate) at element index row * N + column (rate 0: no dropout).
+ * In a gradient product the same argument RECOMPUTES the forward mask (no mask tensor is read), and `saved_scale` lets
+ * d_saved be the DROPPED activation: the derivative is taken at d_saved * saved_scale (= 1 - rate: the kept values carry
+ * 1 / (1 - rate); dropped positions have mask 0 anyway).  dropout_seed = UINT64_MAX in a gradient product whose saved tensor
+ * is a dropped RELU output: no mask is computed at all - that tensor is positive exactly where the unit was kept and active,
+ * relu'(d_saved) carries the mask's zeros and the epilogue only applies 1 / (1 - rate). */
+int tfgnn_sp_gemm_nt_dropout(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                             int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                             int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
+                             int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
+                             void* stream);
 
 /* tfgnn_sp_gemm_tn: the weight-gradient product C[m, n] = sum_k A[k, a_first_col + m] B[k, b_first_col + n] of two SP16
  * operands stored with K as the row index (dW = X^T G of the Dense / edge-MLP kernels, tf.GradientTape in
@@ -591,6 +634,48 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
  * (row-major [M, N]: group_rows = M, stride_row = N, stride_col = 1; dW of stacked kernels [L, D, H] from m = (l, h),
  * n = d: group_rows = H, stride_group = D * H, stride_row = 1, stride_col = H).  d_workspace: 256-byte aligned,
  * tfgnn_sp_gemm_tn_workspace_bytes bytes. */
+/* ---- small passes that share a launch ------------------------------------------------------------------------------
+ * Around the big kernels of a layer sit passes of 5-15 us each that are bound by launch and dependent-load latency, not by
+ * work: weight matrices into SP16 form, the combine pass of the gather's long buckets, the split-K reduction of a weight
+ * gradient.  A `tfgnn_aux_job` describes one of them; tfgnn_aux_launch runs up to 8 per launch (more: several launches),
+ * every job on its own workgroups - the launch takes as long as its longest job.  Jobs of one call must be independent
+ * of each other.  The *_job / *_deferred functions FILL a job (host memory, nothing is launched for it) with exactly the
+ * work the function of the same name without the suffix would have launched; a job holds device pointers - keep the
+ * buffers alive until the launch has run.  (No reference counterpart: TensorFlow schedules these ops one kernel each.) */
+typedef struct tfgnn_aux_job {
+  int kind;            /* 0: nothing to do */
+  unsigned num_blocks; /* workgroups of 256 threads */
+  unsigned char payload[248];
+} tfgnn_aux_job;
+int tfgnn_aux_launch(const tfgnn_aux_job* jobs, int num_jobs, void* stream);
+int tfgnn_sp_split_rows_job(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
+                            int scale_block, void* d_sp, int64_t ld_sp_bytes, float* d_inv_scale,
+                            const float* d_fixed_inv_scale, tfgnn_aux_job* job);
+int tfgnn_sp_split_cols_job(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                            float* d_inv_scale, tfgnn_aux_job* job);
+/* tfgnn_graph_gather_reduce_sp; the combine pass of the long buckets comes back in *combine_job (kind 0: none) */
+int tfgnn_graph_gather_reduce_sp_deferred(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
+                                          const float* d_edge_weight, const float* d_row_scale, const float* d_in,
+                                          int64_t ld_in, int width, void* d_out_sp, int64_t ld_out_sp_bytes,
+                                          float* d_inv_scale, const float* d_fixed_inv_scale, void* d_workspace,
+                                          size_t workspace_bytes, tfgnn_aux_job* combine_job, void* stream);
+/* tfgnn_sp_gemm_tn with BOTH of its small passes as jobs (K <= 131072 rows; TFGNN_ERR_UNSUPPORTED above): nothing is
+ * launched; run *factors_job in a merged launch, then tfgnn_sp_gemm_tn_phase(2, same arguments), then *reduce_job.  A weight
+ * gradient is off the critical path of the backward pass, so the whole product can wait for the next merged launch. */
+int tfgnn_sp_gemm_tn_jobs(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                          const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                          int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                          int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                          size_t workspace_bytes, tfgnn_aux_job* factors_job, tfgnn_aux_job* reduce_job);
+/* tfgnn_sp_gemm_tn: factor pass (with_factors != 0) and product are launched, the split reduction (+ scatter into d_C) comes
+ * back in *reduce_job - a weight gradient is not read before the end of the backward pass, so the reductions of all layers
+ * can share one launch.  The workspace must stay untouched until that launch. */
+int tfgnn_sp_gemm_tn_deferred(int with_factors, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes,
+                              int64_t a_first_col, const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block,
+                              const void* d_B_sp, int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C,
+                              int64_t group_rows, int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate,
+                              void* d_workspace, size_t workspace_bytes, tfgnn_aux_job* reduce_job, void* stream);
+
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block);
 /* Guard of the limit above: the factor pass of every tfgnn_sp_gemm_tn sets a library-wide flag (host-visible without a
  * stream synchronisation; it trails the device by however far the stream is behind) when a NON-ZERO operand row lies more

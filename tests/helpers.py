@@ -102,8 +102,11 @@ class KernelsUsed:
         return False
 
 
+PARITY_LOG_NAME = "parity_r04.json"
+
+
 def record_parity(key: str, **numbers):
-    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r03.json (copied to profiles/ after a
+    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r04.json (copied to profiles/ after a
     run on the GPU box), keyed by GEMM MODE first: {mode: {check: {max error, bound, test id}}}.  A check that runs
     several times in one mode (parametrised tests sharing a label) keeps its worst case."""
     import json
@@ -127,17 +130,45 @@ def record_parity(key: str, **numbers):
         _flush_parity_log()
 
 
+def _worse(a: dict, b: dict) -> dict:
+    """Of two records of the same check, the one with the larger measured errors (ties: the first)."""
+    keys = [k for k in a if k.startswith("max_")] or [k for k in b if k.startswith("max_")]
+    if keys and all(float(b.get(k, 0.0)) >= float(a.get(k, 0.0)) for k in keys) and any(
+            float(b.get(k, 0.0)) > float(a.get(k, 0.0)) for k in keys):
+        keep = dict(b)
+    else:
+        keep = dict(a)
+    keep["count"] = max(int(a.get("count", 1)), int(b.get("count", 1)))
+    return keep
+
+
 def _flush_parity_log():
+    """MERGES this process's records into gpurun_out/parity_r04.json (a partial re-run used to
+    overwrite the snapshot of the full suite).  Idempotent: per (mode, check) the record with the larger error stays."""
     import json
     import os
 
     if not _PARITY_LOG:
         return
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", PARITY_LOG_NAME)
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        with open(path, "w") as f:
-            json.dump({k: v for k, v in _PARITY_LOG.items() if k != "_n"}, f, indent=1, sort_keys=True)
+        merged = {}
+        try:
+            with open(path) as f:
+                merged = json.load(f)
+        except (OSError, ValueError):
+            merged = {}
+        for mode, checks in _PARITY_LOG.items():
+            if mode == "_n":
+                continue
+            slot = merged.setdefault(mode, {})
+            for key, entry in checks.items():
+                slot[key] = _worse(slot[key], entry) if key in slot else entry
+        tmp = path + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
+        os.replace(tmp, path)
     except OSError:
         pass
 

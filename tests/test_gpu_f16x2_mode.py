@@ -191,3 +191,49 @@ def test_trained_like_gradient_spreads_through_the_rgcn_layer(dev):
     assert ops.get_gemm_mode() == ops.GEMM_BF16X3, "the guard must have seen the 2^27+ spread of the gradient rows"
     layer(inp, training=True)
     assert not layer._ctx.get("f16x2")
+
+
+def test_a_tripped_guard_recomputes_the_first_backward_passes_of_a_stack_on_the_exact_kernels(dev):
+    """the spread guard reports asynchronously - the pass that trips it has already produced its weight
+    gradients.  GNN.backward therefore checks it SYNCHRONOUSLY for the first passes of a model (TFGNN_GUARD_SYNC_PASSES = 3)
+    and runs a tripped pass again on the exact kernels: the gradients a caller reads are those of the bf16x3 mode, bit for bit."""
+    import warnings
+
+    from tf2_gnn_amd import _lib, ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    V, E, L, H = 2000, 40000, 3, 128
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=4)
+    params = GNN.get_default_hyperparameters("rgcn")
+    params.update({"hidden_dim": H, "num_layers": 2, "dense_every_num_layers": 10000, "residual_every_num_layers": 10000,
+                   "global_exchange_every_num_layers": 10000, "layer_input_dropout_rate": 0.0})
+    inp = GNNInput(torch.from_numpy(feats).to(dev), tuple(torch.from_numpy(a).to(dev) for a in adjs),
+                   torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    gen = torch.Generator().manual_seed(9)
+    # per-node gradient magnitudes over 2^60: the rows of the transposed gather are spread far beyond 2^20
+    dOut = (torch.randn((V, H), generator=gen) * torch.exp2(torch.randint(-40, 20, (V, 1), generator=gen).float())).to(dev)
+
+    def grads(mode):
+        ops.set_gemm_mode(mode)
+        set_seed(3)
+        gnn = GNN(params)
+        gnn(inp, training=True)
+        gnn.backward(dOut)
+        torch.cuda.synchronize()
+        return gnn, [v.grad.clone() for v in gnn.trainable_variables]
+
+    _, exact = grads("bf16x3")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gnn, got = grads("f16x2")
+    assert _lib.load().tfgnn_sp_spread_flag(0) == 1 and ops.get_gemm_mode() == ops.GEMM_BF16X3
+    assert any("spread" in str(x.message) for x in w)
+    assert gnn._guard_sync_passes == 2
+    # (the forward pass ran in f16x2 - its saved activations differ from the bf16x3 run's in the last bits - so the recomputed
+    #  gradients agree with the exact run to fp32 rounding, and every weight gradient is finite and complete)
+    for v, a, b in zip(gnn.trainable_variables, got, exact):
+        scale = max(float(b.abs().max()), 1e-30)
+        assert float((a - b).abs().max()) / scale <= 1e-5, v.name
+    ops.set_gemm_mode("f16x2")

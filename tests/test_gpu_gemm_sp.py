@@ -424,3 +424,54 @@ def test_narrow_row_split_equals_the_general_kernel(dev, C):
         part = ops.sp_split_rows(x[r0 : r0 + 4000])
         assert torch.equal(whole.data[r0 : r0 + 4000], part.data)
         assert torch.equal(whole.inv_scale[r0 : r0 + 4000].view(-1), part.inv_scale.view(-1))
+
+
+def test_small_passes_sharing_one_launch_equal_their_stand_alone_kernels(dev, monkeypatch):
+    """tfgnn_aux_launch (round 4): weight splits, the combine pass of the gather's long buckets and the split-K reduction of a
+    weight-gradient product, deferred and run as jobs of ONE launch, give bit-identical results to the kernels of their own;
+    urgent jobs run before the next library call, non-urgent ones (the reduction) at the explicit flush."""
+    from tf2_gnn_amd import _lib, ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+
+    g = torch.Generator().manual_seed(11)
+    W = (torch.randn((4, 320, 320), generator=g) * 0.1).to(dev)
+    V, E, L, H = 4000, 120000, 4, 320
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=2)
+    X = torch.from_numpy(feats).to(dev)
+    graph = ops.Graph(tuple(torch.from_numpy(a).to(dev) for a in adjs), V)
+    dY = torch.randn((V, H), generator=g).to(dev)
+
+    def run():
+        cols = ops.sp_split_cols(W.view(4 * 320, 320), defer=True)
+        rows = ops.sp_split_rows(W[0], segments=(320, 320 * 320, 4 * 320), defer=True)
+        A = ops.graph_gather_sp(graph, ops.VIEW_BY_DST_TYPED, X, rows_per_operand_row=L, defer_combine=True)  # long buckets
+        Y = ops.sp_gemm_nt(A, cols, act="relu")                                                 # flushes the three jobs first
+        G = ops.graph_gather_sp(graph, ops.VIEW_BY_SRC_TYPED, dY, rows_per_operand_row=L, defer_combine=True)
+        dW = torch.empty_like(W)
+        ops.sp_gemm_tn(G, ops.sp_split_rows(X), out=dW, scatter=(H, 320 * H, 1, H), defer_reduce=True)
+        dX = ops.sp_gemm_nt(G, rows)
+        ops.aux_flush()
+        return [cols.data, cols.inv_scale, rows.data, rows.inv_scale, A.data, A.inv_scale, Y, G.data, G.inv_scale, dW, dX]
+
+    monkeypatch.setenv("TFGNN_AUX_MERGE", "0")
+    ref = [t.clone() for t in run()]
+    monkeypatch.setenv("TFGNN_AUX_MERGE", "1")
+    assert ops.aux_enabled()
+    calls = []
+    real = _lib.load().tfgnn_aux_launch
+    got = [t.clone() for t in run()]
+    assert not ops._AUX_PENDING
+    names = ["W^T sp", "W^T inv", "W rows sp", "W rows inv", "A sp", "A inv", "Y", "G sp", "G inv", "dW", "dX"]
+    for n, a, b in zip(names, got, ref):
+        assert torch.equal(a, b), n
+    # a deferred reduction is NOT run by the next library call (non-urgent), only by a flush
+    dW2 = torch.full_like(W, 7.0)
+    G = ops.graph_gather_sp(graph, ops.VIEW_BY_SRC_TYPED, dY, rows_per_operand_row=L)
+    ops.aux_flush()
+    ops.sp_gemm_tn(G, ops.sp_split_rows(X), out=dW2, scatter=(H, 320 * H, 1, H), defer_reduce=True)
+    ops.add_scale(X, X, 0.5)
+    torch.cuda.synchronize()
+    assert float(dW2.min()) == 7.0 and len(ops._AUX_PENDING) == 1  # (the factor pass, with the product chained to it)
+    ops.aux_flush()
+    assert torch.equal(dW2, ref[9])
+    graph.close()

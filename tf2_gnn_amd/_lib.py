@@ -30,6 +30,13 @@ _SIGNATURES = [
         [c_int, c_int64, POINTER(c_void_p), POINTER(c_int64), c_void_p, POINTER(c_void_p)],
     ),
     ("tfgnn_graph_wait", c_int, [c_void_p]),
+    (
+        "tfgnn_graph_create_parts_async",
+        c_int,
+        [c_int, c_int64, POINTER(c_void_p), POINTER(c_int64), ctypes.c_uint, c_void_p, POINTER(c_void_p)],
+    ),
+    ("tfgnn_graph_ensure", c_int, [c_void_p, ctypes.c_uint, c_void_p]),
+    ("tfgnn_graph_parts", ctypes.c_uint, [c_void_p]),
     ("tfgnn_graph_destroy_async", c_int, [c_void_p, c_void_p]),
     ("tfgnn_graph_array", c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
     ("tfgnn_graph_dims", c_int, [c_void_p, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
@@ -224,9 +231,47 @@ _SIGNATURES = [
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    ("tfgnn_aux_launch", c_int, [c_void_p, c_int, c_void_p]),
+    (
+        "tfgnn_sp_split_rows_job",
+        c_int,
+        [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    ("tfgnn_sp_split_cols_job", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    (
+        "tfgnn_graph_gather_reduce_sp_deferred",
+        c_int,
+        [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+         c_size_t, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_sp_gemm_tn_jobs",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_sp_gemm_tn_deferred",
+        c_int,
+        [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_sp_gemm_nt_dropout",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_float,
+         ctypes.c_uint64, c_void_p],
+    ),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+
+class AuxJob(ctypes.Structure):
+    """tfgnn_aux_job (include/tfgnn.h): one small pass of a merged launch"""
+
+    _fields_ = [("kind", c_int), ("num_blocks", ctypes.c_uint), ("payload", ctypes.c_ubyte * 248)]
 
 _lib = None
 

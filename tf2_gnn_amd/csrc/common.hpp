@@ -63,6 +63,65 @@ static inline int64_t splitk_want(int64_t tiles, int64_t K) {
   return std::max<int64_t>(1, std::min<int64_t>(256 / tiles, 64));
 }
 
+// ---- dropout masks (gnn.py:285-288, [ext] tf.nn.dropout: keep with probability 1 - rate, scale kept values by 1/(1-rate)) ----
+// Counter-based: the decision of element i of a call is a pure function of (seed, i), so the kernel that PRODUCES a tensor can
+// drop it in its epilogue, the stand-alone kernel gives the same mask, and the backward pass RECOMPUTES the mask instead of
+// reading one back (no mask tensor exists on the fused path).  32-bit arithmetic (two v_mul_lo_u32 per element; the 64-bit
+// splitmix finaliser of rounds 1-3 cost ~200 VALU cycles per element - fine in a bandwidth-bound kernel, not in a product's
+// epilogue): the host turns the call's seed into two well-mixed words (splitmix64), the element hashes its index xor the first
+// with the "lowbias32" finaliser and xors the second; 24 bits of the word are the uniform number compared with rate * 2^24.
+struct DropoutKey {
+  uint32_t s0, s1;
+  uint32_t threshold;  // keep iff u24 >= threshold, threshold = ceil(rate * 2^24)
+  float scale;         // 1 / (1 - rate)
+};
+static inline DropoutKey dropout_key(uint64_t seed, float rate) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  DropoutKey k;
+  k.s0 = (uint32_t)z;
+  k.s1 = (uint32_t)(z >> 32);
+  const double t = (double)rate * 16777216.0;
+  uint32_t th = (uint32_t)t;
+  if ((double)th < t) ++th;
+  k.threshold = th;
+  k.scale = 1.f / (1.f - rate);
+  return k;
+}
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// One hash serves the FOUR elements of an aligned group (idx / 4): element e takes the word rotated left by 8 e bits, i.e. its
+// decision hangs on a byte of its own (the top byte of its 24-bit number; the lower 16 bits are shared with neighbours and
+// matter only within 2^-8 of the threshold).  Every element's number is uniform; the hash (two quarter-rate multiplies)
+// costs half a multiply per element - an epilogue of 160 elements per thread spent ~12 us on one hash per element.
+__device__ __forceinline__ uint32_t dropout_word(const DropoutKey& k, uint64_t group) {
+  uint32_t s = k.s0;
+  const uint32_t hi = (uint32_t)(group >> 32);
+  if (hi) s ^= lowbias32(hi * 0x9E3779B9u + 1u);  // tensors of more than 2^34 elements
+  return lowbias32((uint32_t)group ^ s) ^ k.s1;
+}
+__device__ __forceinline__ float dropout_from_word(const DropoutKey& k, uint32_t w, int e) {
+  const uint32_t u24 = __builtin_rotateleft32(w, 8u * (unsigned)e) >> 8;
+  return u24 >= k.threshold ? k.scale : 0.f;
+}
+// mask value (0 or 1/(1-rate)) of flat element index idx
+__device__ __forceinline__ float dropout_mask_at(const DropoutKey& k, uint64_t idx) {
+  return dropout_from_word(k, dropout_word(k, idx >> 2), (int)(idx & 3));
+}
+// the masks of elements idx .. idx + 3 (idx % 4 == 0)
+__device__ __forceinline__ float4 dropout_mask4(const DropoutKey& k, uint64_t idx) {
+  const uint32_t w = dropout_word(k, idx >> 2);
+  return make_float4(dropout_from_word(k, w, 0), dropout_from_word(k, w, 1), dropout_from_word(k, w, 2), dropout_from_word(k, w, 3));
+}
+
 constexpr float kSmallNumber = 1e-7f;  // tf2_gnn/utils/constants.py:2
 constexpr float kFloatLowest = -3.402823466e+38f;
 

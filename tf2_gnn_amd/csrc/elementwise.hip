@@ -271,26 +271,15 @@ add_scale_kernel(const float* __restrict__ x, const float* __restrict__ y, float
     out[i] = alpha * (x[i] + y[i]);
 }
 
-// ---- dropout (gnn.py:285-288, [ext] tf.nn.dropout: keep with prob 1-rate, scale by 1/(1-rate)) ---
-// counter-based generator (splitmix64 finaliser over seed ^ index): reproducible for a given seed,
-// independent of the launch geometry.  The mask (0 or 1/(1-rate)) is stored for the backward pass.
-__device__ __forceinline__ uint32_t mix_hash(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (uint32_t)(x >> 32);
-}
-
+// ---- dropout (gnn.py:285-288, [ext] tf.nn.dropout): masks are counter-based (common.hpp dropout_mask_at): reproducible for
+// a given seed, independent of the launch geometry, and identical in every kernel that draws them (this file, the epilogue of
+// the split-operand product).  The mask (0 or 1/(1-rate)) is stored for the backward pass when the caller asks for it.
 __global__ void __launch_bounds__(256)
-dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n,
-                       float rate, uint64_t seed) {
-  const float scale = 1.f / (1.f - rate);
+dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n, DropoutKey key) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float u = (float)(mix_hash(seed * 0xD1342543DE82EF95ull + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
-    const float m = u >= rate ? scale : 0.f;
-    mask[i] = m;
-    y[i] = x[i] * m;
+    const float m = dropout_mask_at(key, (uint64_t)i);
+    if (mask) mask[i] = m;
+    if (y) y[i] = x[i] * m;
   }
 }
 
@@ -301,8 +290,7 @@ dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float
 template <int VPL>
 __global__ void __launch_bounds__(256)
 dropout_forward_sp_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t rows, int cols,
-                          float rate, uint64_t seed, uint8_t* __restrict__ out_sp, int64_t ld_sp, float* __restrict__ inv_out) {
-  const float scale = 1.f / (1.f - rate);
+                          DropoutKey key, uint8_t* __restrict__ out_sp, int64_t ld_sp, float* __restrict__ inv_out) {
   const int sub = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (r >= rows) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
@@ -314,14 +302,10 @@ dropout_forward_sp_kernel(const float* __restrict__ x, float* __restrict__ y, fl
     const int c = (sub + 16 * j) * 4;
     if (c < cols) {
       const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
-      float m[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float u = (float)(mix_hash(seed * 0xD1342543DE82EF95ull + (uint64_t)(base + c + e)) >> 8) * (1.0f / 16777216.0f);
-        m[e] = u >= rate ? scale : 0.f;
-      }
+      const float4 m4 = dropout_mask4(key, (uint64_t)(base + c));  // cols % 16 == 0: base + c is a multiple of 4
+      const float m[4] = {m4.x, m4.y, m4.z, m4.w};
       v[j] = make_float4(xv.x * m[0], xv.y * m[1], xv.z * m[2], xv.w * m[3]);
-      *reinterpret_cast<float4*>(mask + base + c) = make_float4(m[0], m[1], m[2], m[3]);
+      if (mask) *reinterpret_cast<float4*>(mask + base + c) = m4;
       *reinterpret_cast<float4*>(y + base + c) = v[j];
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
       if (v[j].x != v[j].x || v[j].y != v[j].y || v[j].z != v[j].z || v[j].w != v[j].w) mx = __builtin_inff();
@@ -564,9 +548,10 @@ extern "C" int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask
   TFGNN_REQUIRE(n >= 0, "negative size");
   TFGNN_REQUIRE(rate >= 0.f && rate < 1.f, "dropout rate must be in [0, 1), got %f", (double)rate);
   if (n == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_x && d_y && d_mask, "NULL pointer");
+  // d_y == NULL: only the mask of (seed, rate) is (re)generated - the fused producers draw the same one in their epilogues
+  TFGNN_REQUIRE((d_y == nullptr || d_x != nullptr) && (d_y || d_mask), "NULL pointer");
   hipLaunchKernelGGL(dropout_forward_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask,
-                     n, rate, seed);
+                     n, dropout_key(seed, rate));
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -582,7 +567,7 @@ extern "C" int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_m
     return TFGNN_ERR_UNSUPPORTED;
   }
   if (rows == 0) return TFGNN_OK;
-  TFGNN_REQUIRE(d_x && d_y && d_mask && d_out_sp && d_inv_scale, "NULL pointer");
+  TFGNN_REQUIRE(d_x && d_y && d_out_sp && d_inv_scale, "NULL pointer");  // d_mask may be NULL: it can be regenerated
   TFGNN_REQUIRE(ld_out_sp_bytes >= cols * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0 &&
                     (uintptr_t)d_x % 16 == 0 && (uintptr_t)d_y % 16 == 0 && (uintptr_t)d_mask % 16 == 0,
                 "tfgnn_dropout_forward_sp: SP16 rows must be 64-byte aligned, fp32 tensors 16-byte aligned");
@@ -590,7 +575,7 @@ extern "C" int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_m
   const int vpl = (int)ceil_div(cols, 64);
 #define DROP_SP(V)                                                                                                      \
   hipLaunchKernelGGL((dropout_forward_sp_kernel<V>), grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask, rows, (int)cols, \
-                     rate, seed, (uint8_t*)d_out_sp, ld_out_sp_bytes, d_inv_scale)
+                     dropout_key(seed, rate), (uint8_t*)d_out_sp, ld_out_sp_bytes, d_inv_scale)
   if (vpl <= 2) DROP_SP(2);
   else if (vpl <= 4) DROP_SP(4);
   else if (vpl <= 5) DROP_SP(5);

@@ -425,17 +425,36 @@ int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, i
                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t stride_c, void* workspace, size_t workspace_bytes, hipStream_t s, int* status);
 
+int gemm_f16x2_mode();
+void gemm_f16x2_set(int on);
 }  // namespace tfgnn
 
 extern "C" int tfgnn_gemm_set_mode(int mode) {
   using namespace tfgnn;
-  TFGNN_REQUIRE(mode == TFGNN_GEMM_FP32 || mode == TFGNN_GEMM_BF16X3 || mode == TFGNN_GEMM_BF16X3_EXACT,
+  TFGNN_REQUIRE(mode == TFGNN_GEMM_FP32 || mode == TFGNN_GEMM_BF16X3 || mode == TFGNN_GEMM_BF16X3_EXACT || mode == TFGNN_GEMM_F16X2,
                 "unknown GEMM mode %d", mode);
-  gemm_x3_set_mode(mode);
+  if (mode == TFGNN_GEMM_F16X2) {
+    // (re-)arm the spread guard: a factor pass still in flight could set the flag after it has been cleared - wait for the
+    // device first (a mode switch is rare)
+    (void)hipDeviceSynchronize();
+    (void)tfgnn_sp_spread_flag(1);
+    gemm_x3_set_mode(TFGNN_GEMM_BF16X3);
+    gemm_f16x2_set(1);
+  } else {
+    gemm_x3_set_mode(mode);
+    gemm_f16x2_set(0);
+  }
   return TFGNN_OK;
 }
 
-extern "C" int tfgnn_gemm_get_mode(void) { return tfgnn::gemm_x3_mode(); }
+extern "C" int tfgnn_gemm_get_mode(void) {
+  using namespace tfgnn;
+  if (gemm_f16x2_mode()) {
+    if (!tfgnn_sp_spread_flag(0)) return TFGNN_GEMM_F16X2;
+    gemm_f16x2_set(0);  // the guard tripped: exact kernels from here on (sticky)
+  }
+  return gemm_x3_mode();
+}
 
 extern "C" int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A,
                                         int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,

@@ -31,6 +31,7 @@
 
 #include <type_traits>
 
+#include "aux_jobs.hpp"
 #include "common.hpp"
 #include "sp16.hpp"
 
@@ -80,52 +81,20 @@ struct SpArgs {
   uint8_t* out_sp;
   int64_t ld_out_sp;
   float* out_inv;  // [M]
+  // dropout in the epilogue (drop_on = 1): the result - after bias, activation and the gradient factors - times the mask of
+  // element index row * drop_ld + column (common.hpp dropout_mask_at: the mask tfgnn_dropout_forward draws for that seed).
+  // drop_on = 2 (gradient products, relu): the saved tensor IS the dropped relu output - it is positive exactly where the
+  // unit was kept and active, so relu'(saved) already carries the mask's zeros and only 1 / (1 - rate) is left to apply
+  int drop_on;
+  int64_t drop_ld;
+  DropoutKey drop;
+  float saved_scale;  // act'(saved * saved_scale): the saved tensor is a dropped activation (scaled by 1/(1-rate) where kept)
 };
 
 // ------------------------------------------------------------------------------------------------------
 // fp32 -> SP16 conversion
 // ------------------------------------------------------------------------------------------------------
-// One wave per (row, scale block).  Source element (r, c): src[r * ld + (c / seg_len) * seg_stride + c % seg_len]
-// (seg_len = C, seg_stride = 0: a plain row-major matrix; otherwise a row assembled from C / seg_len segments, e.g.
-// row d of [W_0[d,:] | W_1[d,:] | ...] from the stacked kernels [L, D, H]).  Two passes over the block (the second
-// one hits L1 / L2).
-__device__ __forceinline__ void sp_split_rows_body(const float* __restrict__ src, int64_t ld, int64_t seg_len,
-                                                   int64_t seg_stride, int64_t R, int64_t C, int sb,
-                                                   uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
-                                                   const float* __restrict__ fixed_inv, unsigned block) {
-  const int lane = threadIdx.x & 63;
-  const int nblk = (int)(C / sb);
-  const int64_t item = (int64_t)block * 4 + (threadIdx.x >> 6);
-  if (item >= R * nblk) return;
-  const int64_t r = item / nblk;
-  const int blk = (int)(item - r * nblk);
-  const float* srow = src + r * ld;
-  const int64_t c0 = (int64_t)blk * sb;
-  float s, iv;
-  if (fixed_inv) {  // caller-chosen scale (a tensor-wide bound): inv given, s = 1 / inv (a power of two)
-    iv = fixed_inv[0];
-    s = 1.f / iv;
-  } else {
-    float mx = 0.f;
-    for (int c = lane * 4; c < sb; c += 256) {
-      const int64_t cc = c0 + c;
-      const int64_t sg = cc / seg_len;
-      const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
-    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    s = sp_scale_for_max(mx, &iv);
-  }
-  if (inv && lane == 0) inv[item] = iv;
-  uint8_t* drow = dst + r * ld_dst;
-  for (int c = lane * 4; c < sb; c += 256) {
-    const int64_t cc = c0 + c;
-    const int64_t sg = cc / seg_len;
-    const float4 v = *reinterpret_cast<const float4*>(srow + sg * seg_stride + (cc - sg * seg_len));
-    sp_store4(drow, cc, v, s);
-  }
-}
-
+// (the conversion bodies live in aux_jobs.hpp: they also run as jobs of the merged small-pass launch, tfgnn_aux_launch)
 __global__ void __launch_bounds__(256) sp_split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t seg_len,
                                                             int64_t seg_stride, int64_t R, int64_t C, int sb,
                                                             uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
@@ -177,72 +146,6 @@ __global__ void sp_inv_scale_kernel(const float* bound, float* inv) {
   float iv;
   (void)sp_scale_for_max(fabsf(bound[0]), &iv);
   inv[0] = iv;
-}
-
-// SP16 rows from the COLUMNS of a row-major fp32 matrix: dst row n, column k = src[k * ld + n]  (a Keras kernel
-// [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  Workgroup (x, y): 16 dst rows, the
-// y-th slice of K; every workgroup takes the column maxima over ALL k itself (a weight matrix is L2 resident), so the
-// slices need no second launch.
-__device__ __forceinline__ void sp_split_cols_body(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
-                                                   uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
-                                                   unsigned bx, unsigned by, unsigned ny) {
-  __shared__ float red[64][4];
-  __shared__ float tile[16][65];
-  __shared__ float sc[16];
-  const int tid = threadIdx.x;
-  const int64_t n0 = (int64_t)bx * 16;
-  const int kq = tid >> 2, nq = (tid & 3) * 4;  // this thread: k = kq + 64 i, columns n0 + nq .. +3
-  const bool ok = n0 + nq < N;                  // N % 4 == 0
-  float4 mx = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t k0 = kq; k0 < K; k0 += 4 * 64) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t k = k0 + u * 64;
-      v[u] = (ok && k < K) ? *reinterpret_cast<const float4*>(src + k * ld + n0 + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      mx.x = fmaxf(mx.x, fabsf(v[u].x)); mx.y = fmaxf(mx.y, fabsf(v[u].y));
-      mx.z = fmaxf(mx.z, fabsf(v[u].z)); mx.w = fmaxf(mx.w, fabsf(v[u].w));
-    }
-  }
-  // reduce over the 64 k-rows of threads with the same nq: lanes 4 apart inside a wave (xor 4 .. 32), then the 4 waves
-#pragma unroll
-  for (int o = 4; o < 64; o <<= 1) {
-    mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
-    mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
-  }
-  if ((tid & 63) < 4) {
-    float* r = &red[(tid >> 6) * 4 + (tid & 3)][0];
-    r[0] = mx.x; r[1] = mx.y; r[2] = mx.z; r[3] = mx.w;
-  }
-  __syncthreads();
-  if (tid < 16) {  // column n0 + tid = chunk tid / 4, component tid % 4
-    float m = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w * 4 + (tid >> 2)][tid & 3]);
-    float iv;
-    sc[tid] = sp_scale_for_max(m, &iv);
-    if (inv && by == 0 && n0 + tid < N) inv[n0 + tid] = iv;
-  }
-  __syncthreads();
-  const int64_t kper = (((K + ny - 1) / ny) + 63) & ~63ll;
-  const int64_t kend = (by + 1) * kper < K ? (by + 1) * kper : K;
-  for (int64_t kb = by * kper; kb < kend; kb += 64) {
-    const int64_t k = kb + kq;
-    float4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok && k < K) v = *reinterpret_cast<const float4*>(src + k * ld + n0 + nq);
-    tile[nq + 0][kq] = v.x; tile[nq + 1][kq] = v.y; tile[nq + 2][kq] = v.z; tile[nq + 3][kq] = v.w;
-    __syncthreads();
-    // 16 rows x 64 k = 256 float4 items: thread -> row tid / 16, k4 = (tid % 16) * 4
-    const int rr = tid >> 4, k4 = (tid & 15) * 4;
-    if (n0 + rr < N && kb + k4 < K) {
-      const float4 o = {tile[rr][k4], tile[rr][k4 + 1], tile[rr][k4 + 2], tile[rr][k4 + 3]};
-      sp_store4(dst + (n0 + rr) * ld_dst, kb + k4, o, sc[rr]);
-    }
-    __syncthreads();
-  }
 }
 
 __global__ void __launch_bounds__(256) sp_split_cols_kernel(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
@@ -615,6 +518,10 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
           }
         }
         if (GRAD && savp) {
+          if (g.saved_scale != 1.f) {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) { sv[j].x *= g.saved_scale; sv[j].y *= g.saved_scale; sv[j].z *= g.saved_scale; sv[j].w *= g.saved_scale; }
+          }
           auto dact_row = [&](auto act_c) {
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
@@ -639,6 +546,12 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
           if (GRAD) {
             w[q][j].x *= m[j].x; w[q][j].y *= m[j].y; w[q][j].z *= m[j].z; w[q][j].w *= m[j].w;
             if (savp) { w[q][j].x *= sv[j].x; w[q][j].y *= sv[j].y; w[q][j].z *= sv[j].z; w[q][j].w *= sv[j].w; }
+          }
+          if (g.drop_on == 1) {
+            const float4 dm = dropout_mask4(g.drop, (uint64_t)(rowq[q] * g.drop_ld + wcol0 + (l8 + 8 * j) * 4));  // N % 4 == 0
+            w[q][j].x *= dm.x; w[q][j].y *= dm.y; w[q][j].z *= dm.z; w[q][j].w *= dm.w;
+          } else if (g.drop_on == 2) {  // the mask is in the saved tensor (see SpArgs)
+            w[q][j].x *= g.drop.scale; w[q][j].y *= g.drop.scale; w[q][j].z *= g.drop.scale; w[q][j].w *= g.drop.scale;
           }
           mx = fmaxf(mx, fmaxf(fmaxf(fabsf(w[q][j].x), fabsf(w[q][j].y)), fmaxf(fabsf(w[q][j].z), fabsf(w[q][j].w))));
           if (w[q][j].x != w[q][j].x || w[q][j].y != w[q][j].y || w[q][j].z != w[q][j].z || w[q][j].w != w[q][j].w)
@@ -675,7 +588,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
     for (int it0 = 0; it0 < NIT; it0 += 4) {
       float4 v[4], m[4], sv[4], o[4];
       bool ok[4];
-      int64_t coff[4];
+      int64_t coff[4], doff[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = lane + (it0 + j) * 64;
@@ -684,6 +597,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         ok[j] = row < g.M;
         const int64_t rr = ok[j] ? row : g.M - 1;
         coff[j] = rr * g.ldc + col;
+        doff[j] = rr * g.drop_ld + col;
         v[j] = *reinterpret_cast<const float4*>(patch + pr * G::PATCH_LD + c4 * 4);
         if (GRAD) {
           m[j] = mulp ? *reinterpret_cast<const float4*>(mulp + rr * g.ld_mul + col) : float4{1.f, 1.f, 1.f, 1.f};
@@ -692,6 +606,10 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         if (g.accumulate) o[j] = *reinterpret_cast<const float4*>(cptr + coff[j]);
       }
       if (GRAD && savp) {  // sv <- act'(saved), one dispatch per four float4
+        if (g.saved_scale != 1.f) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sv[j].x *= g.saved_scale; sv[j].y *= g.saved_scale; sv[j].z *= g.saved_scale; sv[j].w *= g.saved_scale; }
+        }
         auto dact_chunk = [&](auto act_c) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -716,6 +634,12 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         if (GRAD) {
           w.x *= m[j].x; w.y *= m[j].y; w.z *= m[j].z; w.w *= m[j].w;
           if (savp) { w.x *= sv[j].x; w.y *= sv[j].y; w.z *= sv[j].z; w.w *= sv[j].w; }
+        }
+        if (g.drop_on == 1) {
+          const float4 dm = dropout_mask4(g.drop, (uint64_t)doff[j]);
+          w.x *= dm.x; w.y *= dm.y; w.z *= dm.z; w.w *= dm.w;
+        } else if (g.drop_on == 2) {
+          w.x *= g.drop.scale; w.y *= g.drop.scale; w.z *= g.drop.scale; w.w *= g.drop.scale;
         }
         if (g.accumulate) { w.x += o[j].x; w.y += o[j].y; w.z += o[j].z; w.w += o[j].w; }
         if (ok[j]) *reinterpret_cast<float4*>(cptr + coff[j]) = w;
@@ -823,16 +747,16 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
   if (slice_max) {  // the slices' maxima were taken by sp_tn_slice_max_kernel
     for (int i = threadIdx.x; i < nchunks; i += 1024) mx = fmaxf(mx, slice_max[b * nchunks + i]);
   } else
-  for (int64_t k0 = threadIdx.x; k0 < K; k0 += 8 * 1024) {
-    float va[8], vb[8];
+  for (int64_t k0 = threadIdx.x; k0 < K; k0 += 32 * 1024) {  // 64 loads in flight per thread: K = 30 000 is one round
+    float va[32], vb[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int64_t k = k0 + u * 1024;
       va[u] = k < K ? inv_a[k * ld_a + b] : 0.f;
       vb[u] = (k < K && inv_b) ? inv_b[k * ld_b] : 1.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) mx = fmaxf(mx, va[u] * vb[u]);
+    for (int u = 0; u < 32; ++u) mx = fmaxf(mx, va[u] * vb[u]);
   }
 #pragma unroll
   for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1155,21 +1079,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   store_tile(std::integral_constant<int, 1>{});
 }
 
-// C[(m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col] (+)= ref[blk(m)] * sum_z partial[z][m][n]
-__global__ void __launch_bounds__(256) sp_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
-                                                           const float* __restrict__ ref, int64_t a_col0, int a_sb,
-                                                           float* __restrict__ C, int64_t group_rows, int64_t stride_group,
-                                                           int64_t stride_row, int64_t stride_col, int accumulate, int64_t slab) {
-  const int64_t total = M * N;  // slab >= total: floats per split (the product pads M to a multiple of 128)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * slab + i];
-    const int64_t m = i / N, n = i - m * N;
-    s *= ref[(a_col0 + m) / a_sb];
-    float* c = C + (m / group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col;
-    *c = accumulate ? *c + s : s;
-  }
-}
+__global__ void __launch_bounds__(256) sp_tn_reduce_kernel(AuxTnReduce a) { sp_tn_reduce_body(a, blockIdx.x, gridDim.x); }
 
 static int sp_tn_splits(int64_t M, int64_t N, int64_t K, int bn) {
   const int64_t tiles = (M / SP_BM) * (N / bn);
@@ -1323,8 +1233,10 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
                            int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                            int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                            int act_of_saved, const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
-                           float* d_out_inv_scale, void* stream) {
+                           float* d_out_inv_scale, void* stream, float dropout_rate = 0.f, uint64_t dropout_seed = 0,
+                           float saved_scale = 1.f) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && (d_C || d_out_sp), "tfgnn_sp_gemm_nt: null pointer");
+  TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "tfgnn_sp_gemm_nt: dropout rate must be in [0, 1), got %f", (double)dropout_rate);
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
   const int bn = sp_tile_width(N);
   if (!bn) {
@@ -1351,6 +1263,12 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   g.B = (const uint8_t*)d_B_sp; g.ldb = ldb_bytes; g.b_inv = d_b_inv_scale;
   g.C = d_C; g.ldc = ldc; g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.mul = d_mul; g.ld_mul = ld_mul; g.saved = d_saved; g.ld_saved = ld_saved; g.dact = act_of_saved;
+  g.saved_scale = saved_scale;
+  g.drop_on = dropout_rate > 0.f ? (dropout_seed == ~0ull ? 2 : 1) : 0;
+  if (g.drop_on == 2)
+    TFGNN_REQUIRE(d_saved && act_of_saved == TFGNN_ACT_RELU, "tfgnn_sp_gemm_nt_dropout: the mask-from-saved form needs a relu saved tensor");
+  g.drop_ld = N;
+  g.drop = dropout_key(dropout_seed, dropout_rate);
   g.n_tiles = (unsigned)(N / bn);
   if (d_out_sp) {
     TFGNN_REQUIRE(N == bn && !accumulate && d_out_inv_scale, "tfgnn_sp_gemm_nt_sp: the split result needs N = 128, 256 or 320 (one column "
@@ -1390,6 +1308,17 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
                          act, 0, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale, stream);
 }
 
+int tfgnn_sp_gemm_nt_dropout(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
+                             int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                             int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
+                             int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
+                             void* stream) {
+  return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
+                         act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale,
+                         stream, dropout_rate, dropout_seed, saved_scale);
+}
+
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
   const int bn = sp_tile_width(N);
   if (!bn || M <= 0 || a_scale_block <= 0) return 0;
@@ -1403,7 +1332,8 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
                            const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
                            int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
                            int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
-                           size_t workspace_bytes, void* stream) {
+                           size_t workspace_bytes, void* stream, tfgnn_aux_job* reduce_job = nullptr,
+                           tfgnn_aux_job* factors_job = nullptr) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale, "tfgnn_sp_gemm_tn: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
   const int bn = sp_tile_width(N);
@@ -1432,6 +1362,11 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   hipStream_t s = (hipStream_t)stream;
   _Float16* F = (_Float16*)d_workspace;
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
+  if (phases & 16) {  // the factor pass as a job of a merged launch (operands of up to 128k rows: one-stage factor pass)
+    TFGNN_REQUIRE(factors_job != nullptr && sp_tn_fchunks(K) == SP_TN_FCHUNKS, "tfgnn_sp_gemm_tn: factors job needs K <= 131072");
+    AuxTnFactors fa{d_a_inv_scale, nblk, d_b_inv_scale, 1, K, F, kpad, ref, sp_spread_flag_device(), SP_TN_FCHUNKS};
+    aux_job_set(factors_job, AUX_TN_FACTORS, (unsigned)(nblk * SP_TN_FCHUNKS), fa);
+  }
   if (phases & 1) {
     const int fch = sp_tn_fchunks(K);
     float* slice_max = nullptr;
@@ -1477,11 +1412,19 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
     TFGNN_LAUNCH_CHECK();
   }
 #undef SP_LAUNCH_TN
-  if (!(phases & 4)) return TFGNN_OK;
+  if (!(phases & 12)) return TFGNN_OK;
   const int64_t total = M * N;
-  hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s,
-                     (const float*)g.partial, splits_used, M, N, (const float*)ref, a_first_col, a_scale_block, d_C, group_rows,
-                     stride_group, stride_row, stride_col, accumulate, Mp * N);
+  AuxTnReduce ra{};
+  ra.partial = g.partial; ra.splits = splits_used; ra.M = M; ra.N = N; ra.ref = ref; ra.a_col0 = a_first_col; ra.a_sb = a_scale_block;
+  ra.C = d_C; ra.group_rows = group_rows; ra.stride_group = stride_group; ra.stride_row = stride_row; ra.stride_col = stride_col;
+  ra.accumulate = accumulate; ra.slab = Mp * N;
+  const unsigned rblocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 2048);
+  if (phases & 8) {  // the reduction as a job of a later merged launch (tfgnn_aux_launch) instead of a launch of its own
+    TFGNN_REQUIRE(reduce_job != nullptr, "tfgnn_sp_gemm_tn: reduce_job is NULL");
+    aux_job_set(reduce_job, AUX_TN_REDUCE, rblocks, ra);
+    return TFGNN_OK;
+  }
+  hipLaunchKernelGGL(sp_tn_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ra);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -1505,6 +1448,65 @@ int tfgnn_sp_gemm_tn_phase(int phases, int64_t M, int64_t N, int64_t K, const vo
   return sp_gemm_tn_impl(phases, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block, d_B_sp, ldb_bytes,
                          b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate, d_workspace,
                          workspace_bytes, stream);
+}
+
+/* factors (if asked for) + product now, the split reduction as a job for tfgnn_aux_launch */
+int tfgnn_sp_gemm_tn_deferred(int with_factors, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                              const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                              int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                              int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                              size_t workspace_bytes, tfgnn_aux_job* reduce_job, void* stream) {
+  TFGNN_REQUIRE(reduce_job != nullptr, "tfgnn_sp_gemm_tn_deferred: reduce_job is NULL");
+  return sp_gemm_tn_impl((with_factors ? 1 : 0) | 2 | 8, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols,
+                         a_scale_block, d_B_sp, ldb_bytes, b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row,
+                         stride_col, accumulate, d_workspace, workspace_bytes, stream, reduce_job);
+}
+
+/* nothing is launched: the factor pass and the split reduction of tfgnn_sp_gemm_tn as jobs; the product itself is
+ * tfgnn_sp_gemm_tn_phase(2, ...) with the same arguments, after the factors job and before the reduce job have run */
+int tfgnn_sp_gemm_tn_jobs(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                          const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                          int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                          int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                          size_t workspace_bytes, tfgnn_aux_job* factors_job, tfgnn_aux_job* reduce_job) {
+  TFGNN_REQUIRE(reduce_job != nullptr && factors_job != nullptr, "tfgnn_sp_gemm_tn_jobs: NULL job");
+  if (K > 131072) {
+    set_error("tfgnn_sp_gemm_tn_jobs: operands of more than 131072 rows take the two-stage factor pass (tfgnn_sp_gemm_tn_deferred)");
+    return TFGNN_ERR_UNSUPPORTED;
+  }
+  return sp_gemm_tn_impl(16 | 8, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block, d_B_sp,
+                         ldb_bytes, b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate,
+                         d_workspace, workspace_bytes, nullptr, reduce_job, factors_job);
+}
+
+int tfgnn_sp_split_rows_job(const float* d_src, int64_t ld, int64_t seg_len, int64_t seg_stride, int64_t rows, int64_t cols,
+                            int scale_block, void* d_sp, int64_t ld_sp_bytes, float* d_inv_scale,
+                            const float* d_fixed_inv_scale, tfgnn_aux_job* job) {
+  TFGNN_REQUIRE(d_src && d_sp && job, "tfgnn_sp_split_rows_job: null pointer");
+  TFGNN_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0, "tfgnn_sp_split_rows_job: cols must be a positive multiple of 16");
+  if (scale_block <= 0) scale_block = (int)cols;
+  if (seg_len <= 0) { seg_len = cols; seg_stride = 0; }
+  TFGNN_REQUIRE(scale_block % 16 == 0 && cols % scale_block == 0, "tfgnn_sp_split_rows_job: scale_block must divide cols and be a multiple of 16");
+  TFGNN_REQUIRE(seg_len % 4 == 0 && cols % seg_len == 0 && ld % 4 == 0 && seg_stride % 4 == 0 && (uintptr_t)d_src % 16 == 0,
+                "tfgnn_sp_split_rows_job: source must be 16-byte aligned with segment length / strides multiples of 4");
+  TFGNN_REQUIRE(ld_sp_bytes >= cols * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_rows_job: bad SP16 leading dimension / alignment");
+  AuxSplitRows a{d_src, ld, seg_len, seg_stride, rows, cols, scale_block, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale, d_fixed_inv_scale};
+  const int64_t items = rows * (cols / scale_block);
+  TFGNN_REQUIRE(ceil_div(items, 4) < (1ll << 31), "tfgnn_sp_split_rows_job: too many rows");
+  aux_job_set(job, AUX_SPLIT_ROWS, (unsigned)ceil_div(items, 4), a);
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_split_cols_job(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                            float* d_inv_scale, tfgnn_aux_job* job) {
+  TFGNN_REQUIRE(d_src && d_sp && job, "tfgnn_sp_split_cols_job: null pointer");
+  TFGNN_REQUIRE(K > 0 && N > 0 && K % 16 == 0 && N % 4 == 0 && ld % 4 == 0 && (uintptr_t)d_src % 16 == 0,
+                "tfgnn_sp_split_cols_job: K must be a multiple of 16, N and ld multiples of 4");
+  TFGNN_REQUIRE(ld_sp_bytes >= K * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_cols_job: bad SP16 leading dimension / alignment");
+  AuxSplitCols a{d_src, ld, K, N, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale, (unsigned)ceil_div(N, 16),
+                 (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, K / 128))};
+  aux_job_set(job, AUX_SPLIT_COLS, a.ncx * a.ncy, a);
+  return TFGNN_OK;
 }
 
 int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream) {

@@ -45,6 +45,17 @@ extern "C" int tfgnn_launch_counts(int64_t* out_counts, int n) {
   return TFGNN_OK;
 }
 
+namespace tfgnn {
+int graph_require_parts(const tfgnn_graph* g, unsigned need, const char* who) {
+  const unsigned missing = need & ~g->parts;
+  if (!missing) return TFGNN_OK;
+  set_error("%s: the graph handle lacks part%s%s%s%s (requested 0x%x at creation): tfgnn_graph_ensure(graph, parts, stream) builds it",
+            who, (missing & TFGNN_GRAPH_PART_PLAN_TYPED) ? " PLAN_TYPED" : "", (missing & TFGNN_GRAPH_PART_PLAN_NODE) ? " PLAN_NODE" : "",
+            (missing & TFGNN_GRAPH_PART_COMPACT) ? " COMPACT" : "", (missing & TFGNN_GRAPH_PART_EDGE_MAPS) ? " EDGE_MAPS" : "", g->parts);
+  return TFGNN_ERR_INVALID_ARGUMENT;
+}
+}  // namespace tfgnn
+
 extern "C" const char* tfgnn_last_error(void) { return tfgnn::g_err; }
 extern "C" const char* tfgnn_version(void) { return "tfgnn 0.1 gfx950"; }
 
@@ -134,10 +145,14 @@ static int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
+constexpr int EL_INLINE = 8;  // edge-list tables of up to this many types travel in the kernel arguments (no copy commands)
 struct EdgeLists {
-  const int32_t* const* adj;  // device array of L device pointers
+  const int32_t* const* adj;  // device array of L device pointers (L > EL_INLINE)
   const int64_t* edge_off;    // device [L+1]
+  const int32_t* adj_v[EL_INLINE];
+  int64_t off_v[EL_INLINE + 1];
   int L;
+  int inline_tables;
 };
 
 __device__ __forceinline__ int find_type(const int64_t* __restrict__ edge_off, int L, int64_t g) {
@@ -149,71 +164,136 @@ __device__ __forceinline__ int find_type(const int64_t* __restrict__ edge_off, i
   return lo;
 }
 
-// ---- bucketing = one LSD radix sort per CSR (no global atomics, deterministic) -------------------
+// (source, target, type) of edge g of the concatenated adjacency lists
+__device__ __forceinline__ void load_edge(const EdgeLists& el, int64_t g, int64_t& src, int64_t& dst, int& l) {
+  const int32_t* a;
+  if (el.inline_tables) {
+    l = 0;
+#pragma unroll
+    for (int i = 1; i < EL_INLINE; ++i) l += (i < el.L && el.off_v[i] <= g) ? 1 : 0;
+    a = el.adj_v[l] + 2 * (g - el.off_v[l]);
+  } else {
+    l = find_type(el.edge_off, el.L, g);
+    a = el.adj[l] + 2 * (g - el.edge_off[l]);
+  }
+  src = a[0];
+  dst = a[1];
+}
+
+// ---- bucketing = one LSD radix sort for BOTH CSRs (no global atomics, deterministic) -----------------
 // composite key of an edge: (row << sec_bits) | sec, row = node * L + type (the bucket), sec = the
 // node at the other end; payload = position of the edge in the concatenated adjacency lists.  Sorting
 // by the composite puts edges in bucket order with ascending columns inside a bucket (canonical).
 // Global memory atomics cost ~10 ns each on this chip (they execute at the memory side: the XCD L2s
 // are not coherent), which made a counting sort with 4 atomics per edge take ~1 ms per batch.
-constexpr int RS_THREADS = 256;
+//
+// Round 4: the by-target and the by-source sort run in the SAME launches (blockIdx.y = side); keys are 32 bits wide when
+// row and column bits fit (cfg-2: 17 + 15), else 64; there is no scan launch - a scatter workgroup takes the column prefix
+// of its tile and the digit bases from the [digit][tile] table itself (256 threads x tiles/4 int4 loads, L2 resident); a
+// wave owns 1024 CONSECUTIVE keys of its tile and its own running digit bases, so the scatter rounds need no workgroup
+// barrier (two per tile in all, where the waves used to take turns: four per round).  Per digit: one histogram launch and
+// one scatter launch for both sides (the first histogram comes out of the key-building kernel): 8 launches for 32-bit keys
+// where the two sorts took 40.
+constexpr int RS_THREADS = 512;
 constexpr int RS_ROUNDS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // 4096 keys per workgroup
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_WAVE_KEYS = 64 * RS_ROUNDS;     // consecutive keys per wave
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // 8192 keys per workgroup
 constexpr int RS_RADIX = 256;
 
-__global__ void fill_keys_kernel(EdgeLists el, int64_t E, int64_t V, int sec_bits, uint64_t* __restrict__ comp_d,
-                                 uint64_t* __restrict__ comp_s, uint32_t* __restrict__ pay,
-                                 int32_t* __restrict__ err_flag) {
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < E; g += (int64_t)gridDim.x * blockDim.x) {
-    const int l = find_type(el.edge_off, el.L, g);
-    const int32_t* a = el.adj[l] + 2 * (g - el.edge_off[l]);
-    int64_t src = a[0], dst = a[1];
-    if (src < 0 || src >= V || dst < 0 || dst >= V) {
-      atomicOr(err_flag, 1);  // rare path; the build is rejected in tfgnn_graph_wait
-      src = 0;
-      dst = 0;
+// keys of both sides + the digit-0 histogram of every tile: hist[(side * 256 + digit) * nblk_ld + tile]
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS)
+fill_keys_kernel(EdgeLists el, int64_t E, int64_t V, int sec_bits, KeyT* __restrict__ comp_d, KeyT* __restrict__ comp_s,
+                 int32_t* __restrict__ hist, int nblk_ld, int32_t* __restrict__ err_flag) {
+  __shared__ int32_t h[2][RS_RADIX];
+  const int tid = threadIdx.x;
+  (&h[0][0])[tid] = 0;  // RS_THREADS == 2 * RS_RADIX
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t g = base + r * RS_THREADS + tid;
+    if (g < E) {
+      int64_t src, dst;
+      int l;
+      load_edge(el, g, src, dst, l);
+      if (src < 0 || src >= V || dst < 0 || dst >= V) {
+        atomicOr(err_flag, 1);  // rare path; the build is rejected in tfgnn_graph_wait
+        src = 0;
+        dst = 0;
+      }
+      const KeyT kd = (KeyT)(((uint64_t)(dst * el.L + l) << sec_bits) | (uint64_t)src);
+      const KeyT ks = (KeyT)(((uint64_t)(src * el.L + l) << sec_bits) | (uint64_t)dst);
+      comp_d[g] = kd;
+      comp_s[g] = ks;
+      atomicAdd(&h[0][(int)(kd & (RS_RADIX - 1))], 1);  // LDS atomics
+      atomicAdd(&h[1][(int)(ks & (RS_RADIX - 1))], 1);
     }
-    comp_d[g] = ((uint64_t)(dst * el.L + l) << sec_bits) | (uint64_t)src;
-    comp_s[g] = ((uint64_t)(src * el.L + l) << sec_bits) | (uint64_t)dst;
-    pay[g] = (uint32_t)g;
   }
+  __syncthreads();
+  hist[(int64_t)tid * nblk_ld + blockIdx.x] = (&h[0][0])[tid];
 }
 
-// hist[digit * nblocks + block] = number of keys of this workgroup's tile with that digit
+// hist[(side * 256 + digit) * nblk_ld + tile] = number of keys of the tile with that digit; grid (tiles, 2 sides)
+template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
-rs_hist_kernel(const uint64_t* __restrict__ comp, int64_t n, int shift, int32_t* __restrict__ hist, int nblocks) {
+rs_hist_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s, int64_t n, int shift,
+               int32_t* __restrict__ hist, int nblk_ld) {
   __shared__ int32_t h[RS_RADIX];
   const int tid = threadIdx.x;
-  h[tid] = 0;
+  const int side = blockIdx.y;
+  const KeyT* __restrict__ comp = side ? comp_s : comp_d;
+  if (tid < RS_RADIX) h[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const int64_t idx = base + r * RS_THREADS + tid;
-    if (idx < n) atomicAdd(&h[(int)((comp[idx] >> shift) & (RS_RADIX - 1))], 1);  // LDS atomic
+    if (idx < n) atomicAdd(&h[(int)((comp[idx] >> shift) & (RS_RADIX - 1))], 1);
   }
   __syncthreads();
-  hist[(int64_t)tid * nblocks + blockIdx.x] = h[tid];
+  if (tid < RS_RADIX) hist[(int64_t)(side * RS_RADIX + tid) * nblk_ld + blockIdx.x] = h[tid];
 }
 
-// stable scatter: keys keep their input order inside a digit (tile order, then round, wave, lane)
+// stable scatter of one digit, both sides: keys keep their input order inside a digit (tile, then wave, round, lane =
+// index order).  pay_in == NULL: the payload is the key's index (first pass).
+template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
-rs_scatter_kernel(const uint64_t* __restrict__ comp_in, const uint32_t* __restrict__ pay_in, int64_t n, int shift,
-                  const int32_t* __restrict__ offs, int nblocks, uint64_t* __restrict__ comp_out,
-                  uint32_t* __restrict__ pay_out) {
-  __shared__ int32_t base[RS_RADIX];
+rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, const uint32_t* __restrict__ pin_d,
+                  const uint32_t* __restrict__ pin_s, int64_t n, int shift, const int32_t* __restrict__ hist, int nblk,
+                  int nblk_ld, KeyT* __restrict__ out_d, KeyT* __restrict__ out_s, uint32_t* __restrict__ pout_d,
+                  uint32_t* __restrict__ pout_s) {
+  __shared__ int32_t wbase[RS_WAVES][RS_RADIX];  // per wave: digit counts, then running output positions
+  __shared__ int32_t wtot[RS_RADIX / 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  base[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
-  __syncthreads();
-  const int64_t tile = (int64_t)blockIdx.x * RS_TILE;
+  const int side = blockIdx.y;
+  const KeyT* __restrict__ kin = side ? in_s : in_d;
+  const uint32_t* __restrict__ pin = side ? pin_s : pin_d;
+  KeyT* __restrict__ kout = side ? out_s : out_d;
+  uint32_t* __restrict__ pout = side ? pout_s : pout_d;
+  volatile int32_t* mine_base = &wbase[wave][0];
+#pragma unroll
+  for (int i = 0; i < RS_RADIX / 64; ++i) mine_base[lane + 64 * i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // 1. keys into registers; digit counts of this wave (one leader lane per digit and round adds the group size)
+  const int64_t wave0 = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_KEYS;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  KeyT key[RS_ROUNDS];
+  uint32_t pl[RS_ROUNDS];
+  int32_t info[RS_ROUNDS];  // rank | group size << 8 | valid << 16
+#pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
-    const int64_t idx = tile + r * RS_THREADS + tid;
+    const int64_t idx = wave0 + r * 64 + lane;
     const bool valid = idx < n;
-    const uint64_t c = valid ? comp_in[idx] : 0;
-    const uint32_t pl = valid ? pay_in[idx] : 0;
-    const int d = (int)((c >> shift) & (RS_RADIX - 1));
-    // lanes of this wave holding the same digit
+    key[r] = valid ? kin[idx] : (KeyT)0;
+    pl[r] = valid ? (pin ? pin[idx] : (uint32_t)idx) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const bool valid = wave0 + r * 64 + lane < n;
+    const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -222,31 +302,84 @@ rs_scatter_kernel(const uint64_t* __restrict__ comp_in, const uint32_t* __restri
     }
     const int rank = __popcll(peers & lt_mask);
     const int cnt = __popcll(peers);
-    int mybase = 0;
-    for (int w = 0; w < RS_THREADS / 64; ++w) {  // waves take their turn: keeps the order stable
-      if (wave == w && valid && rank == 0) {
-        mybase = base[d];
-        base[d] = mybase + cnt;
+    info[r] = valid ? (rank | (cnt << 8) | (1 << 16)) : 0;
+    if (valid && rank == 0) mine_base[d] = mine_base[d] + cnt;  // leaders of one round hold distinct digits
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // 2. thread d: keys with digit d in the tiles before this one + the digit's global base -> the waves' first positions
+  int32_t tot = 0, before = 0, incl = 0;
+  if (tid < RS_RADIX) {
+    const int32_t* __restrict__ row = hist + (int64_t)(side * RS_RADIX + tid) * nblk_ld;
+    const int me = (int)blockIdx.x;
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
+      int4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = b0 + 4 * u < nblk ? *reinterpret_cast<const int4*>(row + b0 + 4 * u) : make_int4(0, 0, 0, 0);  // nblk_ld % 4 == 0
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 4 * u;
+        const int e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (b + k < nblk) {
+            tot += e[k];
+            if (b + k < me) before += e[k];
+          }
       }
-      __syncthreads();
     }
-    const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
-    const int pos = __shfl(mybase, leader, 64) + rank;
+    // exclusive scan of tot over the 256 digits: inside the wave, then over the four waves
+    incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < RS_RADIX) {
+    int32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    int32_t running = off + incl - tot + before;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) {
+      const int32_t c = wbase[w][tid];
+      wbase[w][tid] = running;
+      running += c;
+    }
+  }
+  __syncthreads();
+  // 3. scatter: every wave on its own (LDS accesses of one wave execute in program order)
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const bool valid = (info[r] >> 16) & 1;
+    const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
+    const int rank = info[r] & 255, cnt = (info[r] >> 8) & 255;
+    const int32_t b = valid ? mine_base[d] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) mine_base[d] = b + cnt;
+    __builtin_amdgcn_wave_barrier();
     if (valid) {
-      comp_out[pos] = c;
-      pay_out[pos] = pl;
+      kout[b + rank] = key[r];
+      pout[b + rank] = pl[r];
     }
   }
 }
 
-// rowptr[r] = first sorted position whose bucket is >= r
-__global__ void rowptr_from_sorted_kernel(const uint64_t* __restrict__ comp, int64_t E, int sec_bits, int64_t R,
-                                          int32_t* __restrict__ rowptr) {
+// rowptr[r] = first sorted position whose bucket is >= r; grid.y = side
+template <typename KeyT>
+__global__ void rowptr_from_sorted_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s, int64_t E,
+                                          int sec_bits, int64_t R, int32_t* __restrict__ rowptr_d,
+                                          int32_t* __restrict__ rowptr_s) {
+  const KeyT* __restrict__ comp = blockIdx.y ? comp_s : comp_d;
+  int32_t* __restrict__ rowptr = blockIdx.y ? rowptr_s : rowptr_d;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R; r += (int64_t)gridDim.x * blockDim.x) {
     int64_t lo = 0, hi = E;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
-      if ((int64_t)(comp[mid] >> sec_bits) < r) lo = mid + 1; else hi = mid;
+      if ((int64_t)((uint64_t)comp[mid] >> sec_bits) < r) lo = mid + 1; else hi = mid;
     }
     rowptr[r] = (int32_t)lo;
   }
@@ -255,7 +388,21 @@ __global__ void rowptr_from_sorted_kernel(const uint64_t* __restrict__ comp, int
 // work items for rows longer than LONG_ROW_THRESHOLD (see graph.hpp / spmm.hip); counters = {items,
 // multi-item rows, partial slots}.  The order in which rows claim their slots is irrelevant: a row's
 // items are contiguous and are always combined in chunk order.
-__global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, int long_threshold, int chunk_edges,
+// One job per view; a launch takes the two views of a pair (typed: by target / by source; node: likewise) side by side.
+struct PlanJob {
+  const int32_t* rowptr;
+  int64_t R;
+  int thr, chunk;
+  int32_t* counters;  // {items, multi-item rows, partial slots, short rows}
+  int32_t *item_row, *item_chunk, *item_slot, *multi_row, *multi_base, *multi_n;
+  int32_t *bin_count, *bin_cursor, *short_rows;
+  int want_items;  // E > 0
+};
+struct PlanJobs {
+  PlanJob j[2];
+};
+
+__device__ __forceinline__ void plan_rows_body(const int32_t* __restrict__ rowptr, int64_t R, int long_threshold, int chunk_edges,
                                  int32_t* __restrict__ counters,
                                  int32_t* __restrict__ item_row, int32_t* __restrict__ item_chunk,
                                  int32_t* __restrict__ item_slot, int32_t* __restrict__ multi_row,
@@ -282,11 +429,9 @@ __global__ void plan_rows_kernel(const int32_t* __restrict__ rowptr, int64_t R, 
 }
 
 // ---- short rows ordered by length (CsrPlan::short_rows) ------------------------------------------
-__global__ void __launch_bounds__(256)
-short_hist_kernel(const int32_t* __restrict__ rowptr, int64_t R, int thr, int32_t* __restrict__ bin_count,
-                  int32_t* __restrict__ num_short) {
-  __shared__ int h[SHORT_BINS];
-  __shared__ int n_short;
+__device__ __forceinline__ void
+short_hist_body(const int32_t* __restrict__ rowptr, int64_t R, int thr, int32_t* __restrict__ bin_count,
+                int32_t* __restrict__ num_short, int* h, int& n_short) {
   for (int i = threadIdx.x; i <= thr; i += 256) h[i] = 0;
   if (threadIdx.x == 0) n_short = 0;
   __syncthreads();
@@ -305,13 +450,33 @@ short_hist_kernel(const int32_t* __restrict__ rowptr, int64_t R, int thr, int32_
   if (threadIdx.x == 0 && n_short) atomicAdd(num_short, n_short);
 }
 
+// blockIdx.y = view of the pair + 2 * job: job 0 = length histogram of the short rows, job 1 = items of the long rows
+__global__ void __launch_bounds__(256) plan_hist_kernel(PlanJobs jobs) {
+  __shared__ int h[SHORT_BINS];
+  __shared__ int n_short;
+  const PlanJob& j = jobs.j[blockIdx.y & 1];
+  if (j.R <= 0) return;
+  if ((blockIdx.y >> 1) == 0) {
+    short_hist_body(j.rowptr, j.R, j.thr, j.bin_count, j.counters + 3, h, n_short);
+  } else if (j.want_items) {
+    plan_rows_body(j.rowptr, j.R, j.thr, j.chunk, j.counters, j.item_row, j.item_chunk, j.item_slot, j.multi_row, j.multi_base,
+                   j.multi_n);
+  }
+}
+
 // short_rows = rows with len <= thr in order of descending length (the order inside one length is arbitrary and
 // has no effect on any result: every row is reduced on its own)
 constexpr int SHORT_TILE_ROWS = 8;  // rows per thread and tile: one global atomic per (tile, length) pair
-__global__ void __launch_bounds__(256)
-short_scatter_kernel(const int32_t* __restrict__ rowptr, int64_t R, int thr, const int32_t* __restrict__ bin_count,
-                     int32_t* __restrict__ bin_cursor, int32_t* __restrict__ short_rows) {
+__global__ void __launch_bounds__(256) short_scatter_kernel(PlanJobs jobs) {
   __shared__ int h[SHORT_BINS], base[SHORT_BINS], start[SHORT_BINS];
+  const PlanJob& j = jobs.j[blockIdx.y];
+  const int32_t* __restrict__ rowptr = j.rowptr;
+  const int64_t R = j.R;
+  const int thr = j.thr;
+  const int32_t* __restrict__ bin_count = j.bin_count;
+  int32_t* __restrict__ bin_cursor = j.bin_cursor;
+  int32_t* __restrict__ short_rows = j.short_rows;
+  if (R <= 0) return;
   if (threadIdx.x == 0) {
     int acc = 0;
     for (int i = thr; i >= 0; --i) {
@@ -396,32 +561,43 @@ __global__ void nz_cols_kernel(const int32_t* __restrict__ cpos, const int32_t* 
   }
 }
 
-__global__ void invdeg_rows_kernel(const int32_t* __restrict__ rowptr_d, int64_t R, int L,
-                                   float* __restrict__ invdeg_d, int32_t* __restrict__ nodeptr_d,
-                                   const int32_t* __restrict__ rowptr_s, int32_t* __restrict__ nodeptr_s) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R;
-       r += (int64_t)gridDim.x * blockDim.x) {
-    if (r < R) {
-      int32_t len = rowptr_d[r + 1] - rowptr_d[r];
-      // gnn_edge_mlp.py:102-106: 1.0 / (num_incoming + SMALL_NUMBER), evaluated in fp32 like TF
-      invdeg_d[r] = len > 0 ? 1.0f / ((float)len + kSmallNumber) : 0.f;
+// blockIdx.y = 0 / 1: unpack the sorted keys of the by-target / by-source side; blockIdx.y = 2: per-row arrays
+// (1 / in-degree, node pointers).  The degree that normalises an edge is always the in-degree of its TARGET for its type,
+// i.e. the length of by-target row (target, type) - read from rowptr_d directly, so the three jobs share one launch.
+template <typename KeyT>
+__global__ void unpack_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s, const uint32_t* __restrict__ pay_d,
+                              const uint32_t* __restrict__ pay_s, int sec_bits, int64_t E, int L, int64_t R,
+                              const int32_t* __restrict__ rowptr_d, const int32_t* __restrict__ rowptr_s,
+                              int32_t* __restrict__ col_d, int32_t* __restrict__ eid_d, int32_t* __restrict__ coll_d,
+                              float* __restrict__ invdeg_edge_d, int32_t* __restrict__ eid_to_pos, int32_t* __restrict__ row_node,
+                              int32_t* __restrict__ col_s, int32_t* __restrict__ eid_s, int32_t* __restrict__ coll_s,
+                              float* __restrict__ invdeg_edge_s, float* __restrict__ invdeg_d, int32_t* __restrict__ nodeptr_d,
+                              int32_t* __restrict__ nodeptr_s, int first_job) {
+  const int job = (int)blockIdx.y + first_job;
+  if (job == 2) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R; r += (int64_t)gridDim.x * blockDim.x) {
+      if (r < R) {
+        const int32_t len = rowptr_d[r + 1] - rowptr_d[r];
+        // gnn_edge_mlp.py:102-106: 1.0 / (num_incoming + SMALL_NUMBER), evaluated in fp32 like TF
+        invdeg_d[r] = len > 0 ? 1.0f / ((float)len + kSmallNumber) : 0.f;
+      }
+      if (r % L == 0) {
+        nodeptr_d[r / L] = rowptr_d[r];
+        nodeptr_s[r / L] = rowptr_s[r];
+      }
     }
-    if (r % L == 0) {
-      nodeptr_d[r / L] = rowptr_d[r];
-      nodeptr_s[r / L] = rowptr_s[r];
-    }
+    return;
   }
-}
-
-__global__ void unpack_kernel(const uint64_t* __restrict__ comp, const uint32_t* __restrict__ pay, int sec_bits,
-                              int64_t E, int L, int32_t* __restrict__ col, int32_t* __restrict__ eid,
-                              int32_t* __restrict__ coll, const float* __restrict__ invdeg_d,
-                              float* __restrict__ invdeg_edge, int by_src,
-                              int32_t* __restrict__ eid_to_pos, int32_t* __restrict__ row_node) {
+  const int by_src = job;
+  const KeyT* __restrict__ comp = by_src ? comp_s : comp_d;
+  const uint32_t* __restrict__ pay = by_src ? pay_s : pay_d;
+  int32_t* __restrict__ col = by_src ? col_s : col_d;
+  int32_t* __restrict__ eid = by_src ? eid_s : eid_d;
+  int32_t* __restrict__ coll = by_src ? coll_s : coll_d;
+  float* __restrict__ invdeg_edge = by_src ? invdeg_edge_s : invdeg_edge_d;
   const uint64_t sec_mask = ((uint64_t)1 << sec_bits) - 1;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E;
-       p += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t c = comp[p];
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t c = (uint64_t)comp[p];
     const int32_t other = (int32_t)(c & sec_mask);
     const int32_t id = (int32_t)pay[p];
     const int32_t row = (int32_t)(c >> sec_bits);
@@ -430,10 +606,13 @@ __global__ void unpack_kernel(const uint64_t* __restrict__ comp, const uint32_t*
     eid[p] = id;
     const int64_t cl = (int64_t)other * L + l;
     coll[p] = (int32_t)cl;
-    if (row_node) row_node[p] = row / L;
-    // the degree that normalises an edge is always the in-degree of its TARGET for its type
-    invdeg_edge[p] = by_src ? invdeg_d[cl] : invdeg_d[row];
-    if (eid_to_pos) eid_to_pos[id] = (int32_t)p;
+    const int64_t trow = by_src ? cl : (int64_t)row;  // the by-target bucket of this edge
+    const int32_t len = rowptr_d[trow + 1] - rowptr_d[trow];
+    invdeg_edge[p] = len > 0 ? 1.0f / ((float)len + kSmallNumber) : 0.f;
+    if (!by_src) {
+      row_node[p] = row / L;
+      eid_to_pos[id] = (int32_t)p;
+    }
   }
 }
 
@@ -550,14 +729,160 @@ static void graph_release_all(tfgnn_graph* g, hipStream_t last_use = nullptr, bo
   delete g;
 }
 
-extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
-                                        const int32_t* const* d_adjacency, const int64_t* num_edges,
-                                        void* stream, tfgnn_graph** out_graph) {
+namespace {
+using namespace tfgnn;
+
+constexpr unsigned kPartsAll = TFGNN_GRAPH_PART_PLAN_TYPED | TFGNN_GRAPH_PART_PLAN_NODE | TFGNN_GRAPH_PART_COMPACT |
+                               TFGNN_GRAPH_PART_EDGE_MAPS;
+
+// long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
+// views 91 us at (48, 512) vs 104 us at (16, 192) (134 us in natural row order at (16, 128)); the node views -
+// all edge types of a node in one row - 121 us at (32, 512) vs 128 us at (64, 512) (138 us in natural order).  TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override the typed views, TFGNN_LONG_ROW_NODE /
+// TFGNN_ITEM_CHUNK_NODE the node views, for probing.
+void view_plan_parameters(int view_long[4], int view_chunk[4]) {
+  static const int env_long = [] { const char* e = getenv("TFGNN_LONG_ROW"); return e ? atoi(e) : 0; }();
+  static const int env_chunk = [] { const char* e = getenv("TFGNN_ITEM_CHUNK"); return e ? atoi(e) : 0; }();
+  static const int env_long_n = [] { const char* e = getenv("TFGNN_LONG_ROW_NODE"); return e ? atoi(e) : 0; }();
+  static const int env_chunk_n = [] { const char* e = getenv("TFGNN_ITEM_CHUNK_NODE"); return e ? atoi(e) : 0; }();
+  const int dl[4] = {LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD, LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD};
+  const int dc[4] = {ITEM_CHUNK_TYPED, ITEM_CHUNK, ITEM_CHUNK_TYPED, ITEM_CHUNK};
+  for (int v = 0; v < 4; ++v) {
+    const bool node_view = v & 1;
+    view_long[v] = dl[v];
+    view_chunk[v] = dc[v];
+    if ((node_view ? env_long_n : env_long) > 0) view_long[v] = node_view ? env_long_n : env_long;
+    if ((node_view ? env_chunk_n : env_chunk) > 0) view_chunk[v] = node_view ? env_chunk_n : env_chunk;
+    if (view_long[v] > SHORT_BINS - 1) view_long[v] = SHORT_BINS - 1;
+    if (view_chunk[v] < view_long[v]) view_chunk[v] = view_long[v];
+  }
+}
+
+unsigned blocks_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 8192)); }
+
+// the plans of one pair of views (node_views = 0: views 0 and 2, 1: views 1 and 3): two launches.
+// counters: the 64-int counter block (zeroed), bins: [4 views][2][SHORT_BINS] (zeroed)
+int build_plans(tfgnn_graph* g, int node_views, int32_t* counters, int32_t* bins, hipStream_t s) {
+  PlanJobs jobs{};
+  int64_t max_rows = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int v = 2 * k + node_views;
+    CsrPlan& pl = g->views[v].plan;
+    PlanJob& j = jobs.j[k];
+    j.rowptr = g->views[v].rowptr;
+    j.R = g->views[v].num_rows;
+    j.thr = pl.long_threshold;
+    j.chunk = pl.item_chunk_edges;
+    j.counters = counters + 16 + 4 * v;
+    j.item_row = pl.item_row; j.item_chunk = pl.item_chunk; j.item_slot = pl.item_slot;
+    j.multi_row = pl.multi_row; j.multi_base = pl.multi_base; j.multi_n = pl.multi_n;
+    j.bin_count = bins + (size_t)v * 2 * SHORT_BINS;
+    j.bin_cursor = j.bin_count + SHORT_BINS;
+    j.short_rows = pl.short_rows;
+    j.want_items = g->E > 0;
+    max_rows = std::max(max_rows, j.R);
+  }
+  if (max_rows <= 0) return TFGNN_OK;
+  hipLaunchKernelGGL(plan_hist_kernel, dim3(blocks_for(max_rows), 4), dim3(256), 0, s, jobs);
+  TFGNN_LAUNCH_CHECK();
+  const unsigned scat_blocks = (unsigned)std::min<int64_t>(ceil_div(max_rows, 256 * SHORT_TILE_ROWS), 4096);
+  hipLaunchKernelGGL(short_scatter_kernel, dim3(scat_blocks, 2), dim3(256), 0, s, jobs);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+size_t compact_scratch_bytes(int64_t R, int64_t V) {
+  return (size_t)(R + 2) * 4 + 256 + (scan_scratch_elems(R + 1) + scan_scratch_elems(V + 1)) * 4 + 64;
+}
+
+// non-empty buckets in type-major order, for both bucketings; nz_off -> the pinned staging block
+int build_compact(tfgnn_graph* g, char* scratch, hipStream_t s) {
+  const int L = g->L;
+  const int64_t V = g->V, R = g->R;
+  int32_t* flags = (int32_t*)scratch;
+  int32_t* scan_tmp = (int32_t*)(scratch + (((size_t)(R + 2) * 4 + 255) & ~(size_t)255));
+  for (int side = 0; side < 2; ++side) {
+    CompactBuckets& cb = g->compact[side];
+    const int32_t* rp = side == 0 ? g->rowptr_d : g->rowptr_s;
+    if (L > 0) {
+      hipLaunchKernelGGL(nz_flags_kernel, dim3(blocks_for(R + 1)), dim3(256), 0, s, rp, V, L, flags, cb.nodeptr_nz);
+      int rc = exclusive_scan_i32(flags, flags, R + 1, scan_tmp, s);
+      if (rc) return rc;
+      rc = exclusive_scan_i32(cb.nodeptr_nz, cb.nodeptr_nz, V + 1, scan_tmp, s);
+      if (rc) return rc;
+      if (R > 0) {
+        hipLaunchKernelGGL(nz_fill_kernel, dim3(blocks_for(R)), dim3(256), 0, s, rp, flags, V, L, cb.cpos, cb.nzrow,
+                           cb.nz_node, cb.nz_off);
+        hipLaunchKernelGGL(nz_cols_kernel, dim3(blocks_for(V)), dim3(256), 0, s, cb.cpos, cb.nodeptr_nz, V, L, cb.col_nz);
+      } else {
+        TFGNN_HIP_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
+      }
+    } else {
+      TFGNN_HIP_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
+      TFGNN_HIP_CHECK(hipMemsetAsync(cb.nodeptr_nz, 0, (V + 1) * 4, s));
+    }
+    TFGNN_HIP_CHECK(hipMemcpyAsync((char*)g->pinned + 256 + (size_t)(L + 1) * 16 + (size_t)side * (L + 1) * 4, cb.nz_off,
+                                   (size_t)(L + 1) * 4, hipMemcpyDeviceToHost, s));
+  }
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+int build_edge_maps(tfgnn_graph* g, hipStream_t s) {
+  if (g->E > 0) {
+    hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(g->E)), dim3(256), 0, s, g->eid_s, g->eid2pos, g->E, g->src2dst, g->dst2src);
+    TFGNN_LAUNCH_CHECK();
+  }
+  return TFGNN_OK;
+}
+
+// the sort of both sides + everything derived per edge and per row; KeyT = uint32_t when row and column bits fit
+template <typename KeyT>
+int build_core(tfgnn_graph* g, const EdgeLists& el, int sec_bits, int total_bits, char* keys, char* pays, int32_t* hist, int nblk,
+               int nblk_ld, int32_t* counters, hipStream_t s) {
+  const int64_t E = g->E, R = g->R, V = g->V;
+  const int L = g->L;
+  KeyT* kbuf[2][2];  // [side][ping-pong]
+  uint32_t* pbuf[2][2];
+  for (int side = 0; side < 2; ++side)
+    for (int b = 0; b < 2; ++b) {
+      kbuf[side][b] = (KeyT*)(keys + (size_t)(side * 2 + b) * (size_t)E * 8);
+      pbuf[side][b] = (uint32_t*)(pays + (size_t)(side * 2 + b) * (size_t)E * 4);
+    }
+  hipLaunchKernelGGL((fill_keys_kernel<KeyT>), dim3(nblk), dim3(RS_THREADS), 0, s, el, E, V, sec_bits, kbuf[0][0], kbuf[1][0],
+                     hist, nblk_ld, counters + 2);
+  int cur = 0;
+  bool first = true;
+  for (int shift = 0; shift < total_bits; shift += 8) {
+    if (!first)
+      hipLaunchKernelGGL((rs_hist_kernel<KeyT>), dim3(nblk, 2), dim3(RS_THREADS), 0, s, (const KeyT*)kbuf[0][cur],
+                         (const KeyT*)kbuf[1][cur], E, shift, hist, nblk_ld);
+    hipLaunchKernelGGL((rs_scatter_kernel<KeyT>), dim3(nblk, 2), dim3(RS_THREADS), 0, s, (const KeyT*)kbuf[0][cur],
+                       (const KeyT*)kbuf[1][cur], first ? (const uint32_t*)nullptr : (const uint32_t*)pbuf[0][cur],
+                       first ? (const uint32_t*)nullptr : (const uint32_t*)pbuf[1][cur], E, shift, (const int32_t*)hist, nblk, nblk_ld,
+                       kbuf[0][cur ^ 1], kbuf[1][cur ^ 1], pbuf[0][cur ^ 1], pbuf[1][cur ^ 1]);
+    cur ^= 1;
+    first = false;
+  }
+  hipLaunchKernelGGL((rowptr_from_sorted_kernel<KeyT>), dim3(blocks_for(R + 1), 2), dim3(256), 0, s, (const KeyT*)kbuf[0][cur],
+                     (const KeyT*)kbuf[1][cur], E, sec_bits, R, g->rowptr_d, g->rowptr_s);
+  hipLaunchKernelGGL((unpack_kernel<KeyT>), dim3(blocks_for(std::max(E, R + 1)), 3), dim3(256), 0, s, (const KeyT*)kbuf[0][cur],
+                     (const KeyT*)kbuf[1][cur], (const uint32_t*)pbuf[0][cur], (const uint32_t*)pbuf[1][cur], sec_bits, E, L, R,
+                     (const int32_t*)g->rowptr_d, (const int32_t*)g->rowptr_s, g->col_d, g->eid_d, g->coll_d, g->invdeg_edge_d,
+                     g->eid2pos, g->tgt_d, g->col_s, g->eid_s, g->coll_s, g->invdeg_edge_s, g->invdeg_d, g->nodeptr_d,
+                     g->nodeptr_s, 0);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+}  // namespace
+
+static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                             const int64_t* num_edges, unsigned parts, void* stream, tfgnn_graph** out_graph) {
   using namespace tfgnn;
   TFGNN_REQUIRE(out_graph != nullptr, "out_graph is NULL");
   *out_graph = nullptr;
   TFGNN_REQUIRE(num_edge_types >= 0 && num_nodes >= 0, "negative sizes");
   TFGNN_REQUIRE(num_edge_types == 0 || (d_adjacency && num_edges), "adjacency arrays are NULL");
+  TFGNN_REQUIRE((parts & ~kPartsAll) == 0, "unknown graph part bits 0x%x", parts);
   hipStream_t s = (hipStream_t)stream;
   const int L = num_edge_types;
   const int64_t V = num_nodes;
@@ -571,6 +896,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   const int64_t R = V * (int64_t)L;
   TFGNN_REQUIRE(R < ((int64_t)1 << 31) - 1 && E < ((int64_t)1 << 31) - 1,
                 "graph too large for int32 indexing (V*L=%lld, E=%lld)", (long long)R, (long long)E);
+  TFGNN_REQUIRE(L <= 256, "at most 256 edge types are supported (got %d)", L);
 
   tfgnn_graph* g = new tfgnn_graph();
   g->L = L;
@@ -578,14 +904,14 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   g->E = E;
   g->R = R;
 
-  // persistent arrays
+  // persistent arrays (all parts have their place in the slab whether they are built now or later)
   SlabPlan plan;
   const size_t o_rowptr_d = plan.take((R + 1) * 4), o_rowptr_s = plan.take((R + 1) * 4);
   const size_t o_col_d = plan.take(E * 4), o_eid_d = plan.take(E * 4), o_coll_d = plan.take(E * 4);
   const size_t o_col_s = plan.take(E * 4), o_eid_s = plan.take(E * 4), o_coll_s = plan.take(E * 4);
   const size_t o_nodeptr_d = plan.take((V + 1) * 4), o_nodeptr_s = plan.take((V + 1) * 4);
   const size_t o_src2dst = plan.take(E * 4), o_dst2src = plan.take(E * 4);
-  const size_t o_tgt_d = plan.take(E * 4);
+  const size_t o_tgt_d = plan.take(E * 4), o_eid2pos = plan.take(E * 4);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
   size_t o_cb[2][6];
@@ -597,23 +923,8 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     o_cb[side][4] = plan.take((V + 1) * 4);            // nodeptr_nz
     o_cb[side][5] = plan.take((R + 1) * 4);            // col_nz
   }
-  // long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
-  // views 91 us at (48, 512) vs 104 us at (16, 192) (134 us in natural row order at (16, 128)); the node views -
-  // all edge types of a node in one row - 121 us at (32, 512) vs 128 us at (64, 512) (138 us in natural order).  TFGNN_LONG_ROW / TFGNN_ITEM_CHUNK override the typed views, TFGNN_LONG_ROW_NODE /
-  // TFGNN_ITEM_CHUNK_NODE the node views, for probing.
-  static const int env_long = [] { const char* e = getenv("TFGNN_LONG_ROW"); return e ? atoi(e) : 0; }();
-  static const int env_chunk = [] { const char* e = getenv("TFGNN_ITEM_CHUNK"); return e ? atoi(e) : 0; }();
-  static const int env_long_n = [] { const char* e = getenv("TFGNN_LONG_ROW_NODE"); return e ? atoi(e) : 0; }();
-  static const int env_chunk_n = [] { const char* e = getenv("TFGNN_ITEM_CHUNK_NODE"); return e ? atoi(e) : 0; }();
-  int view_long[4] = {LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD, LONG_ROW_THRESHOLD_TYPED, LONG_ROW_THRESHOLD};
-  int view_chunk[4] = {ITEM_CHUNK_TYPED, ITEM_CHUNK, ITEM_CHUNK_TYPED, ITEM_CHUNK};
-  for (int v = 0; v < 4; ++v) {
-    const bool node_view = v & 1;
-    if ((node_view ? env_long_n : env_long) > 0) view_long[v] = node_view ? env_long_n : env_long;
-    if ((node_view ? env_chunk_n : env_chunk) > 0) view_chunk[v] = node_view ? env_chunk_n : env_chunk;
-    if (view_long[v] > SHORT_BINS - 1) view_long[v] = SHORT_BINS - 1;
-    if (view_chunk[v] < view_long[v]) view_chunk[v] = view_long[v];
-  }
+  int view_long[4], view_chunk[4];
+  view_plan_parameters(view_long, view_chunk);
   const int min_long = std::min(std::min(view_long[0], view_long[1]), std::min(view_long[2], view_long[3]));
   const int min_chunk = std::min(std::min(view_chunk[0], view_chunk[1]), std::min(view_chunk[2], view_chunk[3]));
   const size_t max_items = (size_t)(E / min_long + 1), max_multi = (size_t)(E / min_chunk + 1);
@@ -625,24 +936,18 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   size_t o_short[4];
   for (int v = 0; v < 4; ++v) o_short[v] = plan.take((size_t)((v & 1) ? V : R) * 4 + 4);
   const size_t persistent = plan.total;
-  // build-time scratch (freed with a second allocation)
+  // build-time scratch (freed by tfgnn_graph_wait)
   SlabPlan tmp;
-  const int rs_blocks = (int)ceil_div(E > 0 ? E : 1, RS_TILE);
-  const size_t t_comp_d = tmp.take(E * 8), t_comp_s = tmp.take(E * 8);
-  const size_t t_comp_alt_d = tmp.take(E * 8), t_comp_alt_s = tmp.take(E * 8);
-  const size_t t_pay_a = tmp.take(E * 4), t_pay_d0 = tmp.take(E * 4), t_pay_d1 = tmp.take(E * 4);
-  const size_t t_pay_s0 = tmp.take(E * 4), t_pay_s1 = tmp.take(E * 4);
-  const size_t t_hist = tmp.take((size_t)RS_RADIX * rs_blocks * 4 + 16);
-  const size_t t_counters = tmp.take(64 * 4);
-  const size_t t_bins = tmp.take((size_t)4 * 2 * SHORT_BINS * 4);
-  const size_t t_scan = tmp.take((scan_scratch_elems(R + 1) + scan_scratch_elems((int64_t)RS_RADIX * rs_blocks)) * 4 + 16);
-  const size_t t_eid2pos = tmp.take(E * 4);
+  const int nblk = (int)ceil_div(E > 0 ? E : 1, RS_TILE);
+  const int nblk_ld = (nblk + 3) & ~3;
+  const size_t t_keys = tmp.take((size_t)E * 8 * 4), t_pays = tmp.take((size_t)E * 4 * 4);
+  const size_t t_hist = tmp.take((size_t)2 * RS_RADIX * nblk_ld * 4 + 16);
+  const size_t t_counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS) * 4);  // counters, then the bins: one memset
   const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
-  const size_t t_flags = tmp.take((R + 2) * 4);
+  const size_t t_compact = tmp.take((parts & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(R, V) : 0);
 
   char* slab = nullptr;
   char* scratch = nullptr;
-  TFGNN_REQUIRE(L <= 256, "at most 256 edge types are supported (got %d)", L);
   const size_t pinned_need = 256 + (size_t)(L + 1) * 16 + (size_t)(L + 1) * 8;
   hipError_t he = dev_alloc((void**)&slab, persistent, &g->slab_bytes, s);
   if (he == hipSuccess) {
@@ -677,6 +982,7 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   g->src2dst = (int32_t*)(slab + o_src2dst);
   g->dst2src = (int32_t*)(slab + o_dst2src);
   g->tgt_d = (int32_t*)(slab + o_tgt_d);
+  g->eid2pos = (int32_t*)(slab + o_eid2pos);
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
   g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
@@ -689,22 +995,27 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     cb.nodeptr_nz = (int32_t*)(slab + o_cb[side][4]);
     cb.col_nz = (int32_t*)(slab + o_cb[side][5]);
   }
+  // gather views (tfgnn_graph_view order) and the places of their long-row plans
+  g->views[0].rowptr = g->rowptr_d;  g->views[0].num_rows = R; g->views[0].col = g->col_d;
+  g->views[1].rowptr = g->nodeptr_d; g->views[1].num_rows = V; g->views[1].col = g->coll_d;
+  g->views[2].rowptr = g->rowptr_s;  g->views[2].num_rows = R; g->views[2].col = g->col_s;
+  g->views[3].rowptr = g->nodeptr_s; g->views[3].num_rows = V; g->views[3].col = g->coll_s;
+  for (int v = 0; v < 4; ++v) {
+    CsrPlan& pl = g->views[v].plan;
+    pl.item_row = (int32_t*)(slab + o_item[v][0]);
+    pl.item_chunk = (int32_t*)(slab + o_item[v][1]);
+    pl.item_slot = (int32_t*)(slab + o_item[v][2]);
+    pl.multi_row = (int32_t*)(slab + o_multi[v][0]);
+    pl.multi_base = (int32_t*)(slab + o_multi[v][1]);
+    pl.multi_n = (int32_t*)(slab + o_multi[v][2]);
+    pl.long_threshold = view_long[v];
+    pl.item_chunk_edges = view_chunk[v];
+    pl.short_rows = (int32_t*)(slab + o_short[v]);
+  }
 
-  uint64_t* comp_d = (uint64_t*)(scratch + t_comp_d);
-  uint64_t* comp_s = (uint64_t*)(scratch + t_comp_s);
-  uint64_t* comp_alt_d = (uint64_t*)(scratch + t_comp_alt_d);
-  uint64_t* comp_alt_s = (uint64_t*)(scratch + t_comp_alt_s);
-  uint32_t* pay_a = (uint32_t*)(scratch + t_pay_a);
-  uint32_t* pay_d0 = (uint32_t*)(scratch + t_pay_d0);
-  uint32_t* pay_d1 = (uint32_t*)(scratch + t_pay_d1);
-  uint32_t* pay_s0 = (uint32_t*)(scratch + t_pay_s0);
-  uint32_t* pay_s1 = (uint32_t*)(scratch + t_pay_s1);
   int32_t* hist = (int32_t*)(scratch + t_hist);
   int32_t* counters = (int32_t*)(scratch + t_counters);
-  int32_t* scan_tmp = (int32_t*)(scratch + t_scan);
-  int32_t* eid2pos = (int32_t*)(scratch + t_eid2pos);
-  const int32_t** d_ptrs = (const int32_t**)(scratch + t_ptrs);
-  int64_t* d_off = (int64_t*)(scratch + t_off);
+  int32_t* bins = counters + 64;
 
   int rc = TFGNN_OK;
   auto fail = [&](int code) {
@@ -721,146 +1032,69 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
     }                                                                                          \
   } while (0)
 
-  G_CHECK(hipMemsetAsync(counters, 0, 64 * 4, s));
-  int32_t* bins = (int32_t*)(scratch + t_bins);
-  G_CHECK(hipMemsetAsync(bins, 0, (size_t)4 * 2 * SHORT_BINS * 4, s));
-  // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
-  {
+  G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS) * 4, s));
+  EdgeLists el{};
+  el.L = L;
+  el.inline_tables = L <= EL_INLINE;
+  if (el.inline_tables) {
+    for (int l = 0; l < EL_INLINE; ++l) el.adj_v[l] = l < L ? d_adjacency[l] : nullptr;
+    for (int l = 0; l <= EL_INLINE; ++l) el.off_v[l] = l <= L ? edge_off[l] : E;
+  } else {
+    // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
+    const int32_t** d_ptrs = (const int32_t**)(scratch + t_ptrs);
+    int64_t* d_off = (int64_t*)(scratch + t_off);
     char* hp = (char*)g->pinned + 256;
     const int32_t** h_ptrs = (const int32_t**)hp;
     int64_t* h_off = (int64_t*)(hp + (size_t)(L + 1) * 8);
     for (int l = 0; l < L; ++l) h_ptrs[l] = d_adjacency[l];
     for (int l = 0; l <= L; ++l) h_off[l] = edge_off[l];
-    if (L > 0) G_CHECK(hipMemcpyAsync(d_ptrs, h_ptrs, (size_t)L * 8, hipMemcpyHostToDevice, s));
+    G_CHECK(hipMemcpyAsync(d_ptrs, h_ptrs, (size_t)L * 8, hipMemcpyHostToDevice, s));
     G_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
+    el.adj = d_ptrs;
+    el.edge_off = d_off;
   }
 
-  EdgeLists el{d_ptrs, d_off, L};
-  const int threads = 256;
-  auto blocks_for = [&](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, threads), 8192)); };
-
-  // sort the edges into (bucket, column) order, once per bucketing
-  int sec_bits = 1;
-  while (((int64_t)1 << sec_bits) < V) ++sec_bits;
-  int row_bits = 1;
-  while (((int64_t)1 << row_bits) < (R > 0 ? R : 1)) ++row_bits;
-  const uint64_t* sorted_d = comp_d;
-  const uint64_t* sorted_s = comp_s;
-  const uint32_t* pay_d = pay_a;
-  const uint32_t* pay_s = pay_a;
+  // sort the edges into (bucket, column) order for both bucketings, then everything per edge and per row
   if (E > 0) {
-    hipLaunchKernelGGL(fill_keys_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, el, E, V, sec_bits, comp_d, comp_s,
-                       pay_a, counters + 2);
+    int sec_bits = 1;
+    while (((int64_t)1 << sec_bits) < V) ++sec_bits;
+    int row_bits = 1;
+    while (((int64_t)1 << row_bits) < (R > 0 ? R : 1)) ++row_bits;
     const int total_bits = sec_bits + row_bits;
-    for (int side = 0; side < 2; ++side) {
-      // private ping-pong buffers per side; both sorts start from the shared identity payload pay_a
-      uint64_t* cbuf[2] = {side == 0 ? comp_d : comp_s, side == 0 ? comp_alt_d : comp_alt_s};
-      uint32_t* pbuf[2] = {side == 0 ? pay_d0 : pay_s0, side == 0 ? pay_d1 : pay_s1};
-      const uint64_t* cin = cbuf[0];
-      const uint32_t* pin = pay_a;
-      int pass = 0;
-      for (int shift = 0; shift < total_bits; shift += 8, ++pass) {
-        uint64_t* cout = cbuf[(pass + 1) & 1];
-        uint32_t* pout = pbuf[pass & 1];
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(rs_blocks), dim3(RS_THREADS), 0, s, cin, E, shift, hist, rs_blocks);
-        rc = exclusive_scan_i32(hist, hist, (int64_t)RS_RADIX * rs_blocks, scan_tmp, s);
-        if (rc) return fail(rc);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(rs_blocks), dim3(RS_THREADS), 0, s, cin, pin, E, shift, hist,
-                           rs_blocks, cout, pout);
-        cin = cout;
-        pin = pout;
-      }
-      if (side == 0) {
-        sorted_d = cin;
-        pay_d = pin;
-      } else {
-        sorted_s = cin;
-        pay_s = pin;
-      }
-    }
-    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, sorted_d, E, sec_bits,
-                       R, g->rowptr_d);
-    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, sorted_s, E, sec_bits,
-                       R, g->rowptr_s);
+    char* keys = scratch + t_keys;
+    char* pays = scratch + t_pays;
+    rc = total_bits <= 32 ? build_core<uint32_t>(g, el, sec_bits, total_bits, keys, pays, hist, nblk, nblk_ld, counters, s)
+                          : build_core<uint64_t>(g, el, sec_bits, total_bits, keys, pays, hist, nblk, nblk_ld, counters, s);
+    if (rc) return fail(rc);
   } else {
     G_CHECK(hipMemsetAsync(g->rowptr_d, 0, (R + 1) * 4, s));
     G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
-  }
-  if (L > 0) {
-    hipLaunchKernelGGL(invdeg_rows_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, g->rowptr_d, R, L,
-                       g->invdeg_d, g->nodeptr_d, g->rowptr_s, g->nodeptr_s);
-  } else {
-    G_CHECK(hipMemsetAsync(g->nodeptr_d, 0, (V + 1) * 4, s));
-    G_CHECK(hipMemsetAsync(g->nodeptr_s, 0, (V + 1) * 4, s));
-  }
-  if (E > 0) {
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, sorted_d, pay_d, sec_bits, E, L,
-                       g->col_d, g->eid_d, g->coll_d, g->invdeg_d, g->invdeg_edge_d, 0, eid2pos, g->tgt_d);
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, sorted_s, pay_s, sec_bits, E, L,
-                       g->col_s, g->eid_s, g->coll_s, g->invdeg_d, g->invdeg_edge_s, 1, (int32_t*)nullptr,
-                       (int32_t*)nullptr);
-    hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(E)), dim3(threads), 0, s, g->eid_s, eid2pos, E,
-                       g->src2dst, g->dst2src);
-  }
-  // non-empty buckets in type-major order, for both bucketings
-  {
-    int32_t* flags = (int32_t*)(scratch + t_flags);
-    for (int side = 0; side < 2; ++side) {
-      CompactBuckets& cb = g->compact[side];
-      const int32_t* rp = side == 0 ? g->rowptr_d : g->rowptr_s;
-      if (L > 0) {
-        hipLaunchKernelGGL(nz_flags_kernel, dim3(blocks_for(R + 1)), dim3(threads), 0, s, rp, V, L, flags, cb.nodeptr_nz);
-        rc = exclusive_scan_i32(flags, flags, R + 1, scan_tmp, s);
-        if (rc) return fail(rc);
-        rc = exclusive_scan_i32(cb.nodeptr_nz, cb.nodeptr_nz, V + 1, scan_tmp, s);
-        if (rc) return fail(rc);
-        if (R > 0) {
-          hipLaunchKernelGGL(nz_fill_kernel, dim3(blocks_for(R)), dim3(threads), 0, s, rp, flags, V, L, cb.cpos, cb.nzrow,
-                             cb.nz_node, cb.nz_off);
-          hipLaunchKernelGGL(nz_cols_kernel, dim3(blocks_for(V)), dim3(threads), 0, s, cb.cpos, cb.nodeptr_nz, V, L,
-                             cb.col_nz);
-        } else {
-          G_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
-        }
-      } else {
-        G_CHECK(hipMemsetAsync(cb.nz_off, 0, (size_t)(L + 1) * 4, s));
-        G_CHECK(hipMemsetAsync(cb.nodeptr_nz, 0, (V + 1) * 4, s));
-      }
-      G_CHECK(hipMemcpyAsync((char*)g->pinned + 256 + (size_t)(L + 1) * 16 + (size_t)side * (L + 1) * 4, cb.nz_off,
-                             (size_t)(L + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (L > 0) {
+      hipLaunchKernelGGL((unpack_kernel<uint32_t>), dim3(blocks_for(R + 1), 1), dim3(256), 0, s, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (int64_t)0, L, R,
+                         (const int32_t*)g->rowptr_d, (const int32_t*)g->rowptr_s, g->col_d, g->eid_d, g->coll_d, g->invdeg_edge_d,
+                         g->eid2pos, g->tgt_d, g->col_s, g->eid_s, g->coll_s, g->invdeg_edge_s, g->invdeg_d, g->nodeptr_d,
+                         g->nodeptr_s, 2);
+    } else {
+      G_CHECK(hipMemsetAsync(g->nodeptr_d, 0, (V + 1) * 4, s));
+      G_CHECK(hipMemsetAsync(g->nodeptr_s, 0, (V + 1) * 4, s));
     }
   }
-  // gather views + long-row plans (tfgnn_graph_view order)
-  g->views[0].rowptr = g->rowptr_d;  g->views[0].num_rows = R; g->views[0].col = g->col_d;
-  g->views[1].rowptr = g->nodeptr_d; g->views[1].num_rows = V; g->views[1].col = g->coll_d;
-  g->views[2].rowptr = g->rowptr_s;  g->views[2].num_rows = R; g->views[2].col = g->col_s;
-  g->views[3].rowptr = g->nodeptr_s; g->views[3].num_rows = V; g->views[3].col = g->coll_s;
-  for (int v = 0; v < 4; ++v) {
-    CsrPlan& pl = g->views[v].plan;
-    pl.item_row = (int32_t*)(slab + o_item[v][0]);
-    pl.item_chunk = (int32_t*)(slab + o_item[v][1]);
-    pl.item_slot = (int32_t*)(slab + o_item[v][2]);
-    pl.multi_row = (int32_t*)(slab + o_multi[v][0]);
-    pl.multi_base = (int32_t*)(slab + o_multi[v][1]);
-    pl.multi_n = (int32_t*)(slab + o_multi[v][2]);
-    pl.long_threshold = view_long[v];
-    pl.item_chunk_edges = view_chunk[v];
-    pl.short_rows = (int32_t*)(slab + o_short[v]);
-    if (g->views[v].num_rows > 0) {
-      int32_t* bc = bins + (size_t)v * 2 * SHORT_BINS;
-      const int64_t nr = g->views[v].num_rows;
-      const unsigned hist_blocks = (unsigned)std::min<int64_t>(ceil_div(nr, 256), 1024);
-      const unsigned scat_blocks = (unsigned)std::min<int64_t>(ceil_div(nr, 256 * SHORT_TILE_ROWS), 4096);
-      hipLaunchKernelGGL(short_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, g->views[v].rowptr, nr, view_long[v], bc,
-                         counters + 16 + 4 * v + 3);
-      hipLaunchKernelGGL(short_scatter_kernel, dim3(scat_blocks), dim3(256), 0, s, g->views[v].rowptr, nr, view_long[v],
-                         bc, bc + SHORT_BINS, pl.short_rows);
-    }
-    if (E > 0 && g->views[v].num_rows > 0) {
-      hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks_for(g->views[v].num_rows)), dim3(threads), 0, s,
-                         g->views[v].rowptr, g->views[v].num_rows, view_long[v], view_chunk[v], counters + 16 + 4 * v, pl.item_row,
-                         pl.item_chunk, pl.item_slot, pl.multi_row, pl.multi_base, pl.multi_n);
-    }
+  if (parts & TFGNN_GRAPH_PART_PLAN_TYPED) {
+    rc = build_plans(g, 0, counters, bins, s);
+    if (rc) return fail(rc);
+  }
+  if (parts & TFGNN_GRAPH_PART_PLAN_NODE) {
+    rc = build_plans(g, 1, counters, bins, s);
+    if (rc) return fail(rc);
+  }
+  if (parts & TFGNN_GRAPH_PART_EDGE_MAPS) {
+    rc = build_edge_maps(g, s);
+    if (rc) return fail(rc);
+  }
+  if (parts & TFGNN_GRAPH_PART_COMPACT) {
+    rc = build_compact(g, scratch + t_compact, s);
+    if (rc) return fail(rc);
   }
   {
     hipError_t le = hipGetLastError();
@@ -872,10 +1106,80 @@ extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes,
   G_CHECK(hipMemcpyAsync(g->pinned, counters, 64 * 4, hipMemcpyDeviceToHost, s));
   G_CHECK(hipEventRecord((hipEvent_t)g->event, s));
 #undef G_CHECK
+  g->parts = parts;
   g->pending = true;
   *out_graph = g;
   return TFGNN_OK;
 }
+
+extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                                        const int64_t* num_edges, void* stream, tfgnn_graph** out_graph) {
+  return graph_create_impl(num_edge_types, num_nodes, d_adjacency, num_edges, kPartsAll, stream, out_graph);
+}
+
+extern "C" int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
+                                              const int64_t* num_edges, unsigned parts, void* stream, tfgnn_graph** out_graph) {
+  return graph_create_impl(num_edge_types, num_nodes, d_adjacency, num_edges, parts, stream, out_graph);
+}
+
+static void graph_read_counters(tfgnn_graph* g, unsigned parts) {
+  const int32_t* h_counters = (const int32_t*)g->pinned;
+  for (int v = 0; v < 4; ++v) {
+    if (!(parts & ((v & 1) ? TFGNN_GRAPH_PART_PLAN_NODE : TFGNN_GRAPH_PART_PLAN_TYPED))) continue;
+    g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
+    g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
+    g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
+    g->views[v].plan.num_short = h_counters[16 + 4 * v + 3];
+  }
+  if (parts & TFGNN_GRAPH_PART_COMPACT)
+    for (int side = 0; side < 2; ++side) {
+      const int32_t* h = (const int32_t*)((const char*)g->pinned + 256 + (size_t)(g->L + 1) * 16 + (size_t)side * (g->L + 1) * 4);
+      for (int l = 0; l <= g->L; ++l) g->compact[side].h_nz_off[l] = h[l];
+      g->compact[side].num_nz = h[g->L];
+    }
+}
+
+// Build the parts that were not requested at creation (tfgnn_graph_create_parts_async) on `stream`; blocks the host until
+// they are there (their sizes come back from the device).  A no-op for parts the handle already has.
+extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(g != nullptr, "graph is NULL");
+  TFGNN_REQUIRE((parts & ~kPartsAll) == 0, "unknown graph part bits 0x%x", parts);
+  const unsigned missing = parts & ~g->parts;
+  if (!missing) return TFGNN_OK;
+  TFGNN_REQUIRE(!g->pending, "tfgnn_graph_wait has not been called");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS) * 4;
+  const size_t c_take = (c_bytes + 255) & ~(size_t)255;
+  const size_t need = c_take + ((missing & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(g->R, g->V) : 0);
+  char* scratch = nullptr;
+  size_t got = 0;
+  hipError_t he = dev_alloc((void**)&scratch, need, &got, s);
+  if (he != hipSuccess) {
+    set_error("tfgnn_graph_ensure: allocation of %zu bytes failed: %s", need, hipGetErrorString(he));
+    return TFGNN_ERR_HIP;
+  }
+  int32_t* counters = (int32_t*)scratch;
+  int rc = TFGNN_OK;
+  hipError_t e = hipMemsetAsync(counters, 0, c_bytes, s);
+  if (e == hipSuccess && (missing & TFGNN_GRAPH_PART_PLAN_TYPED)) rc = build_plans(g, 0, counters, counters + 64, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_PLAN_NODE)) rc = build_plans(g, 1, counters, counters + 64, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_EDGE_MAPS)) rc = build_edge_maps(g, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_COMPACT)) rc = build_compact(g, scratch + c_take, s);
+  if (e == hipSuccess && !rc) e = hipMemcpyAsync(g->pinned, counters, 64 * 4, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  dev_release(scratch, got);
+  if (rc) return rc;
+  if (e != hipSuccess || e2 != hipSuccess) {
+    set_error("tfgnn_graph_ensure failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return TFGNN_ERR_HIP;
+  }
+  graph_read_counters(g, missing);
+  g->parts |= missing;
+  return TFGNN_OK;
+}
+
+extern "C" unsigned tfgnn_graph_parts(const tfgnn_graph* g) { return g ? g->parts : 0u; }
 
 extern "C" int tfgnn_graph_wait(tfgnn_graph* g) {
   using namespace tfgnn;
@@ -884,17 +1188,7 @@ extern "C" int tfgnn_graph_wait(tfgnn_graph* g) {
   TFGNN_HIP_CHECK(hipEventSynchronize((hipEvent_t)g->event));
   g->pending = false;
   const int32_t* h_counters = (const int32_t*)g->pinned;
-  for (int v = 0; v < 4; ++v) {
-    g->views[v].plan.num_items = h_counters[16 + 4 * v + 0];
-    g->views[v].plan.num_multi = h_counters[16 + 4 * v + 1];
-    g->views[v].plan.num_partials = h_counters[16 + 4 * v + 2];
-    g->views[v].plan.num_short = h_counters[16 + 4 * v + 3];
-  }
-  for (int side = 0; side < 2; ++side) {
-    const int32_t* h = (const int32_t*)((const char*)g->pinned + 256 + (size_t)(g->L + 1) * 16 + (size_t)side * (g->L + 1) * 4);
-    for (int l = 0; l <= g->L; ++l) g->compact[side].h_nz_off[l] = h[l];
-    g->compact[side].num_nz = h[g->L];
-  }
+  graph_read_counters(g, g->parts);
   const bool bad_index = h_counters[2] != 0;
   dev_release(g->scratch, g->scratch_bytes);  // build-time scratch is no longer needed
   g->scratch = nullptr;
@@ -1014,6 +1308,10 @@ extern "C" int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stre
 extern "C" int tfgnn_graph_nonempty_offsets(const tfgnn_graph* g, int by_src, int32_t* h_offsets) {
   TFGNN_REQUIRE(g != nullptr && h_offsets != nullptr, "NULL argument");
   TFGNN_REQUIRE(!g->pending, "tfgnn_graph_wait has not been called");
+  {
+    const int rc = tfgnn::graph_require_parts(g, TFGNN_GRAPH_PART_COMPACT, "tfgnn_graph_nonempty_offsets");
+    if (rc) return rc;
+  }
   for (int l = 0; l <= g->L; ++l) h_offsets[l] = g->compact[by_src ? 1 : 0].h_nz_off[l];
   return TFGNN_OK;
 }
@@ -1029,6 +1327,15 @@ extern "C" int tfgnn_graph_dims(const tfgnn_graph* g, int64_t* num_nodes, int* n
 
 extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void** d_ptr, int64_t* count) {
   TFGNN_REQUIRE(g != nullptr && d_ptr != nullptr && count != nullptr, "NULL argument");
+  {
+    unsigned need = 0;
+    if (array_id == TFGNN_G_SRC2DST_POS) need = TFGNN_GRAPH_PART_EDGE_MAPS;
+    if (array_id >= TFGNN_G_NZ_CPOS_BY_DST && array_id <= TFGNN_G_NZ_COL_BY_SRC) need = TFGNN_GRAPH_PART_COMPACT;
+    if (need) {
+      const int rc = tfgnn::graph_require_parts(g, need, "tfgnn_graph_array");
+      if (rc) return rc;
+    }
+  }
   switch (array_id) {
     case TFGNN_G_ROWPTR_BY_DST: *d_ptr = g->rowptr_d; *count = g->R + 1; break;
     case TFGNN_G_COL_BY_DST: *d_ptr = g->col_d; *count = g->E; break;

@@ -61,6 +61,8 @@ struct tfgnn_graph {
   int32_t *rowptr_d = nullptr, *col_d = nullptr, *eid_d = nullptr, *coll_d = nullptr;
   int32_t *rowptr_s = nullptr, *col_s = nullptr, *eid_s = nullptr, *coll_s = nullptr;
   int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *dst2src = nullptr, *tgt_d = nullptr;
+  int32_t* eid2pos = nullptr;  // edge id -> position in the by-target order
+  unsigned parts = 0;          // TFGNN_GRAPH_PART_* bits that have been built (the sort and the per-edge arrays always are)
   float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
   tfgnn::GraphView views[4];  // tfgnn_graph_view order
   tfgnn::CompactBuckets compact[2];  // 0: by target, 1: by source
@@ -73,3 +75,8 @@ struct tfgnn_graph {
   void* event = nullptr;   // hipEvent_t recorded after the last build command
   bool pending = false;
 };
+
+namespace tfgnn {
+// TFGNN_OK, or TFGNN_ERR_INVALID_ARGUMENT (error text set) when the handle lacks one of the parts in `need`
+int graph_require_parts(const tfgnn_graph* g, unsigned need, const char* who);
+}  // namespace tfgnn

@@ -710,6 +710,10 @@ static int rgat_row_softmax(const tfgnn_graph* g, const float* s_src, const floa
   if (K <= 0 || K > MAX_HEADS || (K & (K - 1))) return TFGNN_ERR_UNSUPPORTED;  // lane = slot * K + head needs a power of two
   if (g->E == 0) return TFGNN_OK;
   TFGNN_REQUIRE(s_src && s_tgt && att && (!bwd || (da && dz)), "NULL pointer");
+  {
+    const int prc = graph_require_parts(g, TFGNN_GRAPH_PART_PLAN_NODE | TFGNN_GRAPH_PART_EDGE_MAPS, "tfgnn_rgat_attention");
+    if (prc) return prc;
+  }
   const GraphView& gv = g->views[1];  // by target, all edge types of a node in one row
   const CsrPlan& pl = gv.plan;
   const size_t need = (size_t)pl.num_partials * K * 2 * 4;

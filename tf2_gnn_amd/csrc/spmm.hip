@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "aux_jobs.hpp"
 #include "common.hpp"
 #include "graph.hpp"
 #include "sp16.hpp"
@@ -125,6 +126,7 @@ struct GatherArgs {
   int64_t ld_out_sp;
   float* inv_out;          // [rows] 2^-e of every output row (not written when fixed_inv is given)
   const float* fixed_inv;  // nullable: one caller-chosen 2^-e for the whole tensor
+  tfgnn_aux_job* combine_job;  // host pointer, nullable: receive the combine pass as a job instead of launching it
 };
 
 // scale of one output row from the maximum over its LANES lanes (lanes of one group are contiguous)
@@ -376,38 +378,15 @@ __global__ void __launch_bounds__(256) csr_gather_combine_kernel(GatherArgs a) {
   }
 }
 
-// SP16 output: one wave per multi-item row (width <= 2048 floats)
-__global__ void __launch_bounds__(256) csr_gather_combine_sp_kernel(GatherArgs a) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= a.num_multi) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t row = a.multi_row[m];
-  const int32_t base = a.multi_base[m], n = a.multi_n[m];
-  const float rs = a.row_scale ? a.row_scale[row] : 1.f;
-  float4 sum[8];
-  float mx = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = (lane + i * 64) * 4;
-    sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < a.width) {
-      for (int k = 0; k < n; ++k) {
-        const float4 p = *reinterpret_cast<const float4*>(a.partial + (int64_t)(base + k) * a.width + c);
-        sum[i].x += p.x; sum[i].y += p.y; sum[i].z += p.z; sum[i].w += p.w;
-      }
-      sum[i].x *= rs; sum[i].y *= rs; sum[i].z *= rs; sum[i].w *= rs;
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(sum[i].x), fabsf(sum[i].y)), fmaxf(fabsf(sum[i].z), fabsf(sum[i].w))));
-    }
-  }
-  const int64_t orow = a.out_row_map ? a.out_row_map[row] : row;
-  const float sc = sp_row_scale<64>(a, mx, orow, lane == 0);
-  uint8_t* drow = a.out_sp + orow * a.ld_out_sp;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = (lane + i * 64) * 4;
-    if (c < a.width) sp_store4(drow, c, sum[i], sc);
-  }
+// SP16 output: one wave per multi-item row (width <= 2048 floats); the body is shared with the merged small-pass launch
+static AuxCombineSp combine_sp_args(const GatherArgs& a) {
+  AuxCombineSp c{};
+  c.multi_row = a.multi_row; c.multi_base = a.multi_base; c.multi_n = a.multi_n; c.num_multi = a.num_multi;
+  c.row_scale = a.row_scale; c.partial = a.partial; c.width = a.width; c.out_row_map = a.out_row_map;
+  c.out_sp = a.out_sp; c.ld_out_sp = a.ld_out_sp; c.inv_out = a.inv_out; c.fixed_inv = a.fixed_inv;
+  return c;
 }
+__global__ void __launch_bounds__(256) csr_gather_combine_sp_kernel(AuxCombineSp a) { combine_sp_body(a, blockIdx.x); }
 
 // One launch covers both kinds of work: workgroups [0, num_items) each take one item of a long row
 // (longest work first), the remaining workgroups take 256/LPR short rows each.
@@ -451,8 +430,12 @@ static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
     hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE, true>), dim3(units, 1), block, 0, s, a, num_items);
     TFGNN_LAUNCH_CHECK();
     if (a.num_multi > 0) {
-      hipLaunchKernelGGL(csr_gather_combine_sp_kernel, dim3((unsigned)ceil_div(a.num_multi, 4)), block, 0, s, a);
-      TFGNN_LAUNCH_CHECK();
+      if (a.combine_job) {  // the caller launches the combine pass itself, together with other small passes
+        aux_job_set(a.combine_job, AUX_COMBINE_SP, (unsigned)ceil_div(a.num_multi, 4), combine_sp_args(a));
+      } else {
+        hipLaunchKernelGGL(csr_gather_combine_sp_kernel, dim3((unsigned)ceil_div(a.num_multi, 4)), block, 0, s, combine_sp_args(a));
+        TFGNN_LAUNCH_CHECK();
+      }
     }
     return TFGNN_OK;
   }
@@ -572,12 +555,18 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
                              const float* d_in, int64_t ld_in, int width, float* d_out,
                              int64_t ld_out, int reduce_op, int pre_act, int post_act,
                              void* d_workspace, size_t workspace_bytes, void* stream, void* d_out_sp, int64_t ld_out_sp,
-                             float* d_inv_scale, const float* d_fixed_inv) {
+                             float* d_inv_scale, const float* d_fixed_inv, tfgnn_aux_job* combine_job = nullptr) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   TFGNN_REQUIRE(view >= 0 && view <= 5, "unknown graph view %d", view);
   TFGNN_REQUIRE(width >= 0 && ew_heads >= 1, "bad sizes");
   // views 4 / 5: the typed views 0 / 2 with compact output (one row per NON-EMPTY bucket, type-major)
+  {
+    unsigned need = (view == 1 || view == 3) ? TFGNN_GRAPH_PART_PLAN_NODE : TFGNN_GRAPH_PART_PLAN_TYPED;
+    if (view >= 4) need |= TFGNN_GRAPH_PART_COMPACT;
+    const int prc = graph_require_parts(g, need, "tfgnn_graph_gather_reduce");
+    if (prc) return prc;
+  }
   const int32_t* out_map = nullptr;
   if (view >= 4) {
     out_map = g->compact[view - 4].cpos;
@@ -596,6 +585,8 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
   a.row_scale = d_row_scale; a.num_rows = gv.num_rows; a.in = d_in; a.ld_in = ld_in; a.width = width;
   a.out = d_out; a.ld_out = d_out_sp ? (int64_t)width : ld_out; a.pre_act = pre_act; a.post_act = post_act;
   a.out_sp = (uint8_t*)d_out_sp; a.ld_out_sp = ld_out_sp; a.inv_out = d_inv_scale; a.fixed_inv = d_fixed_inv;
+  a.combine_job = combine_job;
+  if (combine_job) combine_job->kind = 0, combine_job->num_blocks = 0;
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = p.long_threshold;
   a.out_row_map = out_map;
@@ -634,4 +625,20 @@ extern "C" int tfgnn_graph_gather_reduce_sp(const tfgnn_graph* g, int view, cons
   return graph_gather_impl(g, view, d_col_override, d_edge_weight, 1, d_row_scale, d_in, ld_in, width, nullptr, 0,
                            TFGNN_REDUCE_SUM, TFGNN_ACT_NONE, TFGNN_ACT_NONE, d_workspace, workspace_bytes, stream, d_out_sp,
                            ld_out_sp_bytes, d_inv_scale, d_fixed_inv_scale);
+}
+
+/* tfgnn_graph_gather_reduce_sp whose combine pass (the partial sums of buckets cut into several items) comes back as a job
+ * for tfgnn_aux_launch instead of being launched: kind 0 = there is nothing to combine. */
+extern "C" int tfgnn_graph_gather_reduce_sp_deferred(const tfgnn_graph* g, int view, const int32_t* d_col_override,
+                                                     const float* d_edge_weight, const float* d_row_scale, const float* d_in,
+                                                     int64_t ld_in, int width, void* d_out_sp, int64_t ld_out_sp_bytes,
+                                                     float* d_inv_scale, const float* d_fixed_inv_scale, void* d_workspace,
+                                                     size_t workspace_bytes, tfgnn_aux_job* combine_job, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(d_out_sp && (d_inv_scale || d_fixed_inv_scale) && combine_job, "tfgnn_graph_gather_reduce_sp_deferred: NULL output");
+  TFGNN_REQUIRE(ld_out_sp_bytes >= (int64_t)width * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0,
+                "tfgnn_graph_gather_reduce_sp_deferred: bad SP16 leading dimension / alignment");
+  return graph_gather_impl(g, view, d_col_override, d_edge_weight, 1, d_row_scale, d_in, ld_in, width, nullptr, 0,
+                           TFGNN_REDUCE_SUM, TFGNN_ACT_NONE, TFGNN_ACT_NONE, d_workspace, workspace_bytes, stream, d_out_sp,
+                           ld_out_sp_bytes, d_inv_scale, d_fixed_inv_scale, combine_job);
 }

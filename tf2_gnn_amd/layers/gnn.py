@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from .. import ops
@@ -99,6 +101,7 @@ class GNN:
         self._ctx = None
         self._dropout_calls = 0
         self.dropout_seed = 0
+        self._guard_sync_passes = int(os.environ.get("TFGNN_GUARD_SYNC_PASSES", "3"))  # see backward()
 
     # ---- Keras-like plumbing ----------------------------------------------------------------
     @property
@@ -177,10 +180,20 @@ class GNN:
 
     def call(self, inputs: GNNInput, training: bool = False, return_all_representations: bool = False):
         """gnn.py:234-274: [V, hidden_dim], or (that, tuple of num_layers+1 x [V, hidden_dim])."""
-        cur, all_reprs = self._internal_call(inputs, training)
+        cur, all_reprs = self._internal_call(inputs, training, need_all_representations=return_all_representations)
         if return_all_representations:
             return cur, all_reprs
         return cur
+
+    def graph_parts(self, num_nodes: int, edges_per_type) -> int:
+        """Union of what the layers of this stack read from a batch's graph handle (``MessagePassing.graph_parts``): hand it
+        to ``ops.Graph(..., parts=)`` when the handle is built ahead of the step (input pipeline)."""
+        if not self._mp_layers:  # not built yet: the first call builds everything
+            return ops.G_PARTS_ALL
+        parts = 0
+        for mp in self._mp_layers:
+            parts |= mp.graph_parts(num_nodes, edges_per_type, self._hidden_dim)
+        return parts
 
     @staticmethod
     def _tiles(n: int) -> bool:
@@ -199,18 +212,23 @@ class GNN:
             return False
         return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
 
-    def _dense(self, x, w: Variable, act_name):
-        """bias-free Dense + activation (gnn.py:136-141,163-170); gelu keeps its pre-activation."""
+    def _dense(self, x, w: Variable, act_name, drop=None):
+        """bias-free Dense + activation (gnn.py:136-141,163-170); gelu keeps its pre-activation.  ``drop`` = (rate, seed) of
+        the layer-input dropout that follows: applied in the product's epilogue where the split-operand kernel runs it.
+        -> (output, pre-activation | None, dropout applied?)"""
         if x.shape[0] > 0 and self._dense_f16x2(w.value.shape[0], w.value.shape[1]):
-            wt = ops.sp_weight_operand(w.value, "cols", lambda: ops.sp_split_cols(w.value))
+            wt = ops.sp_weight_operand(w.value, "cols", lambda: ops.sp_split_cols(w.value, defer=True))
             if act_name == "gelu":
                 pre = ops.sp_gemm_nt(ops.sp_rows_of(x), wt)
-                return ops.activation_forward("gelu", pre), pre
-            return ops.sp_gemm_nt(ops.sp_rows_of(x), wt, act=act_name), None
+                return ops.activation_forward("gelu", pre), pre, False
+            if drop is not None and w.value.shape[1] in (128, 256, 320):
+                out, _ = ops.sp_gemm_nt_split(ops.sp_rows_of(x), wt, act=act_name, dropout=drop)  # dropped, fp32 + split form
+                return out, None, True
+            return ops.sp_gemm_nt(ops.sp_rows_of(x), wt, act=act_name), None, False
         if act_name == "gelu":
             pre = ops.gemm(x, w.value)
-            return ops.activation_forward("gelu", pre), pre
-        return ops.gemm(x, w.value, act=act_name), None
+            return ops.activation_forward("gelu", pre), pre, False
+        return ops.gemm(x, w.value, act=act_name), None, False
 
     def _dense_backward(self, x, w: Variable, gpre, act_grad=None, need_input_grad=True):
         """w.grad = x^T gpre; returns gpre w^T (* act'(saved) of the op below, ``act_grad``) or None."""
@@ -221,20 +239,38 @@ class GNN:
             if not need_input_grad:
                 return None
             if self._tiles(d_in):
-                wr = ops.sp_weight_operand(w.value, "rows", lambda: ops.sp_split_rows(w.value))
+                wr = ops.sp_weight_operand(w.value, "rows", lambda: ops.sp_split_rows(w.value, defer=True))
                 return ops.sp_gemm_nt(g_sp, wr, act_grad=act_grad)
             return ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=act_grad)
         w.grad = ops.gemm(x, gpre, trans_a=True)
         return ops.gemm_grad(gpre, w.value, trans_b=True, act_grad=act_grad) if need_input_grad else None
 
-    def _internal_call(self, inputs: GNNInput, training: bool = False):
-        """gnn.py:276-329, same op order."""
+    def _fuse_dropout_statically(self, layer_idx: int) -> bool:
+        """May the dropout at the input of layer ``layer_idx`` be applied by the op that produces that input?  Only where the
+        backward pass hands the mask to an input-gradient product as well (no residual sum at this layer) and nothing but a
+        Dense / the projection / a message passing layer precedes it."""
+        if os.environ.get("TFGNN_FUSED_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
+            return False
+        if layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and self._residual_every_num_layers >= self._num_layers):
+            return False
+        if layer_idx == 0:
+            return True
+        prev = layer_idx - 1
+        return not self._use_inter_layer_layernorm and str(prev) not in self._global_exchange_layers
+
+    def _internal_call(self, inputs: GNNInput, training: bool = False, need_all_representations: bool = True):
+        """gnn.py:276-329, same op order.  With ``need_all_representations=False`` (what ``call`` passes unless asked for the
+        tuple) the outputs nobody reads - a layer's result BEFORE the next layer's input dropout - are not materialised: their
+        producer drops them in its epilogue, and the second result is None."""
         X = inputs.node_features
         V = X.shape[0]
-        graph = get_graph(inputs.adjacency_lists, V)
+        adj = inputs.adjacency_lists
+        graph = adj if isinstance(adj, ops.Graph) else get_graph(
+            adj, V, parts=self.graph_parts(V, [int(a.shape[0]) if a.numel() else 0 for a in adj]))
+        graph = get_graph(graph, V)
         rate = float(self._params["layer_input_dropout_rate"])
         steps = []
-        import os
+        NL = self._num_layers
 
         if training and ops.get_gemm_mode() == ops.GEMM_F16X2 and os.environ.get("TFGNN_BATCHED_WEIGHT_SPLIT", "0") == "1":
             # Opt-in: both split forms of every layer's kernel stack in ONE launch at the start of the step instead of two
@@ -247,60 +283,104 @@ class GNN:
                       and mp._path() == "A" and mp._f16x2_eligible(V, self._hidden_dim, graph.num_edge_types, self._hidden_dim)]
             if len(stacks) > 1 and len({tuple(w.shape) for w in stacks}) == 1:
                 ops.sp_split_weights(stacks)
-        cur, pre0 = self._dense(X, self._initial_projection_layer, self._init_act)
-        ctx = {"X": X, "h0": cur, "pre0": pre0, "steps": steps}
+        # the dropout seeds, in the order the stack draws them (one per layer input, one per global exchange)
+        drop_seed, ex_seed = [None] * NL, {}
+        for i in range(NL):
+            if training and rate > 0.0:
+                self._dropout_calls += 1
+                drop_seed[i] = self.dropout_seed * 1000003 + self._dropout_calls
+            if str(i) in self._global_exchange_layers:
+                self._dropout_calls += 1
+                ex_seed[i] = self.dropout_seed * 1000003 + self._dropout_calls
+
+        def drop_for(i, producer_output_is_read):
+            """(rate, seed) if the producer of layer i's input may apply that layer's dropout itself"""
+            if i >= NL or drop_seed[i] is None or producer_output_is_read or not self._fuse_dropout_statically(i):
+                return None
+            return (rate, drop_seed[i])
+
+        cur, pre0, dropped = self._dense(X, self._initial_projection_layer, self._init_act,
+                                         drop=drop_for(0, need_all_representations))
+        ctx = {"X": X, "h0": cur, "pre0": pre0, "steps": steps, "h0_scale": (1.0 - rate) if dropped else 1.0,
+               "all_representations": need_all_representations}
         last = cur
         all_reprs = [cur]
         for layer_idx, mp_layer in enumerate(self._mp_layers):
             st = {}
-            if training and rate > 0.0:
-                self._dropout_calls += 1
-                cur, st["mask"] = ops.dropout_forward(cur, rate, self.dropout_seed * 1000003 + self._dropout_calls)
+            if drop_seed[layer_idx] is not None:
+                if dropped:  # the producer of `cur` applied this mask in its epilogue; nothing is stored
+                    st["drop"] = ops.DropoutSpec(rate, drop_seed[layer_idx], tuple(cur.shape), cur.device)
+                else:
+                    cur, st["mask"] = ops.dropout_forward(cur, rate, drop_seed[layer_idx])
+            dropped = False
             if layer_idx % self._residual_every_num_layers == 0:
                 tmp = cur
                 if layer_idx > 0:
                     cur = ops.add_scale(cur, last, 0.5)
                 last = tmp
+            dense_here = layer_idx % self._dense_every_num_layers == 0
+            has_ex = str(layer_idx) in self._global_exchange_layers
             # a Dense right behind this layer takes its input as a split operand: let the layer's product write it
             mp_layer._want_split_output = bool(getattr(mp_layer, "_always_split_output", False)) or (
-                layer_idx % self._dense_every_num_layers == 0 and str(layer_idx) not in self._global_exchange_layers
+                dense_here and not has_ex
                 and not self._use_inter_layer_layernorm and self._dense_f16x2(self._hidden_dim, self._hidden_dim)
             )
+            # ... and the next layer's input dropout, when this layer's output goes straight into it
+            direct = not (dense_here or has_ex or self._use_inter_layer_layernorm)
+            mp_layer._fused_output_dropout = drop_for(layer_idx + 1, need_all_representations) if direct else None
+            mp_layer._fused_output_dropout_done = False
             cur = mp_layer(MessagePassingInput(node_embeddings=cur, adjacency_lists=graph), training=training)
+            dropped = bool(mp_layer._fused_output_dropout_done)
+            mp_layer._fused_output_dropout = None
             all_reprs.append(cur)
-            if str(layer_idx) in self._global_exchange_layers:  # gnn.py:307-315
+            if has_ex:  # gnn.py:307-315
                 ex = self._global_exchange_layers[str(layer_idx)]
-                self._dropout_calls += 1
-                ex.dropout_seed = self.dropout_seed * 1000003 + self._dropout_calls
+                ex.dropout_seed = ex_seed[layer_idx]
                 cur = ex(GraphGlobalExchangeInput(cur, inputs.node_to_graph_map, inputs.num_graphs), training=training)
             if self._use_inter_layer_layernorm:
                 g_, b_ = self._inter_layer_layernorms[layer_idx]
                 st["ln_in"] = cur
                 cur, st["ln_mean"], st["ln_rstd"] = ops.layernorm_forward(cur, g_.value, b_.value, 1e-3)
-            if layer_idx % self._dense_every_num_layers == 0:
+            if dense_here:
                 st["dense_in"] = cur
-                cur, st["dense_pre"] = self._dense(cur, self._dense_layers[str(layer_idx)], self._dense_act)
+                cur, st["dense_pre"], dropped = self._dense(cur, self._dense_layers[str(layer_idx)], self._dense_act,
+                                                            drop=drop_for(layer_idx + 1, False))
                 st["dense_out"] = cur
+                st["dense_out_scale"] = (1.0 - rate) if dropped else 1.0
             steps.append(st)
         self._ctx = ctx
-        return cur, tuple(all_reprs)
+        return cur, (tuple(all_reprs) if need_all_representations else None)
+
+    def dropout_masks(self):
+        """The layer-input dropout masks of the last training-mode forward pass, one [V, H] tensor (0 or 1/(1-rate)) or None
+        per layer - stored ones as they are, fused ones (applied in a producer's epilogue, never stored) regenerated from
+        their seed."""
+        if self._ctx is None:
+            raise RuntimeError("no forward pass recorded")
+        out = []
+        for st in self._ctx["steps"]:
+            out.append(st["mask"] if "mask" in st else (st["drop"].mask() if "drop" in st else None))
+        return out
 
     # ---- backward (stands in for tf.GradientTape, models/graph_task_model.py:347-357) ---------
     def _tail_first_backward_op(self, layer_idx: int, ctx):
         """What the backward pass meets first below layer ``layer_idx``'s input gradient (after its dropout mask): the
         activation of the last forward op of layer ``layer_idx - 1`` (Dense, else the message passing layer itself), or
-        of the initial projection for layer 0.  -> (activation name, saved tensor) or None if that op is not a plain
-        activation (LayerNorm / global exchange in between, no activation)."""
+        of the initial projection for layer 0.  -> (activation name, saved tensor[, saved_scale]) or None if that op is not a
+        plain activation (LayerNorm / global exchange in between, no activation); saved_scale = 1 - rate when the saved
+        tensor is the DROPPED output of that op (its producer applied the next dropout): the derivative is taken at
+        saved * saved_scale."""
         if layer_idx == 0:
             if self._init_act is None:
                 return None
-            return self._init_act, (ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
+            return self._init_act, (ctx["pre0"] if self._init_act == "gelu" else ctx["h0"]), ctx.get("h0_scale", 1.0)
         prev = layer_idx - 1
         st = ctx["steps"][prev]
         if prev % self._dense_every_num_layers == 0:
             if self._dense_act is None:
                 return None
-            return self._dense_act, (st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"])
+            return (self._dense_act, (st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"]),
+                    st.get("dense_out_scale", 1.0))
         if self._use_inter_layer_layernorm or str(prev) in self._global_exchange_layers:
             return None
         return self._mp_layers[prev].activation_backward_spec()
@@ -323,18 +403,42 @@ class GNN:
         extras = list(grad_all_representations) if grad_all_representations is not None else [None] * (self._num_layers + 1)
         if len(extras) != self._num_layers + 1:
             raise ValueError(f"grad_all_representations needs {self._num_layers + 1} entries, got {len(extras)}")
+        if grad_all_representations is not None and not ctx.get("all_representations", True) and any(e is not None for e in extras):
+            raise ValueError("grad_all_representations given, but the forward pass ran without return_all_representations=True "
+                             "(the intermediate results were not materialised)")
         g = grad_output
         if g is None:  # only intermediate results were read: the last op's output gets no gradient of its own
             g = torch.zeros_like(ctx["steps"][-1].get("dense_out", ctx["h0"])) if self._num_layers else None
         g_is_pre = False  # g already carries the activation derivative of the op differentiated next
         g_last = None
         try:
-            return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
+            was_f16x2 = ops.get_gemm_mode() == ops.GEMM_F16X2
+            result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
+            if was_f16x2 and self._guard_sync_passes > 0:
+                # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
+                # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
+                # first passes of a model (TFGNN_GUARD_SYNC_PASSES, default 3: whether a model's gradient rows are spread
+                # that far shows at once - RGAT's attention-weighted rows trip it on the first step) wait for the pass and,
+                # if it tripped, run it again on the exact kernels; later trips demote the mode from the NEXT pass on and
+                # say so (ops.get_gemm_mode warns), but the tripping pass itself is not recomputed (README.md).
+                self._guard_sync_passes -= 1
+                if ops.f16x2_guard_tripped_sync():
+                    ops.get_gemm_mode()  # demotes (sticky) and warns
+                    for v in self.trainable_variables:
+                        v.grad = None
+                    result = self._backward_walk(ctx, g, False, None, extras, need_input_grad)
+            return result
         finally:
             # stand-alone layer.backward() calls after this pass join the second stream themselves again
             for mp in self._mp_layers:
                 mp._defer_aux_join = False
+            ops.aux_flush()        # the deferred split reductions of the weight gradients: one launch for all layers
             ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
+
+    @staticmethod
+    def _activation_backward_scaled(act, g, saved, saved_scale):
+        _, spec = ops.plain_epilogue(None, (act, saved, saved_scale))
+        return ops.activation_backward(act, g, spec[1])
 
     def _backward_walk(self, ctx, g, g_is_pre, g_last, extras, need_input_grad):
         for layer_idx in range(self._num_layers - 1, -1, -1):
@@ -347,9 +451,9 @@ class GNN:
                 w = self._dense_layers[str(layer_idx)]
                 gpre = g
                 if self._dense_act is not None and not g_is_pre:
-                    gpre = ops.activation_backward(
-                        self._dense_act, g, st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"]
-                    )
+                    gpre = self._activation_backward_scaled(
+                        self._dense_act, g, st["dense_pre"] if self._dense_act == "gelu" else st["dense_out"],
+                        st.get("dense_out_scale", 1.0))
                 nxt = None if (has_ln or has_ex or extras[layer_idx + 1] is not None) else mp.activation_backward_spec()
                 g = self._dense_backward(st["dense_in"], w, gpre, act_grad=nxt)
                 g_is_pre = nxt is not None
@@ -361,7 +465,7 @@ class GNN:
             if extras[layer_idx + 1] is not None:  # g is the plain gradient here (the fusions above were switched off)
                 g = ops.add_scale(g, extras[layer_idx + 1], 1.0)
             residual_here = layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and g_last is None)
-            mask = st.get("mask")
+            mask = st.get("mask", st.get("drop"))  # a stored mask tensor, or the spec of one applied by the producer
             if not residual_here:
                 nxt = None if extras[layer_idx] is not None else self._tail_first_backward_op(layer_idx, ctx)
                 # the gradient this layer hands down goes straight into a Dense / projection weight-gradient product when
@@ -381,12 +485,13 @@ class GNN:
                     g = ops.add_scale(g, g_last, 1.0)
                     g_last = None
                 if mask is not None:
-                    g = ops.mul(g, mask)
+                    g = ops.mul(g, mask.mask() if isinstance(mask, ops.DropoutSpec) else mask)
         if extras[0] is not None:
             g = ops.add_scale(g, extras[0], 1.0)
         gpre = g
         if self._init_act is not None and not g_is_pre:
-            gpre = ops.activation_backward(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"])
+            gpre = self._activation_backward_scaled(self._init_act, g, ctx["pre0"] if self._init_act == "gelu" else ctx["h0"],
+                                                    ctx.get("h0_scale", 1.0))
         return self._dense_backward(ctx["X"], self._initial_projection_layer, gpre, need_input_grad=need_input_grad)
 
 

@@ -114,8 +114,8 @@ class GGNN(GNN_Edge_MLP):
         ru["kernel"].grad = ops.sp_gemm_tn(ops.sp_rows_of(ctx["agg"]), dmx_sp)  # agg^T dmx  [H, 3H]
         ru["recurrent_kernel"].grad = ops.sp_gemm_tn(ops.sp_rows_of(X), dmh_sp)  # h^T dmh
         ru["bias"].grad = bias_grad
-        d_agg = ops.sp_gemm_nt(dmx_sp, ops.sp_weight_operand(Wk, "rows", lambda: ops.sp_split_rows(Wk)))
-        dX = ops.sp_gemm_nt(dmh_sp, ops.sp_weight_operand(Wr, "rows", lambda: ops.sp_split_rows(Wr)), out=dh_direct,
+        d_agg = ops.sp_gemm_nt(dmx_sp, ops.sp_weight_operand(Wk, "rows", lambda: ops.sp_split_rows(Wk, defer=True)))
+        dX = ops.sp_gemm_nt(dmh_sp, ops.sp_weight_operand(Wr, "rows", lambda: ops.sp_split_rows(Wr, defer=True)), out=dh_direct,
                             accumulate=True, out_mul=out_mul)
         # the message path adds its term into the same buffer (GNN_Edge_MLP._backward_A_f16x2 consumes the request)
         self._dx_accumulate = (dX, out_mul)

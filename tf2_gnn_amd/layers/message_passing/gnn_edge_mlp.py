@@ -163,6 +163,21 @@ class GNN_Edge_MLP(MessagePassing):
         """Did a subclass replace the message function?  Then the node-side formulations below do not apply."""
         return not getattr(type(self)._message_function, "_tfgnn_builtin", False)
 
+    def graph_parts(self, num_nodes: int, edges_per_type, in_dim: int) -> int:
+        """path A without target states reads the typed views only (forward: buckets by target, backward: by source); with
+        one message per edge (molecule-sized batches) the node view as well.  Everything else: all parts."""
+        import os
+        from types import SimpleNamespace
+
+        if (self._user_message_function() or self._path() != "A" or self._use_target_state_as_input or self._compact_opt_in
+                or os.environ.get("TFGNN_COMPACT_BUCKETS") == "1"):
+            return ops.G_PARTS_ALL
+        shape = SimpleNamespace(num_edge_types=len(edges_per_type), num_edges=int(sum(edges_per_type)), num_nodes=int(num_nodes),
+                                edges_per_type=tuple(int(c) for c in edges_per_type))
+        if messages_per_edge(self, shape, in_dim, self._hidden_dim):
+            return ops.G_PART_PLAN_TYPED | ops.G_PART_PLAN_NODE
+        return ops.G_PART_PLAN_TYPED
+
     # ---- which formulation ------------------------------------------------------------------
     def _path(self) -> str:
         linear = self._edge_type_mlps.num_layers == 1
@@ -371,15 +386,23 @@ class GNN_Edge_MLP(MessagePassing):
         if self._f16x2_eligible(V, D, L, H):
             # f16x2: the gather writes [A_0 | ... | A_{L-1}] directly as the split operand (one scale per (node, type)
             # bucket), the kernels are split once per value, the product only moves data and multiplies
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L)
-            Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H)))
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L, defer_combine=True)
+            Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H), defer=True))
             gelu_split = fuse_act == "gelu"
             want_split = getattr(self, "_want_split_output", False) or getattr(self, "_always_split_output", False)
-            if want_split and not gelu_split and H in (128, 256, 320):
+            drop = getattr(self, "_fused_output_dropout", None)  # (rate, seed) of the NEXT layer's input dropout (GNN stack)
+            out_scale = 1.0
+            if drop is not None and not gelu_split and H in (128, 256, 320) and type(self)._finish is GNN_Edge_MLP._finish:
+                # this layer's output is only ever read through that dropout: apply the mask in the product's epilogue and
+                # write the dropped result in both forms (fp32 for the next gather, SP16 for its weight-gradient product)
+                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, dropout=drop)
+                self._fused_output_dropout_done = True
+                out_scale = 1.0 - float(drop[0])
+            elif want_split and not gelu_split and H in (128, 256, 320):
                 pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act)  # the consumer finds the split form with sp_rows_of
             else:
                 pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)
-            ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True}
+            ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True, "out_scale": out_scale}
             if gelu_split:
                 ctx["pre"] = pre
                 return ops.activation_forward("gelu", pre), ctx
@@ -417,7 +440,8 @@ class GNN_Edge_MLP(MessagePassing):
         W = mlps.kernels[0]  # [L, D, H]
         import os
 
-        G_sp = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED, d_agg.contiguous(), edge_weight=ew_s, rows_per_operand_row=L)
+        G_sp = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED, d_agg.contiguous(), edge_weight=ew_s, rows_per_operand_row=L,
+                                   defer_combine=True)
         # the weight gradient dW = X^T G is off the critical path of the backward pass: its two small passes (per-k factors,
         # split reduction) run on the library's second stream beside the big kernels around them
         overlap = os.environ.get("TFGNN_TN_OVERLAP", "0") == "1"
@@ -425,7 +449,7 @@ class GNN_Edge_MLP(MessagePassing):
         if overlap:
             dW = torch.empty_like(W)
             tn = ops.SpGemmTnOverlapped(G_sp, ops.sp_rows_of(X), out=dW, scatter=(H, D * H, 1, H))  # factors: second stream
-        Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H)))
+        Wh_sp = ops.sp_weight_operand(W, "rows", lambda: ops.sp_split_rows(W[0], segments=(H, D * H, L * H), defer=True))
         epi = getattr(self, "_out_epilogue", None)
         acc = getattr(self, "_dx_accumulate", None)
         if acc is not None:
@@ -448,7 +472,10 @@ class GNN_Edge_MLP(MessagePassing):
         else:
             X_sp = ops.sp_rows_of(X)  # written by the dropout kernel when X came out of one
             dW = torch.empty_like(W)
-            ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))  # element ((l, h), d) -> dW[l, d, h]
+            # element ((l, h), d) -> dW[l, d, h].  (The split reduction stays right behind the product: deferred into a later
+            # merged launch - ops.sp_gemm_tn(defer_reduce=True) - it finds its 41 MB of partials evicted and takes 45 us
+            # instead of 14.)
+            ops.sp_gemm_tn(G_sp, X_sp, out=dW, scatter=(H, D * H, 1, H))
         mlps.grads = [dW]
         mlps.publish_grads()
         return dX
@@ -758,7 +785,9 @@ class GNN_Edge_MLP(MessagePassing):
         if ctx is None or not self._plain_base_backward() or ctx.get("fused_act") is None:
             return None
         act = ctx["fused_act"]
-        return act, (ctx["pre"] if act == "gelu" else ctx["out"])
+        # (third entry: the saved output is a DROPPED one - the next layer's dropout ran in this layer's product epilogue -
+        # and carries 1 / (1 - rate) where kept: the derivative is taken at saved * scale)
+        return act, (ctx["pre"] if act == "gelu" else ctx["out"]), (1.0 if act == "gelu" else ctx.get("out_scale", 1.0))
 
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
         if not self._plain_base_backward() or (self._ctx is not None and self._ctx.get("generic")):
@@ -782,7 +811,8 @@ class GNN_Edge_MLP(MessagePassing):
         if act is None:
             return grad_output
         saved = ctx["pre"] if act == "gelu" else ctx["out"]
-        return ops.activation_backward(act, grad_output, saved)
+        _, spec = ops.plain_epilogue(None, (act, saved, 1.0 if act == "gelu" else ctx.get("out_scale", 1.0)))
+        return ops.activation_backward(act, grad_output, spec[1])
 
     def _backward_messages(self, d_agg, ctx):
         """d(aggregated messages) [V, H] -> dX [V, D]; fills the edge-MLP kernel gradients."""
@@ -804,7 +834,7 @@ class GNN_Edge_MLP(MessagePassing):
             dM = self._message_grads(g, d_agg, ctx, Y, g.array(ops.G_COLL_BY_DST), g.array(ops.G_TARGET_BY_DST), ew_d,
                                      node_scale, self._ident_e(g)[: g.num_edges])
             G = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, dM, col=g.array(ops.G_SRC2DST_POS)).view(V, L, H)
-        elif ctx.get("f16x2"):
+        elif ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2:  # (not after the spread guard demoted the mode)
             return self._backward_A_f16x2(d_agg, ctx, g, X, ew_s)
         else:
             # G[u, l, :] = sum over edges (u -> v) of type l of w_e * d_agg[v, :]

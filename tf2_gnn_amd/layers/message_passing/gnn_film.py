@@ -30,6 +30,9 @@ class GNN_FiLM(GNN_Edge_MLP):
     edge-MLP machinery of GNN_Edge_MLP, modulated per edge (csrc/edge.hip tfgnn_film_edge_*), then the general
     aggregation kernel."""
 
+    def graph_parts(self, num_nodes, edges_per_type, in_dim) -> int:
+        return ops.G_PARTS_ALL  # compact buckets / per-edge forms: every derived table of the handle
+
     @classmethod
     def get_default_hyperparameters(cls):
         these_hypers = {

@@ -117,7 +117,7 @@ def _graph_key(adjacency_lists, num_nodes: int) -> tuple:
     )
 
 
-def get_graph(adjacency_lists, num_nodes: int) -> "ops.Graph":
+def get_graph(adjacency_lists, num_nodes: int, parts: int = ops.G_PARTS_ALL) -> "ops.Graph":
     """The bucketed Graph of a batch, built once and shared by every layer / pass that is handed the same adjacency
     tensors.  An entry holds references to those tensors, so their addresses cannot be given to another batch while
     the entry is alive (a key of addresses alone would return a stale Graph when the allocator reuses them); an
@@ -131,7 +131,7 @@ def get_graph(adjacency_lists, num_nodes: int) -> "ops.Graph":
     key = _graph_key(adjacency_lists, num_nodes)
     entry = _GRAPH_CACHE.get(key)
     if entry is None:
-        g = ops.Graph(adjacency_lists, num_nodes)
+        g = ops.Graph(adjacency_lists, num_nodes, parts=parts)
         _GRAPH_CACHE[key] = (g, adjacency_lists)
         while len(_GRAPH_CACHE) > _GRAPH_CACHE_SIZE:
             _GRAPH_CACHE.popitem(last=False)
@@ -168,6 +168,12 @@ class MessagePassing:
             "message_activation_before_aggregation": False,  # Change to True to apply activation _before_ aggregation.
             "hidden_dim": 7,
         }
+
+    def graph_parts(self, num_nodes: int, edges_per_type, in_dim: int) -> int:
+        """Which derived tables of the batch's graph handle this layer reads (ops.G_PART_*), for a batch of that shape: a
+        stack whose layers need only some of them skips the preparation kernels of the rest (include/tfgnn.h
+        tfgnn_graph_create_parts_async).  A hint, not a contract: a missing part is built on first use.  Default: all."""
+        return ops.G_PARTS_ALL
 
     def __init__(self, params: Dict[str, Any], **kwargs):
         self.name = kwargs.get("name", type(self).__name__)
@@ -416,6 +422,7 @@ class MessagePassing:
 
 
 def apply_gradient_epilogue(g, out_mul, out_act_grad):
+    out_mul, out_act_grad = ops.plain_epilogue(out_mul, out_act_grad)
     if out_mul is not None:
         g = ops.mul(g, out_mul)
     if out_act_grad is not None:

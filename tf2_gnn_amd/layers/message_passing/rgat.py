@@ -96,7 +96,7 @@ class RGAT(MessagePassing):
         f16 = self._f16x2_eligible(V, X.shape[1], L, H)
         if f16:
             # f16x2: Y = X [W_0 | ... | W_{L-1}] on split operands (X's split form comes from the dropout kernel in a GNN stack)
-            Wn = ops.sp_weight_operand(self._kernels, "cols", lambda: ops.sp_split_cols(self._kernels))
+            Wn = ops.sp_weight_operand(self._kernels, "cols", lambda: ops.sp_split_cols(self._kernels, defer=True))
             Y = ops.sp_gemm_nt(ops.sp_rows_of(X), Wn)
         else:
             Y = ops.gemm(X, self._kernels)  # [V, L*H] == rows (v, l) of width H
@@ -153,6 +153,7 @@ class RGAT(MessagePassing):
         if E == 0:
             return att, None
         att_by_src = torch.empty((E, K), dtype=torch.float32, device=dev) if training else None
+        g.ensure(ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_MAPS)
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
         rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(att_by_src),
@@ -211,6 +212,7 @@ class RGAT(MessagePassing):
             )
         )
         dz = torch.empty((E, K), dtype=torch.float32, device=dev)
+        g.ensure(ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_MAPS)
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
         rc = lib.tfgnn_rgat_attention_backward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), K, ops._ptr(dz),
@@ -250,7 +252,7 @@ class RGAT(MessagePassing):
                                                    ops._ptr(dY_sp.data), ops._ptr(dY_sp.inv_scale), ops._stream())
             if rc == 0:
                 d_kernels = ops.gemm(X, dY.view(V, L * H), trans_a=True)  # X^T dY  [D, L*H]
-                Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels))
+                Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels, defer=True))
                 dX = ops.sp_gemm_nt(dY_sp, Wr)
             elif rc != -4:
                 _lib.check(rc)

@@ -19,6 +19,9 @@ class RGIN(GNN_Edge_MLP):
     Aggregation MLP only if ``num_aggr_MLP_hidden_layers`` is not None (rgin.py:79-85); the layer
     ignores ``message_activation_before_aggregation`` (rgin.py:88-106)."""
 
+    def graph_parts(self, num_nodes, edges_per_type, in_dim) -> int:
+        return ops.G_PARTS_ALL  # compact buckets / per-edge forms: every derived table of the handle
+
     @classmethod
     def get_default_hyperparameters(cls):
         these_hypers = {

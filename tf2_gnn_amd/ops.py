@@ -6,6 +6,7 @@ current HIP stream, every FLOP and byte of the hot path runs in libtfgnn.so.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -38,8 +39,69 @@ def act_id(name_or_id) -> int:
         raise ValueError(f"Unknown activation function: {name_or_id}")
 
 
-def _stream() -> int:
+def _raw_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _stream() -> int:
+    """The launch stream of a library call.  Every wrapper evaluates this right before its C call, which makes it the one
+    place where deferred small passes (``aux_defer``) that the coming kernel may depend on are launched first."""
+    if _AUX_PENDING and _AUX_URGENT[0]:
+        aux_flush(everything=False)
+    return _raw_stream()
+
+
+# ---- small passes that share a launch (include/tfgnn.h tfgnn_aux_launch) ---------------------------------------------------------
+# A deferred job runs at the next library launch on the stream (urgent jobs: something may read their result) or at the next
+# flush that has an urgent job / an explicit aux_flush() (non-urgent: results nobody reads before the end of the pass, e.g. the
+# split-K reductions of weight gradients).  Deferring only ever moves a pass LATER, and nothing is launched between a deferral
+# and the flush that runs it, so every input of a job is complete and none is overwritten in between; non-urgent jobs own
+# their inputs (the workspace of a weight-gradient product is kept by the job).  Jobs pending on one stream are flushed before
+# work is enqueued for another stream.
+_AUX_PENDING = []     # [(AuxJob, keep-alive tuple)]
+_AUX_URGENT = [False]
+_AUX_STREAM = [None]
+
+
+def aux_enabled() -> bool:
+    import os
+
+    return os.environ.get("TFGNN_AUX_MERGE", "1") != "0"
+
+
+def aux_defer(job, keep=(), urgent: bool = True, then=None) -> None:
+    """Queue a tfgnn_aux_job (``_lib.AuxJob``; kind 0 = nothing) for the next merged launch.  ``then()`` runs right after the
+    launch that carries the job (work that needs the job's result but is itself off the critical path: a weight-gradient
+    product behind its factor pass)."""
+    if (job.kind == 0 or job.num_blocks == 0) and then is None:
+        return
+    st = _raw_stream()
+    if _AUX_PENDING and _AUX_STREAM[0] != st:
+        aux_flush()
+    _AUX_STREAM[0] = st
+    _AUX_PENDING.append((job, keep, then))
+    if urgent:
+        _AUX_URGENT[0] = True
+
+
+def aux_flush(everything: bool = True) -> None:
+    """Launch what has been deferred so far (one launch per 8 jobs) on the stream it was deferred for, then the work chained
+    to those jobs.  ``everything``: repeat until nothing is pending (chained work may defer further non-urgent jobs - the
+    reduction behind a deferred product); otherwise one round (what ``_stream()`` does before a library call)."""
+    while _AUX_PENDING:
+        batch = list(_AUX_PENDING)
+        del _AUX_PENDING[:]
+        _AUX_URGENT[0] = False
+        live = [j for j, _, _ in batch if j.kind != 0 and j.num_blocks != 0]
+        st = _AUX_STREAM[0]
+        if live:
+            jobs = (_lib.AuxJob * len(live))(*live)
+            _lib.check(_lib.load().tfgnn_aux_launch(jobs, len(jobs), st))
+        for _, _, then in batch:
+            if then is not None:
+                then()
+        if not everything:
+            break
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -115,6 +177,16 @@ class _DevArray:
  G_NZ_OFF_BY_DST, G_NZ_NODEPTR_BY_DST, G_NZ_COL_BY_DST, G_NZ_CPOS_BY_SRC, G_NZ_ROW_BY_SRC, G_NZ_NODE_BY_SRC,
  G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC) = range(27)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
+# parts of a graph handle beyond the two sorted edge orders (include/tfgnn.h tfgnn_graph_part)
+G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PARTS_ALL = 1, 2, 4, 8, 15
+_VIEW_PARTS = {0: G_PART_PLAN_TYPED, 1: G_PART_PLAN_NODE, 2: G_PART_PLAN_TYPED, 3: G_PART_PLAN_NODE,
+               4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT}
+
+
+def _array_parts(array_id: int) -> int:
+    if array_id == G_SRC2DST_POS:
+        return G_PART_EDGE_MAPS
+    return G_PART_COMPACT if G_NZ_CPOS_BY_DST <= array_id <= G_NZ_COL_BY_SRC else 0
 
 
 class Graph:
@@ -122,10 +194,12 @@ class Graph:
     and for forward + backward.  ``adjacency_lists``: sequence of int32 device tensors [E_l, 2]
     with rows (source, target), exactly ``GNNInput.adjacency_lists`` (layers/gnn.py:241-244)."""
 
-    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, wait: bool = True):
+    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, wait: bool = True, parts: int = G_PARTS_ALL):
         """wait=False: the build is only enqueued on the current stream (pipelining the next batch's
         bucketing behind the current step, like the reference's prefetching input pipeline); call
-        ``wait()`` - and order the consuming stream after the build stream - before using it."""
+        ``wait()`` - and order the consuming stream after the build stream - before using it.
+        parts: which derived tables to build now (G_PART_*; ``GNN.graph_parts`` names what a layer stack reads); a part that
+        turns out to be missing is built on first use (``ensure``: correct, but it blocks the host once)."""
         lib = _lib.load()
         adjs = []
         for i, a in enumerate(adjacency_lists):
@@ -143,9 +217,11 @@ class Graph:
         handle = ctypes.c_void_p()
         self._h = None
         _lib.check(
-            lib.tfgnn_graph_create_async(L, int(num_nodes), ptrs, counts, _stream(), ctypes.byref(handle))
+            lib.tfgnn_graph_create_parts_async(L, int(num_nodes), ptrs, counts, int(parts) & G_PARTS_ALL, _stream(),
+                                               ctypes.byref(handle))
         )
         self._h = handle
+        self.parts = int(parts) & G_PARTS_ALL
         self._pending = True
         self.num_nodes = int(num_nodes)
         self.num_edge_types = L
@@ -168,9 +244,18 @@ class Graph:
                 raise
         return self
 
+    def ensure(self, parts: int) -> "Graph":
+        """Build the parts that were not requested at creation, on the current stream (tfgnn_graph_ensure; blocks the host)."""
+        if parts & ~self.parts:
+            self.wait()
+            _lib.check(_lib.load().tfgnn_graph_ensure(self._h, int(parts), _stream()))
+            self.parts |= int(parts)
+        return self
+
     def array(self, array_id: int) -> torch.Tensor:
         if array_id in self._cache:
             return self._cache[array_id]
+        self.ensure(_array_parts(array_id))
         lib = _lib.load()
         p = ctypes.c_void_p()
         n = ctypes.c_int64()
@@ -189,6 +274,7 @@ class Graph:
         key = ("nz_off", bool(by_src))
         off = self._cache.get(key)
         if off is None:
+            self.ensure(G_PART_COMPACT)
             buf = (ctypes.c_int32 * (self.num_edge_types + 1))()
             _lib.check(_lib.load().tfgnn_graph_nonempty_offsets(self._h, int(by_src), buf))
             off = list(buf)
@@ -297,6 +383,7 @@ def graph_gather(
     if edge_weight is not None:
         edge_weight = edge_weight.contiguous()
         heads = edge_weight.shape[1] if edge_weight.dim() == 2 else 1
+    graph.ensure(_VIEW_PARTS[view])
     ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, width)
     ws = _workspace(inp.device, ws_bytes) if ws_bytes else None
     _lib.check(
@@ -309,6 +396,58 @@ def graph_gather(
     return out
 
 
+class DropoutSpec:
+    """A layer-input dropout whose mask is not stored: (rate, seed, shape).  The producer of the tensor applied the mask in its
+    epilogue (``sp_gemm_nt(..., dropout=...)``); the backward pass hands the spec to a product that RECOMPUTES the mask, or -
+    on a path without such an epilogue - materialises it once with ``mask()`` (the tensor ``dropout_forward`` would have
+    returned for this seed)."""
+
+    def __init__(self, rate: float, seed: int, shape, device):
+        self.rate, self.seed, self.shape, self.device = float(rate), int(seed), tuple(shape), device
+        self._mask = None
+
+    @property
+    def keep(self) -> float:
+        return 1.0 - self.rate
+
+    def mask(self) -> torch.Tensor:
+        if self._mask is None:
+            self._mask = dropout_mask(self.shape, self.rate, self.seed, self.device)
+        return self._mask
+
+
+def plain_epilogue(out_mul, act_grad):
+    """-> (mask tensor | None, (activation, saved) | None): the gradient factors for a kernel WITHOUT the recomputing
+    epilogue.  ``out_mul`` may be a DropoutSpec (materialised), ``act_grad`` a triple (activation, saved, saved_scale) -
+    the derivative at saved * saved_scale, saved being a dropped activation (one more pass over it here)."""
+    if isinstance(out_mul, DropoutSpec):
+        out_mul = out_mul.mask()
+    if act_grad is not None and len(act_grad) == 3:
+        act, saved, scale = act_grad
+        if float(scale) != 1.0:
+            saved = add_scale(saved, saved, 0.5 * float(scale))
+        act_grad = (act, saved)
+    return out_mul, act_grad
+
+
+def _native_epilogue(out_mul, act_grad, dropout, saved_scale):
+    """the same specs for the split-operand product, which takes them as they are"""
+    spec = out_mul if isinstance(out_mul, DropoutSpec) else None
+    if spec is not None:
+        if dropout is not None:
+            raise ValueError("two dropout masks on one product")
+        dropout, out_mul = (spec.rate, spec.seed), None
+    if act_grad is not None and len(act_grad) == 3:
+        saved_scale = float(act_grad[2])
+        act_grad = (act_grad[0], act_grad[1])
+        if (spec is not None and act_grad[0] == "relu" and abs(saved_scale - spec.keep) < 1e-12 and saved_scale != 1.0
+                and tuple(act_grad[1].shape) == spec.shape):
+            # the saved tensor is the relu output dropped with THIS mask: it is positive exactly where the unit was kept and
+            # active - no mask needs to be recomputed (tfgnn_sp_gemm_nt_dropout, seed UINT64_MAX)
+            dropout = (spec.rate, 0xFFFFFFFFFFFFFFFF)
+    return out_mul, act_grad, dropout, saved_scale
+
+
 @_writes_out
 def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None, accumulate=False) -> torch.Tensor:
     """out = (a @ op(b)) * out_mul * act'(saved) (+ out if ``accumulate``): an input-gradient product with the element-wise
@@ -318,6 +457,7 @@ def gemm_grad(a, b, *, trans_b=False, out=None, out_mul=None, act_grad=None, acc
     product (with ``accumulate`` the result is added into ``out`` and ``out`` is returned)."""
     if accumulate and out is None:
         raise ValueError("accumulate=True needs out")
+    out_mul, act_grad = plain_epilogue(out_mul, act_grad)
     if out_mul is None and act_grad is None:
         return gemm(a, b, trans_b=trans_b, out=out, accumulate=accumulate)
     lib = _lib.load()
@@ -362,45 +502,47 @@ _spread_warned = [False]
 
 
 def _f16x2_on() -> bool:
-    if _f16x2[0] is None:
-        import os
+    """Is the library in mode f16x2 (include/tfgnn.h TFGNN_GEMM_F16X2)?  The library itself holds the mode and demotes it when
+    the spread guard of the split weight-gradient product trips (tfgnn_gemm_get_mode); this mirror only warns once."""
+    on = _lib.load().tfgnn_gemm_get_mode() == GEMM_F16X2
+    if _f16x2[0] and not on and not _spread_warned[0] and _lib.load().tfgnn_sp_spread_flag(0):
+        _spread_warned[0] = True
+        import warnings
 
-        _f16x2[0] = os.environ.get("TFGNN_GEMM_MODE", "f16x2") in ("f16x2", "")
-        if _f16x2[0]:
-            _lib.check(_lib.load().tfgnn_gemm_set_mode(GEMM_BF16X3))
-    if _f16x2[0] and _lib.load().tfgnn_sp_spread_flag(0):
-        # the guard of the split-operand weight-gradient product (include/tfgnn.h, tfgnn_sp_spread_flag): an operand's row
-        # scales spread over more than 2^20 - from here on the layers take the exact bf16x3 kernels (sticky until
-        # set_gemm_mode("f16x2") is called again)
-        _f16x2[0] = False
-        if not _spread_warned[0]:
-            _spread_warned[0] = True
-            import warnings
-
-            warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread over more than 2^20 in magnitude; "
-                          "the f16x2 layer paths are switched to the exact bf16x3 kernels (ops.set_gemm_mode('f16x2') re-arms them)")
-    return _f16x2[0]
+        warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread over more than 2^20 in magnitude; "
+                      "the f16x2 layer paths are switched to the exact bf16x3 kernels (ops.set_gemm_mode('f16x2') re-arms them)")
+    _f16x2[0] = on
+    return on
 
 
 def set_gemm_mode(mode) -> int:
     """Select how the Dense products are evaluated: "fp32" (fp32 MFMA), "bf16x3" (exact 3-way bf16 split of both operands,
-    6 piece products), "bf16x3_9" (all 9) - include/tfgnn.h, tfgnn_gemm_set_mode - or "f16x2": the layers hand the hot
-    products pre-split SP16 operands (tfgnn_sp_gemm_*: 2-way fp16 split, 3 piece products, the gather writes the
-    operand) and every other product runs as in "bf16x3".  "f16x2" is the DEFAULT (environment TFGNN_GEMM_MODE overrides);
-    its spread guard (tfgnn_sp_spread_flag) demotes it to "bf16x3" when an operand's row scales spread over more than 2^20.
-    Returns the previous mode id."""
+    6 piece products), "bf16x3_9" (all 9) or "f16x2": the layers hand the hot products pre-split SP16 operands
+    (tfgnn_sp_gemm_*: 2-way fp16 split, 3 piece products, the gather writes the operand) and every other product runs as in
+    "bf16x3" - include/tfgnn.h, tfgnn_gemm_set_mode.  "f16x2" is the DEFAULT of the library (environment TFGNN_GEMM_MODE
+    overrides); its spread guard (tfgnn_sp_spread_flag) demotes it to "bf16x3" when an operand's row scales spread over more
+    than 2^20; setting "f16x2" again re-arms the guard (waits for the device).  Returns the previous mode id."""
     lib = _lib.load()
     prev = get_gemm_mode()
     mode = _GEMM_MODE_NAMES.get(mode, mode)
-    if mode == GEMM_F16X2:
-        lib.tfgnn_sp_spread_flag(1)  # re-arm the spread guard
+    aux_flush()
+    _lib.check(lib.tfgnn_gemm_set_mode(mode))
     _f16x2[0] = mode == GEMM_F16X2
-    _lib.check(lib.tfgnn_gemm_set_mode(GEMM_BF16X3 if mode == GEMM_F16X2 else mode))
     return prev
 
 
 def get_gemm_mode() -> int:
-    return GEMM_F16X2 if _f16x2_on() else _lib.load().tfgnn_gemm_get_mode()
+    _f16x2_on()
+    return _lib.load().tfgnn_gemm_get_mode()
+
+
+def f16x2_guard_tripped_sync() -> bool:
+    """Wait for the current stream, then read the spread guard: True if a split weight-gradient product enqueued so far met
+    operand rows spread over more than 2^20 (its result may have lost low-order rows).  The synchronous form of the guard:
+    ``GNN.backward`` uses it for the first backward passes of a model and recomputes a tripped pass on the exact kernels."""
+    aux_flush()
+    torch.cuda.current_stream().synchronize()
+    return bool(_lib.load().tfgnn_sp_spread_flag(0))
 
 
 @_writes_out
@@ -466,6 +608,7 @@ def _identity_rowptr(device, n: int) -> torch.Tensor:
     return t[: n + 1]
 
 
+@_writes_out
 def gemm_gathered(a: torch.Tensor, row_index: torch.Tensor, b: torch.Tensor, *, trans_b: bool = False,
                   bias: Optional[torch.Tensor] = None, act=ACT_NONE, out: Optional[torch.Tensor] = None,
                   accumulate: Optional[str] = None) -> torch.Tensor:
@@ -676,6 +819,18 @@ def dropout_forward(x: torch.Tensor, rate: float, seed: int):
     return y, mask
 
 
+def dropout_mask(shape, rate: float, seed: int, device=None) -> torch.Tensor:
+    """The mask (0 or 1/(1-rate)) a dropout call with this seed draws for a tensor of ``shape`` - what ``dropout_forward``
+    returns and what the fused producers (``sp_gemm_nt(..., dropout=(rate, seed))``) apply without storing it."""
+    lib = _lib.load()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    mask = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if mask.numel():
+        _lib.check(lib.tfgnn_dropout_forward(None, None, _ptr(mask), mask.numel(), float(rate), int(seed) & (2**64 - 1), _stream()))
+    return mask
+
+
 def clip(x: torch.Tensor, lower: Optional[float], upper: Optional[float]) -> torch.Tensor:
     """tf.minimum(tf.maximum(x, lower), upper); None = no bound."""
     lib = _lib.load()
@@ -880,7 +1035,7 @@ class SplitOperand:
 
 
 def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed_inv_scale: Optional[torch.Tensor] = None,
-                  out: Optional[SplitOperand] = None) -> SplitOperand:
+                  out: Optional[SplitOperand] = None, defer: bool = False) -> SplitOperand:
     """SP16 form of the rows of ``x`` [R, C] (unit inner stride).  ``segments = (seg_len, seg_stride, cols)``: row r is
     assembled from cols / seg_len pieces x.data[r * ld + j * seg_stride : ... + seg_len] (e.g. row d of
     [W_0[d, :] | W_1[d, :] | ...] from stacked kernels [L, D, H]: x = W[0], segments = (H, D * H, L * H))."""
@@ -899,6 +1054,13 @@ def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed
             out = SplitOperand(data, fixed_inv_scale, rows, cols, 0)  # one scale for the whole tensor
         else:
             out = SplitOperand(data, torch.empty((rows, cols // sb), dtype=torch.float32, device=x.device), rows, cols, sb)
+    if defer and rows > 0 and aux_enabled():  # a job of the next merged small-pass launch (weights: nothing but launch latency)
+        job = _lib.AuxJob()
+        _lib.check(lib.tfgnn_sp_split_rows_job(_ptr(x), ld, seg_len, seg_stride, rows, cols, sb, _ptr(out.data), out.data.stride(0),
+                                               None if fixed_inv_scale is not None else _ptr(out.inv_scale), _ptr(fixed_inv_scale),
+                                               ctypes.byref(job)))
+        aux_defer(job, keep=(x, out.data, out.inv_scale, fixed_inv_scale))
+        return out
     _lib.check(lib.tfgnn_sp_split_rows(_ptr(x), ld, seg_len, seg_stride, rows, cols, sb, _ptr(out.data), out.data.stride(0),
                                        None if fixed_inv_scale is not None else _ptr(out.inv_scale), _ptr(fixed_inv_scale),
                                        _stream()))
@@ -927,22 +1089,31 @@ def sp_rows_of(x: torch.Tensor) -> SplitOperand:
     return op
 
 
-def sp_split_cols(w: torch.Tensor) -> SplitOperand:
-    """SP16 form of w^T for a row-major [K, N] matrix (a Keras kernel): rows = N, cols = K, one scale per row."""
+def sp_split_cols(w: torch.Tensor, defer: bool = False) -> SplitOperand:
+    """SP16 form of w^T for a row-major [K, N] matrix (a Keras kernel): rows = N, cols = K, one scale per row.
+    defer: as a job of the next merged small-pass launch (``aux_defer``)."""
     lib = _lib.load()
     _require_dev(w, torch.float32, "w")
     w, ld = _rowmajor(w, "w")
     K, N = w.shape
     data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
     inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
-    _lib.check(lib.tfgnn_sp_split_cols(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), _stream()))
+    if defer and aux_enabled():
+        job = _lib.AuxJob()
+        _lib.check(lib.tfgnn_sp_split_cols_job(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), ctypes.byref(job)))
+        aux_defer(job, keep=(w, data, inv))
+    else:
+        _lib.check(lib.tfgnn_sp_split_cols(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), _stream()))
     return SplitOperand(data, inv, N, K, K)
 
 
 @_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
-               act_grad=None) -> torch.Tensor:
-    """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt)."""
+               act_grad=None, dropout=None, saved_scale: float = 1.0) -> torch.Tensor:
+    """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt / tfgnn_sp_gemm_nt_dropout).
+    dropout = (rate, seed): the result times the mask ``dropout_forward`` draws for that seed, applied in the epilogue
+    (forward: the next layer's input dropout; gradient product: the recomputed forward mask).  saved_scale: the derivative
+    of ``act_grad`` is taken at saved * saved_scale (saved is a dropped activation)."""
     lib = _lib.load()
     M, K, N = a.rows, a.cols, b.rows
     if b.cols != K:
@@ -956,23 +1127,26 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
     out2, ldc = _rowmajor(out, "out")
     if out2 is not out or tuple(out.shape) != (M, N):
         raise ValueError(f"out must be [{M},{N}] with unit inner stride")
+    out_mul, act_grad, dropout, saved_scale = _native_epilogue(out_mul, act_grad, dropout, saved_scale)
     act_name, saved = act_grad if act_grad is not None else (None, None)
     if bias is not None:
         bias = bias.contiguous()
+    rate, seed = dropout if dropout is not None else (0.0, 0)
     _lib.check(
-        lib.tfgnn_sp_gemm_nt(
+        lib.tfgnn_sp_gemm_nt_dropout(
             M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
             b.data.stride(0),
             _ptr(b.inv_scale), _ptr(out), ldc, _ptr(bias), act_id(act), int(accumulate), _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
-            saved.stride(0) if saved is not None else 0, _stream(),
+            saved.stride(0) if saved is not None else 0, float(saved_scale), None, 0, None, float(rate),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(),
         )
     )
     return out
 
 
 def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out_mul=None, act_grad=None,
-                     want_fp32: bool = True):
+                     want_fp32: bool = True, dropout=None, saved_scale: float = 1.0):
     """As sp_gemm_nt, with the result ALSO (or only: want_fp32=False) written as an SP16 operand with one scale per row
     by the product's epilogue (tfgnn_sp_gemm_nt_sp): the next product's operand without a split pass.  N must be one
     column tile (128, 256 or 320).  -> (fp32 [M, N] | None, SplitOperand); the fp32 tensor remembers its split form
@@ -987,15 +1161,18 @@ def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NON
     out = torch.empty((M, N), dtype=torch.float32, device=dev) if want_fp32 else None
     op = SplitOperand(torch.empty((M, N * 4), dtype=torch.uint8, device=dev), torch.empty((M, 1), dtype=torch.float32, device=dev),
                       M, N, N)
+    out_mul, act_grad, dropout, saved_scale = _native_epilogue(out_mul, act_grad, dropout, saved_scale)
     act_name, saved = act_grad if act_grad is not None else (None, None)
     if bias is not None:
         bias = bias.contiguous()
+    rate, seed = dropout if dropout is not None else (0.0, 0)
     _lib.check(
-        lib.tfgnn_sp_gemm_nt_sp(
+        lib.tfgnn_sp_gemm_nt_dropout(
             M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
-            b.data.stride(0), _ptr(b.inv_scale), _ptr(out), N, _ptr(bias), act_id(act), _ptr(out_mul),
+            b.data.stride(0), _ptr(b.inv_scale), _ptr(out), N, _ptr(bias), act_id(act), 0, _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
-            saved.stride(0) if saved is not None else 0, _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale), _stream(),
+            saved.stride(0) if saved is not None else 0, float(saved_scale), _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale),
+            float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(),
         )
     )
     if out is not None:
@@ -1012,7 +1189,8 @@ def split_rows_remembered(x: torch.Tensor) -> SplitOperand:
 
 
 def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, edge_weight=None, row_scale=None,
-                    fixed_inv_scale: Optional[torch.Tensor] = None, rows_per_operand_row: int = 1) -> SplitOperand:
+                    fixed_inv_scale: Optional[torch.Tensor] = None, rows_per_operand_row: int = 1,
+                    defer_combine: bool = False) -> SplitOperand:
     """graph_gather (plain sums) with the result written as an SP16 operand (tfgnn_graph_gather_reduce_sp).
     ``rows_per_operand_row`` = L folds the rows (v, l) of a typed view into the [V, L * width] operand with one scale
     block per edge type."""
@@ -1030,14 +1208,27 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     inv = None
     if fixed_inv_scale is None:
         inv = torch.empty((num_rows // R, R), dtype=torch.float32, device=inp.device)
+    graph.ensure(_VIEW_PARTS[view])
     ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, width)
     ws = _workspace(inp.device, ws_bytes) if ws_bytes else None
-    _lib.check(
-        lib.tfgnn_graph_gather_reduce_sp(
-            graph._h, view, _ptr(col), _ptr(edge_weight), _ptr(row_scale), _ptr(inp), ld_in, width, _ptr(data), width * 4,
-            _ptr(inv), _ptr(fixed_inv_scale), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+    if defer_combine and aux_enabled():
+        # the combine pass of the long buckets rides with whatever other small pass precedes the consumer (a weight split): the
+        # operand is complete once the next library call has been issued (or after aux_flush())
+        job = _lib.AuxJob()
+        _lib.check(
+            lib.tfgnn_graph_gather_reduce_sp_deferred(
+                graph._h, view, _ptr(col), _ptr(edge_weight), _ptr(row_scale), _ptr(inp), ld_in, width, _ptr(data), width * 4,
+                _ptr(inv), _ptr(fixed_inv_scale), _ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(job), _stream(),
+            )
         )
-    )
+        aux_defer(job, keep=(graph, row_scale, ws, data, inv, fixed_inv_scale))
+    else:
+        _lib.check(
+            lib.tfgnn_graph_gather_reduce_sp(
+                graph._h, view, _ptr(col), _ptr(edge_weight), _ptr(row_scale), _ptr(inp), ld_in, width, _ptr(data), width * 4,
+                _ptr(inv), _ptr(fixed_inv_scale), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+            )
+        )
     if fixed_inv_scale is not None:
         return SplitOperand(data, fixed_inv_scale, num_rows // R, R * width, 0)  # scale_block 0: one scale for the tensor
     return SplitOperand(data, inv, num_rows // R, R * width, width)
@@ -1045,7 +1236,7 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
 
 @_writes_out
 def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
-               scatter=None, accumulate: bool = False) -> torch.Tensor:
+               scatter=None, accumulate: bool = False, defer_reduce: bool = False) -> torch.Tensor:
     """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn).  ``a`` carries one scale per (row, block),
     ``b`` one per row - what sp_split_rows / graph_gather_sp write.  ``a_cols`` / ``b_cols`` = (first column, count)
     select column ranges.  ``scatter`` = (group_rows, stride_group, stride_row, stride_col) writes element (m, n) at
@@ -1066,11 +1257,37 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
         raise ValueError(f"out must be contiguous with {M * N} elements")
     gr, sg, sr, sc = scatter if scatter is not None else (M, 0, N, 1)
     ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(M, N, K, a.cols, a.scale_block)
-    ws = _workspace(a.data.device, ws_bytes + 256) if ws_bytes else None
+    defer_reduce = bool(defer_reduce) and aux_enabled() and ws_bytes > 0
+    if defer_reduce:
+        # ``out`` is complete only after the next aux_flush(): a weight gradient is not read before the end of the backward pass,
+        # so the split reductions of all layers share a launch.  The job owns its workspace until then.
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=a.data.device)
+    else:
+        ws = _workspace(a.data.device, ws_bytes + 256) if ws_bytes else None
     ws_ptr, ws_len = None, 0
     if ws is not None:
         off = (-ws.data_ptr()) % 256
         ws_ptr, ws_len = ctypes.c_void_p(ws.data_ptr() + off), ws.numel() - off
+    if defer_reduce:
+        args = (M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
+                b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len)
+        keep = (ws, out, a.data, a.inv_scale, b.data, b.inv_scale)
+        rjob = _lib.AuxJob()
+        if K <= 131072 and os.environ.get("TFGNN_TN_CHAINED", "0") == "1":  # opt-in: measured slower
+            # the whole product waits for the next merged launch: its factor pass rides there, the product follows it, the
+            # reduction rides in a later one (a weight gradient is off the critical path of the backward pass)
+            fjob = _lib.AuxJob()
+            _lib.check(lib.tfgnn_sp_gemm_tn_jobs(*args, ctypes.byref(fjob), ctypes.byref(rjob)))
+
+            def product():
+                _lib.check(lib.tfgnn_sp_gemm_tn_phase(2, *args, _stream()))
+                aux_defer(rjob, keep=keep, urgent=False)
+
+            aux_defer(fjob, keep=keep, urgent=False, then=product)
+            return out
+        _lib.check(lib.tfgnn_sp_gemm_tn_deferred(1, *args, ctypes.byref(rjob), _stream()))
+        aux_defer(rjob, keep=keep, urgent=False)
+        return out
     _lib.check(
         lib.tfgnn_sp_gemm_tn(
             M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
@@ -1082,8 +1299,6 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
 
 _aux_streams = {}
 _aux_pending = []
-
-
 def aux_stream(device) -> "torch.cuda.Stream":
     """The library's second stream of a device: small passes that are off the critical path (the factor and reduction
     passes of a weight-gradient product) run there beside the big kernels of the main stream."""
