@@ -45,6 +45,7 @@ struct AuxTnReduce {
   int64_t group_rows, stride_group, stride_row, stride_col;
   int accumulate;
   int64_t slab;
+  int ref_ld;  // 0: one reference scale per block (ref[blk]); > 0: one per (split, block) at ref[z * ref_ld + blk]
 };
 struct AuxCombineSp {
   const int32_t *multi_row, *multi_base, *multi_n;
@@ -234,18 +235,33 @@ __device__ __forceinline__ void sp_split_cols_body(const float* __restrict__ src
 __device__ __forceinline__ void sp_tn_reduce_body(const AuxTnReduce& a, unsigned block, unsigned nblocks) {
   const int64_t total = a.M * a.N;  // slab >= total: floats per split (the product pads M to a multiple of 128)
   for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < total; i += (int64_t)nblocks * 256) {
+    const int64_t m = i / a.N, n = i - m * a.N;
+    const int64_t blk = (a.a_col0 + m) / a.a_sb;
     float s = 0.f;
     int z = 0;
-    for (; z + 8 <= a.splits; z += 8) {  // eight loads in flight; the sum stays in split order
-      float v[8];
+    if (a.ref_ld > 0) {  // every split carries its own reference scale (factors computed inside the product kernel)
+      for (; z + 8 <= a.splits; z += 8) {  // eight loads in flight; the sum stays in split order
+        float v[8], r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = a.partial[(int64_t)(z + u) * a.slab + i];
+        for (int u = 0; u < 8; ++u) {
+          v[u] = a.partial[(int64_t)(z + u) * a.slab + i];
+          r[u] = a.ref[(int64_t)(z + u) * a.ref_ld + blk];
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += v[u] * r[u];
+      }
+      for (; z < a.splits; ++z) s += a.partial[(int64_t)z * a.slab + i] * a.ref[(int64_t)z * a.ref_ld + blk];
+    } else {
+      for (; z + 8 <= a.splits; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = a.partial[(int64_t)(z + u) * a.slab + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; z < a.splits; ++z) s += a.partial[(int64_t)z * a.slab + i];
+      s *= a.ref[blk];
     }
-    for (; z < a.splits; ++z) s += a.partial[(int64_t)z * a.slab + i];
-    const int64_t m = i / a.N, n = i - m * a.N;
-    s *= a.ref[(a.a_col0 + m) / a.a_sb];
     const int64_t gi = m / a.group_rows, mi = m - gi * a.group_rows;
     float* dst = a.C + gi * a.stride_group + mi * a.stride_row + n * a.stride_col;
     *dst = a.accumulate ? *dst + s : s;

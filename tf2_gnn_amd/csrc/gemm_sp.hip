@@ -695,6 +695,11 @@ struct SpTnArgs {
   int a_sb;           // columns per scale block of A
   int64_t a_col0;     // first column of A (for the block index of a column)
   int a_nblk;         // scale blocks per row of A
+  // FIK kernels (factors in the kernel, round 4): the scales themselves; every workgroup normalises its own K range
+  const float* inv_a;  // [K][a_nblk]
+  const float* inv_b;  // [K] or NULL
+  float* ref_split;    // [splits][a_nblk]: the reference scale of (split, block), multiplied back by the reduce pass
+  int* spread_flag;
   float* partial;     // [splits][M][N]
   int64_t k_chunk;    // rows of K per split (a multiple of 16)
   unsigned n_tiles;
@@ -785,24 +790,34 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
   if (spread_flag && __any(wide) && (threadIdx.x & 63) == 0) *spread_flag = 1;
 }
 
-template <int TNW>
+// FIK = the per-k factors are computed by the workgroup itself (round 4).  The separate factor pass (sp_tn_factors_kernel:
+// 13 us per product, six products per step) existed because the factors were normalised by the GLOBAL maximum of the scale
+// products; a workgroup only ever multiplies its own K range, so it can normalise by the maximum over THAT range - the reduce
+// pass multiplies every split's partial by the split's own reference.  The factors of the whole range are computed into an
+// LDS table ([step][4 blocks][16 k] fp16, 128 bytes per step, up to SP_TN_FTAB_BYTES: k_chunk <= 2560) while the first ring
+// stages are in flight; the ring loses the 1 KB factor slot per stage and wave 0 its extra DMA per step.
+constexpr int SP_TN_FTAB_BYTES = 20480;
+constexpr int64_t SP_TN_FIK_MAX_CHUNK = (SP_TN_FTAB_BYTES / 128 - 2) * 16;  // rows of K per split: one zeroed step + 128 B of scratch
+template <int TNW, bool FIK>
 struct SpGeoTN : SpGeo<TNW> {
   using B0 = SpGeo<TNW>;
-  static constexpr int FOFF = B0::STG;          // per stage: the factors of the step, [<= 4 blocks][16 k] fp16 (1 KB slot)
-  static constexpr int STG = B0::STG + 1024;
-  static constexpr int ND = B0::ND + 1;         // wave 0 also fetches the factor slot; the other waves issue ND - 1 DMAs
-  static constexpr int NST = (163840 / STG) < 6 ? (163840 / STG) : 6;
+  static constexpr int FOFF = B0::STG;          // !FIK: per stage the factors of the step, [<= 4 blocks][16 k] fp16 (1 KB slot)
+  static constexpr int STG = B0::STG + (FIK ? 0 : 1024);
+  static constexpr int ND = B0::ND + (FIK ? 0 : 1);  // !FIK: wave 0 also fetches the factor slot; the other waves issue ND - 1 DMAs
+  static constexpr int RING_MAX = 163840 - (FIK ? SP_TN_FTAB_BYTES : 0);
+  static constexpr int NST = (RING_MAX / STG) < 6 ? (RING_MAX / STG) : 6;
   static constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;
   static constexpr int VMW = (NST - 3) * ND;        // DMAs that may still be in flight at the end of a step: wave 0 ...
-  static constexpr int VMW1 = (NST - 3) * (ND - 1);  // ... and waves 1 - 3
-  static constexpr int LDS_BYTES = NST * STG;
+  static constexpr int VMW1 = (NST - 3) * (FIK ? ND : ND - 1);  // ... and waves 1 - 3
+  static constexpr int FTAB = NST * STG;            // FIK: LDS offset of the factor table
+  static constexpr int LDS_BYTES = NST * STG + (FIK ? SP_TN_FTAB_BYTES : 0);
   static_assert(NST >= 4 && VMW < 64, "ring depth");
-  static_assert(4 * 32 * B0::PATCH_LD * 4 <= LDS_BYTES, "epilogue patch must fit the ring");
+  static_assert(4 * 32 * B0::PATCH_LD * 4 <= NST * STG, "epilogue patch must fit the ring");
 };
 
-template <int TNW>
+template <int TNW, bool FIK>
 struct SpLoopTN {
-  using G = SpGeoTN<TNW>;
+  using G = SpGeoTN<TNW, FIK>;
   static constexpr int KGB_A = 2048, KGB_B = TNW * 1024;  // bytes per 4-row group: A (4 granule pairs), B (2 TNW pairs)
   half8 (&fa)[2][2][2];
   half8 (&fb)[2][TNW][2];
@@ -839,10 +854,14 @@ struct SpLoopTN {
   // shadow of the matrix pipe (all of it after the last MFMA of the step cost 40 us of a 125 us launch).
   half8 fvA[2];
   template <int ST>
-  __device__ __forceinline__ void load_factors() {
+  __device__ __forceinline__ void load_factors(int step) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    fvA[0] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[0] + ST * G::STG));
-    fvA[1] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[1] + ST * G::STG));
+    // FIK: the table entry of the step (128 bytes per step; steps past the end read the zeroed tail); else the stage's slot
+    const unsigned off = FIK ? (unsigned)step * 128u : (unsigned)(ST * G::STG);
+    fvA[0] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[0] + off));
+    fvA[1] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[1] + off));
+#else
+    (void)step;
 #endif
   }
   template <int I, int SET>
@@ -873,9 +892,11 @@ struct SpLoopTN {
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_b), "n"(ST * G::STG + SP_BM * 64 + (I - G::ND_A) * 1024), "v"(voff_b[I - G::ND_A]), "s"(rs_b),
                    "s"(sidx * step_bytes_b) : "memory");
-    else if (wave0)  // wave-uniform: one 1 KB slot per stage, fetched once
-      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
-                   :: "s"(m0_f), "n"(ST * G::STG + G::FOFF), "v"(voff_f), "s"(rs_f), "s"(sidx * 32u) : "memory");
+    else if constexpr (!FIK) {
+      if (wave0)  // wave-uniform: one 1 KB slot per stage, fetched once
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                     :: "s"(m0_f), "n"(ST * G::STG + G::FOFF), "v"(voff_f), "s"(rs_f), "s"(sidx * 32u) : "memory");
+    }
   }
   template <int I, int N, int ST>
   __device__ __forceinline__ void dma_all(int step) {
@@ -899,7 +920,7 @@ struct SpLoopTN {
   __device__ __forceinline__ void step_items(int sbase) {
     if constexpr (I < NM) {
       mfma_one<I, (S & 1)>();
-      if constexpr (I == 0) load_factors<((S + 1) % G::NST)>();
+      if constexpr (I == 0) load_factors<((S + 1) % G::NST)>(sbase + S + 1);
       if constexpr (I < NR) read_one<I, ((S + 1) & 1), ((S + 1) % G::NST)>();
       else if constexpr (I < NR + G::ND) dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
       if constexpr (I == NM - 1 && NM - NR < G::ND)  // narrow tiles: fewer bare MFMAs than DMAs - the rest goes last
@@ -917,7 +938,7 @@ struct SpLoopTN {
     __builtin_amdgcn_sched_barrier(0);
   }
   __device__ __forceinline__ void wait_landed() {
-    if (wave0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
+    if (FIK || wave0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::VMW1) : "memory");
   }
   template <int S>
@@ -936,10 +957,10 @@ struct SpLoopTN {
   }
 };
 
-template <int TNW>
+template <int TNW, bool FIK>
 __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
-  using G = SpGeoTN<TNW>;
-  using LP = SpLoopTN<TNW>;
+  using G = SpGeoTN<TNW, FIK>;
+  using LP = SpLoopTN<TNW, FIK>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -981,9 +1002,14 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   // the partial result are never read)
   const int blk_last = min((int)((g.a_col0 + row0 + SP_BM - 1) / g.a_sb), g.a_nblk - 1);
   const int nb = blk_last - blk_first + 1;
-  L.rs_f = make_rsrc(reinterpret_cast<const uint8_t*>(g.F + (int64_t)blk_first * g.f_ld + k0),
-                     ((int64_t)(nb - 1) * g.f_ld + ((krows + 15) & ~15ll)) * 2);
-  L.voff_f = lane < 2 * nb ? (unsigned)((lane >> 1) * g.f_ld * 2 + (lane & 1) * 16) : 0x7ffffff0u;  // other lanes: zero fill
+  if constexpr (!FIK) {
+    L.rs_f = make_rsrc(reinterpret_cast<const uint8_t*>(g.F + (int64_t)blk_first * g.f_ld + k0),
+                       ((int64_t)(nb - 1) * g.f_ld + ((krows + 15) & ~15ll)) * 2);
+    L.voff_f = lane < 2 * nb ? (unsigned)((lane >> 1) * g.f_ld * 2 + (lane & 1) * 16) : 0x7ffffff0u;  // other lanes: zero fill
+  } else {
+    L.rs_f = uint4v{0u, 0u, 0u, 0u};
+    L.voff_f = 0u;
+  }
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)lds;
   L.m0_a = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_A * 1024);
   L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
@@ -1026,7 +1052,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int blk = min((int)((g.a_col0 + row0 + wm * 64 + t * 32 + fi) / g.a_sb), blk_last) - blk_first;
-      L.f_addr[t] = lds_base + (unsigned)(G::FOFF + blk * 32 + kg * 16);
+      L.f_addr[t] = lds_base + (unsigned)((FIK ? G::FTAB : G::FOFF) + blk * 32 + kg * 16);
     }
   }
 #pragma unroll
@@ -1038,10 +1064,54 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 
   constexpr int NR = LP::NR;
   L.template dma_prologue<0>();
+  if constexpr (FIK) {
+    // ---- the factors of this workgroup's K range (while the first stages are in flight) --------------------------------
+    // p[k][j] = inv_a[k0 + k, blk_first + j] * inv_b[k0 + k]; ref[j] = max_k p (1 if all zero); table[step][j][k % 16] =
+    // fp16(p / ref[j]) - powers of two, exact down to 2^-24, 0 below and past the range's end
+    _Float16* ftab = reinterpret_cast<_Float16*>(lds + G::FTAB);
+    float (*fmx)[4] = reinterpret_cast<float (*)[4]>(lds + G::FTAB + SP_TN_FTAB_BYTES - 128);  // [4 waves][4 blocks]
+    float* fref = reinterpret_cast<float*>(lds + G::FTAB + SP_TN_FTAB_BYTES - 64);            // 1 / reference of block j
+    const int64_t kpad = (int64_t)(nsteps + 1) * 16;  // one zeroed step past the end: the loop reads the factors one step ahead
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = tid; k < krows; k += SP_NT) {
+      const float ib = g.inv_b ? g.inv_b[k0 + k] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nb) mx[j] = fmaxf(mx[j], g.inv_a[(k0 + k) * g.a_nblk + blk_first + j] * ib);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 32; o; o >>= 1) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o, 64));
+      if (lane == 0) fmx[wave][j] = mx[j];
+    }
+    __syncthreads();
+    if (tid < 4) {
+      float m = fmaxf(fmaxf(fmx[0][tid], fmx[1][tid]), fmaxf(fmx[2][tid], fmx[3][tid]));
+      if (m == 0.f) m = 1.f;
+      fref[tid] = 1.f / m;  // a power of two: exact
+      // every tile of the split that touches the block writes the same value
+      if (tid < nb) g.ref_split[(int64_t)split * g.a_nblk + blk_first + tid] = m;
+    }
+    __syncthreads();
+    bool wide = false;
+    for (int64_t k = tid; k < kpad; k += SP_NT) {
+      const float ib = (k < krows && g.inv_b) ? g.inv_b[k0 + k] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float f = 0.f;
+        if (j < nb && k < krows) f = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j] * ib * fref[j];  // powers of two: exact
+        ftab[(k >> 4) * 64 + j * 16 + (k & 15)] = (_Float16)f;
+        // the spread guard (see sp_tn_factors_kernel), relative to the largest scale product of THIS K range
+        wide |= f < 9.5367431640625e-07f && f > 1e-30f;
+      }
+    }
+    if (g.spread_flag && __any(wide) && lane == 0) *g.spread_flag = 1;
+  }
   L.wait_landed();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  L.template load_factors<0>();
+  L.template load_factors<0>(0);
   L.template read_all<0, NR, 0, 0>();
   L.template scale_all<0, 4, 0>();
   __builtin_amdgcn_sched_barrier(0);
@@ -1324,7 +1394,7 @@ size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t
   if (!bn || M <= 0 || a_scale_block <= 0) return 0;
   const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
   const int64_t nblk = ceil_div(a_total_cols, a_scale_block), kpad = (K + 15) & ~15ll;
-  const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * (1 + SP_TN_MAXCHUNKS) * 4 + 255) & ~(size_t)255);
+  const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * (1 + SP_TN_MAXCHUNKS + 512) * 4 + 255) & ~(size_t)255);
   return factors + (size_t)sp_tn_splits(Mp, N, K, bn) * (size_t)Mp * (size_t)N * 4;
 }
 
@@ -1355,13 +1425,21 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
                 "tfgnn_sp_gemm_tn: 32-column scale blocks need a block-aligned first column (at most 4 blocks per 128-column tile)");
   const int splits = sp_tn_splits(Mp, N, K, bn);
   const int64_t nblk = a_total_cols / a_scale_block, kpad = (K + 15) & ~15ll;
-  const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * (1 + SP_TN_MAXCHUNKS) * 4 + 255) & ~(size_t)255;
+  const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * (1 + SP_TN_MAXCHUNKS + 512) * 4 + 255) & ~(size_t)255;
   const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)Mp * (size_t)N * 4;
   TFGNN_REQUIRE(d_workspace && workspace_bytes >= need && (uintptr_t)d_workspace % 256 == 0,
                 "tfgnn_sp_gemm_tn: workspace too small or unaligned (need %zu bytes)", need);
   hipStream_t s = (hipStream_t)stream;
   _Float16* F = (_Float16*)d_workspace;
   float* ref = (float*)((uint8_t*)d_workspace + f_bytes);
+  // factors in the kernel (FIK): every workgroup normalises its own K range - no factor pass at all
+  static const bool fik_env = [] { const char* e = getenv("TFGNN_TN_FIK"); return !e || atoi(e) != 0; }();
+  const int64_t steps_all = (K + 15) / 16;
+  const int64_t k_chunk_all = ((steps_all + splits - 1) / splits) * 16;
+  const bool fik = fik_env && k_chunk_all <= SP_TN_FIK_MAX_CHUNK && splits <= 512;
+  float* ref_split = ref + nblk * (1 + SP_TN_MAXCHUNKS);  // [splits][nblk]
+  if (fik) phases &= ~(1 | 16);
+  if ((phases & 16) && factors_job) factors_job->kind = 0, factors_job->num_blocks = 0;
   if (phases & 16) {  // the factor pass as a job of a merged launch (operands of up to 128k rows: one-stage factor pass)
     TFGNN_REQUIRE(factors_job != nullptr && sp_tn_fchunks(K) == SP_TN_FCHUNKS, "tfgnn_sp_gemm_tn: factors job needs K <= 131072");
     AuxTnFactors fa{d_a_inv_scale, nblk, d_b_inv_scale, 1, K, F, kpad, ref, sp_spread_flag_device(), SP_TN_FCHUNKS};
@@ -1384,6 +1462,7 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   g.A = (const uint8_t*)d_A_sp + a_first_col * 4; g.lda = lda_bytes;
   g.B = (const uint8_t*)d_B_sp + b_first_col * 4; g.ldb = ldb_bytes;
   g.F = F; g.f_ld = kpad; g.a_sb = a_scale_block; g.a_col0 = a_first_col; g.a_nblk = (int)nblk;
+  g.inv_a = d_a_inv_scale; g.inv_b = d_b_inv_scale; g.ref_split = ref_split; g.spread_flag = sp_spread_flag_device();
   g.partial = (float*)((uint8_t*)d_workspace + f_bytes + r_bytes);
   const int64_t steps = (K + 15) / 16;
   g.k_chunk = ((steps + splits - 1) / splits) * 16;
@@ -1394,28 +1473,37 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   g.splits = (unsigned)splits_used;
   g.per_xcd = (g.tiles * g.splits + 7) / 8;
   dim3 grid(8 * g.per_xcd);
-#define SP_LAUNCH_TN(T)                                                                                            \
+#define SP_LAUNCH_TN(T, FK)                                                                                        \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
+    using TnGeo = SpGeoTN<T, FK>;                                                                                  \
+    constexpr int tn_lds = TnGeo::LDS_BYTES;                                                                       \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                SpGeoTN<T>::LDS_BYTES);                                                            \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                tn_lds);                                                                           \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_sp_tn_kernel<T>), grid, dim3(SP_NT), SpGeoTN<T>::LDS_BYTES, s, g);                    \
+    hipLaunchKernelGGL((gemm_sp_tn_kernel<T, FK>), grid, dim3(SP_NT), tn_lds, s, g);                               \
   } while (0)
   if (phases & 2) {
     count_launch(TFGNN_KFAM_SP_TN);
-    if (bn == 320) SP_LAUNCH_TN(5);
-    else if (bn == 256) SP_LAUNCH_TN(4);
-    else SP_LAUNCH_TN(2);
+    if (fik) {
+      if (bn == 320) SP_LAUNCH_TN(5, true);
+      else if (bn == 256) SP_LAUNCH_TN(4, true);
+      else SP_LAUNCH_TN(2, true);
+    } else {
+      if (bn == 320) SP_LAUNCH_TN(5, false);
+      else if (bn == 256) SP_LAUNCH_TN(4, false);
+      else SP_LAUNCH_TN(2, false);
+    }
     TFGNN_LAUNCH_CHECK();
   }
 #undef SP_LAUNCH_TN
   if (!(phases & 12)) return TFGNN_OK;
   const int64_t total = M * N;
   AuxTnReduce ra{};
-  ra.partial = g.partial; ra.splits = splits_used; ra.M = M; ra.N = N; ra.ref = ref; ra.a_col0 = a_first_col; ra.a_sb = a_scale_block;
+  ra.partial = g.partial; ra.splits = splits_used; ra.M = M; ra.N = N; ra.ref = fik ? ref_split : ref; ra.a_col0 = a_first_col; ra.a_sb = a_scale_block;
+  ra.ref_ld = fik ? (int)nblk : 0;
   ra.C = d_C; ra.group_rows = group_rows; ra.stride_group = stride_group; ra.stride_row = stride_row; ra.stride_col = stride_col;
   ra.accumulate = accumulate; ra.slab = Mp * N;
   const unsigned rblocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 2048);

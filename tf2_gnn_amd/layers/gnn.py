@@ -205,10 +205,12 @@ class GNN:
         or from one split pass where no producer wrote them."""
         import os
 
-        # Opt-in (TFGNN_DENSE_F16X2=1): measured break-even on the benchmark stack (2.66 vs 2.65 ms per step) - the three
-        # K = 320 products get 26 us faster each, the per-step splits of two more weight matrices, the factor and reduce
-        # passes of two more weight-gradient products and the split-writing epilogues take it back (DESIGN.md 4.4)
-        if os.environ.get("TFGNN_DENSE_F16X2", "0") != "1":
+        # On by default since round 4 (TFGNN_DENSE_F16X2=0 turns it off).  Round 3 measured a break-even (2.66 vs 2.65 ms per
+        # step): the three K = 320 products got 26 us faster each, the per-step splits of two more weight matrices and the
+        # factor and reduce passes of two more weight-gradient products took it back.  With the weight splits riding in the
+        # merged small-pass launches, the factors computed inside the weight-gradient kernel and the layer-input dropout in
+        # these products' epilogues (all four dropout passes of the benchmark stack gone) it is worth 2.48 vs 2.51 ms.
+        if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0":
             return False
         return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
 
