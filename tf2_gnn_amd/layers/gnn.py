@@ -102,6 +102,7 @@ class GNN:
         self._dropout_calls = 0
         self.dropout_seed = 0
         self._guard_sync_passes = int(os.environ.get("TFGNN_GUARD_SYNC_PASSES", "3"))  # see backward()
+        self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
 
     # ---- Keras-like plumbing ----------------------------------------------------------------
     @property
@@ -210,7 +211,7 @@ class GNN:
         # factor and reduce passes of two more weight-gradient products took it back.  With the weight splits riding in the
         # merged small-pass launches, the factors computed inside the weight-gradient kernel and the layer-input dropout in
         # these products' epilogues (all four dropout passes of the benchmark stack gone) it is worth 2.48 vs 2.51 ms.
-        if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0":
+        if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0" or not self._dense_split_ok:
             return False
         return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
 
@@ -415,17 +416,32 @@ class GNN:
         g_last = None
         try:
             was_f16x2 = ops.get_gemm_mode() == ops.GEMM_F16X2
-            result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
-            if was_f16x2 and self._guard_sync_passes > 0:
-                # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
-                # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
-                # first passes of a model (TFGNN_GUARD_SYNC_PASSES, default 3: whether a model's gradient rows are spread
-                # that far shows at once - RGAT's attention-weighted rows trip it on the first step) wait for the pass and,
-                # if it tripped, run it again on the exact kernels; later trips demote the mode from the NEXT pass on and
-                # say so (ops.get_gemm_mode warns), but the tripping pass itself is not recomputed (README.md).
-                self._guard_sync_passes -= 1
-                if ops.f16x2_guard_tripped_sync():
-                    ops.get_gemm_mode()  # demotes (sticky) and warns
+            if not (was_f16x2 and self._guard_sync_passes > 0):
+                return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
+            # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
+            # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
+            # first passes of a model (TFGNN_GUARD_SYNC_PASSES, default 3: whether a model's gradient rows are spread
+            # that far shows at once - RGAT's attention-weighted rows trip it on the first step) wait for the pass and,
+            # if it tripped, run it again on exact kernels: first with only this stack's Dense / projection products
+            # demoted (their operand rows - un-normalised sums, attention-weighted gradients - are the usual culprit; the
+            # message products keep their split operands), then, if it trips again, with the whole mode demoted.  Later
+            # trips demote the mode from the NEXT pass on and say so (ops.get_gemm_mode warns), but the tripping pass
+            # itself is not recomputed (README.md).  While this section runs, a set flag does not demote the mode on sight.
+            self._guard_sync_passes -= 1
+            with ops.hold_spread_guard():
+                result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
+                for attempt in range(2):
+                    if not ops.f16x2_guard_tripped_sync():
+                        break
+                    if attempt == 0 and self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
+                        self._dense_split_ok = False
+                        ops.rearm_spread_guard()
+                        import warnings
+
+                        warnings.warn("tf2_gnn_amd: the Dense / projection weight gradients of this GNN have operand rows spread over "
+                                      "more than 2^20; these products take the exact bf16x3 kernels from here on (the pass was recomputed)")
+                    else:
+                        ops.demote_gemm_mode()  # the whole mode (sticky), with a warning
                     for v in self.trainable_variables:
                         v.grad = None
                     result = self._backward_walk(ctx, g, False, None, extras, need_input_grad)

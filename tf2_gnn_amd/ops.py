@@ -504,6 +504,8 @@ _spread_warned = [False]
 def _f16x2_on() -> bool:
     """Is the library in mode f16x2 (include/tfgnn.h TFGNN_GEMM_F16X2)?  The library itself holds the mode and demotes it when
     the spread guard of the split weight-gradient product trips (tfgnn_gemm_get_mode); this mirror only warns once."""
+    if _GUARD_HOLD[0] and _f16x2[0]:
+        return True  # a caller that checks the guard synchronously at the end of its pass decides what a trip demotes
     on = _lib.load().tfgnn_gemm_get_mode() == GEMM_F16X2
     if _f16x2[0] and not on and not _spread_warned[0] and _lib.load().tfgnn_sp_spread_flag(0):
         _spread_warned[0] = True
@@ -532,8 +534,43 @@ def set_gemm_mode(mode) -> int:
 
 
 def get_gemm_mode() -> int:
-    _f16x2_on()
+    if _f16x2_on():
+        return GEMM_F16X2
     return _lib.load().tfgnn_gemm_get_mode()
+
+
+_GUARD_HOLD = [0]
+
+
+def demote_gemm_mode() -> int:
+    """Let the library act on a set spread flag NOW, also inside ``hold_spread_guard`` -> the mode in force afterwards."""
+    held, _GUARD_HOLD[0] = _GUARD_HOLD[0], 0
+    try:
+        return get_gemm_mode()
+    finally:
+        _GUARD_HOLD[0] = held
+
+
+class hold_spread_guard:
+    """Inside this context a tripped spread flag does not demote the mode on sight: the caller reads the flag itself
+    (``f16x2_guard_tripped_sync``) when its pass is complete and decides what to demote (``GNN.backward``)."""
+
+    def __enter__(self):
+        _f16x2_on()
+        _GUARD_HOLD[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _GUARD_HOLD[0] -= 1
+        return False
+
+
+def rearm_spread_guard() -> None:
+    """Clear the spread flag WITHOUT demoting the mode (the caller has dealt with the product that tripped it).  Waits for the
+    stream first: a factor computation still in flight must not set it again."""
+    aux_flush()
+    torch.cuda.current_stream().synchronize()
+    _lib.load().tfgnn_sp_spread_flag(1)
 
 
 def f16x2_guard_tripped_sync() -> bool:
