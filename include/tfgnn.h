@@ -113,8 +113,13 @@ typedef enum {
   TFGNN_GRAPH_PART_PLAN_TYPED = 1, /* long-row plans + length-ordered short rows of the views BY_DST_TYPED / BY_SRC_TYPED */
   TFGNN_GRAPH_PART_PLAN_NODE = 2,  /* ... of the views BY_DST_NODE / BY_SRC_NODE (RGAT, per-edge messages)                */
   TFGNN_GRAPH_PART_COMPACT = 4,    /* non-empty (node, type) buckets, type-major: TFGNN_G_NZ_* and the COMPACT views        */
-  TFGNN_GRAPH_PART_EDGE_MAPS = 8,  /* TFGNN_G_SRC2DST_POS and its inverse (RGAT: attention weights in both edge orders)     */
-  TFGNN_GRAPH_PARTS_ALL = 15
+  TFGNN_GRAPH_PART_EDGE_MAPS = 8,  /* TFGNN_G_SRC2DST_POS and its inverse (RGAT: attention weights in both edge orders);
+                                      implies EDGE_IDS                                                                      */
+  TFGNN_GRAPH_PART_EDGE_IDS = 16,  /* TFGNN_G_EID_BY_DST / _SRC: the position of every bucketed edge in the caller's lists
+                                      (per-edge message forms).  Without it the sort moves 4 bytes per edge and digit instead
+                                      of 8.  Added later by tfgnn_graph_ensure it costs a second sort, which READS THE
+                                      ADJACENCY LISTS OF THE CREATION CALL AGAIN: keep them alive.                          */
+  TFGNN_GRAPH_PARTS_ALL = 31
 } tfgnn_graph_part;
 int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
                                    const int64_t* num_edges, unsigned parts, void* stream, tfgnn_graph** out_graph);

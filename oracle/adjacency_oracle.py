@@ -100,7 +100,8 @@ def bucket_edges(adjacency_lists: Sequence[np.ndarray], num_nodes: int, by: str 
 
     by="dst": row node = edge target, col = edge source   (forward gather)
     by="src": row node = edge source, col = edge target   (backward / transposed gather)
-    Within a row, cols ascend (ties are identical values, so the order is canonical).
+    Within a row the edges keep the order of the adjacency lists (a stable sort by row: what the device bucketing does since
+    round 4 - it sorts over the row bits only; rounds 1-3 also ordered the columns of a row).
     Returns rowptr int32 [V*L+1], col int32 [E], etype int32 [E]."""
     L = len(adjacency_lists)
     srcs, dsts, types = [], [], []
@@ -114,7 +115,7 @@ def bucket_edges(adjacency_lists: Sequence[np.ndarray], num_nodes: int, by: str 
     typ = np.concatenate(types) if types else np.zeros(0, np.int64)
     row_node, col = (dst, src) if by == "dst" else (src, dst)
     key = row_node * L + typ
-    order = np.lexsort((col, key))
+    order = np.argsort(key, kind="stable")
     rowptr = np.zeros(num_nodes * L + 1, dtype=np.int64)
     np.add.at(rowptr, key + 1, 1)
     rowptr = np.cumsum(rowptr)

@@ -67,10 +67,13 @@ def test_cfg2_bucketing_is_a_permutation_and_counts_match(cfg2, dev):
         for l, a in enumerate(adjs):
             np.add.at(counts[:, l], a[:, by], 1)
         assert np.array_equal(np.diff(rowptr), counts.reshape(-1))
-        # columns ascend inside every bucket (canonical order)
+        # inside every bucket the edges keep the order of the adjacency lists (stable sort over the bucket bits, round 4:
+        # sortedness of (bucket, edge id)), and every column is the other end of its edge
+        row_of = np.repeat(np.arange(V * L), np.diff(rowptr)).astype(np.int64)
+        assert np.all(np.diff(row_of * (E + 1) + eid.astype(np.int64)) > 0)
         col = g.array(col_id).cpu().numpy().astype(np.int64)
-        row_of = np.repeat(np.arange(V * L), np.diff(rowptr))
-        assert np.all(np.diff(row_of * (V + 1) + col) >= 0)
+        other = np.concatenate([a[:, 1 - by] for a in adjs]).astype(np.int64)
+        assert np.array_equal(col, other[eid])
 
 
 def test_cfg2_gather_linearity_conservation_determinism(cfg2, dev):

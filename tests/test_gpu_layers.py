@@ -358,29 +358,40 @@ def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
     ref64, _ = orc.gnn_internal_call(params, w64, X.double(), [torch.from_numpy(a) for a in adjs])
     grads = torch.autograd.grad((ref64 * dOut.double()).sum(), leaves, allow_unused=True)
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads)}
+    # the same backward pass in the reference's order and fp32: where ITS weight gradients are further than the bound from
+    # fp64 (four un-normalised edge-MLP layers: states ~ 10^2), the HIP gradients may be at most twice as far
+    import copy
+
+    w32g = copy.deepcopy(w)
+    leaves64, leaves = leaves, []
+    visit(w32g)
+    leaves32, leaves = leaves, leaves64
+    ref32g, _ = orc.gnn_internal_call(params, w32g, X, [torch.from_numpy(a) for a in adjs])
+    grads32 = torch.autograd.grad((ref32g * dOut).sum(), leaves32, allow_unused=True)
+    err32_by_id = {}
+    for t64, g64, g32 in zip(leaves64, grads, grads32):
+        if g64 is not None and g32 is not None:
+            sc = max(1.0, float(g64.abs().max()))
+            err32_by_id[id(t64)] = scaled_error(g32 / sc, g64 / sc)
+
+    def grad_close(got, leaf, what):
+        r = ref_by_id[id(leaf)]
+        scale = max(1.0, float(r.abs().max()))  # relative to the largest entry of the gradient
+        assert_close(got.cpu() / scale, (r / scale).float(), tol=max(1e-5, 2 * err32_by_id.get(id(leaf), 0.0)), what=what)
+
     gnn(inp, training=False)
     gnn.backward(dOut.to(dev))
-    # initial projection
-    gi = gnn._initial_projection_layer.grad
-    r = ref_by_id[id(w64["initial_projection"])]
-    scale = max(1.0, float(r.abs().max()))  # like every other weight gradient below: relative to the largest entry
-    assert_close(gi.cpu() / scale, (r / scale).float(), tol=1e-5, what="d initial projection")
+    grad_close(gnn._initial_projection_layer.grad, w64["initial_projection"], "d initial projection")
     for i, mp in enumerate(gnn._mp_layers):
         ref_k = w64["mp"][i]["edge_mlps"]
         for l in range(L):
             for j, v in enumerate(mp._edge_type_mlps.vars[l]):
-                r = ref_by_id[id(ref_k[l][j])]
-                scale = max(1.0, float(r.abs().max()))
-                assert_close(v.grad.cpu() / scale, (r / scale).float(), tol=1e-5, what=f"layer {i} {v.name}")
+                grad_close(v.grad, ref_k[l][j], f"layer {i} {v.name}")
         if str(i) in gnn._dense_layers:
-            r = ref_by_id[id(w64["dense"][i])]
-            scale = max(1.0, float(r.abs().max()))
-            assert_close(gnn._dense_layers[str(i)].grad.cpu() / scale, (r / scale).float(), tol=1e-5, what=f"dense {i}")
+            grad_close(gnn._dense_layers[str(i)].grad, w64["dense"][i], f"dense {i}")
         if params["use_inter_layer_layernorm"]:
             gam, bet = gnn._inter_layer_layernorms[i]
-            r = ref_by_id[id(w64["layernorm"][i][0])]
-            scale = max(1.0, float(r.abs().max()))
-            assert_close(gam.grad.cpu() / scale, (r / scale).float(), tol=1e-5, what=f"ln gamma {i}")
+            grad_close(gam.grad, w64["layernorm"][i][0], f"ln gamma {i}")
 
 
 def test_gnn_training_dropout_matches_oracle_with_same_masks(dev):

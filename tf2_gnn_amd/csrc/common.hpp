@@ -126,14 +126,18 @@ constexpr float kSmallNumber = 1e-7f;  // tf2_gnn/utils/constants.py:2
 constexpr float kFloatLowest = -3.402823466e+38f;
 
 // ---- activations (tf2_gnn/utils/param_helpers.py:25-33, utils/activation.py:7-14) -------------
-// tanh through the hardware exponential and reciprocal: 1 - 2 / (e^{2x} + 1), absolute error <= 3e-7 over the whole range
-// (saturates correctly: e^{2x} = inf -> 1, 0 -> -1; near 0 the error is that of the subtraction from 1, 6e-8).  The library
-// tanhf costs ~40 instructions with branches: in the epilogue of a K = 320 product (160 elements per thread, all workgroups
-// there at the same time) it was 17 of 51 us (tools/nt_epilogue_probe.py).  The parity bound of the node states is
-// 1e-5 max(1, |ref|) - absolute for |tanh| <= 1.
+// tanh through the hardware exponential: sign(x) (1 - 2 / (e^{2|x|} + 1)).  On |x| the subtracted term is <= 1, the division
+// is IEEE (0.5 ulp), the exponential's relative error (1 ulp + the rounding of 2|x| log2 e) reaches the result damped by
+// 2t / (t + 1)^2 <= 1/2: the result is within ~1.5 ulp of tanh - the class of the library tanhf, whose ~40 instructions with
+// branches were 17 of 51 us in the epilogue of a K = 320 product (160 elements per thread, all workgroups there at the same
+// time; tools/nt_epilogue_probe.py).  (A first version with v_rcp_f32 and without the symmetry was 5 ulp off for x < 0: the
+// backward pass takes 1 - y^2 of the saved output, and a stack of saturated units amplified that to 1.1e-5 in a weight
+// gradient - tests/test_gpu_layers.py::test_gnn_stack_forward_backward_parity.)  Saturates correctly: e^{2|x|} = inf -> 1.
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __expf(2.f * x);
-  return 1.f - __fdividef(2.f, t + 1.f);
+  const float ax = fabsf(x);
+  const float t = __expf(2.f * ax);
+  const float y = 1.f - 2.f / (t + 1.f);
+  return copysignf(y, x);
 }
 
 __device__ __forceinline__ float act_apply(int act, float x) {

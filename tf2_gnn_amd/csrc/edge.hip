@@ -85,6 +85,10 @@ extern "C" int tfgnn_graph_original_order(const tfgnn_graph* g, const float* d_w
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   if (g->E == 0) return TFGNN_OK;
   TFGNN_REQUIRE(d_src_l && d_tgt_l && d_tgt_node, "NULL output");
+  {
+    const int prc = graph_require_parts(g, TFGNN_GRAPH_PART_EDGE_IDS, "tfgnn_graph_original_order");
+    if (prc) return prc;
+  }
   unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(g->E, 256), 8192);
   hipLaunchKernelGGL(original_order_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->eid_d, g->coll_d,
                      g->tgt_d, d_weight_by_dst, g->E, g->L, d_src_l, d_tgt_l, d_tgt_node, d_weight);

@@ -6,9 +6,9 @@
 // (type, node) with scatter_nd, gathering those counts per edge, and concatenating the per-type
 // target lists.  Row r = node * L + edge_type; the in-degree c[l, v] is the length of row v*L+l.
 //
-// Pipeline (all on the caller's stream; deterministic result):
-//   count keys (int atomics) -> exclusive scan -> scatter (col<<32 | edge_id) with an atomic cursor
-//   -> per-row sort of the 64-bit composites (canonical order) -> unpack + derived arrays.
+// Pipeline (all on the caller's stream; deterministic result): one stable LSD radix sort of composite keys (bucket | column)
+// over the bucket bits for both bucketings at once -> row pointers by binary search -> unpack + derived arrays.  Edges of a
+// bucket keep the order of the adjacency lists.
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -51,7 +51,8 @@ int graph_require_parts(const tfgnn_graph* g, unsigned need, const char* who) {
   if (!missing) return TFGNN_OK;
   set_error("%s: the graph handle lacks part%s%s%s%s (requested 0x%x at creation): tfgnn_graph_ensure(graph, parts, stream) builds it",
             who, (missing & TFGNN_GRAPH_PART_PLAN_TYPED) ? " PLAN_TYPED" : "", (missing & TFGNN_GRAPH_PART_PLAN_NODE) ? " PLAN_NODE" : "",
-            (missing & TFGNN_GRAPH_PART_COMPACT) ? " COMPACT" : "", (missing & TFGNN_GRAPH_PART_EDGE_MAPS) ? " EDGE_MAPS" : "", g->parts);
+            (missing & TFGNN_GRAPH_PART_COMPACT) ? " COMPACT" : "",
+            (missing & (TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS)) ? " EDGE_MAPS / EDGE_IDS" : "", g->parts);
   return TFGNN_ERR_INVALID_ARGUMENT;
 }
 }  // namespace tfgnn
@@ -199,16 +200,19 @@ constexpr int RS_ROUNDS = 16;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_WAVE_KEYS = 64 * RS_ROUNDS;     // consecutive keys per wave
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // 8192 keys per workgroup
-constexpr int RS_RADIX = 256;
+constexpr int RS_DIGIT_BITS = 9;
+constexpr int RS_RADIX = 1 << RS_DIGIT_BITS;     // 512 = one digit per thread
+static_assert(RS_RADIX == RS_THREADS, "one digit per thread");
 
-// keys of both sides + the digit-0 histogram of every tile: hist[(side * 256 + digit) * nblk_ld + tile]
+// keys of both sides + the first-digit histogram of every tile: hist[(side * RS_RADIX + digit) * nblk_ld + tile]
 template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
 fill_keys_kernel(EdgeLists el, int64_t E, int64_t V, int sec_bits, KeyT* __restrict__ comp_d, KeyT* __restrict__ comp_s,
                  int32_t* __restrict__ hist, int nblk_ld, int32_t* __restrict__ err_flag) {
   __shared__ int32_t h[2][RS_RADIX];
   const int tid = threadIdx.x;
-  (&h[0][0])[tid] = 0;  // RS_THREADS == 2 * RS_RADIX
+  h[0][tid] = 0;
+  h[1][tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
@@ -227,12 +231,13 @@ fill_keys_kernel(EdgeLists el, int64_t E, int64_t V, int sec_bits, KeyT* __restr
       const KeyT ks = (KeyT)(((uint64_t)(src * el.L + l) << sec_bits) | (uint64_t)dst);
       comp_d[g] = kd;
       comp_s[g] = ks;
-      atomicAdd(&h[0][(int)(kd & (RS_RADIX - 1))], 1);  // LDS atomics
-      atomicAdd(&h[1][(int)(ks & (RS_RADIX - 1))], 1);
+      atomicAdd(&h[0][(int)((kd >> sec_bits) & (RS_RADIX - 1))], 1);  // LDS atomics
+      atomicAdd(&h[1][(int)((ks >> sec_bits) & (RS_RADIX - 1))], 1);
     }
   }
   __syncthreads();
-  hist[(int64_t)tid * nblk_ld + blockIdx.x] = (&h[0][0])[tid];
+  hist[(int64_t)tid * nblk_ld + blockIdx.x] = h[0][tid];
+  hist[(int64_t)(RS_RADIX + tid) * nblk_ld + blockIdx.x] = h[1][tid];
 }
 
 // hist[(side * 256 + digit) * nblk_ld + tile] = number of keys of the tile with that digit; grid (tiles, 2 sides)
@@ -244,7 +249,7 @@ rs_hist_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s,
   const int tid = threadIdx.x;
   const int side = blockIdx.y;
   const KeyT* __restrict__ comp = side ? comp_s : comp_d;
-  if (tid < RS_RADIX) h[tid] = 0;
+  h[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
@@ -253,19 +258,19 @@ rs_hist_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s,
     if (idx < n) atomicAdd(&h[(int)((comp[idx] >> shift) & (RS_RADIX - 1))], 1);
   }
   __syncthreads();
-  if (tid < RS_RADIX) hist[(int64_t)(side * RS_RADIX + tid) * nblk_ld + blockIdx.x] = h[tid];
+  hist[(int64_t)(side * RS_RADIX + tid) * nblk_ld + blockIdx.x] = h[tid];
 }
 
 // stable scatter of one digit, both sides: keys keep their input order inside a digit (tile, then wave, round, lane =
-// index order).  pay_in == NULL: the payload is the key's index (first pass).
-template <typename KeyT>
+// index order).  PAY: a 32-bit payload travels with every key (the edge id; pay_in == NULL: the key's index, first pass).
+template <typename KeyT, bool PAY>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, const uint32_t* __restrict__ pin_d,
                   const uint32_t* __restrict__ pin_s, int64_t n, int shift, const int32_t* __restrict__ hist, int nblk,
                   int nblk_ld, KeyT* __restrict__ out_d, KeyT* __restrict__ out_s, uint32_t* __restrict__ pout_d,
                   uint32_t* __restrict__ pout_s) {
   __shared__ int32_t wbase[RS_WAVES][RS_RADIX];  // per wave: digit counts, then running output positions
-  __shared__ int32_t wtot[RS_RADIX / 64];
+  __shared__ int32_t wtot[RS_WAVES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int side = blockIdx.y;
@@ -281,14 +286,14 @@ rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, 
   const int64_t wave0 = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_KEYS;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   KeyT key[RS_ROUNDS];
-  uint32_t pl[RS_ROUNDS];
+  uint32_t pl[PAY ? RS_ROUNDS : 1];
   int32_t info[RS_ROUNDS];  // rank | group size << 8 | valid << 16
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const int64_t idx = wave0 + r * 64 + lane;
     const bool valid = idx < n;
     key[r] = valid ? kin[idx] : (KeyT)0;
-    pl[r] = valid ? (pin ? pin[idx] : (uint32_t)idx) : 0u;
+    if (PAY) pl[r] = valid ? (pin ? pin[idx] : (uint32_t)idx) : 0u;
   }
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
@@ -296,7 +301,7 @@ rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, 
     const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < RS_DIGIT_BITS; ++b) {
       const unsigned long long m = __ballot((d >> b) & 1);
       peers &= ((d >> b) & 1) ? m : ~m;
     }
@@ -308,8 +313,8 @@ rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, 
   }
   __syncthreads();
   // 2. thread d: keys with digit d in the tiles before this one + the digit's global base -> the waves' first positions
-  int32_t tot = 0, before = 0, incl = 0;
-  if (tid < RS_RADIX) {
+  int32_t tot = 0, before = 0;
+  {
     const int32_t* __restrict__ row = hist + (int64_t)(side * RS_RADIX + tid) * nblk_ld;
     const int me = (int)blockIdx.x;
     for (int b0 = 0; b0 < nblk; b0 += 16) {
@@ -329,17 +334,17 @@ rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, 
           }
       }
     }
-    // exclusive scan of tot over the 256 digits: inside the wave, then over the four waves
-    incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int32_t t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wtot[wave] = incl;
   }
+  // exclusive scan of tot over the digits: inside the wave, then over the waves
+  int32_t incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wave] = incl;
   __syncthreads();
-  if (tid < RS_RADIX) {
+  {
     int32_t off = 0;
     for (int w = 0; w < wave; ++w) off += wtot[w];
     int32_t running = off + incl - tot + before;
@@ -363,7 +368,7 @@ rs_scatter_kernel(const KeyT* __restrict__ in_d, const KeyT* __restrict__ in_s, 
     __builtin_amdgcn_wave_barrier();
     if (valid) {
       kout[b + rank] = key[r];
-      pout[b + rank] = pl[r];
+      if (PAY) pout[b + rank] = pl[r];
     }
   }
 }
@@ -564,7 +569,7 @@ __global__ void nz_cols_kernel(const int32_t* __restrict__ cpos, const int32_t* 
 // blockIdx.y = 0 / 1: unpack the sorted keys of the by-target / by-source side; blockIdx.y = 2: per-row arrays
 // (1 / in-degree, node pointers).  The degree that normalises an edge is always the in-degree of its TARGET for its type,
 // i.e. the length of by-target row (target, type) - read from rowptr_d directly, so the three jobs share one launch.
-template <typename KeyT>
+template <typename KeyT, bool PAY>
 __global__ void unpack_kernel(const KeyT* __restrict__ comp_d, const KeyT* __restrict__ comp_s, const uint32_t* __restrict__ pay_d,
                               const uint32_t* __restrict__ pay_s, int sec_bits, int64_t E, int L, int64_t R,
                               const int32_t* __restrict__ rowptr_d, const int32_t* __restrict__ rowptr_s,
@@ -599,11 +604,10 @@ __global__ void unpack_kernel(const KeyT* __restrict__ comp_d, const KeyT* __res
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t c = (uint64_t)comp[p];
     const int32_t other = (int32_t)(c & sec_mask);
-    const int32_t id = (int32_t)pay[p];
     const int32_t row = (int32_t)(c >> sec_bits);
     const int l = row % L;
     col[p] = other;
-    eid[p] = id;
+    if (PAY) eid[p] = (int32_t)pay[p];
     const int64_t cl = (int64_t)other * L + l;
     coll[p] = (int32_t)cl;
     const int64_t trow = by_src ? cl : (int64_t)row;  // the by-target bucket of this edge
@@ -611,7 +615,7 @@ __global__ void unpack_kernel(const KeyT* __restrict__ comp_d, const KeyT* __res
     invdeg_edge[p] = len > 0 ? 1.0f / ((float)len + kSmallNumber) : 0.f;
     if (!by_src) {
       row_node[p] = row / L;
-      eid_to_pos[id] = (int32_t)p;
+      if (PAY) eid_to_pos[pay[p]] = (int32_t)p;
     }
   }
 }
@@ -733,7 +737,7 @@ namespace {
 using namespace tfgnn;
 
 constexpr unsigned kPartsAll = TFGNN_GRAPH_PART_PLAN_TYPED | TFGNN_GRAPH_PART_PLAN_NODE | TFGNN_GRAPH_PART_COMPACT |
-                               TFGNN_GRAPH_PART_EDGE_MAPS;
+                               TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS;
 
 // long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
 // views 91 us at (48, 512) vs 104 us at (16, 192) (134 us in natural row order at (16, 128)); the node views -
@@ -835,28 +839,32 @@ int build_edge_maps(tfgnn_graph* g, hipStream_t s) {
   return TFGNN_OK;
 }
 
-// the sort of both sides + everything derived per edge and per row; KeyT = uint32_t when row and column bits fit
-template <typename KeyT>
-int build_core(tfgnn_graph* g, const EdgeLists& el, int sec_bits, int total_bits, char* keys, char* pays, int32_t* hist, int nblk,
-               int nblk_ld, int32_t* counters, hipStream_t s) {
+// the sort of both sides + everything derived per edge and per row; KeyT = uint32_t when row and column bits fit.
+// The sort runs over the ROW bits of the composite only (9-bit digits from bit sec_bits up): the column rides in the low bits
+// of the key - edges of a bucket keep the order of the adjacency list (stable), which is all the sums need to be reproducible.
+// PAY: the edge ids travel along as a 32-bit payload (parts that map edges back to the caller's lists).
+template <typename KeyT, bool PAY>
+int build_core(tfgnn_graph* g, const EdgeLists& el, char* keys, char* pays, int32_t* hist, int nblk, int nblk_ld,
+               int32_t* counters, hipStream_t s) {
   const int64_t E = g->E, R = g->R, V = g->V;
   const int L = g->L;
+  const int sec_bits = g->sec_bits, total_bits = g->total_bits;
   KeyT* kbuf[2][2];  // [side][ping-pong]
   uint32_t* pbuf[2][2];
   for (int side = 0; side < 2; ++side)
     for (int b = 0; b < 2; ++b) {
       kbuf[side][b] = (KeyT*)(keys + (size_t)(side * 2 + b) * (size_t)E * 8);
-      pbuf[side][b] = (uint32_t*)(pays + (size_t)(side * 2 + b) * (size_t)E * 4);
+      pbuf[side][b] = PAY ? (uint32_t*)(pays + (size_t)(side * 2 + b) * (size_t)E * 4) : nullptr;
     }
   hipLaunchKernelGGL((fill_keys_kernel<KeyT>), dim3(nblk), dim3(RS_THREADS), 0, s, el, E, V, sec_bits, kbuf[0][0], kbuf[1][0],
                      hist, nblk_ld, counters + 2);
   int cur = 0;
   bool first = true;
-  for (int shift = 0; shift < total_bits; shift += 8) {
+  for (int shift = sec_bits; shift < total_bits; shift += RS_DIGIT_BITS) {
     if (!first)
       hipLaunchKernelGGL((rs_hist_kernel<KeyT>), dim3(nblk, 2), dim3(RS_THREADS), 0, s, (const KeyT*)kbuf[0][cur],
                          (const KeyT*)kbuf[1][cur], E, shift, hist, nblk_ld);
-    hipLaunchKernelGGL((rs_scatter_kernel<KeyT>), dim3(nblk, 2), dim3(RS_THREADS), 0, s, (const KeyT*)kbuf[0][cur],
+    hipLaunchKernelGGL((rs_scatter_kernel<KeyT, PAY>), dim3(nblk, 2), dim3(RS_THREADS), 0, s, (const KeyT*)kbuf[0][cur],
                        (const KeyT*)kbuf[1][cur], first ? (const uint32_t*)nullptr : (const uint32_t*)pbuf[0][cur],
                        first ? (const uint32_t*)nullptr : (const uint32_t*)pbuf[1][cur], E, shift, (const int32_t*)hist, nblk, nblk_ld,
                        kbuf[0][cur ^ 1], kbuf[1][cur ^ 1], pbuf[0][cur ^ 1], pbuf[1][cur ^ 1]);
@@ -865,13 +873,68 @@ int build_core(tfgnn_graph* g, const EdgeLists& el, int sec_bits, int total_bits
   }
   hipLaunchKernelGGL((rowptr_from_sorted_kernel<KeyT>), dim3(blocks_for(R + 1), 2), dim3(256), 0, s, (const KeyT*)kbuf[0][cur],
                      (const KeyT*)kbuf[1][cur], E, sec_bits, R, g->rowptr_d, g->rowptr_s);
-  hipLaunchKernelGGL((unpack_kernel<KeyT>), dim3(blocks_for(std::max(E, R + 1)), 3), dim3(256), 0, s, (const KeyT*)kbuf[0][cur],
+  hipLaunchKernelGGL((unpack_kernel<KeyT, PAY>), dim3(blocks_for(std::max(E, R + 1)), 3), dim3(256), 0, s, (const KeyT*)kbuf[0][cur],
                      (const KeyT*)kbuf[1][cur], (const uint32_t*)pbuf[0][cur], (const uint32_t*)pbuf[1][cur], sec_bits, E, L, R,
                      (const int32_t*)g->rowptr_d, (const int32_t*)g->rowptr_s, g->col_d, g->eid_d, g->coll_d, g->invdeg_edge_d,
                      g->eid2pos, g->tgt_d, g->col_s, g->eid_s, g->coll_s, g->invdeg_edge_s, g->invdeg_d, g->nodeptr_d,
                      g->nodeptr_s, 0);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
+}
+
+// scratch of one run of the sort
+struct CoreScratch {
+  size_t keys, pays, hist, counters, ptrs, off, total;
+  int nblk, nblk_ld;
+};
+CoreScratch core_scratch(int64_t E, int L, bool pay) {
+  CoreScratch c{};
+  SlabPlan tmp;
+  c.nblk = (int)ceil_div(E > 0 ? E : 1, RS_TILE);
+  c.nblk_ld = (c.nblk + 3) & ~3;
+  c.keys = tmp.take((size_t)E * 8 * 4);
+  c.pays = tmp.take(pay ? (size_t)E * 4 * 4 : 0);
+  c.hist = tmp.take((size_t)2 * RS_RADIX * c.nblk_ld * 4 + 16);
+  c.counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS) * 4);  // counters, then the bins: one memset
+  c.ptrs = tmp.take((size_t)(L + 1) * 8);
+  c.off = tmp.take((size_t)(L + 1) * 8);
+  c.total = tmp.total;
+  return c;
+}
+
+// E > 0: keys, sort, row pointers, per-edge arrays of both sides.  `scratch` laid out by core_scratch; the counters block
+// (zeroed by the caller) receives the bad-index flag at [2].  Reads the adjacency lists the handle was created from.
+int run_core(tfgnn_graph* g, bool pay, char* scratch, const CoreScratch& cs, hipStream_t s) {
+  const int L = g->L;
+  EdgeLists el{};
+  el.L = L;
+  el.inline_tables = L <= EL_INLINE;
+  if (el.inline_tables) {
+    for (int l = 0; l < EL_INLINE; ++l) el.adj_v[l] = l < L ? g->h_adj[l] : nullptr;
+    for (int l = 0; l <= EL_INLINE; ++l) el.off_v[l] = l <= L ? g->h_off[l] : g->E;
+  } else {
+    // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
+    const int32_t** d_ptrs = (const int32_t**)(scratch + cs.ptrs);
+    int64_t* d_off = (int64_t*)(scratch + cs.off);
+    char* hp = (char*)g->pinned + 256;
+    const int32_t** h_ptrs = (const int32_t**)hp;
+    int64_t* h_off = (int64_t*)(hp + (size_t)(L + 1) * 8);
+    for (int l = 0; l < L; ++l) h_ptrs[l] = g->h_adj[l];
+    for (int l = 0; l <= L; ++l) h_off[l] = g->h_off[l];
+    TFGNN_HIP_CHECK(hipMemcpyAsync(d_ptrs, h_ptrs, (size_t)L * 8, hipMemcpyHostToDevice, s));
+    TFGNN_HIP_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
+    el.adj = d_ptrs;
+    el.edge_off = d_off;
+  }
+  char* keys = scratch + cs.keys;
+  char* pays = scratch + cs.pays;
+  int32_t* hist = (int32_t*)(scratch + cs.hist);
+  int32_t* counters = (int32_t*)(scratch + cs.counters);
+  if (g->total_bits <= 32)
+    return pay ? build_core<uint32_t, true>(g, el, keys, pays, hist, cs.nblk, cs.nblk_ld, counters, s)
+               : build_core<uint32_t, false>(g, el, keys, pays, hist, cs.nblk, cs.nblk_ld, counters, s);
+  return pay ? build_core<uint64_t, true>(g, el, keys, pays, hist, cs.nblk, cs.nblk_ld, counters, s)
+             : build_core<uint64_t, false>(g, el, keys, pays, hist, cs.nblk, cs.nblk_ld, counters, s);
 }
 }  // namespace
 
@@ -937,14 +1000,21 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   for (int v = 0; v < 4; ++v) o_short[v] = plan.take((size_t)((v & 1) ? V : R) * 4 + 4);
   const size_t persistent = plan.total;
   // build-time scratch (freed by tfgnn_graph_wait)
-  SlabPlan tmp;
-  const int nblk = (int)ceil_div(E > 0 ? E : 1, RS_TILE);
-  const int nblk_ld = (nblk + 3) & ~3;
-  const size_t t_keys = tmp.take((size_t)E * 8 * 4), t_pays = tmp.take((size_t)E * 4 * 4);
-  const size_t t_hist = tmp.take((size_t)2 * RS_RADIX * nblk_ld * 4 + 16);
-  const size_t t_counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS) * 4);  // counters, then the bins: one memset
-  const size_t t_ptrs = tmp.take((size_t)(L + 1) * 8), t_off = tmp.take((size_t)(L + 1) * 8);
-  const size_t t_compact = tmp.take((parts & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(R, V) : 0);
+  if (parts & TFGNN_GRAPH_PART_EDGE_MAPS) parts |= TFGNN_GRAPH_PART_EDGE_IDS;  // the maps are built from the edge ids
+  const bool with_ids = (parts & TFGNN_GRAPH_PART_EDGE_IDS) != 0;
+  const CoreScratch cs = core_scratch(E, L, with_ids);
+  const size_t t_compact = (cs.total + 255) & ~(size_t)255;
+  const size_t scratch_total = t_compact + ((parts & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(R, V) : 0);
+  g->h_adj.assign(d_adjacency, d_adjacency + L);
+  g->h_off = edge_off;
+  {
+    int sec_bits = 1;
+    while (((int64_t)1 << sec_bits) < V) ++sec_bits;
+    int row_bits = 1;
+    while (((int64_t)1 << row_bits) < (R > 0 ? R : 1)) ++row_bits;
+    g->sec_bits = sec_bits;
+    g->total_bits = sec_bits + row_bits;
+  }
 
   char* slab = nullptr;
   char* scratch = nullptr;
@@ -952,7 +1022,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   hipError_t he = dev_alloc((void**)&slab, persistent, &g->slab_bytes, s);
   if (he == hipSuccess) {
     g->slab = slab;
-    he = dev_alloc((void**)&scratch, tmp.total, &g->scratch_bytes, s);
+    he = dev_alloc((void**)&scratch, scratch_total, &g->scratch_bytes, s);
   }
   if (he == hipSuccess) {
     g->scratch = scratch;
@@ -964,7 +1034,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
     if (he == hipSuccess) g->event = ev;
   }
   if (he != hipSuccess) {
-    set_error("graph allocation failed (%zu + %zu bytes): %s", persistent, tmp.total, hipGetErrorString(he));
+    set_error("graph allocation failed (%zu + %zu bytes): %s", persistent, scratch_total, hipGetErrorString(he));
     graph_release_all(g);
     return TFGNN_ERR_HIP;
   }
@@ -1013,8 +1083,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
     pl.short_rows = (int32_t*)(slab + o_short[v]);
   }
 
-  int32_t* hist = (int32_t*)(scratch + t_hist);
-  int32_t* counters = (int32_t*)(scratch + t_counters);
+  int32_t* counters = (int32_t*)(scratch + cs.counters);
   int32_t* bins = counters + 64;
 
   int rc = TFGNN_OK;
@@ -1033,44 +1102,15 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   } while (0)
 
   G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS) * 4, s));
-  EdgeLists el{};
-  el.L = L;
-  el.inline_tables = L <= EL_INLINE;
-  if (el.inline_tables) {
-    for (int l = 0; l < EL_INLINE; ++l) el.adj_v[l] = l < L ? d_adjacency[l] : nullptr;
-    for (int l = 0; l <= EL_INLINE; ++l) el.off_v[l] = l <= L ? edge_off[l] : E;
-  } else {
-    // pointer / offset tables go through the handle's pinned staging block: no host synchronisation
-    const int32_t** d_ptrs = (const int32_t**)(scratch + t_ptrs);
-    int64_t* d_off = (int64_t*)(scratch + t_off);
-    char* hp = (char*)g->pinned + 256;
-    const int32_t** h_ptrs = (const int32_t**)hp;
-    int64_t* h_off = (int64_t*)(hp + (size_t)(L + 1) * 8);
-    for (int l = 0; l < L; ++l) h_ptrs[l] = d_adjacency[l];
-    for (int l = 0; l <= L; ++l) h_off[l] = edge_off[l];
-    G_CHECK(hipMemcpyAsync(d_ptrs, h_ptrs, (size_t)L * 8, hipMemcpyHostToDevice, s));
-    G_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(L + 1) * 8, hipMemcpyHostToDevice, s));
-    el.adj = d_ptrs;
-    el.edge_off = d_off;
-  }
-
-  // sort the edges into (bucket, column) order for both bucketings, then everything per edge and per row
+  // sort the edges into bucket order for both bucketings, then everything per edge and per row
   if (E > 0) {
-    int sec_bits = 1;
-    while (((int64_t)1 << sec_bits) < V) ++sec_bits;
-    int row_bits = 1;
-    while (((int64_t)1 << row_bits) < (R > 0 ? R : 1)) ++row_bits;
-    const int total_bits = sec_bits + row_bits;
-    char* keys = scratch + t_keys;
-    char* pays = scratch + t_pays;
-    rc = total_bits <= 32 ? build_core<uint32_t>(g, el, sec_bits, total_bits, keys, pays, hist, nblk, nblk_ld, counters, s)
-                          : build_core<uint64_t>(g, el, sec_bits, total_bits, keys, pays, hist, nblk, nblk_ld, counters, s);
+    rc = run_core(g, with_ids, scratch, cs, s);
     if (rc) return fail(rc);
   } else {
     G_CHECK(hipMemsetAsync(g->rowptr_d, 0, (R + 1) * 4, s));
     G_CHECK(hipMemsetAsync(g->rowptr_s, 0, (R + 1) * 4, s));
     if (L > 0) {
-      hipLaunchKernelGGL((unpack_kernel<uint32_t>), dim3(blocks_for(R + 1), 1), dim3(256), 0, s, (const uint32_t*)nullptr,
+      hipLaunchKernelGGL((unpack_kernel<uint32_t, false>), dim3(blocks_for(R + 1), 1), dim3(256), 0, s, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (int64_t)0, L, R,
                          (const int32_t*)g->rowptr_d, (const int32_t*)g->rowptr_s, g->col_d, g->eid_d, g->coll_d, g->invdeg_edge_d,
                          g->eid2pos, g->tgt_d, g->col_s, g->eid_s, g->coll_s, g->invdeg_edge_s, g->invdeg_d, g->nodeptr_d,
@@ -1145,13 +1185,18 @@ extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) 
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   TFGNN_REQUIRE((parts & ~kPartsAll) == 0, "unknown graph part bits 0x%x", parts);
+  if (parts & TFGNN_GRAPH_PART_EDGE_MAPS) parts |= TFGNN_GRAPH_PART_EDGE_IDS;
   const unsigned missing = parts & ~g->parts;
   if (!missing) return TFGNN_OK;
   TFGNN_REQUIRE(!g->pending, "tfgnn_graph_wait has not been called");
   hipStream_t s = (hipStream_t)stream;
+  const bool redo_core = (missing & TFGNN_GRAPH_PART_EDGE_IDS) && g->E > 0;
+  // the edge ids were not carried through the sort: run it again with the payload (same order, same arrays - the adjacency
+  // lists of tfgnn_graph_create* are read again and must still be alive)
+  const CoreScratch cs = core_scratch(redo_core ? g->E : 0, g->L, true);
   const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS) * 4;
-  const size_t c_take = (c_bytes + 255) & ~(size_t)255;
-  const size_t need = c_take + ((missing & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(g->R, g->V) : 0);
+  const size_t core_take = (cs.total + 255) & ~(size_t)255;
+  const size_t need = core_take + ((missing & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(g->R, g->V) : 0);
   char* scratch = nullptr;
   size_t got = 0;
   hipError_t he = dev_alloc((void**)&scratch, need, &got, s);
@@ -1159,13 +1204,14 @@ extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) 
     set_error("tfgnn_graph_ensure: allocation of %zu bytes failed: %s", need, hipGetErrorString(he));
     return TFGNN_ERR_HIP;
   }
-  int32_t* counters = (int32_t*)scratch;
+  int32_t* counters = (int32_t*)(scratch + cs.counters);
   int rc = TFGNN_OK;
   hipError_t e = hipMemsetAsync(counters, 0, c_bytes, s);
-  if (e == hipSuccess && (missing & TFGNN_GRAPH_PART_PLAN_TYPED)) rc = build_plans(g, 0, counters, counters + 64, s);
+  if (e == hipSuccess && redo_core) rc = run_core(g, true, scratch, cs, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_PLAN_TYPED)) rc = build_plans(g, 0, counters, counters + 64, s);
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_PLAN_NODE)) rc = build_plans(g, 1, counters, counters + 64, s);
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_EDGE_MAPS)) rc = build_edge_maps(g, s);
-  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_COMPACT)) rc = build_compact(g, scratch + c_take, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_COMPACT)) rc = build_compact(g, scratch + core_take, s);
   if (e == hipSuccess && !rc) e = hipMemcpyAsync(g->pinned, counters, 64 * 4, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipStreamSynchronize(s);
   dev_release(scratch, got);
@@ -1330,6 +1376,7 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
   {
     unsigned need = 0;
     if (array_id == TFGNN_G_SRC2DST_POS) need = TFGNN_GRAPH_PART_EDGE_MAPS;
+    if (array_id == TFGNN_G_EID_BY_DST || array_id == TFGNN_G_EID_BY_SRC) need = TFGNN_GRAPH_PART_EDGE_IDS;
     if (array_id >= TFGNN_G_NZ_CPOS_BY_DST && array_id <= TFGNN_G_NZ_COL_BY_SRC) need = TFGNN_GRAPH_PART_COMPACT;
     if (need) {
       const int rc = tfgnn::graph_require_parts(g, need, "tfgnn_graph_array");

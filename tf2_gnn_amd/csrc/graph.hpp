@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace tfgnn {
 
@@ -63,6 +64,9 @@ struct tfgnn_graph {
   int32_t *nodeptr_d = nullptr, *nodeptr_s = nullptr, *src2dst = nullptr, *dst2src = nullptr, *tgt_d = nullptr;
   int32_t* eid2pos = nullptr;  // edge id -> position in the by-target order
   unsigned parts = 0;          // TFGNN_GRAPH_PART_* bits that have been built (the sort and the per-edge arrays always are)
+  int sec_bits = 0, total_bits = 0;        // composite key: (bucket << sec_bits) | column
+  std::vector<const int32_t*> h_adj;       // the adjacency lists of the creation call (device pointers) and their
+  std::vector<int64_t> h_off;              // offsets in the concatenation: tfgnn_graph_ensure(EDGE_IDS) sorts again
   float *invdeg_d = nullptr, *invdeg_edge_s = nullptr, *invdeg_edge_d = nullptr;
   tfgnn::GraphView views[4];  // tfgnn_graph_view order
   tfgnn::CompactBuckets compact[2];  // 0: by target, 1: by source

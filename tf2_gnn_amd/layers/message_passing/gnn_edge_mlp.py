@@ -175,7 +175,7 @@ class GNN_Edge_MLP(MessagePassing):
         shape = SimpleNamespace(num_edge_types=len(edges_per_type), num_edges=int(sum(edges_per_type)), num_nodes=int(num_nodes),
                                 edges_per_type=tuple(int(c) for c in edges_per_type))
         if messages_per_edge(self, shape, in_dim, self._hidden_dim):
-            return ops.G_PART_PLAN_TYPED | ops.G_PART_PLAN_NODE
+            return ops.G_PART_PLAN_TYPED | ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_IDS
         return ops.G_PART_PLAN_TYPED
 
     # ---- which formulation ------------------------------------------------------------------
@@ -602,6 +602,7 @@ class GNN_Edge_MLP(MessagePassing):
             tgt_l = torch.empty(E, dtype=torch.int32, device=dev)
             tgt_node = torch.empty(E, dtype=torch.int32, device=dev)
             w = torch.empty(E, dtype=torch.float32, device=dev) if ew_d is not None else None
+            g.ensure(ops.G_PART_EDGE_IDS)
             _lib.check(
                 _lib.load().tfgnn_graph_original_order(
                     g._h, ops._ptr(ew_d), ops._ptr(src_l), ops._ptr(tgt_l), ops._ptr(tgt_node), ops._ptr(w), ops._stream()

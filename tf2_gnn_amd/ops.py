@@ -178,14 +178,16 @@ class _DevArray:
  G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC) = range(27)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
 # parts of a graph handle beyond the two sorted edge orders (include/tfgnn.h tfgnn_graph_part)
-G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PARTS_ALL = 1, 2, 4, 8, 15
+G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_EDGE_IDS, G_PARTS_ALL = 1, 2, 4, 8, 16, 31
 _VIEW_PARTS = {0: G_PART_PLAN_TYPED, 1: G_PART_PLAN_NODE, 2: G_PART_PLAN_TYPED, 3: G_PART_PLAN_NODE,
                4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT}
 
 
 def _array_parts(array_id: int) -> int:
     if array_id == G_SRC2DST_POS:
-        return G_PART_EDGE_MAPS
+        return G_PART_EDGE_MAPS | G_PART_EDGE_IDS
+    if array_id in (G_EID_BY_DST, G_EID_BY_SRC):
+        return G_PART_EDGE_IDS
     return G_PART_COMPACT if G_NZ_CPOS_BY_DST <= array_id <= G_NZ_COL_BY_SRC else 0
 
 
@@ -222,6 +224,9 @@ class Graph:
         )
         self._h = handle
         self.parts = int(parts) & G_PARTS_ALL
+        if self.parts & G_PART_EDGE_MAPS:
+            self.parts |= G_PART_EDGE_IDS
+        self._lists = adjs  # ensure(G_PART_EDGE_IDS) reads the edge lists again: they live as long as the handle
         self._pending = True
         self.num_nodes = int(num_nodes)
         self.num_edge_types = L
