@@ -21,4 +21,6 @@ from .layers import (  # noqa: F401
     WeightedSumGraphRepresentation,
 )
 
-__version__ = "0.1.0"
+from .autograd import TorchGNN, TorchGraphTaskModel, TorchMessagePassing, TorchNodesToGraphRepresentation  # noqa: F401,E402
+
+__version__ = "0.2.0"

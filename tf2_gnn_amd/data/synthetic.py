@@ -86,3 +86,23 @@ def make_zipf_typed_batch(num_nodes: int, num_edges: int, num_edge_types: int, f
     adjs = [np.ascontiguousarray(edges[types == l]) for l in range(num_edge_types)]
     feats = rng.standard_normal((num_nodes, feature_dim), dtype=np.float32)
     return feats, adjs
+
+
+def make_ppi_shaped_batch(num_graphs: int = 3, nodes_per_graph: int = 2370, avg_in_degree: int = 14, feature_dim: int = 50,
+                          num_labels: int = 121, seed: int = 0):
+    """PPI stand-in (the real data is not available offline): ``num_graphs`` R-MAT graphs of
+    ``nodes_per_graph`` nodes with ``avg_in_degree`` forward edges per node, one forward edge type - the batch finalisation
+    (tf2_gnn/data/utils.py:9-58 through ``process_adjacency_lists``: self loops + backward edges -> 3 types,
+    ppi_dataset.py:50-58) happens on the device.  -> (features float32 [V, 50], forward edges int32 [E, 2] with node ids of the
+    disjoint union, node_to_graph_map int32 [V], labels float32 [V, 121] in {0, 1})."""
+    rng = np.random.default_rng(seed)
+    edges = []
+    for g in range(num_graphs):
+        e = rmat_edges(nodes_per_graph, nodes_per_graph * avg_in_degree, rng)
+        edges.append(e + g * nodes_per_graph)
+    V = num_graphs * nodes_per_graph
+    feats = rng.standard_normal((V, feature_dim), dtype=np.float32)
+    labels = (rng.random((V, num_labels)) < 0.3).astype(np.float32)
+    n2g = np.repeat(np.arange(num_graphs, dtype=np.int32), nodes_per_graph)
+    return feats, np.ascontiguousarray(np.concatenate(edges, axis=0), dtype=np.int32), n2g, labels
+
