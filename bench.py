@@ -512,6 +512,8 @@ def main():
                 ops.split_rows_remembered(x)
             return ops.Graph(adj_dev, V, wait=False, parts=gnn.graph_parts(V, edges_per_type)), x  # only the tables this stack reads
 
+    allreduce_events = []
+
     def step():
         # a training step ends with an in-place weight update, which invalidates the split forms of the weights the f16x2
         # products cache per value: drop them here so every timed step splits its weights like a training step does
@@ -536,7 +538,13 @@ def main():
         else:
             gnn.backward(dOut)
         if args.allreduce_grads:
+            # timed on the device (events on the launch stream; read after the run): the exchange's share of every rank's step
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
             parallel.allreduce_gradients(gnn.trainable_variables, dist, local_count=float(G if pool is not None else V))
+            ev1.record()
+            allreduce_events.append((ev0, ev1))
+            del allreduce_events[:-64]
         if graph is None:
             g.close()
 
@@ -599,6 +607,11 @@ def main():
     total_edges_per_step = float(gathered[:, 0].sum())
     ms_per_step = 1000.0 * elapsed / args.steps
     value = total_edges_per_step * args.steps / elapsed
+    allreduce_ms_per_rank = None
+    if args.allreduce_grads:
+        torch.cuda.synchronize()
+        mine = [a.elapsed_time(b) for a, b in allreduce_events[-args.steps:]]
+        allreduce_ms_per_rank = parallel.all_gather_scalars([float(np.mean(mine)) if mine else 0.0], dist, dev)[:, 0].tolist()
 
     if sharded:
         shape = (f"G={int(gathered[:, 2].sum())} graphs V={int(gathered[:, 1].sum())} E={int(total_edges_per_step)} (whole job; sharded by graph "
@@ -632,6 +645,7 @@ def main():
                                      if (args.allreduce_grads and world > 1) else "none (graph-sharded batches / replicas)"),
             "edges_per_rank": gathered[:, 0].tolist(),
             "ms_per_step_per_rank": ms_per_step_per_rank,
+            "allreduce_ms_per_step_per_rank": allreduce_ms_per_rank,
         },
     }
     if not args.no_alt_mode:
@@ -853,23 +867,45 @@ def step_breakdown(step, ops, steps=2, top=12):
 # --------------------------------------------------------------------------------------------------------------------
 # rooflines: the dominant kernels of a workload, timed live (HIP events on the launch stream) at the workload's shapes
 # --------------------------------------------------------------------------------------------------------------------
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over tf2_gnn_amd/csrc/*.hip, *.hpp: what tools/parse_pmc.py stores with a counter
+    collection, so that a traffic number measured on older kernels is recognisable."""
+    import hashlib
+
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tf2_gnn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(workload, name):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic_<workload>.json, derived by
-    tools/parse_pmc.py from the committed counter CSVs profiles/r03_pmc_{fetch,write}_<workload>_counter_collection.csv;
-    FETCH_SIZE corrected x2 as calibrated on gfx950 by the streaming kernel in the same pass, MI355X_MICROARCH.md), or None."""
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/<tag>_pmc_traffic_<workload>.json, derived by
+    tools/parse_pmc.py from the committed counter CSVs profiles/<tag>_pmc_{fetch,write}_<workload>_counter_collection.csv;
+    FETCH_SIZE corrected x2 as calibrated on gfx950 by the streaming kernel in the same pass, MI355X_MICROARCH.md)
+    -> (bytes | None, provenance dict | None).  The provenance says which collection the number comes from and whether the
+    kernel sources it was measured on are the ones running now (rounds 1-3 stored no hash: "unknown")."""
     if name is None:
-        return None
+        return None, None
     root = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
+    for tag in ("r04", "r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
         path = os.path.join(root, "profiles", f"{tag}_pmc_traffic_{workload}.json")
         try:
             with open(path) as f:
-                v = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+                doc = json.load(f)
+            v = doc.get(name, {}).get("hbm_bytes_per_launch")
             if v:
-                return v
+                sha = doc.get("_meta", {}).get("kernel_source_sha16")
+                match = "unknown (collected before the sources were hashed)" if sha is None else (sha == kernel_source_sha16())
+                if match is False:
+                    print(f"bench.py: {os.path.basename(path)} was collected on other kernel sources ({sha}); re-run tools/pmc_collect.sh",
+                          file=sys.stderr)
+                return v, {"file": f"profiles/{os.path.basename(path)}", "kernel_sources_match": match}
         except (OSError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
@@ -887,13 +923,13 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         when they were collected (profiles/r02_pmc_traffic_<workload>.json), else the compulsory bytes (every distinct input /
         output byte once).  SURVEY.md 8d's no-reuse gather model (one source row per EDGE) is reported beside it: its rate
         exceeds the HBM peak whenever rows are re-read from L2 / Infinity Cache, so it is not a fraction of any roof."""
-        traffic = _pmc_traffic(args.workload, traffic_key)
+        traffic, traffic_from = _pmc_traffic(args.workload, traffic_key)
         basis_bytes = traffic if traffic else (compulsory_bytes if compulsory_bytes else alg_bytes)
         gbs = basis_bytes / (ms * 1e-3) / 1e9
         blk = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                "achieved_basis": ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch (gfx950-corrected)" if traffic else
                                   ("compulsory bytes (distinct inputs and outputs once)" if compulsory_bytes else "algorithmic bytes")),
-               "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes,
+               "traffic": traffic, "traffic_from": traffic_from, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes,
                "no_reuse_model_rate_GBs": alg_bytes / (ms * 1e-3) / 1e9, "launches_per_step": launches,
                "share_of_step": launches * ms / ms_per_step}
         if compulsory_bytes:
@@ -902,8 +938,9 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
 
     def mfma_block(kernel, ms, flops, executed_factor, peak, launches, traffic_key=None):
         tf = flops / (ms * 1e-3) / 1e12
+        traffic, traffic_from = _pmc_traffic(args.workload, traffic_key)
         blk = {"kernel": kernel, "bound": "mfma", "achieved": tf * executed_factor, "peak": peak, "unit": "TFLOP/s",
-               "frac": tf * executed_factor / peak, "traffic": _pmc_traffic(args.workload, traffic_key), "ms_per_launch": ms,
+               "frac": tf * executed_factor / peak, "traffic": traffic, "traffic_from": traffic_from, "ms_per_launch": ms,
                "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tf, "piece_products_per_fp32_product": executed_factor,
                "launches_per_step": launches, "share_of_step": launches * ms / ms_per_step}
         if peak == MFMA_16BIT_PEAK_TFLOPS:
@@ -941,7 +978,7 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
             Gs = ops.sp_split_rows(torch.randn((V, L * H), device=dev) * 1e-3, scale_block=H)
             dW = torch.empty((L, H, H), device=dev)
             ms = time_kernel(lambda: ops.sp_gemm_tn(Gs, Xs, out=dW, scatter=(H, H * H, 1, H)))
-            out.append(mfma_block("gemm_sp_tn_kernel + factor / split-K reduce kernels (dW = X^T G over K = V rows, transposing LDS reads)",
+            out.append(mfma_block("gemm_sp_tn_kernel (per-k factors computed in the kernel, round 4) + split-K reduce (dW = X^T G over K = V rows, transposing LDS reads)",
                                   ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, NL, "gemm_sp_tn"))
         elif mode == "fp32":
             A = torch.randn((V, L * H), device=dev)

@@ -50,6 +50,17 @@ for name, needle in NEEDLES:
     f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0
     res[name] = {"kernel": [k for k in fetch if all(n in k for n in ((needle,) if isinstance(needle, str) else needle))][0][:160],
                  "fetch_raw_bytes": f, "write_raw_bytes": w, "hbm_bytes_per_launch": f * kf + w * kw}
+# which kernel sources these counters belong to: bench.py compares it with the sources it runs (a traffic number measured on an
+# older kernel is reported as such)
+import hashlib  # noqa: E402
+import os  # noqa: E402
+
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf2_gnn_amd", "csrc")
+_h = hashlib.sha256()
+for _f in sorted(os.listdir(_csrc)):
+    if _f.endswith((".hip", ".hpp")):
+        _h.update(open(os.path.join(_csrc, _f), "rb").read())
+res["_meta"] = {"kernel_source_sha16": _h.hexdigest()[:16]}
 res["all_kernels_raw_kib"] = {k[:120]: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "all_kernels_raw_kib"}, indent=1))
