@@ -57,6 +57,11 @@ typedef enum {
 const char* tfgnn_last_error(void);
 /* "tfgnn <version> gfx950" */
 const char* tfgnn_version(void);
+/* Bumped whenever an existing entry point changes its signature or meaning (round 4: 2 - tfgnn_gemm_grad_epilogue gained
+ * `accumulate` in round 3, tfgnn_gemm_get_mode can return TFGNN_GEMM_F16X2, the bucketing keeps list order inside a bucket).
+ * A binding compares tfgnn_abi_version() with the TFGNN_ABI_VERSION it was written against (tf2_gnn_amd/_lib.py does). */
+#define TFGNN_ABI_VERSION 2
+int tfgnn_abi_version(void);
 
 /* Diagnostics (no reference counterpart): number of launches of each product-kernel family this process has enqueued
  * since the library was loaded - host-side counters, no device work.  The parity tests read them around a layer call
@@ -367,6 +372,9 @@ int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int
 int tfgnn_gemm_gathered(int trans_b, int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, int64_t a_rows,
                         const int32_t* d_row_index, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                         const float* d_bias, int act, int accumulate, void* stream);
+/* 1 if tfgnn_gemm_gathered takes a product of this shape in the current GEMM mode (16-byte aligned operands assumed), else 0:
+ * ask before choosing a formulation that only pays with the fused kernel (one message per edge, gnn_edge_mlp.py:84-100). */
+int tfgnn_gemm_gathered_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t a_rows);
 
 /* Grouped forms of the Dense layer for the per-relation multiply over NON-EMPTY buckets only (rows of
  * the stacked operand are grouped by edge type: group g owns rows [d_group_offsets[g],

@@ -16,6 +16,8 @@ LIB_PATH = Path(__file__).resolve().parent / "libtfgnn.so"
 _SIGNATURES = [
     ("tfgnn_last_error", c_char_p, []),
     ("tfgnn_version", c_char_p, []),
+    ("tfgnn_abi_version", c_int, []),
+    ("tfgnn_gemm_gathered_supported", c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     ("tfgnn_launch_counts", c_int, [POINTER(c_int64), c_int]),
     ("tfgnn_sp_spread_flag", c_int, [c_int]),
     (
@@ -266,6 +268,7 @@ _SIGNATURES = [
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+ABI_VERSION = 2  # include/tfgnn.h TFGNN_ABI_VERSION
 
 
 class AuxJob(ctypes.Structure):
@@ -298,6 +301,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.tfgnn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} speaks ABI version {lib.tfgnn_abi_version()}, this binding was written against {ABI_VERSION} "
+                           "(include/tfgnn.h TFGNN_ABI_VERSION): rebuild with `python -m tf2_gnn_amd.build`")
     _lib = lib
     return lib
 

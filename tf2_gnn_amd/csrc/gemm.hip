@@ -427,6 +427,7 @@ int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, i
 
 int gemm_f16x2_mode();
 void gemm_f16x2_set(int on);
+int gemm_x3_gathered_supported(int nprod, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t a_rows);
 }  // namespace tfgnn
 
 extern "C" int tfgnn_gemm_set_mode(int mode) {
@@ -493,6 +494,10 @@ extern "C" int tfgnn_gemm_gathered(int trans_b, int64_t M, int64_t N, int64_t K,
                            (hipStream_t)stream, &status))
     return status;
   return TFGNN_ERR_UNSUPPORTED;
+}
+
+extern "C" int tfgnn_gemm_gathered_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t a_rows) {
+  return tfgnn::gemm_x3_gathered_supported(tfgnn::gemm_x3_mode(), M, N, K, lda, a_rows);
 }
 
 extern "C" int tfgnn_gemm_gru(int64_t V, int H, int64_t K, const float* d_x, int64_t ld_x, const float* d_kernel_t,

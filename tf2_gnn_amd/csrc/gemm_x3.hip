@@ -1449,6 +1449,16 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
 
 // C[m] = act?( (C[m] if accumulate) + A[index[m]] @ op(B) + bias ) on the streaming kernel; accumulate: 0 no, 1 after the
 // activation, 2 before it.  1 = taken, 0 = shape not covered (caller gathers and multiplies separately).
+// would gemm_x3_gathered_try take a product of this shape (aligned operands assumed)?  The layers ask before they choose the
+// one-message-per-edge formulation (the shape conditions used to be copied into the host mirror)
+int gemm_x3_gathered_supported(int nprod, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t a_rows) {
+  if (!nprod) return 0;
+  X3Args g{};
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.a_rows = a_rows;
+  g.a_index = reinterpret_cast<const int32_t*>(1);  // "indexed": the row limits apply to a_rows
+  return x3k_shape_ok(g) && N % XK_COLS == 0 && N / XK_COLS <= 32 && lda % 4 == 0 ? 1 : 0;
+}
+
 int gemm_x3_gathered_try(int nprod, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t a_rows,
                          const int32_t* index, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
                          int accumulate, hipStream_t s, int* status) {

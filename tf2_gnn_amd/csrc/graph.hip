@@ -58,7 +58,8 @@ int graph_require_parts(const tfgnn_graph* g, unsigned need, const char* who) {
 }  // namespace tfgnn
 
 extern "C" const char* tfgnn_last_error(void) { return tfgnn::g_err; }
-extern "C" const char* tfgnn_version(void) { return "tfgnn 0.1 gfx950"; }
+extern "C" const char* tfgnn_version(void) { return "tfgnn 0.2 gfx950"; }
+extern "C" int tfgnn_abi_version(void) { return TFGNN_ABI_VERSION; }
 
 namespace tfgnn {
 

@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
-from ... import ops
+from ... import _lib, ops
 from .message_passing import (
     apply_gradient_epilogue,
     MessagePassing,
@@ -43,18 +43,29 @@ def mlp_hidden_sizes(out_size: int, hidden_layers) -> List[int]:
     return list(hidden_layers)
 
 
-PER_EDGE_MIN_ROWS = 65536  # rows below which the streaming kernel does not take a gathered product (tfgnn_gemm_gathered)
+PER_EDGE_MIN_ROWS = 65536  # (tests lower it; the library's own threshold is asked through tfgnn_gemm_gathered_supported)
 
 
 def messages_per_edge(layer, g, D, H) -> bool:
     """one product row per EDGE (rows of X read through an index) rather than per (node, type) bucket?  Pays when edges are
-    fewer than buckets and every edge type is large enough for the streaming kernel."""
-    if ops.get_gemm_mode() == ops.GEMM_FP32 or D not in (64, 96, 128) or H % 128 != 0:
+    fewer than buckets and the fused gathered product (tfgnn_gemm_gathered) takes every edge type's product - the library is
+    asked (tfgnn_gemm_gathered_supported), the shape conditions are not restated here."""
+    if ops.get_gemm_mode() == ops.GEMM_FP32:
         return False
     L, E, V = g.num_edge_types, g.num_edges, g.num_nodes
-    if E == 0 or E >= V * L or V * D >= (1 << 30) or layer._aggregation_name == "max" or layer._pre_activation():
+    if E == 0 or E >= V * L or layer._aggregation_name == "max" or layer._pre_activation():
         return False
-    return all(c == 0 or c >= PER_EDGE_MIN_ROWS for c in g.edges_per_type)
+    lib = _lib.load()
+    forced = PER_EDGE_MIN_ROWS < 65536  # the layer-logic tests run the formulation on small graphs (separate gather + product)
+    for c in g.edges_per_type:
+        if c == 0:
+            continue
+        if forced:
+            if c < PER_EDGE_MIN_ROWS or D not in (64, 96, 128) or H % 128 != 0:
+                return False
+        elif not lib.tfgnn_gemm_gathered_supported(int(c), int(H), int(D), int(D), int(V)):
+            return False
+    return True
 
 
 def _relu_input_grad(d_out, W, layer_input, out):
@@ -673,12 +684,24 @@ class GNN_Edge_MLP(MessagePassing):
         return cur, acts
 
     def _first_layer_per_edge(self, g, D, H0, off) -> bool:
-        if ops.get_gemm_mode() == ops.GEMM_FP32 or D not in (64, 96, 128) or H0 % 128 != 0:
+        """the first layer of path C once per edge (two gathered products)?  The same question as ``messages_per_edge`` with the
+        hidden width as the output width (one predicate, asked of the library)."""
+        if E_is_small := (g.num_edges == 0 or g.num_edges >= g.num_nodes * g.num_edge_types):
+            return not E_is_small
+        lib = _lib.load()
+        if ops.get_gemm_mode() == ops.GEMM_FP32:
             return False
-        L, E, V = g.num_edge_types, g.num_edges, g.num_nodes
-        if E == 0 or E >= V * L or V * D >= (1 << 30):
-            return False
-        return all(off[l + 1] - off[l] == 0 or off[l + 1] - off[l] >= PER_EDGE_MIN_ROWS for l in range(L))
+        forced = PER_EDGE_MIN_ROWS < 65536
+        for l in range(g.num_edge_types):
+            c = off[l + 1] - off[l]
+            if c == 0:
+                continue
+            if forced:
+                if c < PER_EDGE_MIN_ROWS or D not in (64, 96, 128) or H0 % 128 != 0:
+                    return False
+            elif not lib.tfgnn_gemm_gathered_supported(int(c), int(H0), int(D), int(D), int(g.num_nodes)):
+                return False
+        return True
 
     def _aggregate_nothing(self, V, X, fuse_act, ctx):
         """aggregation over zero edges: zeros (sum-like) / the float minimum (max), then the activation."""
