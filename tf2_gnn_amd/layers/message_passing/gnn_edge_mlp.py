@@ -686,11 +686,9 @@ class GNN_Edge_MLP(MessagePassing):
     def _first_layer_per_edge(self, g, D, H0, off) -> bool:
         """the first layer of path C once per edge (two gathered products)?  The same question as ``messages_per_edge`` with the
         hidden width as the output width (one predicate, asked of the library)."""
-        if E_is_small := (g.num_edges == 0 or g.num_edges >= g.num_nodes * g.num_edge_types):
-            return not E_is_small
-        lib = _lib.load()
-        if ops.get_gemm_mode() == ops.GEMM_FP32:
+        if g.num_edges == 0 or g.num_edges >= g.num_nodes * g.num_edge_types or ops.get_gemm_mode() == ops.GEMM_FP32:
             return False
+        lib = _lib.load()
         forced = PER_EDGE_MIN_ROWS < 65536
         for l in range(g.num_edge_types):
             c = off[l + 1] - off[l]
