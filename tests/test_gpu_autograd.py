@@ -94,10 +94,10 @@ def test_message_passing_pooling_and_task_model_wrappers(dev):
     p = RGCN.get_default_hyperparameters()
     p["hidden_dim"] = H
     layer = RGCN(p)
-    mp = TorchMessagePassing(layer)
+    mp = TorchMessagePassing(layer).eval()  # (eval: the pooling MLPs would draw fresh dropout masks on the second run)
     pool_layer = WeightedSumGraphRepresentation(graph_representation_size=8, num_heads=2, weighting_fun="softmax",
                                                 scoring_mlp_layers=[16], transformation_mlp_layers=[16])
-    pool = TorchNodesToGraphRepresentation(pool_layer)
+    pool = TorchNodesToGraphRepresentation(pool_layer).eval()
     h = mp(MessagePassingInput(X, adjs))
     z = pool(NodesToGraphRepresentationInput(h, n2g, G))
     loss = z.square().sum()

@@ -257,7 +257,14 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     # un-normalised sums over the 150-edge hub: the aggregate-first product is ONE fp32 chain over L x D = 640 terms at the
     # magnitude of the 150-edge sum (|.| ~ 45), the reference's order a chain over the 150 messages - factor 4 there
     slack = 4 if p.get("normalize_by_num_incoming", True) is False else 2
-    assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, slack * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
+    if p.get("normalize_by_num_incoming", True) is False and cls_name != "RGAT":
+        # un-normalised sums over the hub (states |x| ~ 30 - 100, small entries are the result of cancellation): the yardstick
+        # is the magnitude of the node's state vector, as in check_layer_forward
+        rs = ref.detach().abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert_close(out.cpu().double() / rs, ref.detach() / rs, tol=max(1e-5, slack * scaled_error(ref32.detach().double() / rs, ref.detach() / rs)),
+                     what=name + " fwd")
+    else:
+        assert_close(out.cpu(), ref.detach().float(), tol=max(1e-5, slack * scaled_error(ref32.detach(), ref.detach())), what=name + " fwd")
     grads = torch.autograd.grad((ref * dOut.double()).sum(), [X64] + leaves)
     assert_close(dX.cpu(), grads[0].float(), tol=max(1e-5, slack * scaled_error(dX32, grads[0])), what=name + " dX")
     ref_by_id = {id(t): gr for t, gr in zip(leaves, grads[1:])}
