@@ -124,7 +124,11 @@ typedef enum {
                                       (per-edge message forms).  Without it the sort moves 4 bytes per edge and digit instead
                                       of 8.  Added later by tfgnn_graph_ensure it costs a second sort, which READS THE
                                       ADJACENCY LISTS OF THE CREATION CALL AGAIN: keep them alive.                          */
-  TFGNN_GRAPH_PARTS_ALL = 31
+  TFGNN_GRAPH_PART_DST_PATTERN = 32, /* TFGNN_G_PATTERN_*: the nodes ordered by which of their by-target buckets are empty, and per
+                                      128 positions the union of those patterns - lets the forward product of the aggregate-first
+                                      layers skip the all-zero K blocks of a row tile (TFGNN_VIEW_BY_DST_TYPED_PATTERN, the tile
+                                      mask / row map arguments of tfgnn_sp_gemm_nt_dropout); at most 8 edge types, empty beyond  */
+  TFGNN_GRAPH_PARTS_ALL = 63
 } tfgnn_graph_part;
 int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
                                    const int64_t* num_edges, unsigned parts, void* stream, tfgnn_graph** out_graph);
@@ -161,7 +165,11 @@ typedef enum {
   TFGNN_G_NZ_NODE_BY_SRC = 23,
   TFGNN_G_NZ_OFF_BY_SRC = 24,
   TFGNN_G_NZ_NODEPTR_BY_SRC = 25,
-  TFGNN_G_NZ_COL_BY_SRC = 26
+  TFGNN_G_NZ_COL_BY_SRC = 26,
+  /* part DST_PATTERN (at most 8 edge types; count 0 beyond): nodes ordered by the emptiness pattern of their by-target buckets */
+  TFGNN_G_PATTERN_POS_BY_DST = 27,      /* int32 [V]: node -> position                                  */
+  TFGNN_G_PATTERN_NODE_BY_DST = 28,     /* int32 [V]: position -> node (the row map of a product's output) */
+  TFGNN_G_PATTERN_TILEMASK_BY_DST = 29  /* uint8 [ceil(V/128)]: union of the patterns of 128 positions (bit l: type l non-empty) */
 } tfgnn_graph_array_id;
 
 /* Borrow a device array owned by the handle (valid until tfgnn_graph_destroy). */
@@ -223,7 +231,10 @@ typedef enum {
   /* the two typed views with COMPACT output: row c of the output belongs to the c-th non-empty
    * bucket in type-major order (TFGNN_G_NZ_* arrays); empty buckets produce no row */
   TFGNN_VIEW_BY_DST_TYPED_COMPACT = 4,
-  TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5
+  TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5,
+  /* the by-target typed view with its output rows in PATTERN order: bucket (v, l) is written at row pos[v] * L + l
+   * (TFGNN_G_PATTERN_POS_BY_DST), every bucket has a row (part DST_PATTERN) */
+  TFGNN_VIEW_BY_DST_TYPED_PATTERN = 6
 } tfgnn_graph_view;
 size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* graph, int view, int width);
 int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
@@ -624,13 +635,17 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
  * d_saved be the DROPPED activation: the derivative is taken at d_saved * saved_scale (= 1 - rate: the kept values carry
  * 1 / (1 - rate); dropped positions have mask 0 anyway).  dropout_seed = UINT64_MAX in a gradient product whose saved tensor
  * is a dropped RELU output: no mask is computed at all - that tensor is positive exactly where the unit was kept and active,
- * relu'(d_saved) carries the mask's zeros and the epilogue only applies 1 / (1 - rate). */
+ * relu'(d_saved) carries the mask's zeros and the epilogue only applies 1 / (1 - rate).
+ * d_tile_kmask (uint8 per 128-row tile of A, NULL = all) with a_scale_block > 0: bit b of a tile's byte says whether scale block b
+ * of K holds anything but zeros in that tile - the product skips the other blocks (at most 8 blocks; TFGNN_G_PATTERN_TILEMASK_BY_DST
+ * for an operand written through TFGNN_VIEW_BY_DST_TYPED_PATTERN).  d_row_map (int32 [M], NULL = identity): row r of the product is
+ * written (and its d_mul / d_saved / dropout index taken) at row d_row_map[r] (TFGNN_G_PATTERN_NODE_BY_DST: back to node order). */
 int tfgnn_sp_gemm_nt_dropout(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
                              int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                              int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                              int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
                              int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
-                             void* stream);
+                             const uint8_t* d_tile_kmask, const int32_t* d_row_map, void* stream);
 
 /* tfgnn_sp_gemm_tn: the weight-gradient product C[m, n] = sum_k A[k, a_first_col + m] B[k, b_first_col + n] of two SP16
  * operands stored with K as the row index (dW = X^T G of the Dense / edge-MLP kernels, tf.GradientTape in

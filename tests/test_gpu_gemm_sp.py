@@ -475,3 +475,68 @@ def test_small_passes_sharing_one_launch_equal_their_stand_alone_kernels(dev, mo
     ops.aux_flush()
     assert torch.equal(dW2, ref[9])
     graph.close()
+
+
+@pytest.mark.parametrize("V,E,L,D,H", [(3000, 5000, 4, 128, 128), (1500, 2500, 8, 64, 320), (700, 20000, 3, 320, 256), (130, 90, 2, 16, 128)])
+def test_product_over_pattern_ordered_rows_skipping_empty_blocks_equals_the_plain_product(dev, V, E, L, D, H):
+    """tfgnn_sp_gemm_nt_dropout d_tile_kmask / d_row_map with TFGNN_VIEW_BY_DST_TYPED_PATTERN (round 4): the gather writes
+    bucket (v, l) at row pos[v] of the operand, bit-identical to its row in node order; the product that skips the all-zero type
+    blocks of a row tile and writes its rows back through the row map equals the product over the node-ordered operand BIT
+    FOR BIT - plain, with bias + activation + dropout, and with the split-form output.  (Sparse batches: most buckets are empty;
+    the dense one has a single pattern and nothing to skip; the last has a ragged single tile.)"""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+
+    feats, adjs = make_synthetic_batch(V, E, L, D, seed=V + L)
+    g = ops.Graph([torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in adjs], V)
+    X = torch.from_numpy(feats).to(dev)
+    a_node = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, rows_per_operand_row=L)
+    a_pat = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN, X, rows_per_operand_row=L)
+    node_at = g.array(ops.G_PATTERN_NODE_BY_DST)
+    pos = g.array(ops.G_PATTERN_POS_BY_DST)
+    kmask = g.array(ops.G_PATTERN_TILEMASK_BY_DST)
+    assert kmask.dtype == torch.uint8 and kmask.numel() == (V + 127) // 128
+    idx = node_at.long()
+    assert torch.equal(torch.sort(idx).values, torch.arange(V, device=dev))
+    assert torch.equal(pos.long()[idx], torch.arange(V, device=dev))
+    assert torch.equal(a_pat.data, a_node.data[idx]) and torch.equal(a_pat.inv_scale, a_node.inv_scale[idx])
+    gen = torch.Generator().manual_seed(5)
+    W = (torch.randn((L * D, H), generator=gen) * 0.2).to(dev)
+    w_sp = ops.sp_split_cols(W)
+    bias = torch.randn(H, generator=gen).to(dev)
+    ref = ops.sp_gemm_nt(a_node, w_sp)
+    assert torch.equal(ops.sp_gemm_nt(a_pat, w_sp, row_map=node_at), ref)               # the row map alone
+    assert torch.equal(ops.sp_gemm_nt(a_pat, w_sp, tile_kmask=kmask, row_map=node_at), ref)
+    ref = ops.sp_gemm_nt(a_node, w_sp, bias=bias, act="relu", dropout=(0.2, 77))
+    got = ops.sp_gemm_nt(a_pat, w_sp, bias=bias, act="relu", dropout=(0.2, 77), tile_kmask=kmask, row_map=node_at)
+    assert torch.equal(got, ref)
+    ref32, ref_op = ops.sp_gemm_nt_split(a_node, w_sp, act="tanh", dropout=(0.1, 3))
+    got32, got_op = ops.sp_gemm_nt_split(a_pat, w_sp, act="tanh", dropout=(0.1, 3), tile_kmask=kmask, row_map=node_at)
+    assert torch.equal(got32, ref32) and torch.equal(got_op.data, ref_op.data) and torch.equal(got_op.inv_scale, ref_op.inv_scale)
+    # the mask really describes the operand: a cleared bit = an all-zero block in every row of the tile
+    blocks = a_pat.data.view(V, L, D * 4)
+    for t in range(kmask.numel()):
+        m = int(kmask[t])
+        rows = blocks[t * 128:(t + 1) * 128]
+        for l in range(L):
+            if not (m >> l) & 1:
+                assert not bool(rows[:, l].any()), (t, l)
+    g.close()
+
+
+def test_tile_mask_needs_block_scales_that_tile_k(dev):
+    from tf2_gnn_amd import ops
+
+    x = torch.randn((256, 256), device=dev)
+    a = ops.sp_split_rows(x)  # one scale per row: no blocks to skip
+    w = ops.sp_split_cols(torch.randn((256, 128), device=dev))
+    mask = torch.full((2,), 255, dtype=torch.uint8, device=dev)
+    ops.sp_gemm_nt(a, w, tile_kmask=mask)  # a single block: the mask can only say "run it"
+    a9 = ops.sp_split_rows(torch.randn((256, 9 * 16), device=dev), scale_block=16)
+    w9 = ops.sp_split_cols(torch.randn((9 * 16, 128), device=dev))
+    with pytest.raises(ValueError, match="tile mask"):
+        ops.sp_gemm_nt(a9, w9, tile_kmask=mask)
+    with pytest.raises(ValueError, match="tile_kmask"):
+        ops.sp_gemm_nt(a, w, tile_kmask=mask[:1])
+    with pytest.raises(ValueError, match="row_map"):
+        ops.sp_gemm_nt(a, w, row_map=torch.zeros(5, dtype=torch.int32, device=dev))

@@ -265,3 +265,40 @@ def test_dropout_applied_by_the_producer_equals_the_stand_alone_dropout(dev, mon
     close(dX_f, dX_u, "d node_features")
     for v, a, b in zip(gnn.trainable_variables, g_f, g_u):
         close(a, b, "d " + v.name)
+
+
+@pytest.mark.parametrize("V,E", [(3000, 9000), (3000, 90000)])
+def test_forward_products_over_pattern_ordered_nodes_leave_the_training_step_unchanged(dev, monkeypatch, V, E):
+    """Round 4: the forward product of the RGCN layers runs over the nodes in the order of their bucket-emptiness pattern and
+    skips the all-zero type blocks of each row tile (Graph part DST_PATTERN, TFGNN_NT_SKIP_EMPTY=0 switches it off).  The
+    skipped products are exact zeros and the rows go back to node order in the epilogue: the whole training step (output,
+    d node_features, every weight gradient) of the benchmarked stack must be BIT-EQUAL with and without it - on a batch where
+    most buckets are empty and on one where few are."""
+    from bench import ppi_rgcn_params
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    if ops.get_gemm_mode() != ops.GEMM_F16X2:
+        pytest.skip("the split-operand products")
+    L, H = 4, 320
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=8)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run(flag):
+        monkeypatch.setenv("TFGNN_NT_SKIP_EMPTY", flag)
+        set_seed(5)
+        gnn = GNN(ppi_rgcn_params(H, 4))
+        inp = GNNInput(torch.from_numpy(feats).to(dev), to_dev(adjs, dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+        out = gnn(inp, training=True)
+        dX = gnn.backward(dOut, need_input_grad=True)
+        parts = gnn.graph_parts(V, [len(a) for a in adjs])
+        return out.clone(), dX.clone(), [v.grad.clone() for v in gnn.trainable_variables], parts
+
+    out0, dX0, g0, parts0 = run("0")
+    out1, dX1, g1, parts1 = run("1")
+    assert not parts0 & ops.G_PART_DST_PATTERN and parts1 & ops.G_PART_DST_PATTERN
+    assert torch.equal(out0, out1) and torch.equal(dX0, dX1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)

@@ -263,7 +263,7 @@ _SIGNATURES = [
         c_int,
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_float,
-         ctypes.c_uint64, c_void_p],
+         ctypes.c_uint64, c_void_p, c_void_p, c_void_p],
     ),
 ]
 

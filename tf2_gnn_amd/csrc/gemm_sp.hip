@@ -89,6 +89,10 @@ struct SpArgs {
   int64_t drop_ld;
   DropoutKey drop;
   float saved_scale;  // act'(saved * saved_scale): the saved tensor is a dropped activation (scaled by 1/(1-rate) where kept)
+  // zero-block skipping (round 4): bit b of tile_kmask[row tile] = scale block b of A holds non-zeros in that tile; the other
+  // blocks' k16 steps are not executed.  row_map: output row of product row r (the operand's rows are in pattern order)
+  const uint8_t* tile_kmask;
+  const int32_t* row_map;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -218,6 +222,15 @@ struct SpLoop {
   uint4v rs_a, rs_b;       // buffer descriptors of this tile's A / B rows (wave-uniform)
   unsigned m0_a, m0_b;     // LDS byte address of this wave's first DMA slot in stage 0 (A part / B part)
   int nsteps;
+  // zero-block skipping: logical step s = (position q in the tile's list of non-empty blocks, step r inside the block) runs
+  // physical step blk[q] * bsteps + r (blk: 4 bits each).  bsteps == 0: identity.  brecip = ceil(2^16 / bsteps): s / bsteps
+  // for s < 8 * bsteps, bsteps <= 64
+  unsigned blkmap, bsteps, brecip;
+  __device__ __forceinline__ unsigned phys_step(unsigned s) const {
+    if (!bsteps) return s;
+    const unsigned q = (s * brecip) >> 16;
+    return ((blkmap >> (4u * q)) & 15u) * bsteps + (s - q * bsteps);
+  }
   __device__ __forceinline__ SpLoop(half8 (&fa_)[2][2][2], half8 (&fb_)[2][TNW][2], floatx16 (&acc_)[2][TNW],
                                     unsigned (&aa)[G::NST][2], unsigned (&ba)[G::NST][2], unsigned (&va)[G::ND_A],
                                     unsigned (&vb)[G::ND_B])
@@ -248,7 +261,7 @@ struct SpLoop {
     // written out (not the builtin): with the builtin hipcc keeps one SGPR per (stage, instruction) LDS address -
     // 35 of them at BN = 320 - runs out of SGPRs, parks the buffer descriptors in VGPRs and wraps every DMA in a
     // readfirstlane waterfall loop.  Here m0 is base + immediate: two SGPRs in all.
-    unsigned so = (unsigned)(step < nsteps ? step : nsteps - 1) * 64u;
+    unsigned so = phys_step((unsigned)(step < nsteps ? step : nsteps - 1)) * 64u;
     if constexpr (I < G::ND_A)
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(so) : "memory");
@@ -282,8 +295,9 @@ struct SpLoop {
   __device__ __forceinline__ void scale_frags(int step) {  // plain VALU on the freshly read A fragments
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (step % a_blk_steps == 0) {
-      const int b = step / a_blk_steps;
-      if (b < a_nblk) {
+      const int q = step < nsteps ? step / a_blk_steps : 0;
+      const int b = bsteps ? (int)((blkmap >> (4u * (unsigned)q)) & 15u) : q;
+      if (step < nsteps && b < a_nblk) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const _Float16 f = (_Float16)(a_inv[a_row[t] * a_nblk + b] / a_rmax[t]);  // (a_inv_ld == a_nblk here)
@@ -351,7 +365,17 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   const unsigned tile_m = blockIdx.x / g.n_tiles;
   const int64_t row0 = (int64_t)tile_m * SP_BM;
   const int64_t col0 = (int64_t)tile_n * G::BN;
-  const int nsteps = (int)(g.K >> 4);
+  int nsteps = (int)(g.K >> 4);
+  unsigned blkmap = 0, bsteps = 0;
+  if (g.tile_kmask) {  // only the blocks of K that hold anything in this row tile (wave-uniform: one byte per tile)
+    unsigned m = __builtin_amdgcn_readfirstlane((int)g.tile_kmask[tile_m]) & ((1u << g.a_nblk) - 1u);
+    if (!m) m = 1u;  // an all-empty tile still runs one (zero) block: the epilogue needs defined accumulators and scales
+    int n = 0;
+    for (int b = 0; b < g.a_nblk; ++b)
+      if (m & (1u << b)) blkmap |= (unsigned)b << (4 * n++);
+    bsteps = (unsigned)g.a_blk_steps;
+    nsteps = n * g.a_blk_steps;
+  }
 
   // ---- DMA setup: buffer descriptors over this tile's rows (rows past M / N read as zeros) -------------------
   const int64_t rows_a = g.M - row0 < SP_BM ? g.M - row0 : SP_BM;
@@ -376,6 +400,9 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   L.m0_a = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_A * 1024);
   L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
   L.nsteps = nsteps;
+  L.blkmap = blkmap;
+  L.bsteps = bsteps;
+  L.brecip = bsteps ? (65536u + bsteps - 1u) / bsteps : 0u;
   // lane j of a DMA instruction fills LDS slot j of 16 rows x 64 bytes: row j / 4, slot q' = j % 4 holds source
   // chunk q = q' ^ ((row >> 2) & 3)
   const int drow = lane >> 2;
@@ -506,6 +533,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         const int64_t row = wrow0 + pr;
         okq[q] = row < g.M;
         rowq[q] = okq[q] ? row : g.M - 1;
+        if (g.row_map) rowq[q] = g.row_map[rowq[q]];
         float4 m[TNW], sv[TNW];
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
@@ -595,7 +623,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         const int pr = idx / C4, c4 = idx - pr * C4;
         const int64_t row = wrow0 + pr, col = wcol0 + c4 * 4;
         ok[j] = row < g.M;
-        const int64_t rr = ok[j] ? row : g.M - 1;
+        int64_t rr = ok[j] ? row : g.M - 1;
+        if (g.row_map) rr = g.row_map[rr];
         coff[j] = rr * g.ldc + col;
         doff[j] = rr * g.drop_ld + col;
         v[j] = *reinterpret_cast<const float4*>(patch + pr * G::PATCH_LD + c4 * 4);
@@ -1304,7 +1333,7 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
                            int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                            int act_of_saved, const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                            float* d_out_inv_scale, void* stream, float dropout_rate = 0.f, uint64_t dropout_seed = 0,
-                           float saved_scale = 1.f) {
+                           float saved_scale = 1.f, const uint8_t* d_tile_kmask = nullptr, const int32_t* d_row_map = nullptr) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && (d_C || d_out_sp), "tfgnn_sp_gemm_nt: null pointer");
   TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "tfgnn_sp_gemm_nt: dropout rate must be in [0, 1), got %f", (double)dropout_rate);
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
@@ -1334,6 +1363,13 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   g.C = d_C; g.ldc = ldc; g.bias = d_bias; g.act = act; g.accumulate = accumulate;
   g.mul = d_mul; g.ld_mul = ld_mul; g.saved = d_saved; g.ld_saved = ld_saved; g.dact = act_of_saved;
   g.saved_scale = saved_scale;
+  if (d_tile_kmask) {
+    TFGNN_REQUIRE(g.a_nblk >= 1 && g.a_nblk <= 8 && g.a_blk_steps <= 64 && g.a_blk_steps * g.a_nblk == (int)(K >> 4) && g.a_inv &&
+                      !a_uniform,
+                  "tfgnn_sp_gemm_nt: the tile mask needs 1..8 scale blocks of A (of at most 1024 columns) that tile K");
+    g.tile_kmask = d_tile_kmask;
+  }
+  g.row_map = d_row_map;
   g.drop_on = dropout_rate > 0.f ? (dropout_seed == ~0ull ? 2 : 1) : 0;
   if (g.drop_on == 2)
     TFGNN_REQUIRE(d_saved && act_of_saved == TFGNN_ACT_RELU, "tfgnn_sp_gemm_nt_dropout: the mask-from-saved form needs a relu saved tensor");
@@ -1383,10 +1419,10 @@ int tfgnn_sp_gemm_nt_dropout(int64_t M, int64_t N, int64_t K, const void* d_A_sp
                              int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                              int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
                              int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
-                             void* stream) {
+                             const uint8_t* d_tile_kmask, const int32_t* d_row_map, void* stream) {
   return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
                          act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale,
-                         stream, dropout_rate, dropout_seed, saved_scale);
+                         stream, dropout_rate, dropout_seed, saved_scale, d_tile_kmask, d_row_map);
 }
 
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {

@@ -52,7 +52,7 @@ int graph_require_parts(const tfgnn_graph* g, unsigned need, const char* who) {
   set_error("%s: the graph handle lacks part%s%s%s%s (requested 0x%x at creation): tfgnn_graph_ensure(graph, parts, stream) builds it",
             who, (missing & TFGNN_GRAPH_PART_PLAN_TYPED) ? " PLAN_TYPED" : "", (missing & TFGNN_GRAPH_PART_PLAN_NODE) ? " PLAN_NODE" : "",
             (missing & TFGNN_GRAPH_PART_COMPACT) ? " COMPACT" : "",
-            (missing & (TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS)) ? " EDGE_MAPS / EDGE_IDS" : "", g->parts);
+            (missing & (TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS | TFGNN_GRAPH_PART_DST_PATTERN)) ? " EDGE_MAPS / EDGE_IDS / DST_PATTERN" : "", g->parts);
   return TFGNN_ERR_INVALID_ARGUMENT;
 }
 }  // namespace tfgnn
@@ -567,6 +567,73 @@ __global__ void nz_cols_kernel(const int32_t* __restrict__ cpos, const int32_t* 
   }
 }
 
+// ---- nodes grouped by which of their (node, type) buckets are empty (part DST_PATTERN, round 4) ------------------------------
+// 45 % of the buckets of an R-MAT batch are empty: the 320-column block of such a bucket in [A_0|..|A_{L-1}] is zeros the
+// product multiplies for nothing.  With the rows of a product tile sharing one emptiness pattern the product skips the empty
+// blocks of the whole tile: the gather writes its rows at pos[node] (nodes ordered by pattern), the product walks a per-tile
+// list of K blocks and writes its output rows back to node order.  L <= 8 (one mask byte per node / tile).
+__device__ __forceinline__ int node_pattern(const int32_t* __restrict__ rowptr, int64_t v, int L) {
+  int m = 0;
+  for (int l = 0; l < L; ++l) m |= (rowptr[v * L + l + 1] > rowptr[v * L + l]) ? (1 << l) : 0;
+  return m;
+}
+__global__ void __launch_bounds__(256) pattern_count_kernel(const int32_t* __restrict__ rowptr, int64_t V, int L,
+                                                            int32_t* __restrict__ bins /* [256], zeroed */) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) atomicAdd(&h[node_pattern(rowptr, v, L)], 1);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+// pos[v] = first position of v's pattern + a slot claimed inside the pattern (the order inside a pattern is arbitrary and has
+// no effect on any result: every row is computed on its own, only its place in the operand differs)
+__global__ void __launch_bounds__(256) pattern_place_kernel(const int32_t* __restrict__ rowptr, int64_t V, int L,
+                                                            const int32_t* __restrict__ bins, int32_t* __restrict__ cursor /* [256], zeroed */,
+                                                            int32_t* __restrict__ pos, int32_t* __restrict__ node_at,
+                                                            int32_t* __restrict__ rowmap) {
+  __shared__ int base[256], h[256], slot0[256];
+  {  // patterns with many non-empty buckets first (any fixed order would do): order key (8 - popcount, pattern)
+    h[threadIdx.x] = bins[threadIdx.x];
+    __syncthreads();
+    const int key = ((8 - __popc((int)threadIdx.x)) << 8) | (int)threadIdx.x;
+    int acc = 0;
+    for (int m = 0; m < 256; ++m) acc += ((((8 - __popc(m)) << 8) | m) < key) ? h[m] : 0;
+    base[threadIdx.x] = acc;
+    __syncthreads();
+  }
+  for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < V; v0 += (int64_t)gridDim.x * 256) {
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t v = v0 + threadIdx.x;
+    int m = 0, rank = 0;
+    if (v < V) {
+      m = node_pattern(rowptr, v, L);
+      rank = atomicAdd(&h[m], 1);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) slot0[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (v < V) {
+      const int32_t p = base[m] + slot0[m] + rank;
+      pos[v] = p;
+      node_at[p] = (int32_t)v;
+      for (int l = 0; l < L; ++l) rowmap[v * L + l] = p * L + l;
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(128) pattern_tilemask_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ node_at,
+                                                               int64_t V, int L, uint8_t* __restrict__ tilemask) {
+  __shared__ int m;
+  if (threadIdx.x == 0) m = 0;
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  if (p < V) atomicOr(&m, node_pattern(rowptr, node_at[p], L));
+  __syncthreads();
+  if (threadIdx.x == 0) tilemask[blockIdx.x] = (uint8_t)m;
+}
+
 // blockIdx.y = 0 / 1: unpack the sorted keys of the by-target / by-source side; blockIdx.y = 2: per-row arrays
 // (1 / in-degree, node pointers).  The degree that normalises an edge is always the in-degree of its TARGET for its type,
 // i.e. the length of by-target row (target, type) - read from rowptr_d directly, so the three jobs share one launch.
@@ -738,7 +805,7 @@ namespace {
 using namespace tfgnn;
 
 constexpr unsigned kPartsAll = TFGNN_GRAPH_PART_PLAN_TYPED | TFGNN_GRAPH_PART_PLAN_NODE | TFGNN_GRAPH_PART_COMPACT |
-                               TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS;
+                               TFGNN_GRAPH_PART_EDGE_MAPS | TFGNN_GRAPH_PART_EDGE_IDS | TFGNN_GRAPH_PART_DST_PATTERN;
 
 // long-row plan parameters per view (tools/gather_probe.py sweeps at cfg-2, rows ordered by length): typed
 // views 91 us at (48, 512) vs 104 us at (16, 192) (134 us in natural row order at (16, 128)); the node views -
@@ -832,6 +899,19 @@ int build_compact(tfgnn_graph* g, char* scratch, hipStream_t s) {
   return TFGNN_OK;
 }
 
+// nodes ordered by the emptiness pattern of their by-target buckets (kernels above); pat = the 512 zeroed ints behind the bins
+int build_dst_pattern(tfgnn_graph* g, int32_t* pat, hipStream_t s) {
+  if (g->V <= 0 || g->L <= 0 || g->L > 8) return TFGNN_OK;  // (L > 8: the part stays empty, callers fall back)
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(g->V, 256), 1024);
+  hipLaunchKernelGGL(pattern_count_kernel, dim3(blocks), dim3(256), 0, s, (const int32_t*)g->rowptr_d, g->V, g->L, pat);
+  hipLaunchKernelGGL(pattern_place_kernel, dim3(blocks), dim3(256), 0, s, (const int32_t*)g->rowptr_d, g->V, g->L, (const int32_t*)pat,
+                     pat + 256, g->pat_pos_d, g->pat_node_d, g->pat_rowmap_d);
+  hipLaunchKernelGGL(pattern_tilemask_kernel, dim3((unsigned)ceil_div(g->V, 128)), dim3(128), 0, s, (const int32_t*)g->rowptr_d,
+                     (const int32_t*)g->pat_node_d, g->V, g->L, g->pat_tilemask_d);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
 int build_edge_maps(tfgnn_graph* g, hipStream_t s) {
   if (g->E > 0) {
     hipLaunchKernelGGL(src2dst_kernel, dim3(blocks_for(g->E)), dim3(256), 0, s, g->eid_s, g->eid2pos, g->E, g->src2dst, g->dst2src);
@@ -896,7 +976,7 @@ CoreScratch core_scratch(int64_t E, int L, bool pay) {
   c.keys = tmp.take((size_t)E * 8 * 4);
   c.pays = tmp.take(pay ? (size_t)E * 4 * 4 : 0);
   c.hist = tmp.take((size_t)2 * RS_RADIX * c.nblk_ld * 4 + 16);
-  c.counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS) * 4);  // counters, then the bins: one memset
+  c.counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4);  // counters, the bins, the pattern bins: one memset
   c.ptrs = tmp.take((size_t)(L + 1) * 8);
   c.off = tmp.take((size_t)(L + 1) * 8);
   c.total = tmp.total;
@@ -976,6 +1056,8 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   const size_t o_nodeptr_d = plan.take((V + 1) * 4), o_nodeptr_s = plan.take((V + 1) * 4);
   const size_t o_src2dst = plan.take(E * 4), o_dst2src = plan.take(E * 4);
   const size_t o_tgt_d = plan.take(E * 4), o_eid2pos = plan.take(E * 4);
+  const size_t o_pat_pos = plan.take((V + 1) * 4), o_pat_node = plan.take((V + 1) * 4), o_pat_rowmap = plan.take((R + 1) * 4);
+  const size_t o_pat_mask = plan.take((size_t)ceil_div(V > 0 ? V : 1, 128) + 16);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
   size_t o_cb[2][6];
@@ -1054,6 +1136,10 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   g->dst2src = (int32_t*)(slab + o_dst2src);
   g->tgt_d = (int32_t*)(slab + o_tgt_d);
   g->eid2pos = (int32_t*)(slab + o_eid2pos);
+  g->pat_pos_d = (int32_t*)(slab + o_pat_pos);
+  g->pat_node_d = (int32_t*)(slab + o_pat_node);
+  g->pat_rowmap_d = (int32_t*)(slab + o_pat_rowmap);
+  g->pat_tilemask_d = (uint8_t*)(slab + o_pat_mask);
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
   g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
@@ -1102,7 +1188,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
     }                                                                                          \
   } while (0)
 
-  G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS) * 4, s));
+  G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4, s));
   // sort the edges into bucket order for both bucketings, then everything per edge and per row
   if (E > 0) {
     rc = run_core(g, with_ids, scratch, cs, s);
@@ -1131,6 +1217,10 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   }
   if (parts & TFGNN_GRAPH_PART_EDGE_MAPS) {
     rc = build_edge_maps(g, s);
+    if (rc) return fail(rc);
+  }
+  if (parts & TFGNN_GRAPH_PART_DST_PATTERN) {
+    rc = build_dst_pattern(g, bins + 4 * 2 * SHORT_BINS, s);
     if (rc) return fail(rc);
   }
   if (parts & TFGNN_GRAPH_PART_COMPACT) {
@@ -1195,7 +1285,7 @@ extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) 
   // the edge ids were not carried through the sort: run it again with the payload (same order, same arrays - the adjacency
   // lists of tfgnn_graph_create* are read again and must still be alive)
   const CoreScratch cs = core_scratch(redo_core ? g->E : 0, g->L, true);
-  const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS) * 4;
+  const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4;
   const size_t core_take = (cs.total + 255) & ~(size_t)255;
   const size_t need = core_take + ((missing & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(g->R, g->V) : 0);
   char* scratch = nullptr;
@@ -1212,6 +1302,7 @@ extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) 
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_PLAN_TYPED)) rc = build_plans(g, 0, counters, counters + 64, s);
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_PLAN_NODE)) rc = build_plans(g, 1, counters, counters + 64, s);
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_EDGE_MAPS)) rc = build_edge_maps(g, s);
+  if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_DST_PATTERN)) rc = build_dst_pattern(g, counters + 64 + 4 * 2 * SHORT_BINS, s);
   if (e == hipSuccess && !rc && (missing & TFGNN_GRAPH_PART_COMPACT)) rc = build_compact(g, scratch + core_take, s);
   if (e == hipSuccess && !rc) e = hipMemcpyAsync(g->pinned, counters, 64 * 4, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipStreamSynchronize(s);
@@ -1378,6 +1469,7 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     unsigned need = 0;
     if (array_id == TFGNN_G_SRC2DST_POS) need = TFGNN_GRAPH_PART_EDGE_MAPS;
     if (array_id == TFGNN_G_EID_BY_DST || array_id == TFGNN_G_EID_BY_SRC) need = TFGNN_GRAPH_PART_EDGE_IDS;
+    if (array_id >= TFGNN_G_PATTERN_POS_BY_DST && array_id <= TFGNN_G_PATTERN_TILEMASK_BY_DST) need = TFGNN_GRAPH_PART_DST_PATTERN;
     if (array_id >= TFGNN_G_NZ_CPOS_BY_DST && array_id <= TFGNN_G_NZ_COL_BY_SRC) need = TFGNN_GRAPH_PART_COMPACT;
     if (need) {
       const int rc = tfgnn::graph_require_parts(g, need, "tfgnn_graph_array");
@@ -1400,6 +1492,9 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     case TFGNN_G_INVDEG_EDGE_BY_DST: *d_ptr = g->invdeg_edge_d; *count = g->E; break;
     case TFGNN_G_SRC2DST_POS: *d_ptr = g->src2dst; *count = g->E; break;
     case TFGNN_G_TARGET_BY_DST: *d_ptr = g->tgt_d; *count = g->E; break;
+    case TFGNN_G_PATTERN_POS_BY_DST: *d_ptr = g->L <= 8 ? g->pat_pos_d : nullptr; *count = g->L <= 8 ? g->V : 0; break;
+    case TFGNN_G_PATTERN_NODE_BY_DST: *d_ptr = g->L <= 8 ? g->pat_node_d : nullptr; *count = g->L <= 8 ? g->V : 0; break;
+    case TFGNN_G_PATTERN_TILEMASK_BY_DST: *d_ptr = g->L <= 8 ? (const void*)g->pat_tilemask_d : nullptr; *count = g->L <= 8 ? ceil_div(g->V, 128) : 0; break;
     case TFGNN_G_NZ_CPOS_BY_DST: case TFGNN_G_NZ_CPOS_BY_SRC:
       *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].cpos; *count = g->R; break;
     case TFGNN_G_NZ_ROW_BY_DST: case TFGNN_G_NZ_ROW_BY_SRC:

@@ -545,8 +545,8 @@ extern "C" int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d
 }
 
 extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int view, int width) {
-  if (!g || view < 0 || view > 5 || width <= 0) return 0;
-  if (view >= 4) view = view == 4 ? 0 : 2;
+  if (!g || view < 0 || view > 6 || width <= 0) return 0;
+  if (view >= 4) view = (view == 4 || view == 6) ? 0 : 2;
   return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
 }
 
@@ -558,17 +558,22 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
                              float* d_inv_scale, const float* d_fixed_inv, tfgnn_aux_job* combine_job = nullptr) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
-  TFGNN_REQUIRE(view >= 0 && view <= 5, "unknown graph view %d", view);
+  TFGNN_REQUIRE(view >= 0 && view <= 6, "unknown graph view %d", view);
   TFGNN_REQUIRE(width >= 0 && ew_heads >= 1, "bad sizes");
   // views 4 / 5: the typed views 0 / 2 with compact output (one row per NON-EMPTY bucket, type-major)
   {
     unsigned need = (view == 1 || view == 3) ? TFGNN_GRAPH_PART_PLAN_NODE : TFGNN_GRAPH_PART_PLAN_TYPED;
-    if (view >= 4) need |= TFGNN_GRAPH_PART_COMPACT;
+    if (view == 4 || view == 5) need |= TFGNN_GRAPH_PART_COMPACT;
+    if (view == 6) need |= TFGNN_GRAPH_PART_DST_PATTERN;
     const int prc = graph_require_parts(g, need, "tfgnn_graph_gather_reduce");
     if (prc) return prc;
   }
   const int32_t* out_map = nullptr;
-  if (view >= 4) {
+  if (view == 6) {  // by-target buckets, rows in pattern order
+    TFGNN_REQUIRE(g->L <= 8, "TFGNN_VIEW_BY_DST_TYPED_PATTERN: at most 8 edge types");
+    out_map = g->pat_rowmap_d;
+    view = 0;
+  } else if (view >= 4) {
     out_map = g->compact[view - 4].cpos;
     view = view == 4 ? 0 : 2;
   }

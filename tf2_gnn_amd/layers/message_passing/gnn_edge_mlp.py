@@ -46,6 +46,15 @@ def mlp_hidden_sizes(out_size: int, hidden_layers) -> List[int]:
 PER_EDGE_MIN_ROWS = 65536  # (tests lower it; the library's own threshold is asked through tfgnn_gemm_gathered_supported)
 
 
+def _skip_empty_blocks(L: int, Din: int) -> bool:
+    """Does the forward product of path A run over the nodes in pattern order and skip the all-zero type blocks of a row tile
+    (tfgnn_sp_gemm_nt_dropout d_tile_kmask)?  One edge type has nothing to skip; the library takes at most 8 blocks of at
+    most 1024 columns.  TFGNN_NT_SKIP_EMPTY=0 keeps the node order (A/B measurements)."""
+    import os
+
+    return 2 <= L <= 8 and Din % 16 == 0 and Din <= 1024 and os.environ.get("TFGNN_NT_SKIP_EMPTY", "1") == "1"
+
+
 def messages_per_edge(layer, g, D, H) -> bool:
     """one product row per EDGE (rows of X read through an index) rather than per (node, type) bucket?  Pays when edges are
     fewer than buckets and the fused gathered product (tfgnn_gemm_gathered) takes every edge type's product - the library is
@@ -187,6 +196,8 @@ class GNN_Edge_MLP(MessagePassing):
                                 edges_per_type=tuple(int(c) for c in edges_per_type))
         if messages_per_edge(self, shape, in_dim, self._hidden_dim):
             return ops.G_PART_PLAN_TYPED | ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_IDS
+        if _skip_empty_blocks(shape.num_edge_types, in_dim):
+            return ops.G_PART_PLAN_TYPED | ops.G_PART_DST_PATTERN
         return ops.G_PART_PLAN_TYPED
 
     # ---- which formulation ------------------------------------------------------------------
@@ -397,7 +408,14 @@ class GNN_Edge_MLP(MessagePassing):
         if self._f16x2_eligible(V, D, L, H):
             # f16x2: the gather writes [A_0 | ... | A_{L-1}] directly as the split operand (one scale per (node, type)
             # bucket), the kernels are split once per value, the product only moves data and multiplies
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale, rows_per_operand_row=L, defer_combine=True)
+            # most nodes of a typed graph receive edges of only some types: with the nodes in the order of their emptiness
+            # pattern (Graph part DST_PATTERN) whole 128-row tiles of A have all-zero type blocks, which the product skips.
+            # The product's epilogue writes its rows back in node order, so nothing downstream sees the order.
+            skip = _skip_empty_blocks(L, Din)
+            kmask = g.array(ops.G_PATTERN_TILEMASK_BY_DST) if skip else None
+            rmap = g.array(ops.G_PATTERN_NODE_BY_DST) if skip else None
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale,
+                                       rows_per_operand_row=L, defer_combine=True)
             Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H), defer=True))
             gelu_split = fuse_act == "gelu"
             want_split = getattr(self, "_want_split_output", False) or getattr(self, "_always_split_output", False)
@@ -406,13 +424,14 @@ class GNN_Edge_MLP(MessagePassing):
             if drop is not None and not gelu_split and H in (128, 256, 320) and type(self)._finish is GNN_Edge_MLP._finish:
                 # this layer's output is only ever read through that dropout: apply the mask in the product's epilogue and
                 # write the dropped result in both forms (fp32 for the next gather, SP16 for its weight-gradient product)
-                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, dropout=drop)
+                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, dropout=drop, tile_kmask=kmask, row_map=rmap)
                 self._fused_output_dropout_done = True
                 out_scale = 1.0 - float(drop[0])
             elif want_split and not gelu_split and H in (128, 256, 320):
-                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act)  # the consumer finds the split form with sp_rows_of
+                # the consumer finds the split form with sp_rows_of
+                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, tile_kmask=kmask, row_map=rmap)
             else:
-                pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act)
+                pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act, tile_kmask=kmask, row_map=rmap)
             ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True, "out_scale": out_scale}
             if gelu_split:
                 ctx["pre"] = pre

@@ -175,12 +175,15 @@ class _DevArray:
  G_COLL_BY_SRC, G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_NODEPTR_BY_DST, G_NODEPTR_BY_SRC,
  G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS, G_TARGET_BY_DST, G_NZ_CPOS_BY_DST, G_NZ_ROW_BY_DST, G_NZ_NODE_BY_DST,
  G_NZ_OFF_BY_DST, G_NZ_NODEPTR_BY_DST, G_NZ_COL_BY_DST, G_NZ_CPOS_BY_SRC, G_NZ_ROW_BY_SRC, G_NZ_NODE_BY_SRC,
- G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC) = range(27)
+ G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC, G_PATTERN_POS_BY_DST, G_PATTERN_NODE_BY_DST,
+ G_PATTERN_TILEMASK_BY_DST) = range(30)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
+_BYTE_ARRAYS = {G_PATTERN_TILEMASK_BY_DST}
 # parts of a graph handle beyond the two sorted edge orders (include/tfgnn.h tfgnn_graph_part)
-G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_EDGE_IDS, G_PARTS_ALL = 1, 2, 4, 8, 16, 31
+G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_EDGE_IDS, G_PART_DST_PATTERN, G_PARTS_ALL = 1, 2, 4, 8, 16, 32, 63
 _VIEW_PARTS = {0: G_PART_PLAN_TYPED, 1: G_PART_PLAN_NODE, 2: G_PART_PLAN_TYPED, 3: G_PART_PLAN_NODE,
-               4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT}
+               4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT,
+               6: G_PART_PLAN_TYPED | G_PART_DST_PATTERN}
 
 
 def _array_parts(array_id: int) -> int:
@@ -188,6 +191,8 @@ def _array_parts(array_id: int) -> int:
         return G_PART_EDGE_MAPS | G_PART_EDGE_IDS
     if array_id in (G_EID_BY_DST, G_EID_BY_SRC):
         return G_PART_EDGE_IDS
+    if G_PATTERN_POS_BY_DST <= array_id <= G_PATTERN_TILEMASK_BY_DST:
+        return G_PART_DST_PATTERN
     return G_PART_COMPACT if G_NZ_CPOS_BY_DST <= array_id <= G_NZ_COL_BY_SRC else 0
 
 
@@ -266,9 +271,10 @@ class Graph:
         n = ctypes.c_int64()
         _lib.check(lib.tfgnn_graph_array(self._h, array_id, ctypes.byref(p), ctypes.byref(n)))
         if n.value == 0 or not p.value:
-            t = torch.empty(0, dtype=torch.float32 if array_id in _FLOAT_ARRAYS else torch.int32, device=self.device)
+            dt = torch.float32 if array_id in _FLOAT_ARRAYS else torch.uint8 if array_id in _BYTE_ARRAYS else torch.int32
+            t = torch.empty(0, dtype=dt, device=self.device)
         else:
-            typestr = "<f4" if array_id in _FLOAT_ARRAYS else "<i4"
+            typestr = "<f4" if array_id in _FLOAT_ARRAYS else "|u1" if array_id in _BYTE_ARRAYS else "<i4"
             t = torch.as_tensor(_DevArray(p.value, n.value, typestr, self), device=self.device)
         self._cache[array_id] = t
         return t
@@ -350,7 +356,7 @@ def gather_reduce(
 
 
 (VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE, VIEW_BY_DST_TYPED_COMPACT,
- VIEW_BY_SRC_TYPED_COMPACT) = range(6)
+ VIEW_BY_SRC_TYPED_COMPACT, VIEW_BY_DST_TYPED_PATTERN) = range(7)
 
 
 @_writes_out
@@ -1149,10 +1155,24 @@ def sp_split_cols(w: torch.Tensor, defer: bool = False) -> SplitOperand:
     return SplitOperand(data, inv, N, K, K)
 
 
+def _tile_kmask(t, M):
+    if t is not None and (t.dtype != torch.uint8 or not t.is_cuda or t.numel() < (M + 127) // 128 or not t.is_contiguous()):
+        raise ValueError("tile_kmask must be a contiguous uint8 device tensor with one byte per 128-row tile")
+    return t
+
+
+def _row_map(t, M):
+    if t is not None and (t.dtype != torch.int32 or not t.is_cuda or t.numel() != M or not t.is_contiguous()):
+        raise ValueError("row_map must be a contiguous int32 device tensor with one entry per product row")
+    return t
+
+
 @_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
-               act_grad=None, dropout=None, saved_scale: float = 1.0) -> torch.Tensor:
+               act_grad=None, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None) -> torch.Tensor:
     """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt / tfgnn_sp_gemm_nt_dropout).
+    tile_kmask (uint8 [ceil(M / 128)]): bit b = scale block b of ``a`` holds non-zeros in that row tile, the other blocks are
+    skipped; row_map (int32 [M]): product row r is written at out[row_map[r]] (Graph pattern order, graph_gather_sp).
     dropout = (rate, seed): the result times the mask ``dropout_forward`` draws for that seed, applied in the epilogue
     (forward: the next layer's input dropout; gradient product: the recomputed forward mask).  saved_scale: the derivative
     of ``act_grad`` is taken at saved * saved_scale (saved is a dropped activation)."""
@@ -1181,14 +1201,14 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
             _ptr(b.inv_scale), _ptr(out), ldc, _ptr(bias), act_id(act), int(accumulate), _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
             saved.stride(0) if saved is not None else 0, float(saved_scale), None, 0, None, float(rate),
-            int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(_tile_kmask(tile_kmask, M)), _ptr(_row_map(row_map, M)), _stream(),
         )
     )
     return out
 
 
 def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out_mul=None, act_grad=None,
-                     want_fp32: bool = True, dropout=None, saved_scale: float = 1.0):
+                     want_fp32: bool = True, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None):
     """As sp_gemm_nt, with the result ALSO (or only: want_fp32=False) written as an SP16 operand with one scale per row
     by the product's epilogue (tfgnn_sp_gemm_nt_sp): the next product's operand without a split pass.  N must be one
     column tile (128, 256 or 320).  -> (fp32 [M, N] | None, SplitOperand); the fp32 tensor remembers its split form
@@ -1214,7 +1234,7 @@ def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NON
             b.data.stride(0), _ptr(b.inv_scale), _ptr(out), N, _ptr(bias), act_id(act), 0, _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
             saved.stride(0) if saved is not None else 0, float(saved_scale), _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale),
-            float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(),
+            float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(_tile_kmask(tile_kmask, M)), _ptr(_row_map(row_map, M)), _stream(),
         )
     )
     if out is not None:
@@ -1240,7 +1260,10 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     _require_dev(inp, torch.float32, "inp")
     if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
         raise ValueError("graph_gather_sp: compact views are not supported")
-    num_rows = graph.num_nodes * (graph.num_edge_types if view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED) else 1)
+    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN)
+    num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
+    if view == VIEW_BY_DST_TYPED_PATTERN and graph.num_edge_types > 8:
+        raise ValueError("graph_gather_sp: the pattern order exists for at most 8 edge types")
     inp, ld_in = _rowmajor(inp, "inp")
     width = inp.shape[1]
     R = int(rows_per_operand_row)
