@@ -128,6 +128,7 @@ typedef enum {
                                       128 positions the union of those patterns - lets the forward product of the aggregate-first
                                       layers skip the all-zero K blocks of a row tile (TFGNN_VIEW_BY_DST_TYPED_PATTERN, the tile
                                       mask / row map arguments of tfgnn_sp_gemm_nt_dropout); at most 8 edge types, empty beyond  */
+  TFGNN_GRAPH_PARTS_DEFAULT = 31, /* what tfgnn_graph_create_async builds: everything but the pattern order (on request) */
   TFGNN_GRAPH_PARTS_ALL = 63
 } tfgnn_graph_part;
 int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
@@ -736,6 +737,19 @@ int tfgnn_sp_gemm_tn_phase(int phases, int64_t M, int64_t N, int64_t K, const vo
  * for the gathered gradient): every factor of two costs one bit of the 18 the format has beyond fp32's significand. */
 int tfgnn_absmax(const float* d_x, int64_t n, float scale, float* d_out, void* stream);
 int tfgnn_sp_inv_scale_from_bound(const float* d_bound, float* d_inv_scale, void* stream);
+
+/* tfgnn_graph_gather_reduce with per-head edge weights that ALSO writes, per edge e of the view and head k,
+ *   d_dot_out[pos(e) * ew_heads + k] = sum_{f in head k} d_in[col(e), f] * d_dot_rows[r(e) * ld_dot + f]
+ * r(e) = the row of the view that holds the edge, pos(e) = d_dot_pos[e] (NULL: the edge's position in the view's order).
+ * Reference: the gradient of the attention-weighted message sum w.r.t. the attention values (what tf.GradientTape derives for
+ * tf2_gnn/layers/message_passing/rgat.py:153-163) - on the by-source gather of the backward pass that reads d_agg[target(e)]
+ * anyway, with d_dot_rows = Y and d_dot_pos = TFGNN_G_SRC2DST_POS.  tfgnn_graph_gather_dot_supported: 1 when the head width
+ * (4 .. 64 floats, a power of two) fits the kernel's lane groups, else 0 (callers use tfgnn_rgat_edge_dot). */
+int tfgnn_graph_gather_dot_supported(int width, int ew_heads);
+int tfgnn_graph_gather_reduce_dot(const tfgnn_graph* g, int view, const float* d_edge_weight, int ew_heads, const float* d_in,
+                                  int64_t ld_in, int width, float* d_out, int64_t ld_out, const float* d_dot_rows, int64_t ld_dot,
+                                  const int32_t* d_dot_pos, float* d_dot_out, void* d_workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* tfgnn_graph_gather_reduce (plain sums: embedding_lookup + 1/(c+1e-7) scaling + unsorted_segment_sum,
  * message_passing.py:197-206,172-174, gnn_edge_mlp.py:102-106) writing its rows directly as the SP16 operand of

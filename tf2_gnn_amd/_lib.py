@@ -57,6 +57,13 @@ _SIGNATURES = [
         [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
          c_int, c_int, c_void_p, c_size_t, c_void_p],
     ),
+    ("tfgnn_graph_gather_dot_supported", c_int, [c_int, c_int]),
+    (
+        "tfgnn_graph_gather_reduce_dot",
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
     ("tfgnn_edge_pair_combine", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     ("tfgnn_graph_original_order", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("tfgnn_gemm_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64]),

@@ -1245,7 +1245,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
 
 extern "C" int tfgnn_graph_create_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,
                                         const int64_t* num_edges, void* stream, tfgnn_graph** out_graph) {
-  return graph_create_impl(num_edge_types, num_nodes, d_adjacency, num_edges, kPartsAll, stream, out_graph);
+  return graph_create_impl(num_edge_types, num_nodes, d_adjacency, num_edges, TFGNN_GRAPH_PARTS_DEFAULT, stream, out_graph);
 }
 
 extern "C" int tfgnn_graph_create_parts_async(int num_edge_types, int64_t num_nodes, const int32_t* const* d_adjacency,

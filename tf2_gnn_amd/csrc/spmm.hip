@@ -84,7 +84,63 @@ __device__ __forceinline__ void vunpack<1>(const float& v, float* o) {
 // MODE 0: sum, optional scalar edge weight          (RGCN / GGNN / RGIN forward and backward)
 // MODE 1: sum, per-head edge weights ew[e, K]       (RGAT)
 // MODE 2: general: runtime max / pre-activation, optional scalar edge weight
-enum { MODE_SUM = 0, MODE_HEADS = 1, MODE_GENERAL = 2 };
+// MODE 3: MODE 1 + per edge and head the inner product of the gathered row with a row that belongs to the CSR row
+//         (RGAT backward: d attention[e, k] = <Y[(src_e, l_e)], d_agg[tgt_e]>_k rides on the by-source gather that reads
+//         d_agg[tgt_e] anyway - round 4; before, rgat_edge_dot read Y[(src_e, l_e)] per edge in a pass of its own)
+enum { MODE_SUM = 0, MODE_HEADS = 1, MODE_GENERAL = 2, MODE_HEADS_DOT = 3 };
+__host__ __device__ constexpr bool mode_heads(int mode) { return mode == MODE_HEADS || mode == MODE_HEADS_DOT; }
+
+// value of the lane at distance 1 << S inside its aligned group of 2 << S lanes (S = 3, 2: the mirrored lane - same thing for a sum)
+template <int S>
+__device__ __forceinline__ float dpp_partner(float v) {
+  constexpr int ctrl = S == 0 ? 0xB1 : S == 1 ? 0x4E : S == 2 ? 0x141 : 0x140;  // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+}
+// N values per lane, each to be summed over the 1 << L2 consecutive lanes of the lane's group (N <= 1 << L2): instead of N
+// butterflies the lanes split the values among themselves - at the top log2(N) distances a lane keeps the half of its values
+// its lane bit selects and receives the partner's partial sums of that half - then one butterfly finishes the value left.
+// -> the complete sum of value number `which` (lanes that differ only in the bits below the splitting ones hold copies)
+template <int N, int L2>
+__device__ __forceinline__ float dpp_split_sum(const float (&p)[N], int lane, int& which) {
+  static_assert(N == 1 || N == 2 || N == 4, "values per lane");
+  static_assert((1 << L2) >= N && L2 <= 4, "group");
+  if constexpr (N == 4) {
+    const bool hi = (lane >> (L2 - 1)) & 1;
+    float q[2];
+    q[0] = (hi ? p[2] : p[0]) + dpp_partner<L2 - 1>(hi ? p[0] : p[2]);
+    q[1] = (hi ? p[3] : p[1]) + dpp_partner<L2 - 1>(hi ? p[1] : p[3]);
+    int w;
+    const float r = dpp_split_sum<2, L2 - 1>(q, lane, w);
+    which = (hi ? 2 : 0) + w;
+    return r;
+  } else if constexpr (N == 2) {
+    const bool hi = (lane >> (L2 - 1)) & 1;
+    float q[1];
+    q[0] = (hi ? p[1] : p[0]) + dpp_partner<L2 - 1>(hi ? p[0] : p[1]);
+    int w;
+    const float r = dpp_split_sum<1, L2 - 1>(q, lane, w);
+    which = hi ? 1 : 0;
+    return r;
+  } else {
+    float v = p[0];
+    if constexpr (L2 >= 4) v += dpp_partner<3>(v);
+    if constexpr (L2 >= 3) v += dpp_partner<2>(v);
+    if constexpr (L2 >= 2) v += dpp_partner<1>(v);
+    if constexpr (L2 >= 1) v += dpp_partner<0>(v);
+    which = 0;
+    return v;
+  }
+}
+
+// sum over the 1 << log2n (<= 16) consecutive lanes a lane belongs to (DPP: no LDS traffic); every lane gets the sum
+__device__ __forceinline__ float dpp_group_sum(float v, int log2n) {
+  int x;
+  if (log2n >= 1) { x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false); v += __int_as_float(x); }   // quad_perm [1,0,3,2]
+  if (log2n >= 2) { x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false); v += __int_as_float(x); }   // quad_perm [2,3,0,1]
+  if (log2n >= 3) { x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false); v += __int_as_float(x); }  // row_half_mirror
+  if (log2n >= 4) { x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); v += __int_as_float(x); }  // row_mirror
+  return v;
+}
 
 struct GatherArgs {
   const int32_t* rowptr;
@@ -105,6 +161,13 @@ struct GatherArgs {
   int is_max;
   int ew_heads;    // K (MODE_HEADS)
   int head_width;  // floats per head (MODE_HEADS)
+  // MODE_HEADS_DOT: dot_out[pos(e) * ew_heads + k] = sum over head k of in[col[e]] * dot_rows[CSR row of e]; pos = dot_pos[e]
+  // (nullable: e).  head_width / 4 = 1 << dot_lph_log2 lanes hold a head (<= lanes per row, <= 16)
+  const float* dot_rows;
+  int64_t ld_dot;
+  float* dot_out;
+  const int32_t* dot_pos;
+  int dot_lph_log2;
   int long_threshold;  // rows longer than this are left to the item kernels (0 = never)
   const int32_t* out_row_map;  // nullable: output row of CSR row r is out_row_map[r]; < 0 = no output
   unsigned xcd_units_pad;      // != 0: 1-D XCD-aware grid over (window, unit); set by the launcher
@@ -148,17 +211,45 @@ __device__ __forceinline__ float sp_row_scale(const GatherArgs& a, float mx, int
 // accumulate edges [beg, end) into acc (lane-private chunks)
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE>
 __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t beg, int32_t end, int f0,
-                                                 const bool (&live)[VPL], float (&acc)[VPL][VEC]) {
+                                                 const bool (&live)[VPL], float (&acc)[VPL][VEC], int64_t row) {
   using V = typename VecT<VEC>::type;
   const bool is_max = MODE == MODE_GENERAL && a.is_max;
   int hidx[VPL];
-  if (MODE == MODE_HEADS) {
+  if (mode_heads(MODE)) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) hidx[i] = live[i] ? (f0 + i * LPR * VEC) / a.head_width : 0;
+  }
+  float yv[VPL][VEC];
+  bool dot_writer = false;
+  if constexpr (MODE == MODE_HEADS_DOT) {
+    const float* yrow = a.dot_rows + row * a.ld_dot + f0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) yv[i][c] = 0.f;
+      if (live[i]) vunpack<VEC>(vload<VEC>(yrow + i * LPR * VEC), yv[i]);
+    }
+    dot_writer = ((threadIdx.x % LPR) & ((1 << a.dot_lph_log2) - 1)) == 0;
+  }
+  // the split reduction (one store per edge instead of one per chunk) when the chunk count is 2 or 4 and a head has at
+  // least that many lanes
+  constexpr bool CAN_SPLIT = MODE == MODE_HEADS_DOT && (VPL == 2 || VPL == 4);
+  const bool split = CAN_SPLIT && (1 << a.dot_lph_log2) >= VPL;
+  bool split_writer = false;
+  int split_head = 0;
+  if (split) {  // which value the lane ends up with (dpp_split_sum), fixed per lane
+    constexpr int SPLIT_BITS = VPL == 4 ? 2 : 1;
+    const int lane = threadIdx.x % LPR;
+    const int which = (lane >> (a.dot_lph_log2 - SPLIT_BITS)) & (VPL - 1);
+    const int f = f0 + which * LPR * VEC;
+    // copies sit in the lanes that differ in the bits below the splitting ones: the lane with those bits clear writes
+    split_writer = (lane & ((1 << (a.dot_lph_log2 - SPLIT_BITS)) - 1)) == 0 && f < a.width;
+    split_head = f / a.head_width;
   }
   for (int32_t e = beg; e < end; e += UNROLL) {
     int32_t idx[UNROLL];
     int32_t eid[UNROLL];
+    int32_t dpos[UNROLL];
     float w[UNROLL];
     bool ok[UNROLL];
 #pragma unroll
@@ -168,7 +259,8 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
       ee = ok[u] ? ee : end - 1;
       eid[u] = ee;
       idx[u] = a.col[ee];
-      w[u] = (MODE != MODE_HEADS && a.ew) ? a.ew[ee] : 1.f;
+      if constexpr (MODE == MODE_HEADS_DOT) dpos[u] = a.dot_pos ? a.dot_pos[ee] : ee;
+      w[u] = (!mode_heads(MODE) && a.ew) ? a.ew[ee] : 1.f;
     }
     V v[UNROLL][VPL];
     float wh[UNROLL][VPL];
@@ -179,7 +271,7 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
       for (int i = 0; i < VPL; ++i) {
         if (live[i]) {
           v[u][i] = vload<VEC>(src + i * LPR * VEC);
-          if (MODE == MODE_HEADS) wh[u][i] = a.ew[(int64_t)eid[u] * a.ew_heads + hidx[i]];
+          if (mode_heads(MODE)) wh[u][i] = a.ew[(int64_t)eid[u] * a.ew_heads + hidx[i]];
         }
       }
     }
@@ -191,7 +283,7 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
           if (live[i]) {
             float x[VEC];
             vunpack<VEC>(v[u][i], x);
-            const float wt = MODE == MODE_HEADS ? wh[u][i] : w[u];
+            const float wt = mode_heads(MODE) ? wh[u][i] : w[u];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
               float m = wt * x[c];
@@ -203,6 +295,45 @@ __device__ __forceinline__ void accumulate_edges(const GatherArgs& a, int32_t be
               }
             }
           }
+        }
+      }
+    }
+    if constexpr (MODE == MODE_HEADS_DOT) {
+      // all lanes of a row group walk the same edges, so the exchange is convergent inside the group (DPP moves data inside
+      // a 16-lane row only; other groups of the wave may sit in another iteration, their lanes are not read)
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t pos = dpos[u];
+        float p[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          p[i] = 0.f;
+          if (live[i]) {
+            float x[VEC];
+            vunpack<VEC>(v[u][i], x);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) p[i] += x[c] * yv[i][c];
+          }
+        }
+        if constexpr (CAN_SPLIT) {
+          if (split) {
+            const int lane = threadIdx.x % LPR;
+            int which = 0;
+            float r = 0.f;
+            switch (a.dot_lph_log2) {  // (wave-uniform)
+              case 1: if constexpr (VPL <= 2) r = dpp_split_sum<VPL, 1>(p, lane, which); break;
+              case 2: r = dpp_split_sum<VPL, 2>(p, lane, which); break;
+              case 3: r = dpp_split_sum<VPL, 3>(p, lane, which); break;
+              default: r = dpp_split_sum<VPL, 4>(p, lane, which); break;
+            }
+            if (ok[u] && split_writer) a.dot_out[pos * a.ew_heads + split_head] = r;
+            continue;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          const float r = dpp_group_sum(p[i], a.dot_lph_log2);
+          if (ok[u] && live[i] && dot_writer) a.dot_out[pos * a.ew_heads + hidx[i]] = r;
         }
       }
     }
@@ -235,7 +366,7 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[i][c] = is_max ? kFloatLowest : 0.f;
   }
-  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
+  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc, row);
 
   const float rs = a.row_scale ? a.row_scale[row] : 1.f;
   if constexpr (SP) {  // VEC == 4, one window: the lane group holds the whole row
@@ -303,7 +434,7 @@ __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item,
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[i][c] = is_max ? kFloatLowest : 0.f;
   }
-  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc);
+  accumulate_edges<LPR, VPL, VEC, UNROLL, MODE>(a, beg, end, f0, live, acc, row);
 #pragma unroll
   for (int i = 0; i < VPL; ++i)
 #pragma unroll
@@ -461,6 +592,15 @@ template <int LPR, int VPL, int VEC, int UNROLL>
 static int launch_variant(const GatherArgs& a, int mode, int num_items, hipStream_t s) {
   if (mode == MODE_SUM) return launch_mode<LPR, VPL, VEC, UNROLL, MODE_SUM>(a, num_items, s);
   if (mode == MODE_HEADS) return launch_mode<LPR, VPL, VEC, UNROLL, MODE_HEADS>(a, num_items, s);
+  if (mode == MODE_HEADS_DOT) {
+    if constexpr (VEC == 4) {
+      TFGNN_REQUIRE((1 << a.dot_lph_log2) <= LPR, "fused edge products: a head is wider than a lane group (width %d)", a.width);
+      return launch_mode<LPR, VPL, VEC, UNROLL, MODE_HEADS_DOT>(a, num_items, s);
+    } else {
+      set_error("fused edge products need 16-byte aligned rows");
+      return TFGNN_ERR_UNSUPPORTED;
+    }
+  }
   return launch_mode<LPR, VPL, VEC, UNROLL, MODE_GENERAL>(a, num_items, s);
 }
 
@@ -472,10 +612,16 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
     TFGNN_REQUIRE(a.head_width > 0 && a.width % a.head_width == 0 && a.width / a.head_width == a.ew_heads,
                   "width %d is not ew_heads %d x head_width %d", a.width, a.ew_heads, a.head_width);
     mode = MODE_HEADS;
+    if (a.dot_out) {
+      TFGNN_REQUIRE(a.dot_rows && a.ld_dot >= a.width && a.ld_dot % 4 == 0 && (uintptr_t)a.dot_rows % 16 == 0,
+                    "fused edge products: bad row operand");
+      mode = MODE_HEADS_DOT;
+    }
   }
+  TFGNN_REQUIRE(!a.dot_out || mode == MODE_HEADS_DOT, "fused edge products ride on the per-head weighted sums only");
   const bool vec4 = (a.width % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) &&
                     (((uintptr_t)a.in | (uintptr_t)a.out) % 16 == 0) && (!a.out_sp || a.ld_out_sp % 64 == 0) &&
-                    (mode != MODE_HEADS || a.head_width % 4 == 0);
+                    (!mode_heads(mode) || a.head_width % 4 == 0);
   TFGNN_REQUIRE(vec4 || !a.out_sp, "SP16 gather output needs 16-byte aligned rows");
   if (!vec4) {
     // scalar path (odd widths: unit tests, tiny models): 16 lanes x 4 floats per pass
@@ -494,7 +640,7 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
   // L2-resident slicing: gather 32-float (128 B) windows of the rows, XCD by XCD, when one window of
   // ALL source rows fits an XCD's 4 MiB L2 but the full rows do not (cfg-2: 3.84 MB vs 38 MB).
   static const int sliced_knob = [] { const char* e = getenv("TFGNN_GATHER_SLICED"); return e ? atoi(e) : -1; }();
-  const bool can_slice = a.num_src_rows > 0 && chunks > 16 && mode != MODE_HEADS;
+  const bool can_slice = a.num_src_rows > 0 && chunks > 16 && !mode_heads(mode);
   // Measured at cfg-2 (tools/gather_probe.py): 322 us sliced vs 160 us whole-row - ten passes over the
   // index arrays with 128-byte requests lose more than the L2 hits win.  Off unless TFGNN_GATHER_SLICED=1.
   const bool want_slice = sliced_knob > 0;
@@ -550,12 +696,15 @@ extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int v
   return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
 }
 
+extern "C" int tfgnn_graph_gather_dot_supported(int width, int ew_heads);
 static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_col_override,
                              const float* d_edge_weight, int ew_heads, const float* d_row_scale,
                              const float* d_in, int64_t ld_in, int width, float* d_out,
                              int64_t ld_out, int reduce_op, int pre_act, int post_act,
                              void* d_workspace, size_t workspace_bytes, void* stream, void* d_out_sp, int64_t ld_out_sp,
-                             float* d_inv_scale, const float* d_fixed_inv, tfgnn_aux_job* combine_job = nullptr) {
+                             float* d_inv_scale, const float* d_fixed_inv, tfgnn_aux_job* combine_job = nullptr,
+                             const float* d_dot_rows = nullptr, int64_t ld_dot = 0, const int32_t* d_dot_pos = nullptr,
+                             float* d_dot_out = nullptr) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
   TFGNN_REQUIRE(view >= 0 && view <= 6, "unknown graph view %d", view);
@@ -595,6 +744,14 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = p.long_threshold;
   a.out_row_map = out_map;
+  if (d_dot_out) {
+    TFGNN_REQUIRE(ew_heads > 1 && d_edge_weight && width % ew_heads == 0, "tfgnn_graph_gather_reduce_dot: per-head edge weights only");
+    const int lph = width / ew_heads / 4;
+    TFGNN_REQUIRE(tfgnn_graph_gather_dot_supported(width, ew_heads), "tfgnn_graph_gather_reduce_dot: unsupported head width %d",
+                  width / ew_heads);
+    a.dot_rows = d_dot_rows; a.ld_dot = ld_dot; a.dot_out = d_dot_out; a.dot_pos = d_dot_pos;
+    a.dot_lph_log2 = 31 - __builtin_clz((unsigned)lph);
+  }
   a.num_src_rows = d_col_override ? 0 : ((view == 1 || view == 3) ? g->R : g->V);  // rows of `in`
   a.item_row = p.item_row; a.item_chunk = p.item_chunk; a.item_slot = p.item_slot;
   a.partial = (float*)d_workspace; a.item_chunk_edges = p.item_chunk_edges;
@@ -616,6 +773,34 @@ extern "C" int tfgnn_graph_gather_reduce(const tfgnn_graph* g, int view, const i
                                          void* d_workspace, size_t workspace_bytes, void* stream) {
   return graph_gather_impl(g, view, d_col_override, d_edge_weight, ew_heads, d_row_scale, d_in, ld_in, width, d_out, ld_out,
                            reduce_op, pre_act, post_act, d_workspace, workspace_bytes, stream, nullptr, 0, nullptr, nullptr);
+}
+
+/* can tfgnn_graph_gather_reduce_dot take rows of `width` floats in `ew_heads` heads?  (a head = 4, 8, .. 64 floats that a
+ * lane group of the gather holds in 1..16 consecutive lanes) */
+extern "C" int tfgnn_graph_gather_dot_supported(int width, int ew_heads) {
+  if (width <= 0 || ew_heads <= 1 || width % ew_heads) return 0;
+  const int hw = width / ew_heads;
+  if (hw % 4 || width % 4) return 0;
+  const int lph = hw / 4, chunks = width / 4;
+  if (lph & (lph - 1)) return 0;
+  const int lanes_per_row = chunks <= 8 ? 8 : (chunks <= 80 ? 16 : 32);  // gather_dispatch's choice
+  return lph <= 16 && lph <= lanes_per_row;
+}
+
+/* tfgnn_graph_gather_reduce with per-head edge weights that ALSO writes, per edge e of the view and head k,
+ *   d_dot_out[pos(e) * ew_heads + k] = sum_{f in head k} d_in[col(e), f] * d_dot_rows[r(e) * ld_dot + f]
+ * where r(e) is the row of the view the edge belongs to and pos(e) = d_dot_pos[e] (NULL: e, the edge's position in the view's
+ * order).  RGAT backward: the by-source gather of d_agg[tgt] with d_dot_rows = Y yields d attention in by-target order through
+ * d_dot_pos = TFGNN_G_SRC2DST_POS (replaces tfgnn_rgat_edge_dot, one pass over the edges less). */
+extern "C" int tfgnn_graph_gather_reduce_dot(const tfgnn_graph* g, int view, const float* d_edge_weight, int ew_heads,
+                                             const float* d_in, int64_t ld_in, int width, float* d_out, int64_t ld_out,
+                                             const float* d_dot_rows, int64_t ld_dot, const int32_t* d_dot_pos, float* d_dot_out,
+                                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(d_dot_rows && d_dot_out, "tfgnn_graph_gather_reduce_dot: NULL pointer");
+  return graph_gather_impl(g, view, nullptr, d_edge_weight, ew_heads, nullptr, d_in, ld_in, width, d_out, ld_out, TFGNN_REDUCE_SUM,
+                           TFGNN_ACT_NONE, TFGNN_ACT_NONE, d_workspace, workspace_bytes, stream, nullptr, 0, nullptr, nullptr, nullptr,
+                           d_dot_rows, ld_dot, d_dot_pos, d_dot_out);
 }
 
 extern "C" int tfgnn_graph_gather_reduce_sp(const tfgnn_graph* g, int view, const int32_t* d_col_override,

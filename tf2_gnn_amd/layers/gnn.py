@@ -190,7 +190,7 @@ class GNN:
         """Union of what the layers of this stack read from a batch's graph handle (``MessagePassing.graph_parts``): hand it
         to ``ops.Graph(..., parts=)`` when the handle is built ahead of the step (input pipeline)."""
         if not self._mp_layers:  # not built yet: the first call builds everything
-            return ops.G_PARTS_ALL
+            return ops.G_PARTS_DEFAULT
         parts = 0
         for mp in self._mp_layers:
             parts |= mp.graph_parts(num_nodes, edges_per_type, self._hidden_dim)

@@ -191,7 +191,7 @@ class GNN_Edge_MLP(MessagePassing):
 
         if (self._user_message_function() or self._path() != "A" or self._use_target_state_as_input or self._compact_opt_in
                 or os.environ.get("TFGNN_COMPACT_BUCKETS") == "1"):
-            return ops.G_PARTS_ALL
+            return ops.G_PARTS_DEFAULT
         shape = SimpleNamespace(num_edge_types=len(edges_per_type), num_edges=int(sum(edges_per_type)), num_nodes=int(num_nodes),
                                 edges_per_type=tuple(int(c) for c in edges_per_type))
         if messages_per_edge(self, shape, in_dim, self._hidden_dim):

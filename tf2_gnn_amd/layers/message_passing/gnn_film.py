@@ -31,7 +31,7 @@ class GNN_FiLM(GNN_Edge_MLP):
     aggregation kernel."""
 
     def graph_parts(self, num_nodes, edges_per_type, in_dim) -> int:
-        return ops.G_PARTS_ALL  # compact buckets / per-edge forms: every derived table of the handle
+        return ops.G_PARTS_DEFAULT  # compact buckets / per-edge forms: every derived table of the handle
 
     @classmethod
     def get_default_hyperparameters(cls):

@@ -117,7 +117,7 @@ def _graph_key(adjacency_lists, num_nodes: int) -> tuple:
     )
 
 
-def get_graph(adjacency_lists, num_nodes: int, parts: int = ops.G_PARTS_ALL) -> "ops.Graph":
+def get_graph(adjacency_lists, num_nodes: int, parts: int = ops.G_PARTS_DEFAULT) -> "ops.Graph":
     """The bucketed Graph of a batch, built once and shared by every layer / pass that is handed the same adjacency
     tensors.  An entry holds references to those tensors, so their addresses cannot be given to another batch while
     the entry is alive (a key of addresses alone would return a stale Graph when the allocator reuses them); an
@@ -173,7 +173,7 @@ class MessagePassing:
         """Which derived tables of the batch's graph handle this layer reads (ops.G_PART_*), for a batch of that shape: a
         stack whose layers need only some of them skips the preparation kernels of the rest (include/tfgnn.h
         tfgnn_graph_create_parts_async).  A hint, not a contract: a missing part is built on first use.  Default: all."""
-        return ops.G_PARTS_ALL
+        return ops.G_PARTS_DEFAULT
 
     def __init__(self, params: Dict[str, Any], **kwargs):
         self.name = kwargs.get("name", type(self).__name__)

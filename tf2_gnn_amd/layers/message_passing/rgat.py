@@ -1,4 +1,5 @@
 """Relational Graph Attention Network layer - mirror of tf2_gnn/layers/message_passing/rgat.py."""
+import os
 from typing import Any, Dict
 
 import torch
@@ -177,6 +178,26 @@ class RGAT(MessagePassing):
 
     def backward(self, grad_output: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(out) -> d(loss)/d(node_embeddings); fills the kernel / attention gradients."""
+        return self._backward(grad_output, False, None, None)
+
+    def activation_backward_spec(self):
+        ctx = self._ctx
+        if ctx is None or type(self).backward is not RGAT.backward or ctx.get("fused_act") is None:
+            return None
+        act = ctx["fused_act"]
+        return act, (ctx["pre"] if act == "gelu" else ctx["out"])
+
+    def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
+        """backward() whose input-gradient product dX = dY W^T applies the caller's next element-wise steps (dropout mask of
+        this layer's input, activation derivative of the layer below) in its epilogue, and which takes a gradient the layer
+        above already multiplied by this layer's activation derivative."""
+        if type(self).backward is not RGAT.backward:
+            return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+        return self._backward(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+
+    def _backward(self, grad_output, grad_is_pre_activation, out_mul, out_act_grad) -> torch.Tensor:
+        from .message_passing import apply_gradient_epilogue
+
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward called before a forward pass")
@@ -189,28 +210,34 @@ class RGAT(MessagePassing):
         dev = X.device
         act = ctx["fused_act"]
         d_agg = grad_output
-        if act is not None:
+        if act is not None and not grad_is_pre_activation:
             d_agg = ops.activation_backward(act, grad_output, ctx["pre"] if act == "gelu" else ctx["out"])
         d_agg = d_agg.contiguous()
         if L == 0 or E == 0:
             for v in self._variables:
                 v.grad = torch.zeros_like(v.value)
-            return torch.zeros_like(X)
+            return torch.zeros_like(X)  # (zero times the caller's factors)
         s2d = g.array(ops.G_SRC2DST_POS)
         ident_e = self._ident(g, E)
         # (1) dY[(u,l),k,:] = sum over out-edges e of (u,l): a_ek * d_agg[tgt_e, k, :]
         att_s = ctx.get("att_by_src")  # written by the forward row kernels in training mode
         if att_s is None:
             att_s = ops.gather_reduce(ident_e[: E + 1], s2d, att)  # attention re-ordered to the by-src edge order
-        dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]
-        # (2) gradient w.r.t. the attention values, softmax + leaky_relu backward
-        da = torch.empty((E, K), dtype=torch.float32, device=dev)
-        _lib.check(
-            lib.tfgnn_rgat_edge_dot(
-                ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(Y),
-                ops._ptr(d_agg), E, K, H, ops._ptr(da), ops._stream(),
+        # (2) gradient w.r.t. the attention values: da[e,k] = <Y[(src_e, l_e)], d_agg[tgt_e]>_k.  The gather of (1) reads
+        #     d_agg[tgt_e] for every out-edge of (u, l) with Y[(u, l)] fixed per row: the products ride on it and land in
+        #     by-target order through the edge map (round 4; a pass of its own over the edges before, 112 us at configs[2])
+        if K > 1 and ops.graph_gather_dot_supported(H, K) and os.environ.get("TFGNN_RGAT_FUSED_DOT", "1") == "1":
+            dY, da = ops.graph_gather_dot(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s, dot_rows=Y.view(V * L, H), dot_pos=s2d)
+        else:
+            dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]
+            da = torch.empty((E, K), dtype=torch.float32, device=dev)
+            _lib.check(
+                lib.tfgnn_rgat_edge_dot(
+                    ops._ptr(g.array(ops.G_COLL_BY_DST)), ops._ptr(g.array(ops.G_TARGET_BY_DST)), ops._ptr(Y),
+                    ops._ptr(d_agg), E, K, H, ops._ptr(da), ops._stream(),
+                )
             )
-        )
+        # softmax + leaky_relu backward
         dz = torch.empty((E, K), dtype=torch.float32, device=dev)
         g.ensure(ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_MAPS)
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
@@ -253,7 +280,11 @@ class RGAT(MessagePassing):
             if rc == 0:
                 d_kernels = ops.gemm(X, dY.view(V, L * H), trans_a=True)  # X^T dY  [D, L*H]
                 Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels, defer=True))
-                dX = ops.sp_gemm_nt(dY_sp, Wr)
+                if getattr(self, "_want_split_input_grad", False) and D in (128, 256, 320):
+                    dX, _ = ops.sp_gemm_nt_split(dY_sp, Wr, out_mul=out_mul, act_grad=out_act_grad)
+                else:
+                    dX = ops.sp_gemm_nt(dY_sp, Wr, out_mul=out_mul, act_grad=out_act_grad)
+                out_mul = out_act_grad = None  # applied
             elif rc != -4:
                 _lib.check(rc)
         if dX is None:
@@ -269,4 +300,6 @@ class RGAT(MessagePassing):
         for i in range(L):
             self._edge_type_to_message_computation_layer[i].grad = d_kernels[:, i * H : (i + 1) * H]
             self._edge_type_to_attention_parameters[i].grad = d_attn[i]
+        if out_mul is not None or out_act_grad is not None:
+            dX = apply_gradient_epilogue(dX, out_mul, out_act_grad)
         return dX

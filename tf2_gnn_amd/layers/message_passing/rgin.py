@@ -20,7 +20,7 @@ class RGIN(GNN_Edge_MLP):
     ignores ``message_activation_before_aggregation`` (rgin.py:88-106)."""
 
     def graph_parts(self, num_nodes, edges_per_type, in_dim) -> int:
-        return ops.G_PARTS_ALL  # compact buckets / per-edge forms: every derived table of the handle
+        return ops.G_PARTS_DEFAULT  # compact buckets / per-edge forms: every derived table of the handle
 
     @classmethod
     def get_default_hyperparameters(cls):

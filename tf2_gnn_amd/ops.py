@@ -181,6 +181,7 @@ _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
 _BYTE_ARRAYS = {G_PATTERN_TILEMASK_BY_DST}
 # parts of a graph handle beyond the two sorted edge orders (include/tfgnn.h tfgnn_graph_part)
 G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_EDGE_IDS, G_PART_DST_PATTERN, G_PARTS_ALL = 1, 2, 4, 8, 16, 32, 63
+G_PARTS_DEFAULT = G_PARTS_ALL & ~G_PART_DST_PATTERN  # the pattern order is built for the layers that ask for it
 _VIEW_PARTS = {0: G_PART_PLAN_TYPED, 1: G_PART_PLAN_NODE, 2: G_PART_PLAN_TYPED, 3: G_PART_PLAN_NODE,
                4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT,
                6: G_PART_PLAN_TYPED | G_PART_DST_PATTERN}
@@ -201,7 +202,7 @@ class Graph:
     and for forward + backward.  ``adjacency_lists``: sequence of int32 device tensors [E_l, 2]
     with rows (source, target), exactly ``GNNInput.adjacency_lists`` (layers/gnn.py:241-244)."""
 
-    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, wait: bool = True, parts: int = G_PARTS_ALL):
+    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, wait: bool = True, parts: int = G_PARTS_DEFAULT):
         """wait=False: the build is only enqueued on the current stream (pipelining the next batch's
         bucketing behind the current step, like the reference's prefetching input pipeline); call
         ``wait()`` - and order the consuming stream after the build stream - before using it.
@@ -405,6 +406,49 @@ def graph_gather(
         )
     )
     return out
+
+
+def graph_gather_dot_supported(width: int, heads: int) -> bool:
+    return bool(_lib.load().tfgnn_graph_gather_dot_supported(int(width), int(heads)))
+
+
+def graph_gather_dot(graph: "Graph", view: int, inp: torch.Tensor, *, edge_weight: torch.Tensor, dot_rows: torch.Tensor,
+                     dot_pos: Optional[torch.Tensor] = None):
+    """graph_gather with per-head edge weights [E, K] that also returns, per edge e of the view and head k, the inner product
+    of the gathered row inp[col(e)] with dot_rows[row of e] over the head's columns, written at position dot_pos[e] (None: e)
+    (tfgnn_graph_gather_reduce_dot) -> (sums [rows, width], products [E, K])."""
+    lib = _lib.load()
+    _require_dev(inp, torch.float32, "inp")
+    _require_dev(dot_rows, torch.float32, "dot_rows")
+    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED)
+    if view not in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_NODE):
+        raise ValueError("graph_gather_dot: the four plain views only")
+    num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
+    inp, ld_in = _rowmajor(inp, "inp")
+    dot_rows, ld_dot = _rowmajor(dot_rows, "dot_rows")
+    width = inp.shape[1]
+    if edge_weight.dim() != 2 or edge_weight.shape[0] != graph.num_edges:
+        raise ValueError("graph_gather_dot: edge_weight must be [E, K]")
+    edge_weight = edge_weight.contiguous()
+    heads = edge_weight.shape[1]
+    if tuple(dot_rows.shape) != (num_rows, width):
+        raise ValueError(f"dot_rows must be [{num_rows},{width}], got {tuple(dot_rows.shape)}")
+    if dot_pos is not None and (dot_pos.dtype != torch.int32 or dot_pos.numel() != graph.num_edges or not dot_pos.is_contiguous()):
+        raise ValueError("dot_pos must be a contiguous int32 tensor with one entry per edge")
+    dots = torch.empty((graph.num_edges, heads), dtype=torch.float32, device=inp.device)
+    if graph.num_edges == 0:
+        return torch.zeros((num_rows, width), dtype=torch.float32, device=inp.device), dots
+    out = torch.empty((num_rows, width), dtype=torch.float32, device=inp.device)
+    graph.ensure(_VIEW_PARTS[view])
+    ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, width)
+    ws = _workspace(inp.device, ws_bytes) if ws_bytes else None
+    _lib.check(
+        lib.tfgnn_graph_gather_reduce_dot(
+            graph._h, view, _ptr(edge_weight), heads, _ptr(inp), ld_in, width, _ptr(out), out.stride(0), _ptr(dot_rows), ld_dot,
+            _ptr(dot_pos), _ptr(dots), _ptr(ws), ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    return out, dots
 
 
 class DropoutSpec:
