@@ -245,7 +245,7 @@ def test_gemm_split_k_weight_gradient_shape(dev):
     assert_close(o1.cpu() / 141.0, (ref / 141.0).float(), tol=3e-6, what="split-k")
 
 
-@pytest.mark.parametrize("width", [3, 7, 12, 32, 64, 128, 256, 320, 512, 1280])
+@pytest.mark.parametrize("width", [3, 4, 7, 8, 12, 32, 64, 128, 256, 320, 512, 1280])
 @pytest.mark.parametrize("reduce", ["sum", "max"])
 def test_gather_reduce_matches_oracle(dev, width, reduce):
     from tf2_gnn_amd import ops

@@ -648,6 +648,8 @@ static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
     a.xcd_units_pad = 1;
     return launch_variant<8, 1, 4, 8>(a, mode, num_items, s);
   }
+  // (rows of 8 floats - RGAT's per-head logit gradients summed per bucket - leave six of the eight lanes of the next variant
+  // idle; a two-lane variant measured SLOWER, 28 vs 23 us at configs[2]: the launch is bound by the walk along the rows)
   if (chunks <= 8) return launch_variant<8, 1, 4, 8>(a, mode, num_items, s);
   if (chunks <= 16) return launch_variant<16, 1, 4, 8>(a, mode, num_items, s);
   if (chunks <= 32) return launch_variant<16, 2, 4, 4>(a, mode, num_items, s);
