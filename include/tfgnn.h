@@ -397,6 +397,13 @@ int tfgnn_gemm_gathered_supported(int64_t M, int64_t N, int64_t K, int64_t lda, 
 int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows,
                             int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
                             int64_t stride_b, float* d_C, int64_t ldc, int act, void* stream);
+/* tfgnn_gemm_grouped_rows (act none) times act'(d_saved) - d_saved [rows, N] indexed like C - in the product's epilogue: the
+ * input-gradient product of a per-relation MLP layer (gnn_edge_mlp.py:84-100 under tf.GradientTape) with the derivative of the
+ * hidden relu below it.  TFGNN_ERR_UNSUPPORTED when the active kernel has no such epilogue (fp32 mode, odd shapes): the
+ * caller runs tfgnn_gemm_grouped_rows and tfgnn_activation_backward. */
+int tfgnn_gemm_grouped_rows_grad(int trans_b, int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows, int64_t N,
+                                 int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int64_t stride_b,
+                                 float* d_C, int64_t ldc, int act_of_saved, const float* d_saved, int64_t ld_saved, void* stream);
 size_t tfgnn_gemm_grouped_k_workspace_bytes(int num_groups, int64_t max_group_rows, int64_t M, int64_t N);
 int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows, int64_t M,
                          int64_t N, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
@@ -411,6 +418,10 @@ int tfgnn_gemm_grouped_k(int num_groups, const int32_t* d_group_offsets, int64_t
 int tfgnn_activation_forward(int act, const float* d_x, float* d_y, int64_t n, void* stream);
 int tfgnn_activation_backward(int act, const float* d_dy, const float* d_saved, float* d_dx,
                               int64_t n, void* stream);
+/* dx = (dy * mul) * act'(saved): tfgnn_mul (the dropout mask of a layer input, gnn.py:285-288) followed by
+ * tfgnn_activation_backward (the activation of the layer below) in one pass, bit-equal to the two calls.  16-byte aligned. */
+int tfgnn_activation_backward_mul(int act, const float* d_dy, const float* d_saved, const float* d_mul, float* d_dx, int64_t n,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GRUCell gate math ([ext] tf.keras.layers.GRUCell TF2 defaults: reset_after=True, gates z|r|h,

@@ -201,6 +201,14 @@ def test_grouped_gemms_match_fp64(dev, gemm_mode, mode, N, K):
         refW = A[sl].double().t() @ Gr[sl].double()
         scale = max(1.0, float(refW.abs().max()))
         assert_close(dW[i].cpu() / scale, (refW / scale).float(), tol=1e-5, what=f"grouped k g{i}")
+    # the input-gradient form with the derivative of the hidden activation below in the epilogue (tfgnn_gemm_grouped_rows_grad;
+    # a separate pass where the kernel has no such epilogue): the same bits as the product followed by activation_backward
+    saved = torch.relu(torch.randn((R, K), generator=g)).to(dev)
+    fused = ops.gemm_grouped_rows(Gr.to(dev), off_dev, off_h, W.to(dev), trans_b=True, act_grad=("relu", saved))
+    assert torch.equal(fused, ops.activation_backward("relu", outT, saved))
+    saved_t = torch.tanh(torch.randn((R, K), generator=g)).to(dev)
+    fused = ops.gemm_grouped_rows(Gr.to(dev), off_dev, off_h, W.to(dev), trans_b=True, act_grad=("tanh", saved_t))
+    assert torch.equal(fused, ops.activation_backward("tanh", outT, saved_t))
 
 
 def test_gemm_asymmetric_identity(dev):
@@ -323,6 +331,11 @@ def test_activation_forward_backward(dev, act):
     saved = xd if act == "gelu" else yd
     dx = ops.activation_backward(act, dy, saved)
     assert_close(dx.cpu(), gx.float(), tol=5e-6, what=f"{act} bwd")
+    # with the dropout mask of the layer input in the same pass (tfgnn_activation_backward_mul): the bits of the two passes
+    g = torch.randn(xd.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    m = ((torch.rand(xd.shape, generator=torch.Generator().manual_seed(3)) > 0.2).float() / 0.8).to(dev)
+    assert torch.equal(ops.activation_backward(act, g, saved, mul=m), ops.activation_backward(act, ops.mul(g, m), saved))
+    assert torch.equal(ops.activation_backward(act, g[1:], saved[1:], mul=m[1:]), ops.activation_backward(act, ops.mul(g, m), saved)[1:])
 
 
 def test_gru_gates_forward_backward(dev):

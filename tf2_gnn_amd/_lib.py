@@ -93,6 +93,12 @@ _SIGNATURES = [
         [c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
          c_int64, c_int, c_void_p],
     ),
+    (
+        "tfgnn_gemm_grouped_rows_grad",
+        c_int,
+        [c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+         c_int64, c_int, c_void_p, c_int64, c_void_p],
+    ),
     ("tfgnn_gemm_grouped_k_workspace_bytes", c_size_t, [c_int, c_int64, c_int64, c_int64]),
     (
         "tfgnn_gemm_grouped_k",
@@ -103,6 +109,7 @@ _SIGNATURES = [
     ("tfgnn_graph_nonempty_offsets", c_int, [c_void_p, c_int, POINTER(c_int32)]),
     ("tfgnn_activation_forward", c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     ("tfgnn_activation_backward", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("tfgnn_activation_backward_mul", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     (
         "tfgnn_gemm_gru",
         c_int,

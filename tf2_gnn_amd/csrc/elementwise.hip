@@ -41,6 +41,25 @@ act_backward_kernel(int act, const float* __restrict__ dy, const float* __restri
   for (; i < n; ++i) dx[i] = dy[i] * act_grad(act, saved[i]);
 }
 
+// dx = dy * mul * act'(saved): the dropout mask of a layer input and the activation derivative of the layer below in one pass
+__global__ void __launch_bounds__(256)
+act_backward_mul_kernel(int act, const float* __restrict__ dy, const float* __restrict__ saved, const float* __restrict__ mul,
+                        float* __restrict__ dx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (; i + 3 < n; i += stride * 4) {
+    float4 g = *reinterpret_cast<const float4*>(dy + i);
+    const float4 s = *reinterpret_cast<const float4*>(saved + i);
+    const float4 m = *reinterpret_cast<const float4*>(mul + i);
+    g.x = (g.x * m.x) * act_grad(act, s.x);  // (the order of tfgnn_mul followed by tfgnn_activation_backward: same bits)
+    g.y = (g.y * m.y) * act_grad(act, s.y);
+    g.z = (g.z * m.z) * act_grad(act, s.z);
+    g.w = (g.w * m.w) * act_grad(act, s.w);
+    *reinterpret_cast<float4*>(dx + i) = g;
+  }
+  for (; i < n; ++i) dx[i] = (dy[i] * mul[i]) * act_grad(act, saved[i]);
+}
+
 __global__ void act_forward_scalar_kernel(int act, const float* x, float* y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = act_apply(act, x[i]);
@@ -424,6 +443,21 @@ extern "C" int tfgnn_activation_backward(int act, const float* d_dy, const float
     hipLaunchKernelGGL(act_backward_kernel, dim3(ew_blocks(ceil_div(n, 4))), dim3(256), 0, s, act, d_dy, d_saved, d_dx, n);
   else
     hipLaunchKernelGGL(act_backward_scalar_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, act, d_dy, d_saved, d_dx, n);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_activation_backward_mul(int act, const float* d_dy, const float* d_saved, const float* d_mul, float* d_dx,
+                                             int64_t n, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_dy && d_saved && d_mul && d_dx, "NULL pointer");
+  TFGNN_REQUIRE(act >= TFGNN_ACT_NONE && act <= TFGNN_ACT_SIGMOID, "unknown activation %d", act);
+  TFGNN_REQUIRE((((uintptr_t)d_dy | (uintptr_t)d_saved | (uintptr_t)d_mul | (uintptr_t)d_dx) & 15) == 0,
+                "tfgnn_activation_backward_mul: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(act_backward_mul_kernel, dim3(ew_blocks(ceil_div(n, 4))), dim3(256), 0, (hipStream_t)stream, act, d_dy, d_saved,
+                     d_mul, d_dx, n);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }

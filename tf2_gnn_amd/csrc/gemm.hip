@@ -420,7 +420,8 @@ int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t 
 
 int gemm_x3_try_grouped_rows(int nprod, int trans_b, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t N,
                              int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t stride_b,
-                             float* C, int64_t ldc, int act, hipStream_t s, int* status);
+                             float* C, int64_t ldc, int act, hipStream_t s, int* status, int dact = 0, const float* saved = nullptr,
+                             int64_t ld_saved = 0);
 int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t M, int64_t N,
                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t stride_c, void* workspace, size_t workspace_bytes, hipStream_t s, int* status);
@@ -628,6 +629,30 @@ extern "C" int tfgnn_gemm_grouped_rows(int trans_b, int num_groups, const int32_
   else launch_cfg<2, 2, 1, 1, true>(g, 0, trans_b, grid, s);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
+}
+
+/* tfgnn_gemm_grouped_rows times act'(saved) (saved [rows, N], indexed like C) in the product's epilogue: the input-gradient
+ * product of a per-relation MLP layer with the derivative of the hidden activation below it.  Only the bf16x3 kernels have
+ * the epilogue: TFGNN_ERR_UNSUPPORTED otherwise (the caller multiplies with tfgnn_activation_backward). */
+extern "C" int tfgnn_gemm_grouped_rows_grad(int trans_b, int num_groups, const int32_t* d_group_offsets, int64_t max_group_rows,
+                                            int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
+                                            int64_t stride_b, float* d_C, int64_t ldc, int act_of_saved, const float* d_saved,
+                                            int64_t ld_saved, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(num_groups >= 0 && max_group_rows >= 0 && N >= 0 && K >= 0, "negative size");
+  if (num_groups == 0 || max_group_rows == 0 || N == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_group_offsets && d_A && d_B && d_C && d_saved, "NULL pointer");
+  TFGNN_REQUIRE(lda >= K && ldb >= (trans_b ? K : N) && ldc >= N && ld_saved >= N, "bad leading dimension");
+  TFGNN_REQUIRE(num_groups <= 65535, "too many groups");
+  TFGNN_REQUIRE(act_of_saved >= TFGNN_ACT_NONE && act_of_saved <= TFGNN_ACT_SIGMOID, "unknown activation %d", act_of_saved);
+  if (const int nprod = gemm_x3_mode()) {
+    int status = TFGNN_OK;
+    if (gemm_x3_try_grouped_rows(nprod, trans_b, num_groups, d_group_offsets, max_group_rows, N, K, d_A, lda, d_B, ldb, stride_b, d_C,
+                                 ldc, TFGNN_ACT_NONE, (hipStream_t)stream, &status, act_of_saved, d_saved, ld_saved))
+      return status;
+  }
+  set_error("tfgnn_gemm_grouped_rows_grad: no fused epilogue for this mode / shape");
+  return TFGNN_ERR_UNSUPPORTED;
 }
 
 extern "C" size_t tfgnn_gemm_grouped_k_workspace_bytes(int num_groups, int64_t max_group_rows, int64_t M, int64_t N) {

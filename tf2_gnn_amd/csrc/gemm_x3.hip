@@ -631,6 +631,8 @@ __global__ void __launch_bounds__(X3_NT, TN == 2 ? 4 : 2) gemm_x3s_kernel(X3Args
     g.A += gb * g.lda;
     g.C += gb * g.ldc;
     g.B += (int64_t)blockIdx.y * g.strideB;
+    if (g.mul) g.mul += gb * g.ld_mul;        // the gradient factors are indexed like C
+    if (g.saved) g.saved += gb * g.ld_saved;
   }
   const int64_t k_begin = (int64_t)bz * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
@@ -1515,13 +1517,16 @@ static void launch_bn(const X3Args& g, dim3 grid, int bn, int nprod, int trans_a
 // C[rows g] = act(A[rows g] @ op(B + g stride_b)) on the specialised kernel; 1 = taken
 int gemm_x3_try_grouped_rows(int nprod, int trans_b, int num_groups, const int32_t* group_off, int64_t max_rows, int64_t N,
                              int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t stride_b,
-                             float* C, int64_t ldc, int act, hipStream_t s, int* status) {
+                             float* C, int64_t ldc, int act, hipStream_t s, int* status, int dact, const float* saved,
+                             int64_t ld_saved) {
   *status = TFGNN_OK;
   const int bn = x3_tile_width(N);
   if (!bn || K < 64 || K % 4 || lda % 4 || ldb % 4 || ldc % 4 || stride_b % 4) return 0;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16) return 0;
+  if (saved && (ld_saved % 4 || (uintptr_t)saved % 16)) return 0;
   X3Args g{};
   g.M = max_rows; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.saved = saved; g.ld_saved = ld_saved; g.dact = dact;
   g.act = act; g.splits = 1; g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
   g.group_mode = 1; g.group_off = group_off; g.strideB = stride_b;
   g.n_tiles = (unsigned)(N / bn);

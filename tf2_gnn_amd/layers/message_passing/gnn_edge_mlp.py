@@ -603,8 +603,9 @@ class GNN_Edge_MLP(MessagePassing):
         for j in range(mlps.num_layers - 1, -1, -1):
             inp = ctx["Xc"] if j == 0 else acts[j - 1]
             grads[j] = ops.gemm_grouped_k(inp, dcur, off_dev, off_h, L)
-            dprev = ops.gemm_grouped_rows(dcur, off_dev, off_h, mlps.kernels[j], trans_b=True)
-            dcur = ops.activation_backward("relu", dprev, inp) if j > 0 else dprev
+            # (hidden layers: relu' of the layer below rides in the product's epilogue)
+            dcur = ops.gemm_grouped_rows(dcur, off_dev, off_h, mlps.kernels[j], trans_b=True,
+                                         act_grad=("relu", inp) if j > 0 else None)
         mlps.grads = grads
         mlps.publish_grads()
         # dX[u] = sum over the non-empty (u, l) pairs

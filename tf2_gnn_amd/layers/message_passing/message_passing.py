@@ -423,6 +423,8 @@ class MessagePassing:
 
 def apply_gradient_epilogue(g, out_mul, out_act_grad):
     out_mul, out_act_grad = ops.plain_epilogue(out_mul, out_act_grad)
+    if out_mul is not None and out_act_grad is not None:
+        return ops.activation_backward(out_act_grad[0], g, out_act_grad[1], mul=out_mul)  # one pass, same bits
     if out_mul is not None:
         g = ops.mul(g, out_mul)
     if out_act_grad is not None:

@@ -765,14 +765,27 @@ def activation_forward(act, x: torch.Tensor, out: Optional[torch.Tensor] = None)
 
 
 @_writes_out
-def activation_backward(act, dy: torch.Tensor, saved: torch.Tensor, out: Optional[torch.Tensor] = None):
-    """dx = dy * act'(.), derivative evaluated from the saved output (saved input for gelu)."""
+def activation_backward(act, dy: torch.Tensor, saved: torch.Tensor, out: Optional[torch.Tensor] = None,
+                        mul: Optional[torch.Tensor] = None):
+    """dx = dy * act'(.), derivative evaluated from the saved output (saved input for gelu).  ``mul``: dx = (dy * mul) * act'(.)
+    in the same pass (tfgnn_activation_backward_mul)."""
     lib = _lib.load()
     _require_dev(dy, torch.float32, "dy")
     dy = dy.contiguous()
     saved = saved.contiguous()
     if out is None:
         out = torch.empty_like(dy)
+    if mul is not None:
+        mul = mul.contiguous()
+        if mul.shape != dy.shape:
+            raise ValueError("activation_backward: mul must have the gradient's shape")
+        if (dy.data_ptr() | saved.data_ptr() | mul.data_ptr() | out.data_ptr()) % 16 == 0:
+            _lib.check(lib.tfgnn_activation_backward_mul(act_id(act), _ptr(dy), _ptr(saved), _ptr(mul), _ptr(out), dy.numel(),
+                                                         _stream()))
+            return out
+        tmp = torch.empty_like(dy)  # (unaligned views: the two-pass form)
+        _lib.check(lib.tfgnn_mul(_ptr(dy), _ptr(mul), _ptr(tmp), dy.numel(), _stream()))
+        dy = tmp
     _lib.check(
         lib.tfgnn_activation_backward(act_id(act), _ptr(dy), _ptr(saved), _ptr(out), dy.numel(), _stream())
     )
@@ -1028,9 +1041,10 @@ def transpose_batched(x: torch.Tensor) -> torch.Tensor:
 
 
 @_writes_out
-def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=False, act=ACT_NONE, out=None):
+def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=False, act=ACT_NONE, out=None, act_grad=None):
     """out[rows g] = act(a[rows g] @ op(b_stack[g])) for row groups [off[g], off[g+1]).
-    b_stack: [G, K, N] (or [G, N, K] with trans_b)."""
+    b_stack: [G, K, N] (or [G, N, K] with trans_b).  act_grad = (activation, saved [rows, N]): the result times act'(saved),
+    in the product's epilogue where the active kernel has one (tfgnn_gemm_grouped_rows_grad), by a separate pass otherwise."""
     lib = _lib.load()
     a, lda = _rowmajor(a, "a")
     G = b_stack.shape[0]
@@ -1045,6 +1059,21 @@ def gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, *, trans_b=Fals
         out = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
     out2, ldc = _rowmajor(out, "out")
     max_rows = max((group_off_host[i + 1] - group_off_host[i] for i in range(G)), default=0)
+    if act_grad is not None:
+        if act_id(act) != act_id(ACT_NONE):
+            raise ValueError("gemm_grouped_rows: act and act_grad exclude each other")
+        saved, ld_saved = _rowmajor(act_grad[1], "saved")
+        if tuple(saved.shape) != (a.shape[0], N):
+            raise ValueError(f"saved must be [{a.shape[0]},{N}]")
+        rc = lib.tfgnn_gemm_grouped_rows_grad(
+            int(trans_b), G, _ptr(group_off_dev), max_rows, N, K, _ptr(a), lda, _ptr(b_stack), b_stack.stride(1),
+            b_stack.stride(0), _ptr(out), ldc, act_id(act_grad[0]), _ptr(saved), ld_saved, _stream())
+        if rc == 0:
+            return out
+        if rc != -4:
+            _lib.check(rc)
+        res = gemm_grouped_rows(a, group_off_dev, group_off_host, b_stack, trans_b=trans_b, out=out)
+        return activation_backward(act_grad[0], res, act_grad[1])
     _lib.check(
         lib.tfgnn_gemm_grouped_rows(
             int(trans_b), G, _ptr(group_off_dev), max_rows, N, K, _ptr(a), lda, _ptr(b_stack), b_stack.stride(1),
