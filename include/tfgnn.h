@@ -374,7 +374,8 @@ int tfgnn_gemm_grad_epilogue(int trans_a, int trans_b, int64_t M, int64_t N, int
                              int64_t ld_saved, int accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* The Dense layer over GATHERED rows: C[m, :] = act( (C[m, :] if accumulate == 2) + A[row_index[m], :] @ op(B) + bias )
- * (+ C[m, :] if accumulate == 1), A [a_rows, lda] fp32, row_index [M] int32 in [0, a_rows).
+ * (+ C[m, :] if accumulate == 1), A [a_rows, lda] fp32, row_index [M] int32 in [0, a_rows); an index outside that range
+ * reads as a row of zeros (it never aliases another row).
  * Replaces tf.nn.embedding_lookup(node_embeddings, sources / targets) followed by the first Dense layer of an edge MLP
  * (gnn_edge_mlp.py:84-100 with message_passing.py:195-206): the per-edge input [x_src || x_tgt] W = x_src W_s + x_tgt W_t is
  * two calls (the second with accumulate = 2 and the MLP's activation) and the [E, 2D] concatenation is never written.

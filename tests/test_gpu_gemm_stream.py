@@ -160,3 +160,28 @@ def test_gathered_rows_product(dev, x3_mode, M, V, K, N, tb, epi):
     assert k.delta["gemm_stream"] == (1 if streaming else 0), k.delta
     scale = max(1.0, 0.2 * float(K) ** 0.5)
     assert_close(res.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"gathered product {x3_mode} {(M, V, K, N, tb, epi)}")
+
+
+def test_gathered_rows_product_reads_an_out_of_range_index_as_a_zero_row(dev, x3_mode):
+    """row indices reach the streaming kernel unchecked and its 24-bit multiply would alias another row.  An index
+    outside [0, a_rows) now reads as zeros (negative, one past the end, far beyond 2^24) - the neighbours are untouched."""
+    from tf2_gnn_amd import ops
+
+    M, V, K, N = 70000, 5000, 128, 128
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn((V, K), generator=g)
+    B = torch.randn((K, N), generator=g) * 0.2
+    idx = torch.randint(0, V, (M,), generator=g, dtype=torch.int64)
+    bad = {3: -1, 64: V, 40000: (1 << 24) + 5, M - 1: -(1 << 24)}
+    good = idx.clone()
+    for pos, val in bad.items():
+        idx[pos] = val
+    with KernelsUsed() as k:
+        res = ops.gemm_gathered(X.to(dev), idx.to(torch.int32).to(dev), B.to(dev))
+    assert k.delta["gemm_stream"] == 1
+    ref = ops.gemm_gathered(X.to(dev), good.to(torch.int32).to(dev), B.to(dev))
+    keep = torch.ones(M, dtype=torch.bool)
+    for pos in bad:
+        keep[pos] = False
+        assert torch.equal(res[pos].cpu(), torch.zeros(N)), pos
+    assert torch.equal(res.cpu()[keep], ref.cpu()[keep])

@@ -1031,10 +1031,16 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   const int Mi = (int)g.M;
   const unsigned a_row_bytes = (unsigned)g.lda * 4u, a_lane_bytes = (unsigned)kg * (K / 2) * 4u;
   const int32_t* __restrict__ a_index = g.a_index;
+  const unsigned a_rows_u = (unsigned)g.a_rows;
   auto row_off = [&](int tile) {
     int row = tile * 32 + li;
     if (row >= Mi) row = Mi - 1;
-    if (a_index) row = a_index[row];  // gathered rows (per-edge products over node states): a lane's row is its own anyway
+    if (a_index) {  // gathered rows (per-edge products over node states): a lane's row is its own anyway
+      row = a_index[row];
+      // an index outside [0, a_rows) must not alias another row through the 24-bit multiply: an offset past the buffer
+      // descriptor (its size stays 8 KiB below 2^32: x3k_shape_ok) reads as a row of zeros
+      if ((unsigned)row >= a_rows_u) return 0xFFFFE000u;
+    }
     return __umul24((unsigned)row, a_row_bytes) + a_lane_bytes;  // v_mad_u32_u24 (rows, 4 lda < 2^24: launch site)
   };
   const __amdgpu_buffer_rsrc_t a_rsrc =
@@ -1303,7 +1309,7 @@ static int64_t x3k_min_rows() {
 static bool x3k_shape_ok(const X3Args& g) {
   if (x3k_min_rows() <= 0 || g.M < x3k_min_rows() || g.K % 32 || g.K < 32 || g.K > 128) return false;
   const int64_t src_rows = g.a_index ? g.a_rows : g.M;
-  return src_rows * g.lda < (1ll << 30) && src_rows < (1 << 24) && g.M < (1ll << 31) - 64 && g.lda < (1 << 22);
+  return src_rows * g.lda < (1ll << 30) - 2048 && src_rows < (1 << 24) && g.M < (1ll << 31) - 64 && g.lda < (1 << 22);
 }
 
 // 1 = the streaming kernel took the product (NN / NT, K in {32, 64, 96, 128}, N a multiple of 128, many rows)
