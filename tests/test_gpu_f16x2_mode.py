@@ -147,6 +147,38 @@ def test_spread_guard_flags_wide_row_spreads_and_demotes_the_mode(dev):
     assert lib.tfgnn_sp_spread_flag(0) == 0 and ops.get_gemm_mode() == ops.GEMM_F16X2
 
 
+@pytest.mark.parametrize("magnitude", [1.0, 1e-9, 1e-20, 1e12])
+@pytest.mark.parametrize("K", [4096, 200000])
+def test_all_zero_rows_of_small_operands_do_not_trip_the_spread_guard(dev, magnitude, K):
+    """Round 4 (the ppi workload): an all-zero row carries the marker scale 2^-126; the guard used to recognise it by the
+    size of its FACTOR (marker / largest scale product < 1e-30), so with operands of 1e-9 - a loss gradient - every empty
+    bucket looked like a row 2^-90 below the rest and the first step demoted the mode.  Zero rows are now recognised by their
+    own scale: no flag at any magnitude (in-kernel factors at K = 4096, the factor pass at K = 200 000), product exact to the
+    usual bound; a real spread still trips."""
+    from tf2_gnn_amd import _lib, ops
+
+    lib = _lib.load()
+    ops.set_gemm_mode("f16x2")
+    M, N = 256, 128
+    g = torch.Generator().manual_seed(K)
+    a = torch.randn((K, M), generator=g) * magnitude
+    b = torch.randn((K, N), generator=g)
+    a[::3] = 0.0
+    a[1::3, :128] = 0.0  # zero in one scale block only
+    b[5::11] = 0.0
+    got = ops.sp_gemm_tn(ops.sp_split_rows(a.to(dev), scale_block=128), ops.sp_split_rows(b.to(dev))).cpu()
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 0 and ops.get_gemm_mode() == ops.GEMM_F16X2
+    ref = a.double().t() @ b.double()
+    mag = a.double().abs().t() @ b.double().abs()
+    assert float(((got.double() - ref).abs() / mag).max()) <= 2e-6
+    a[7] *= 1e-9  # one real row 2^-30 below the rest
+    ops.sp_gemm_tn(ops.sp_split_rows(a.to(dev), scale_block=128), ops.sp_split_rows(b.to(dev)))
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 1
+    ops.set_gemm_mode("f16x2")  # re-arm for the tests that follow
+
+
 def test_trained_like_gradient_spreads_through_the_rgcn_layer(dev):
     """Gradients of a trained network are not N(0,1): per-node magnitudes over 1e-6 .. 1e2 on hub-normalised rows (1 / degree
     down to 1 / 200).  The split-operand backward keeps every dW entry within 1e-5 of the largest and dX within the

@@ -53,6 +53,10 @@ WIDE_CASES = [
     ("rgcn_h128", "RGCN", {}, 128, 4, True),
     ("rgcn_h256_tanh_mean", "RGCN", {"message_activation_function": "tanh", "aggregation_function": "mean"}, 256, 2, True),
     ("rgcn_h320", "RGCN", {}, 320, 4, True),
+    # L * H not a multiple of the 128-column tile of the weight-gradient product (PPI: 3 edge types, H = 320; one edge type)
+    ("rgcn_h320_three_types", "RGCN", {}, 320, 3, True),
+    ("rgcn_h320_one_type", "RGCN", {}, 320, 1, True),
+    ("ggnn_h320_three_types", "GGNN", {}, 320, 3, True),
     ("rgcn_h128_max", "RGCN", {"aggregation_function": "max"}, 128, 4, False),
     ("rgcn_h128_target", "RGCN", {"use_target_state_as_input": True}, 128, 4, False),
     ("ggnn_h128_nonorm", "GGNN", {"normalize_by_num_incoming": False}, 128, 5, True),  # the qm9-ggnn workload's layer

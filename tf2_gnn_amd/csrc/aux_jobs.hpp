@@ -297,9 +297,10 @@ __device__ __forceinline__ void sp_tn_factors_body(const AuxTnFactors& a, unsign
   const int64_t kend = (chunk + 1) * per < a.f_ld ? (chunk + 1) * per : a.f_ld;
   bool wide = false;
   for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 256) {
-    const float f = k < a.K ? a.inv_a[k * a.ld_a + b] * (a.inv_b ? a.inv_b[k * a.ld_b] : 1.f) * r : 0.f;
+    const float ia = k < a.K ? a.inv_a[k * a.ld_a + b] : 0.f, ib = (k < a.K && a.inv_b) ? a.inv_b[k * a.ld_b] : 1.f;
+    const float f = ia * ib * r;
     a.F[(int64_t)b * a.f_ld + k] = (_Float16)f;
-    wide |= f < 9.5367431640625e-07f && f > 1e-30f;  // the spread guard of sp_tn_factors_kernel (gemm_sp.hip)
+    wide |= sp_row_too_small(f, ia, ib);  // the spread guard of sp_tn_factors_kernel (gemm_sp.hip)
   }
   if (a.spread_flag && __any(wide) && (threadIdx.x & 63) == 0) *a.spread_flag = 1;
 }

@@ -806,7 +806,8 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
   const int64_t kend = (chunk + 1) * per < f_ld ? (chunk + 1) * per : f_ld;
   bool wide = false;
   for (int64_t k = chunk * per + threadIdx.x; k < kend; k += 1024) {
-    const float f = k < K ? inv_a[k * ld_a + b] * (inv_b ? inv_b[k * ld_b] : 1.f) * r : 0.f;
+    const float ia = k < K ? inv_a[k * ld_a + b] : 0.f, ib = (k < K && inv_b) ? inv_b[k * ld_b] : 1.f;
+    const float f = ia * ib * r;
     F[(int64_t)b * f_ld + k] = (_Float16)f;
     // a NON-ZERO row more than 2^20 below the block's largest scale product (all-zero rows carry the smallest normal
     // scale, 2^-126: their factor is 0 and they contribute nothing).  Below 2^-13 a row's elements start to keep fewer
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
     // rows' elements - far below the fp32 rounding of the sum, which is why the benchmark's own gradient rows (hub-normalised,
     // 2^16 apart) give dW errors of 6e-7 of the largest entry; past 2^-20 fewer than 15 bits are left and at 2^-24 the
     // row drops out: reported, see tfgnn_sp_spread_flag
-    wide |= f < 9.5367431640625e-07f && f > 1e-30f;
+    wide |= sp_row_too_small(f, ia, ib);
   }
   if (spread_flag && __any(wide) && (threadIdx.x & 63) == 0) *spread_flag = 1;
 }
@@ -1128,11 +1129,14 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
       const float ib = (k < krows && g.inv_b) ? g.inv_b[k0 + k] : 1.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float f = 0.f;
-        if (j < nb && k < krows) f = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j] * ib * fref[j];  // powers of two: exact
+        float f = 0.f, ia = 0.f;
+        if (j < nb && k < krows) {
+          ia = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j];
+          f = ia * ib * fref[j];  // powers of two: exact
+        }
         ftab[(k >> 4) * 64 + j * 16 + (k & 15)] = (_Float16)f;
         // the spread guard (see sp_tn_factors_kernel), relative to the largest scale product of THIS K range
-        wide |= f < 9.5367431640625e-07f && f > 1e-30f;
+        wide |= sp_row_too_small(f, ia, ib);
       }
     }
     if (g.spread_flag && __any(wide) && lane == 0) *g.spread_flag = 1;

@@ -26,6 +26,15 @@ __device__ __forceinline__ float sp_scale_for_max(float mx, float* inv) {
   return __uint_as_float((unsigned)(127 + e) << 23);
 }
 
+// the spread guard of the weight-gradient product: is a row's factor f = inv_a * inv_b / (largest such product) more than 2^20
+// below the reference although the row holds something?  All-zero rows are recognised by THEIR OWN scale - the marker
+// 2^-126 sp_scale_for_max gives them (also rows whose largest entry is below 2^-112: nothing) - not by the size of f: with
+// small operands (a loss gradient of 1e-9 against unit activations) the marker divided by the reference is no longer "tiny"
+// and every empty bucket used to trip the guard (round 4: the ppi workload lost the split-operand path on its first step).
+__device__ __forceinline__ bool sp_row_too_small(float f, float inv_a, float inv_b) {
+  return f < 9.5367431640625e-07f && inv_a > 1.2e-38f && inv_b > 1.2e-38f;
+}
+
 __device__ __forceinline__ void sp_split(float xs, _Float16& h, _Float16& l) {
   h = (_Float16)xs;  // v_cvt_f16_f32: round to nearest even
   const float r = xs - (float)h;

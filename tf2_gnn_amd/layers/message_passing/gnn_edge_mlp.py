@@ -378,7 +378,7 @@ class GNN_Edge_MLP(MessagePassing):
             return n % 128 == 0 or n % 320 == 0
 
         return (ops.get_gemm_mode() == ops.GEMM_F16X2 and not self._use_target_state_as_input and L > 0 and V > 0
-                and D % 16 == 0 and D <= 512 and 32 <= H <= 512 and tiles(H) and tiles(D) and (L * H) % 128 == 0)
+                and D % 16 == 0 and D <= 512 and 32 <= H <= 512 and tiles(H) and tiles(D))
 
     def _forward_A(self, X, g, fuse_act):
         if self._use_compact_buckets(g):
