@@ -457,6 +457,12 @@ int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, con
                                 void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
                                 float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
                                 void* d_workspace, size_t workspace_bytes, void* stream);
+/* ... with that factor = the mask tfgnn_dropout_forward draws for (dropout_seed, dropout_rate) over the [V, H] layer input,
+ * recomputed per element: no mask tensor is read (none exists when the layer input was dropped with d_mask = NULL). */
+int tfgnn_gru_gates_backward_sp_dropout(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
+                                        void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
+                                        float* d_dh_direct, float dropout_rate, uint64_t dropout_seed, float* d_bias_grad, int64_t V,
+                                        int H, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* tf.maximum(x, lower) then tf.minimum(., upper) (nodes_to_graph_representation.py:194-197; pass -inf / +inf for an absent
  * bound) and its gradient: dx = dy where lower <= x <= upper, else 0 (TensorFlow's MaximumMinimumGrad). */

@@ -246,7 +246,7 @@ def test_dropout_applied_by_the_producer_equals_the_stand_alone_dropout(dev, mon
         dX = gnn.backward(dOut, need_input_grad=True)
         grads = [v.grad.clone() for v in gnn.trainable_variables]
         masks = [m.clone() for m in gnn.dropout_masks()]
-        fused = ["drop" in st for st in gnn._ctx["steps"]]
+        fused = [bool(st.get("drop_by_producer")) for st in gnn._ctx["steps"]]  # (a "drop" spec alone: dropped by its own pass, mask not stored)
         gnn._dropout_calls = calls0  # the next run draws the same masks
         return out.clone(), dX.clone(), grads, masks, fused
 
@@ -306,3 +306,68 @@ def test_forward_products_over_pattern_ordered_nodes_leave_the_training_step_unc
     assert torch.equal(out0, out1) and torch.equal(dX0, dX1)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("model,H,L,over", [
+    ("ggnn", 128, 3, {}),
+    ("rgat", 128, 4, {"num_heads": 8}),
+    ("rgcn", 320, 4, {"use_inter_layer_layernorm": True}),  # LayerNorm between the layers: no producer epilogue for the dropout
+    ("rgcn", 128, 2, {"residual_every_num_layers": 2}),     # residual sums: the mask stays a stored tensor at those layers
+], ids=["ggnn", "rgat", "rgcn_layernorm", "rgcn_residual"])
+def test_layer_input_dropout_without_a_stored_mask_equals_the_stored_one(dev, monkeypatch, model, H, L, over):
+    """Round 4: where the layer that reads a dropped input recomputes the mask in an epilogue of its backward pass
+    (MessagePassing.recomputes_input_dropout: GGNN - all three terms of d h -, RGAT, RGCN path A), GNN drops the input WITHOUT
+    storing the mask (ops.dropout_forward(want_mask=False)) and hands a DropoutSpec down.  Same seeds with
+    TFGNN_RECOMPUTE_DROPOUT=0 / 1: identical output (the same masks), gradients equal to fp32 rounding (the mask multiplies
+    the terms of a sum instead of the sum), and no stored mask where the layer said it recomputes."""
+    from bench import model_params
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.data import make_synthetic_batch
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import set_seed
+
+    if ops.get_gemm_mode() != ops.GEMM_F16X2:
+        pytest.skip("the recomputing epilogues belong to the split-operand products")
+    V, E = 2000, 30000
+    feats, adjs = make_synthetic_batch(V, E, L, H, seed=3)
+    dOut = torch.randn((V, H), generator=torch.Generator().manual_seed(4)).to(dev)
+    NL = 4
+    params = model_params(model, H, NL, num_heads=over.get("num_heads"))
+    params.update({k: v for k, v in over.items() if k != "num_heads"})
+
+    def run(flag):
+        monkeypatch.setenv("TFGNN_RECOMPUTE_DROPOUT", flag)
+        set_seed(11)
+        gnn = GNN(params)
+        inp = GNNInput(torch.from_numpy(feats).to(dev), to_dev(adjs, dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+        gnn(inp, training=False)  # builds the layers (a layer answers recomputes_input_dropout once it is built)
+        out = gnn(inp, training=True, return_all_representations=True)[0]  # (all representations: no producer-side dropout)
+        dX = gnn.backward(dOut, need_input_grad=True)
+        # per layer: "stored" (a mask tensor), "producer" (dropped in the epilogue of the op before - the Dense after layer 0
+        # is not among the returned representations), "recomputed" (dropped by its own pass, mask not stored)
+        how = ["stored" if "mask" in st else ("producer" if st.get("drop_by_producer") else "recomputed") for st in gnn._ctx["steps"]]
+        masks = [m.clone() for m in gnn.dropout_masks()]
+        return out.clone(), dX.clone(), [v.grad.clone() for v in gnn.trainable_variables], how, masks, [v.name for v in gnn.trainable_variables]
+
+    out0, dX0, g0, how0, m0, names = run("0")
+    out1, dX1, g1, how1, m1, _ = run("1")
+    assert "recomputed" not in how0, how0
+    r = int(params["residual_every_num_layers"])
+    for i in range(NL):
+        residual_here = i % r == 0 and not (i == 0 and r >= NL)
+        if how0[i] == "stored":
+            assert how1[i] == ("stored" if residual_here else "recomputed"), (i, how0, how1)
+        else:
+            assert how1[i] == how0[i], (i, how0, how1)
+    assert "recomputed" in how1, how1
+    for a, b in zip(m0, m1):
+        assert torch.equal(a, b)
+    assert torch.equal(out0, out1)
+
+    def close(a, b, what):
+        err = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+        assert err <= 2e-6, (what, err)
+
+    close(dX1, dX0, "d node_features")
+    for n, a, b in zip(names, g1, g0):
+        close(a, b, "d " + n)

@@ -128,6 +128,12 @@ _SIGNATURES = [
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
          c_int, c_void_p, c_size_t, c_void_p],
     ),
+    (
+        "tfgnn_gru_gates_backward_sp_dropout",
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, ctypes.c_uint64, c_void_p,
+         c_int64, c_int, c_void_p, c_size_t, c_void_p],
+    ),
     ("tfgnn_colsum_workspace_bytes", c_size_t, [c_int64, c_int]),
     ("tfgnn_colsum", c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("tfgnn_add_scale", c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),

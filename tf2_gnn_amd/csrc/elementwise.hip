@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256)
 gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __restrict__ gates, const float* __restrict__ mh,
                              const float* __restrict__ h, uint8_t* __restrict__ dmx_sp, float* __restrict__ dmx_inv,
                              uint8_t* __restrict__ dmh_sp, float* __restrict__ dmh_inv, float* __restrict__ dh_direct,
-                             const float* __restrict__ out_mul, float* __restrict__ partial, int64_t V) {
+                             const float* __restrict__ out_mul, float* __restrict__ partial, int64_t V, int drop_on,
+                             DropoutKey drop) {
   constexpr int H = 64 * UPL;
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), W = (int64_t)gridDim.x * 4;
@@ -162,7 +163,10 @@ gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __re
       const float dpz = dz * z * (1.f - z);
       const float dpr = dpc * hh * r * (1.f - r);
       x[0][u] = dpz; x[1][u] = dpr; x[2][u] = dpc; y[u] = dpc * r;
-      dh_direct[v * H + j] = out_mul ? g * z * out_mul[v * H + j] : g * z;
+      // the factor of d h: a stored mask, or the mask tfgnn_dropout_forward draws for (seed, rate) at element v H + j recomputed
+      float keep = out_mul ? out_mul[v * H + j] : 1.f;
+      if (drop_on) keep = dropout_mask_at(drop, (uint64_t)(v * H + j));
+      dh_direct[v * H + j] = (out_mul || drop_on) ? g * z * keep : g * z;
       cs[0][u] += dpz; cs[1][u] += dpr; cs[2][u] += dpc;
       cs[3][u] += dpz; cs[4][u] += dpr; cs[5][u] += dpc * r;
       const float m2 = fmaxf(fabsf(dpz), fabsf(dpr));
@@ -494,12 +498,17 @@ extern "C" size_t tfgnn_gru_gates_backward_sp_workspace_bytes(int64_t V, int H) 
   return (size_t)gates_sp_waves(V) * 6 * (size_t)H * 4;
 }
 
-extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
-                                           void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
-                                           float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
-                                           void* d_workspace, size_t workspace_bytes, void* stream) {
+static int gru_gates_backward_sp_impl(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
+                                      void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
+                                      float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
+                                      void* d_workspace, size_t workspace_bytes, void* stream, float dropout_rate,
+                                      uint64_t dropout_seed) {
   using namespace tfgnn;
   TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
+  TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f && !(dropout_rate > 0.f && d_out_mul),
+                "tfgnn_gru_gates_backward_sp: a stored mask or a recomputed one, rate in [0, 1)");
+  const int drop_on = dropout_rate > 0.f ? 1 : 0;
+  const DropoutKey drop = dropout_key(dropout_seed, dropout_rate);
   if (H % 64 != 0 || H > 512) return TFGNN_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (V == 0) {
@@ -516,7 +525,7 @@ extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d
   const dim3 grid(waves / 4), block(256);
 #define GATES_SP(U)                                                                                                     \
   hipLaunchKernelGGL(gru_gates_backward_sp_kernel<U>, grid, block, 0, s, d_dh_new, d_gates, d_mh, d_h, (uint8_t*)d_dmx_sp, \
-                     d_dmx_inv_scale, (uint8_t*)d_dmh_sp, d_dmh_inv_scale, d_dh_direct, d_out_mul, partial, V)
+                     d_dmx_inv_scale, (uint8_t*)d_dmh_sp, d_dmh_inv_scale, d_dh_direct, d_out_mul, partial, V, drop_on, drop)
   switch (H / 64) {
     case 1: GATES_SP(1); break;
     case 2: GATES_SP(2); break;
@@ -533,6 +542,25 @@ extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(6 * H, 64)), dim3(256), 0, s, partial, waves, 6 * H, d_bias_grad);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
+}
+
+extern "C" int tfgnn_gru_gates_backward_sp(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
+                                           void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
+                                           float* d_dh_direct, const float* d_out_mul, float* d_bias_grad, int64_t V, int H,
+                                           void* d_workspace, size_t workspace_bytes, void* stream) {
+  return gru_gates_backward_sp_impl(d_dh_new, d_gates, d_mh, d_h, d_dmx_sp, d_dmx_inv_scale, d_dmh_sp, d_dmh_inv_scale, d_dh_direct,
+                                    d_out_mul, d_bias_grad, V, H, d_workspace, workspace_bytes, stream, 0.f, 0);
+}
+
+/* tfgnn_gru_gates_backward_sp with the factor of d h = the dropout mask tfgnn_dropout_forward draws for (seed, rate) over the
+ * [V, H] layer input, recomputed per element instead of read (no mask tensor exists when the layer input was dropped without
+ * storing one) */
+extern "C" int tfgnn_gru_gates_backward_sp_dropout(const float* d_dh_new, const float* d_gates, const float* d_mh, const float* d_h,
+                                                   void* d_dmx_sp, float* d_dmx_inv_scale, void* d_dmh_sp, float* d_dmh_inv_scale,
+                                                   float* d_dh_direct, float dropout_rate, uint64_t dropout_seed, float* d_bias_grad,
+                                                   int64_t V, int H, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return gru_gates_backward_sp_impl(d_dh_new, d_gates, d_mh, d_h, d_dmx_sp, d_dmx_inv_scale, d_dmh_sp, d_dmh_inv_scale, d_dh_direct,
+                                    nullptr, d_bias_grad, V, H, d_workspace, workspace_bytes, stream, dropout_rate, dropout_seed);
 }
 
 extern "C" size_t tfgnn_colsum_workspace_bytes(int64_t M, int N) {

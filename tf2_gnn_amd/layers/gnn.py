@@ -261,6 +261,17 @@ class GNN:
         prev = layer_idx - 1
         return not self._use_inter_layer_layernorm and str(prev) not in self._global_exchange_layers
 
+    def _recompute_dropout(self, layer_idx: int, mp_layer, V: int, D: int, L: int) -> bool:
+        """Drop the input of layer ``layer_idx`` WITHOUT storing the mask?  Where the backward pass hands the mask to the layer
+        (no residual sum here) and the layer recomputes it in a product epilogue (MessagePassing.recomputes_input_dropout).
+        TFGNN_RECOMPUTE_DROPOUT=0: always store it."""
+        if os.environ.get("TFGNN_RECOMPUTE_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
+            return False
+        if layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and self._residual_every_num_layers >= self._num_layers):
+            return False
+        # (a layer that has not been built yet - the first call of the stack - keeps the stored mask)
+        return bool(getattr(mp_layer, "built", False) and mp_layer.recomputes_input_dropout(V, D, L))
+
     def _internal_call(self, inputs: GNNInput, training: bool = False, need_all_representations: bool = True):
         """gnn.py:276-329, same op order.  With ``need_all_representations=False`` (what ``call`` passes unless asked for the
         tuple) the outputs nobody reads - a layer's result BEFORE the next layer's input dropout - are not materialised: their
@@ -313,6 +324,11 @@ class GNN:
             if drop_seed[layer_idx] is not None:
                 if dropped:  # the producer of `cur` applied this mask in its epilogue; nothing is stored
                     st["drop"] = ops.DropoutSpec(rate, drop_seed[layer_idx], tuple(cur.shape), cur.device)
+                    st["drop_by_producer"] = True
+                elif self._recompute_dropout(layer_idx, mp_layer, V, int(cur.shape[1]), graph.num_edge_types):
+                    # the layer's backward pass recomputes the mask in a product epilogue: drop without storing it
+                    st["drop"] = ops.DropoutSpec(rate, drop_seed[layer_idx], tuple(cur.shape), cur.device)
+                    cur, _ = ops.dropout_forward(cur, rate, drop_seed[layer_idx], want_mask=False)
                 else:
                     cur, st["mask"] = ops.dropout_forward(cur, rate, drop_seed[layer_idx])
             dropped = False

@@ -96,6 +96,28 @@ class GGNN(GNN_Edge_MLP):
         dX_msgs = self._backward_messages(d_agg, ctx)
         return ops.add_scale(dX_msgs, dX_state, 1.0)
 
+    def recomputes_input_dropout(self, num_nodes: int, in_dim: int, num_edge_types: int) -> bool:
+        """the three terms of d(node_embeddings) each take the recomputed mask in their epilogue (_backward_f16x2)"""
+        H = self._hidden_dim
+        return (type(self).backward is GGNN.backward and H % 64 == 0 and H <= 512 and in_dim == H and not self._user_message_function()
+                and self._path() == "A" and self._f16x2_eligible(num_nodes, in_dim, num_edge_types, H))
+
+    def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
+        """With a DropoutSpec as ``out_mul`` (a layer input dropped without a stored mask) the mask is recomputed in the epilogues
+        of the three terms of d(node_embeddings) - the gate-gradient kernel's dh_new * z and the two accumulating products -
+        instead of a pass over [V, H] afterwards (a STORED mask costs three more reads there: measured slower, so tensors keep
+        the generic route)."""
+        from .message_passing import apply_gradient_epilogue
+
+        ctx = self._ctx
+        if (grad_is_pre_activation or ctx is None or not isinstance(out_mul, ops.DropoutSpec) or type(self).backward is not GGNN.backward
+                or not (ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2)):
+            return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+        dX = self._backward_f16x2(grad_output, ctx, ctx["X"], out_mul=out_mul)
+        if dX is None:
+            return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)
+        return apply_gradient_epilogue(dX, None, out_act_grad) if out_act_grad is not None else dX
+
     def _backward_f16x2(self, grad_output, ctx, X, out_mul=None):
         """The GRU part of the backward pass on split operands (round 3): the gate-gradient kernel writes dmx / dmh only as
         SP16 operands (with the bias gradients folded in), the two kernel gradients are tfgnn_sp_gemm_tn products (K = V
@@ -125,6 +147,6 @@ class GGNN(GNN_Edge_MLP):
                 return dX_msgs  # == dX, accumulated in place
         finally:
             self._dx_accumulate = None
-        if out_mul is not None:
-            dX_msgs = ops.mul(dX_msgs, out_mul)
+        if out_mul is not None:  # the message path took a route without an accumulating product
+            dX_msgs = ops.mul(dX_msgs, out_mul.mask() if isinstance(out_mul, ops.DropoutSpec) else out_mul)
         return ops.add_scale(dX_msgs, dX, 1.0)

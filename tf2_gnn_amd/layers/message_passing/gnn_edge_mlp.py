@@ -831,6 +831,15 @@ class GNN_Edge_MLP(MessagePassing):
         # and carries 1 / (1 - rate) where kept: the derivative is taken at saved * scale)
         return act, (ctx["pre"] if act == "gelu" else ctx["out"]), (1.0 if act == "gelu" else ctx.get("out_scale", 1.0))
 
+    def recomputes_input_dropout(self, num_nodes: int, in_dim: int, num_edge_types: int) -> bool:
+        """path A on split operands: the mask rides in the epilogue of dX = G W^T (tfgnn_sp_gemm_nt_dropout recomputes it)"""
+        from types import SimpleNamespace
+
+        if (not self._plain_base_backward() or self._user_message_function() or self._path() != "A" or self._use_target_state_as_input
+                or not self._f16x2_eligible(num_nodes, in_dim, num_edge_types, self._hidden_dim)):
+            return False
+        return True
+
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
         if not self._plain_base_backward() or (self._ctx is not None and self._ctx.get("generic")):
             return super().backward_with_epilogue(grad_output, grad_is_pre_activation, out_mul, out_act_grad)

@@ -412,6 +412,13 @@ class MessagePassing:
         skip it when handed the already multiplied gradient (grad_is_pre_activation); None otherwise."""
         return None
 
+    def recomputes_input_dropout(self, num_nodes: int, in_dim: int, num_edge_types: int) -> bool:
+        """Will backward_with_epilogue apply the dropout mask of this layer's input by RECOMPUTING it from (rate, seed) in a
+        product epilogue?  Then the layer stack does not store the mask (ops.dropout_forward(want_mask=False)) and hands a
+        DropoutSpec down.  A layer that answers True and then takes another route materialises the mask once
+        (ops.plain_epilogue): correct, one pass slower."""
+        return False
+
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
         """backward(), then d(node_embeddings) * out_mul * act'(saved) - the element-wise factors the caller would
         apply next (dropout mask of this layer's input, activation derivative of the layer below).  Generic form:

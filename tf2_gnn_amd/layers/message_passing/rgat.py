@@ -187,6 +187,10 @@ class RGAT(MessagePassing):
         act = ctx["fused_act"]
         return act, (ctx["pre"] if act == "gelu" else ctx["out"])
 
+    def recomputes_input_dropout(self, num_nodes: int, in_dim: int, num_edge_types: int) -> bool:
+        return (type(self).backward is RGAT.backward and num_edge_types == self._num_edge_types
+                and self._f16x2_eligible(num_nodes, in_dim, num_edge_types, self._hidden_dim))
+
     def backward_with_epilogue(self, grad_output, grad_is_pre_activation=False, out_mul=None, out_act_grad=None):
         """backward() whose input-gradient product dX = dY W^T applies the caller's next element-wise steps (dropout mask of
         this layer's input, activation derivative of the layer below) in its epilogue, and which takes a gradient the layer

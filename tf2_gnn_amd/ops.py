@@ -857,7 +857,8 @@ def gru_gates_backward(dh_new, gates, mh, h):
 def gru_gates_backward_sp(dh_new, gates, mh, h, out_mul=None):
     """gru_gates_backward with dmx / dmh written ONLY as SP16 split operands (one scale per row) and the bias gradients
     [2, 3H] folded in (tfgnn_gru_gates_backward_sp) -> (dmx_sp, dmh_sp, dh_direct, bias_grad), or None when the library has
-    no such kernel for this width (H % 64 != 0 or H > 512).  ``out_mul`` [V, H]: factor of dh_direct (a dropout mask)."""
+    no such kernel for this width (H % 64 != 0 or H > 512).  ``out_mul`` [V, H]: factor of dh_direct (a dropout mask); a
+    DropoutSpec: the mask is recomputed from (rate, seed) in the kernel (tfgnn_gru_gates_backward_sp_dropout)."""
     lib = _lib.load()
     V, H = h.shape
     if H % 64 != 0 or H > 512:
@@ -872,10 +873,18 @@ def gru_gates_backward_sp(dh_new, gates, mh, h, out_mul=None):
     bias_grad = torch.empty((2, 3 * H), dtype=torch.float32, device=dev)
     ws_bytes = lib.tfgnn_gru_gates_backward_sp_workspace_bytes(V, H)
     ws = _workspace(dev, ws_bytes) if ws_bytes else None
-    rc = lib.tfgnn_gru_gates_backward_sp(_ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx.data), _ptr(dmx.inv_scale),
-                                         _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct),
-                                         _ptr(out_mul.contiguous() if out_mul is not None else None), _ptr(bias_grad), V, H, _ptr(ws),
-                                         ws.numel() if ws is not None else 0, _stream())
+    if isinstance(out_mul, DropoutSpec):
+        if out_mul.shape != (V, H):
+            raise ValueError("gru_gates_backward_sp: the dropout spec is not one of the layer input")
+        rc = lib.tfgnn_gru_gates_backward_sp_dropout(_ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx.data),
+                                                     _ptr(dmx.inv_scale), _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct),
+                                                     float(out_mul.rate), int(out_mul.seed) & (2**64 - 1), _ptr(bias_grad), V, H,
+                                                     _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    else:
+        rc = lib.tfgnn_gru_gates_backward_sp(_ptr(dh_new), _ptr(gates), _ptr(mh), _ptr(h.contiguous()), _ptr(dmx.data),
+                                             _ptr(dmx.inv_scale), _ptr(dmh.data), _ptr(dmh.inv_scale), _ptr(dh_direct),
+                                             _ptr(out_mul.contiguous() if out_mul is not None else None), _ptr(bias_grad), V, H,
+                                             _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     if rc == -4:
         return None
     _lib.check(rc)
@@ -903,13 +912,15 @@ def add_scale(x: torch.Tensor, y: torch.Tensor, alpha: float) -> torch.Tensor:
     return out
 
 
-def dropout_forward(x: torch.Tensor, rate: float, seed: int):
+def dropout_forward(x: torch.Tensor, rate: float, seed: int, want_mask: bool = True):
     """-> (y, mask) with mask in {0, 1/(1-rate)}.  In f16x2 mode a 2-D result that can be a split operand (width a
-    multiple of 16, <= 512) is also written in the SP16 format by the same kernel and remembered for ``sp_rows_of``."""
+    multiple of 16, <= 512) is also written in the SP16 format by the same kernel and remembered for ``sp_rows_of``.
+    want_mask=False: the mask is not stored (-> (y, None)); whoever needs it recomputes it from (rate, seed)
+    (``DropoutSpec``, the epilogues of the split-operand products, ``dropout_mask``)."""
     lib = _lib.load()
     x = x.contiguous()
     y = torch.empty_like(x)
-    mask = torch.empty_like(x)
+    mask = torch.empty_like(x) if want_mask else None
     if _f16x2_on() and x.dim() == 2 and x.shape[1] % 16 == 0 and 32 <= x.shape[1] <= 512 and x.shape[0] > 0:
         rows, cols = x.shape
         op = SplitOperand(torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device),
