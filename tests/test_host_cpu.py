@@ -189,3 +189,42 @@ def test_task_model_requires_edge_type_count_and_labels():
     p = QM9RegressionTask.get_default_hyperparameters("ggnn")
     assert p["gnn_message_calculation_class"] == "ggnn" and p["out_layer_dropout_keep_prob"] == 1.0
     assert p["use_intermediate_gnn_results"] is False and "optimizer" in p
+
+
+def test_round4_host_side_queries_and_validation_without_gpu():
+    """Entry points of round 4 that decide or validate on the host: the shape query of the fused edge products, the ABI number,
+    the argument checks of the new element-wise / grouped calls (rejected before any HIP call)."""
+    from tf2_gnn_amd import _lib
+
+    lib = _lib.load()
+    assert lib.tfgnn_abi_version() == _lib.ABI_VERSION
+    # heads of 4 .. 64 floats (a power of two) that fit the gather's lane groups
+    table = {(256, 8): 1, (128, 8): 1, (128, 4): 1, (96, 3): 1, (64, 16): 1, (512, 8): 1, (64, 2): 1, (2048, 32): 1,
+             (256, 1): 0, (96, 8): 0, (100, 4): 0, (0, 4): 0, (256, 0): 0, (30, 3): 0, (1024, 8): 0, (24, 2): 0}
+    for (width, heads), want in table.items():
+        assert lib.tfgnn_graph_gather_dot_supported(width, heads) == want, (width, heads)
+    assert lib.tfgnn_activation_backward_mul(0, None, None, None, None, -1, None) == -1
+    assert lib.tfgnn_activation_backward_mul(0, None, None, None, None, 0, None) == 0       # empty: a no-op
+    assert lib.tfgnn_activation_backward_mul(99, None, None, None, None, 4, None) == -1      # (NULL pointers are caught first)
+    assert lib.tfgnn_gemm_grouped_rows_grad(0, 0, None, 0, 8, 8, None, 8, None, 8, 64, None, 8, 1, None, 8, None) == 0
+    assert lib.tfgnn_gemm_grouped_rows_grad(0, 2, None, 4, 8, 8, None, 8, None, 8, 64, None, 8, 1, None, 8, None) == -1
+    assert lib.tfgnn_graph_gather_reduce_dot(None, 0, None, 8, None, 256, 256, None, 256, None, 256, None, None, None, 0, None) == -1
+    assert lib.tfgnn_gru_gates_backward_sp_dropout(None, None, None, None, None, None, None, None, None, 0.1, 7, None, 0, 100, None, 0,
+                                                   None) == -4  # H % 64 != 0: no such kernel, the caller takes the fp32 route
+    assert lib.tfgnn_gru_gates_backward_sp_dropout(None, None, None, None, None, None, None, None, None, 1.5, 7, None, 4, 128, None, 0,
+                                                   None) == -1  # rate outside [0, 1)
+
+
+def test_layers_answer_the_stack_queries_of_round4_before_and_after_build():
+    """MessagePassing.recomputes_input_dropout / graph_parts and the skip predicate are host logic: defaults, and the answers of
+    a layer that cannot take the split-operand route (CPU: mode queries need no device)."""
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers.message_passing import MessagePassing
+    from tf2_gnn_amd.layers.message_passing.gnn_edge_mlp import _skip_empty_blocks
+
+    assert MessagePassing.recomputes_input_dropout(object(), 100, 32, 3) is False
+    assert _skip_empty_blocks(4, 320) and _skip_empty_blocks(8, 1024) and _skip_empty_blocks(2, 16)
+    assert not _skip_empty_blocks(1, 320) and not _skip_empty_blocks(9, 320) and not _skip_empty_blocks(4, 1040) and not _skip_empty_blocks(4, 24)
+    assert ops.G_PARTS_DEFAULT == 31 and ops.G_PARTS_ALL == 63 and not ops.G_PARTS_DEFAULT & ops.G_PART_DST_PATTERN
+    assert ops._VIEW_PARTS[ops.VIEW_BY_DST_TYPED_PATTERN] == ops.G_PART_PLAN_TYPED | ops.G_PART_DST_PATTERN
+    assert ops._array_parts(ops.G_PATTERN_TILEMASK_BY_DST) == ops.G_PART_DST_PATTERN
