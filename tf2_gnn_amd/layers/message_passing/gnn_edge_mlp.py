@@ -833,8 +833,6 @@ class GNN_Edge_MLP(MessagePassing):
 
     def recomputes_input_dropout(self, num_nodes: int, in_dim: int, num_edge_types: int) -> bool:
         """path A on split operands: the mask rides in the epilogue of dX = G W^T (tfgnn_sp_gemm_nt_dropout recomputes it)"""
-        from types import SimpleNamespace
-
         if (not self._plain_base_backward() or self._user_message_function() or self._path() != "A" or self._use_target_state_as_input
                 or not self._f16x2_eligible(num_nodes, in_dim, num_edge_types, self._hidden_dim)):
             return False
