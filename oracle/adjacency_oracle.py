@@ -120,3 +120,36 @@ def bucket_edges(adjacency_lists: Sequence[np.ndarray], num_nodes: int, by: str 
     np.add.at(rowptr, key + 1, 1)
     rowptr = np.cumsum(rowptr)
     return rowptr.astype(np.int32), col[order].astype(np.int32), typ[order].astype(np.int32)
+
+
+def bucket_emptiness_patterns(adjacency_lists: Sequence[np.ndarray], num_nodes: int):
+    """Which by-target buckets of a node hold edges: pattern[v] = sum_l 2^l [bucket (v, l) is not empty] (at most 8 edge types).
+    No reference counterpart - the reference multiplies every edge - this is the specification of the device's
+    TFGNN_GRAPH_PART_DST_PATTERN (include/tfgnn.h): nodes are placed in the order of ``pattern_order_key`` (many non-empty
+    buckets first, equal patterns adjacent; the order INSIDE a pattern is free) and ``tile_masks`` ORs the patterns of every
+    run of 128 positions."""
+    L = len(adjacency_lists)
+    if L > 8:
+        raise ValueError("at most 8 edge types")
+    pattern = np.zeros(num_nodes, dtype=np.int64)
+    for l, adj in enumerate(adjacency_lists):
+        adj = np.asarray(adj, dtype=np.int64).reshape(-1, 2)
+        if adj.shape[0]:
+            pattern[np.unique(adj[:, 1])] |= 1 << l
+    return pattern
+
+
+def pattern_order_key(pattern: np.ndarray) -> np.ndarray:
+    """sort key of a node: (8 - number of non-empty buckets) * 256 + pattern"""
+    pop = np.zeros_like(pattern)
+    for b in range(8):
+        pop += (pattern >> b) & 1
+    return (8 - pop) * 256 + pattern
+
+
+def tile_masks(pattern_by_position: np.ndarray, tile_rows: int = 128) -> np.ndarray:
+    """uint8 [ceil(V / tile_rows)]: OR of the patterns of each run of ``tile_rows`` positions"""
+    n = pattern_by_position.shape[0]
+    pad = (-n) % tile_rows
+    p = np.concatenate([pattern_by_position, np.zeros(pad, dtype=pattern_by_position.dtype)]).reshape(-1, tile_rows)
+    return np.bitwise_or.reduce(p, axis=1).astype(np.uint8)

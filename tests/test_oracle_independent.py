@@ -150,3 +150,29 @@ def test_sigmoid_cross_entropy_and_f1_match_independent_forms():
     f1 = 2 * tp / (2 * tp + fp + fn)
     got, counts = orc.micro_f1(x, z)
     assert abs(got - f1) < 1e-12 and counts == (int(tp), int(fp), int(fn))
+
+
+def test_bucket_emptiness_patterns_hand_worked():
+    """oracle/adjacency_oracle.py: the specification of the device's pattern order on a case small enough to
+    check by hand: 5 nodes, 3 edge types."""
+    import numpy as np
+
+    from oracle import adjacency_oracle as ao
+
+    adjs = [np.array([[0, 1], [2, 1], [3, 4]]),        # type 0 enters nodes 1, 4
+            np.array([[1, 1], [0, 2]]),                # type 1 enters nodes 1, 2
+            np.zeros((0, 2), dtype=np.int64)]          # type 2: no edges
+    pat = ao.bucket_emptiness_patterns(adjs, 5)
+    assert pat.tolist() == [0, 3, 2, 0, 1]
+    key = ao.pattern_order_key(pat)
+    assert key.tolist() == [8 * 256, 6 * 256 + 3, 7 * 256 + 2, 8 * 256, 7 * 256 + 1]
+    order = np.argsort(key, kind="stable")
+    assert order.tolist() == [1, 4, 2, 0, 3]           # two buckets first, then pattern 1 before pattern 2, the empty nodes last
+    assert ao.tile_masks(pat[order], tile_rows=2).tolist() == [3, 2, 0]
+    assert ao.tile_masks(pat[order]).tolist() == [3]
+    # consistent with the bucketing oracle: a set bit <=> a non-empty row of the by-target CSR
+    rowptr, _, _ = ao.bucket_edges(adjs, 5, by="dst")
+    nonempty = (np.diff(rowptr) > 0).reshape(5, 3)
+    assert ((nonempty * (1 << np.arange(3))).sum(axis=1) == pat).all()
+    with np.testing.assert_raises(ValueError):
+        ao.bucket_emptiness_patterns([np.zeros((0, 2))] * 9, 3)
