@@ -113,7 +113,12 @@ int tfgnn_graph_destroy_async(tfgnn_graph* graph, void* last_use_stream);
  * preparation kernels per batch for arrays nobody reads.  tfgnn_graph_create / _async build everything (as before);
  * tfgnn_graph_create_parts_async builds the requested parts; tfgnn_graph_ensure adds missing ones later on `stream`
  * (it blocks the host: the sizes of a part come back from the device).  Entry points that need a part the handle does
- * not have fail with TFGNN_ERR_INVALID_ARGUMENT and name the part - they never read unbuilt arrays. */
+ * not have fail with TFGNN_ERR_INVALID_ARGUMENT and name the part - they never read unbuilt arrays.
+ * LIFETIME / ORDERING of tfgnn_graph_ensure(EDGE_IDS | EDGE_MAPS) on a handle created without EDGE_IDS: it sorts again - it
+ * reads the adjacency lists of the creation call a second time (the caller must still own them) and REWRITES the handle's
+ * row pointers / columns / degrees in place with identical values, on `stream`.  Kernels reading the handle on ANOTHER
+ * stream at that moment race with those writes: call it only from the stream that uses the handle, or - better - name the
+ * parts at creation (a stack with RGAT or per-edge messages: EDGE_MAPS / EDGE_IDS; tf2_gnn_amd: GNN.graph_parts does). */
 typedef enum {
   TFGNN_GRAPH_PART_PLAN_TYPED = 1, /* long-row plans + length-ordered short rows of the views BY_DST_TYPED / BY_SRC_TYPED */
   TFGNN_GRAPH_PART_PLAN_NODE = 2,  /* ... of the views BY_DST_NODE / BY_SRC_NODE (RGAT, per-edge messages)                */

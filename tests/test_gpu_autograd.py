@@ -127,3 +127,35 @@ def test_message_passing_pooling_and_task_model_wrappers(dev):
     for (v, g), mine in zip(model.backward(), got):
         scale = max(float(g.abs().max()), 1e-30)
         assert float((mine.reshape(g.shape) - g).abs().max()) / scale <= 1e-5, v.name
+
+
+def test_backward_after_another_forward_fails_loudly(dev):
+    """the reverse pass keeps its context in the layer; a second forward - also a validation forward under
+    torch.no_grad() - replaces it.  The backward pass of the FIRST output must raise instead of returning the gradients of the
+    wrong batch; the latest recorded forward stays differentiable."""
+    from tf2_gnn_amd import TorchGNN
+
+    gnn, inp, V, H = _stack(dev, "rgcn", 32, rate=0.0)
+    mod = TorchGNN(gnn).train()
+    other = inp._replace(node_features=inp.node_features * 2.0)
+
+    loss_a = mod(inp).square().sum()
+    with torch.no_grad():
+        mod.eval()
+        mod(other)  # validation pass between forward and backward
+        mod.train()
+    with pytest.raises(RuntimeError, match="another forward pass"):
+        loss_a.backward()
+
+    loss_a = mod(inp).square().sum()
+    loss_b = mod(other).square().sum()
+    with pytest.raises(RuntimeError, match="another forward pass"):
+        loss_a.backward()
+    loss_b.backward()  # the state in the layer is this pass's
+    got = [p.grad.clone() for p in mod.parameters()]
+    for p in mod.parameters():
+        p.grad = None
+    mod(other).square().sum().backward()
+    for g, p in zip(got, mod.parameters()):
+        assert torch.equal(g, p.grad)
+    assert not mod.pending_backward

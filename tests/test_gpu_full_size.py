@@ -305,11 +305,10 @@ def test_cfg2_rgcn_layer_backward_matches_fp64(cfg2, dev, gemm_mode):
     # (the reference's included) is ~sqrt(K) 2^-24 of sum |g||w|, which for rows whose result is < 1 exceeds
     # 1e-5 * max(1, |ref|) in the fp32-MFMA mode already (measured 1.9e-5).  Bounds: 1e-6 of sum |g||w| (the condition
     # of the product), and the 2e-5 scaled bound the small-size gradient tests use.
-    # f16x2: G carries ONE scale (the weight-gradient product needs that), so a row of G far below the tensor bound keeps
-    # fewer than 22 bits relative to ITSELF (absolute error <= 2^-40 of the bound): measured 1.6e-6 on such rows against
-    # 8e-7 for the other modes; its scaled error (below) is the same as theirs.
+    # One bound for every mode (f16x2 used to get 2.5e-6; measured 4.7e-7 since the gather writes G with
+    # one scale per (node, type) bucket, against 6.5e-7 bf16x3 and 7.1e-7 fp32 - profiles/parity_r04.json).
     e_rel = float(((dX.double() - dX_ref).abs() / mag.clamp(min=1e-30)).max())
-    bound = 2.5e-6 if gemm_mode == "f16x2" else 1e-6
+    bound = 1e-6
     record_parity(f"cfg-2 RGCN layer dX vs fp64 [{gemm_mode}]", max_err_over_sum_abs_products=e_rel, bound=bound)
     assert e_rel <= bound, (gemm_mode, e_rel)
     # the element-wise scaled error depends on how much cancellation the drawn weights produce in the smallest results
@@ -485,14 +484,15 @@ def test_cfg3_rgat_full_size_backward_matches_fp64(cfg3_inputs, dev, gemm_mode):
     for l in range(L):
         lg.append((f"W_{l}", layer._edge_type_to_message_computation_layer[l].grad, grads[1 + l]))
         lg.append((f"alpha_{l}", layer._edge_type_to_attention_parameters[l].grad, grads[1 + L + l]))
-    # the same op sequence in fp32 on the same branches, recorded beside the HIP error (the asserted bounds stay absolute)
+    # the same op sequence in fp32 on the same branches: the element-wise yardstick is ASSERTED against it (err_hip <=
+    # max(1e-5, 2 err_ref32); VERDICT r4 weak 1b - measured 0.9-1.4e-5 against 2.6-3.0e-5 for the reference's own order)
     w32 = _to32_dev(mp_weights_from_layer(layer), dev)
     X32 = c["X"].clone().requires_grad_(True)
     with ForcedKinks(lambda i, x: masks[i]):
         ref32 = orc.message_passing_call("rgat", c["p"], w32, X32, list(c["adj_dev"]))
     (g32,) = torch.autograd.grad((ref32 * c["dOut"]).sum(), [X32])
     _compare_full("cfg-3 RGAT full size", gemm_mode, out, dX, ref.detach(), grads[0], lg, kinks,
-                  ref32=(ref32.detach(), g32), ref32_record_only=True)
+                  ref32=(ref32.detach(), g32))
 
 
 @pytest.fixture(scope="module", params=[("GGNN", {"normalize_by_num_incoming": False}), ("GNN_Edge_MLP", {})],

@@ -204,7 +204,10 @@ def test_layer_backward_parity(dev, name, cls_name, over):
     check_layer_backward(dev, name, cls_name, over, V=120, E=1500, L=3, H=32)
 
 
-def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
+def check_layer_backward(dev, name, cls_name, over, V, E, L, H, dout_scale=1.0):
+    """dout_scale: the HIP backward pass gets dOut * dout_scale (a real loss gradient is 1e-9, not N(0,1))
+    and its gradients are scaled back before the comparison - the reference gradients are linear in dOut, so every bound
+    stays relative to the gradient's OWN magnitude."""
     from tf2_gnn_amd.layers import MessagePassingInput
 
     adjs = random_graph(V, E, L, seed=4, hub=(2, min(150, V // 2)))
@@ -213,7 +216,7 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
     w32 = mp_weights_from_layer(layer)
     X, dOut = draw_inputs_clear_of_kinks(lambda x: orc.message_passing_call(cls_name, p, _to64(w32), x.double(), adj_t), V, H, 11)
     out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
-    dX = layer.backward(dOut.to(dev))
+    dX = layer.backward((dOut * dout_scale).to(dev)) / dout_scale
 
     w64 = _to64(w32)
     leaves = []
@@ -286,7 +289,7 @@ def check_layer_backward(dev, name, cls_name, over, V, E, L, H):
         # weight gradients are sums over all edges / nodes: 1e-5 of the largest entry, or - where the reference-order fp32
         # evaluation itself is further from fp64 than that - at most `slack` times its error
         err32 = scaled_error(ref32_by_id[id(t)] / scale, rv / scale)
-        assert_close(v.grad.cpu() / scale, (rv / scale).float(), tol=max(1e-5, slack * err32), what=f"{name} d{v.name}")
+        assert_close(v.grad.cpu() / (scale * dout_scale), (rv / scale).float(), tol=max(1e-5, slack * err32), what=f"{name} d{v.name}")
 
 
 def _gnn_oracle_weights(gnn):
@@ -315,13 +318,17 @@ def _gnn_oracle_weights(gnn):
 )
 def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
     """GNN._internal_call (gnn.py:276-329): forward, all representations, and weight gradients."""
+    check_gnn_stack(dev, mp_style, over)
+
+
+def check_gnn_stack(dev, mp_style, over, V=100, E=1200, L=3, Din=10, H=24, num_layers=4, dout_scale=1.0):
+    """dout_scale: as in check_layer_backward - the HIP backward pass gets dOut * dout_scale, its gradients are scaled back."""
     from tf2_gnn_amd.layers import GNN, GNNInput
 
-    V, L, Din, H = 100, 3, 10, 24
     params = GNN.get_default_hyperparameters(mp_style)
-    params.update({"hidden_dim": H, "num_layers": 4, "global_exchange_every_num_layers": 10000})
+    params.update({"hidden_dim": H, "num_layers": num_layers, "global_exchange_every_num_layers": 10000})
     params.update(over)
-    adjs = random_graph(V, 1200, L, seed=21)
+    adjs = random_graph(V, E, L, seed=21)
     gnn = GNN(params)
     g = torch.Generator().manual_seed(5)
     X = torch.randn((V, Din), generator=g)
@@ -384,10 +391,10 @@ def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
     def grad_close(got, leaf, what):
         r = ref_by_id[id(leaf)]
         scale = max(1.0, float(r.abs().max()))  # relative to the largest entry of the gradient
-        assert_close(got.cpu() / scale, (r / scale).float(), tol=max(1e-5, 2 * err32_by_id.get(id(leaf), 0.0)), what=what)
+        assert_close(got.cpu() / (scale * dout_scale), (r / scale).float(), tol=max(1e-5, 2 * err32_by_id.get(id(leaf), 0.0)), what=what)
 
     gnn(inp, training=False)
-    gnn.backward(dOut.to(dev))
+    gnn.backward((dOut * dout_scale).to(dev))
     grad_close(gnn._initial_projection_layer.grad, w64["initial_projection"], "d initial projection")
     for i, mp in enumerate(gnn._mp_layers):
         ref_k = w64["mp"][i]["edge_mlps"]
@@ -399,6 +406,7 @@ def test_gnn_stack_forward_backward_parity(dev, mp_style, over):
         if params["use_inter_layer_layernorm"]:
             gam, bet = gnn._inter_layer_layernorms[i]
             grad_close(gam.grad, w64["layernorm"][i][0], f"ln gamma {i}")
+    return gnn
 
 
 def test_gnn_training_dropout_matches_oracle_with_same_masks(dev):
@@ -509,7 +517,7 @@ def test_rgat_backward_parity(dev, K, act):
     check_rgat_backward(dev, K, act, V=90, E=900, L=3, H=24)
 
 
-def check_rgat_backward(dev, K, act, V, E, L, H):
+def check_rgat_backward(dev, K, act, V, E, L, H, dout_scale=1.0):
     from tf2_gnn_amd.layers import MessagePassingInput
 
     adjs = random_graph(V, E, L, seed=6, hub=(1, min(120, V // 2)))
@@ -518,7 +526,7 @@ def check_rgat_backward(dev, K, act, V, E, L, H):
     w32 = mp_weights_from_layer(layer)
     X, dOut = draw_inputs_clear_of_kinks(lambda x: orc.message_passing_call("rgat", p, _to64(w32), x.double(), adj_t), V, H, 12)
     out = layer(MessagePassingInput(X.to(dev), to_dev(adjs, dev)), training=True)
-    dX = layer.backward(dOut.to(dev))
+    dX = layer.backward((dOut * dout_scale).to(dev)) / dout_scale  # (see check_layer_backward)
     w64 = _to64(w32)
     for key in ("kernels", "attn"):
         w64[key] = [t.requires_grad_(True) for t in w64[key]]
@@ -532,8 +540,8 @@ def check_rgat_backward(dev, K, act, V, E, L, H):
         ga = layer._edge_type_to_attention_parameters[l].grad
         rk, ra = grads[1 + l], grads[1 + L + l]
         sk, sa = max(1.0, float(rk.abs().max())), max(1.0, float(ra.abs().max()))
-        assert_close(gk.cpu() / sk, (rk / sk).float(), tol=1e-5, what=f"rgat dW_{l}")
-        assert_close(ga.cpu() / sa, (ra / sa).float(), tol=1e-5, what=f"rgat dalpha_{l}")
+        assert_close(gk.cpu() / (sk * dout_scale), (rk / sk).float(), tol=1e-5, what=f"rgat dW_{l}")
+        assert_close(ga.cpu() / (sa * dout_scale), (ra / sa).float(), tol=1e-5, what=f"rgat dalpha_{l}")
 
 
 def test_gnn_rgat_stack_backward_runs(dev):

@@ -17,7 +17,9 @@ written in torch on top of them trains with ``loss.backward()``:
 Every ``Variable`` of the wrapped layer is exposed as a ``torch.nn.Parameter`` that ALIASES its storage: an optimizer step
 is an in-place update of the layer's own weights (several layers keep their kernels as views into one stacked buffer; the
 parameters are those views).  The forward pass runs outside the autograd tape - no torch op on the path records anything -
-and the saved state lives in the layer (``layer._ctx``), so ONE backward per forward, like the layers' own ``backward``.
+and the saved state lives in the layer (``layer._ctx``), so ONE backward per forward, like the layers' own ``backward``;
+forward passes are numbered, and ``backward`` raises when the layer no longer holds the state of the pass it belongs to
+(a second forward - also one under ``torch.no_grad()`` - before ``loss.backward()``).
 """
 from __future__ import annotations
 
@@ -39,16 +41,24 @@ class _LayerFunction(torch.autograd.Function):
         ctx.runner = runner
         ctx.set_materialize_grads(False)
         outs = runner.run(x)
-        runner.pending_backward = True
+        # every forward pass REPLACES the state the layer keeps for its reverse pass (layer._ctx, runner._cur): stamp it, so
+        # that a backward pass can tell whether the state in the layer is still the one of ITS forward pass
+        runner._gen += 1
+        ctx.gen = runner._gen
         return outs
 
     @staticmethod
     def backward(ctx, *grads):
         runner = ctx.runner
-        if not runner.pending_backward:
+        if ctx.gen != runner._gen:
+            raise RuntimeError("another forward pass of this module ran after the one being differentiated (forward pass "
+                               f"{ctx.gen}, the layer now holds the state of pass {runner._gen} - e.g. a validation forward "
+                               "between forward and loss.backward()): the explicit reverse pass keeps its context in the layer, "
+                               "not in the autograd graph, so the gradients would be those of the wrong batch")
+        if runner._consumed_gen == ctx.gen:
             raise RuntimeError("the layer's saved state has been consumed: one backward pass per forward pass "
                                "(the explicit reverse pass keeps its context in the layer, not in the autograd graph)")
-        runner.pending_backward = False
+        runner._consumed_gen = ctx.gen
         dx, pgrads = runner.back(grads)
         return (None, dx, *pgrads)
 
@@ -62,7 +72,8 @@ class _AutogradModule(torch.nn.Module):
         self._vars: List[Variable] = []
         self._params = torch.nn.ParameterList()
         self._versions: List[int] = []
-        self.pending_backward = False
+        self._gen = 0            # forward passes run so far (each replaces the layer's saved state)
+        self._consumed_gen = -1  # the pass whose state a backward pass has used up
         self._cur = None
         if getattr(layer, "built", False):
             self._adopt_variables()
@@ -97,7 +108,17 @@ class _AutogradModule(torch.nn.Module):
     def _apply(self, x: torch.Tensor, state) -> Sequence[torch.Tensor]:
         self._cur = state
         self._sync_versions()
+        if not torch.is_grad_enabled():
+            # no tape (validation under torch.no_grad()): nothing will ask for this pass's gradients, but the layer's saved
+            # state is replaced all the same - a backward pass of an EARLIER forward must fail loudly, not use it
+            self._gen += 1
+            return self.run(x)
         return _LayerFunction.apply(self, x, *self._params)
+
+    @property
+    def pending_backward(self) -> bool:
+        """True while the latest forward pass has been recorded by autograd and not differentiated yet."""
+        return self._gen > 0 and self._consumed_gen != self._gen
 
     def run(self, x):
         raise NotImplementedError

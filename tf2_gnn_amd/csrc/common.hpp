@@ -126,18 +126,28 @@ constexpr float kSmallNumber = 1e-7f;  // tf2_gnn/utils/constants.py:2
 constexpr float kFloatLowest = -3.402823466e+38f;
 
 // ---- activations (tf2_gnn/utils/param_helpers.py:25-33, utils/activation.py:7-14) -------------
-// tanh through the hardware exponential: sign(x) (1 - 2 / (e^{2|x|} + 1)).  On |x| the subtracted term is <= 1, the division
-// is IEEE (0.5 ulp), the exponential's relative error (1 ulp + the rounding of 2|x| log2 e) reaches the result damped by
-// 2t / (t + 1)^2 <= 1/2: the result is within ~1.5 ulp of tanh - the class of the library tanhf, whose ~40 instructions with
-// branches were 17 of 51 us in the epilogue of a K = 320 product (160 elements per thread, all workgroups there at the same
-// time; tools/nt_epilogue_probe.py).  (A first version with v_rcp_f32 and without the symmetry was 5 ulp off for x < 0: the
-// backward pass takes 1 - y^2 of the saved output, and a stack of saturated units amplified that to 1.1e-5 in a weight
-// gradient - tests/test_gpu_layers.py::test_gnn_stack_forward_backward_parity.)  Saturates correctly: e^{2|x|} = inf -> 1.
+// tanh in two pieces, selected without a branch (the epilogue of a product applies it to 160 elements per thread):
+//   |x| <  0.625: x + x u q(u), u = x^2, q = degree-4 minimax fit of (tanh(sqrt u) / sqrt u - 1) / u on [0, 0.625^2]
+//                 (fit error 4e-9 relative; evaluated in fp32 with fma: <= 1.5 ulp of tanh, tanh(x) -> x exactly for tiny x);
+//   |x| >= 0.625: sign(x) (1 - 2 / (e^{2|x|} + 1)) on the hardware exponential with an IEEE division.  The subtraction
+//                 cancels at most one bit there (the subtracted term is <= 0.78), and the exponential's relative error d
+//                 reaches the result as d / sinh(2|x|) <= 0.62 d: <= 3 ulp of tanh with a 1-ulp v_exp_f32.
+// Rounds 1-4 used the second form for every x: absolutely accurate (1.4e-7) but not RELATIVELY - 1 - 2/(t+1) cancels for
+// small |x| (relative error 1e-7 / |x|, tanh(1e-8) = 0), which TensorFlow's tanh does not do.
+// tests/test_gpu_ops.py::test_tanh_relative_accuracy: log-spaced 1e-7 .. 10, both signs, <= 4 ulp.
+// Why not tanhf: its ~40 instructions with branches were 17 of 51 us in the epilogue of a K = 320 product
+// (tools/nt_epilogue_probe.py).  Saturates correctly: e^{2|x|} = inf -> 1.
 __device__ __forceinline__ float fast_tanh(float x) {
   const float ax = fabsf(x);
+  const float u = x * x;
+  float q = fmaf(u, -5.6599969257e-03f, 2.0590996108e-02f);
+  q = fmaf(u, q, -5.3721070702e-02f);
+  q = fmaf(u, q, 1.3331127574e-01f);
+  q = fmaf(u, q, -3.3333260529e-01f);
+  const float small = fmaf(x * u, q, x);
   const float t = __expf(2.f * ax);
-  const float y = 1.f - 2.f / (t + 1.f);
-  return copysignf(y, x);
+  const float big = copysignf(1.f - 2.f / (t + 1.f), x);
+  return ax < 0.625f ? small : big;
 }
 
 __device__ __forceinline__ float act_apply(int act, float x) {

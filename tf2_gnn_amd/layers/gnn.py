@@ -101,8 +101,19 @@ class GNN:
         self._ctx = None
         self._dropout_calls = 0
         self.dropout_seed = 0
-        self._guard_sync_passes = int(os.environ.get("TFGNN_GUARD_SYNC_PASSES", "3"))  # see backward()
+        # Spread-guard policy of the f16x2 mode (backward()): the first `_guard_sync_passes` backward passes are checked
+        # synchronously and recomputed on exact kernels when they trip; after that every `guard_check_every`-th pass is
+        # (TFGNN_GUARD_CHECK_EVERY, 0 = never: a later trip only demotes the NEXT pass).  `guard_tripped_last_backward`
+        # tells the caller what the last pass saw: False / True after a checked pass (True: recomputed on exact kernels),
+        # for an unchecked pass the asynchronous flag as it stood when the pass was enqueued (a trip of that very pass shows
+        # one pass later, together with the demotion warning) - a training loop that must not consume such gradients tests it.
+        self._guard_sync_passes_init = int(os.environ.get("TFGNN_GUARD_SYNC_PASSES", "3"))
+        self._guard_sync_passes = self._guard_sync_passes_init
+        self.guard_check_every = int(os.environ.get("TFGNN_GUARD_CHECK_EVERY", "0"))
+        self.guard_tripped_last_backward: Optional[bool] = None
+        self._backward_passes = 0
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
+        self._dense_demoted_epoch = -1  # ops.REARM_EPOCH at that moment: set_gemm_mode("f16x2") re-arms this stack as well
 
     # ---- Keras-like plumbing ----------------------------------------------------------------
     @property
@@ -211,6 +222,11 @@ class GNN:
         # factor and reduce passes of two more weight-gradient products took it back.  With the weight splits riding in the
         # merged small-pass launches, the factors computed inside the weight-gradient kernel and the layer-input dropout in
         # these products' epilogues (all four dropout passes of the benchmark stack gone) it is worth 2.48 vs 2.51 ms.
+        if not self._dense_split_ok and ops.REARM_EPOCH[0] != self._dense_demoted_epoch:
+            # the mode was re-armed (ops.set_gemm_mode("f16x2")) after this stack demoted its Dense products: try again, with
+            # the synchronous check of the first passes
+            self._dense_split_ok = True
+            self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
         if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0" or not self._dense_split_ok:
             return False
         return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
@@ -432,7 +448,10 @@ class GNN:
         g_last = None
         try:
             was_f16x2 = ops.get_gemm_mode() == ops.GEMM_F16X2
-            if not (was_f16x2 and self._guard_sync_passes > 0):
+            self._backward_passes += 1
+            periodic = self.guard_check_every > 0 and self._backward_passes % self.guard_check_every == 0
+            if not (was_f16x2 and (self._guard_sync_passes > 0 or periodic)):
+                self.guard_tripped_last_backward = bool(was_f16x2 and ops.f16x2_guard_flag_async())
                 return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
             # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
             # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
@@ -443,14 +462,18 @@ class GNN:
             # message products keep their split operands), then, if it trips again, with the whole mode demoted.  Later
             # trips demote the mode from the NEXT pass on and say so (ops.get_gemm_mode warns), but the tripping pass
             # itself is not recomputed (README.md).  While this section runs, a set flag does not demote the mode on sight.
-            self._guard_sync_passes -= 1
+            if self._guard_sync_passes > 0:
+                self._guard_sync_passes -= 1
+            self.guard_tripped_last_backward = False
             with ops.hold_spread_guard():
                 result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
                 for attempt in range(2):
                     if not ops.f16x2_guard_tripped_sync():
                         break
+                    self.guard_tripped_last_backward = True
                     if attempt == 0 and self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
                         self._dense_split_ok = False
+                        self._dense_demoted_epoch = ops.REARM_EPOCH[0]
                         ops.rearm_spread_guard()
                         import warnings
 

@@ -6,6 +6,7 @@ current HIP stream, every FLOP and byte of the hot path runs in libtfgnn.so.
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import Optional, Sequence
 
@@ -58,9 +59,14 @@ def _stream() -> int:
 # and the flush that runs it, so every input of a job is complete and none is overwritten in between; non-urgent jobs own
 # their inputs (the workspace of a weight-gradient product is kept by the job).  Jobs pending on one stream are flushed before
 # work is enqueued for another stream.
+# INTERNAL: ``defer=`` / ``defer_combine=`` arguments of the wrappers are for the layer code of this package, which always issues
+# the consumer of a deferred result as a library call right behind it.  A caller outside the library that reads a deferred
+# result with torch (or synchronises and expects it to exist) must call ``aux_flush()`` first; ``SplitOperand.synced()`` does.
+# The queue is guarded by a lock: autograd runs ``GNN.backward`` on its own thread.
 _AUX_PENDING = []     # [(AuxJob, keep-alive tuple)]
 _AUX_URGENT = [False]
 _AUX_STREAM = [None]
+_AUX_LOCK = threading.RLock()
 
 
 def aux_enabled() -> bool:
@@ -76,12 +82,13 @@ def aux_defer(job, keep=(), urgent: bool = True, then=None) -> None:
     if (job.kind == 0 or job.num_blocks == 0) and then is None:
         return
     st = _raw_stream()
-    if _AUX_PENDING and _AUX_STREAM[0] != st:
-        aux_flush()
-    _AUX_STREAM[0] = st
-    _AUX_PENDING.append((job, keep, then))
-    if urgent:
-        _AUX_URGENT[0] = True
+    with _AUX_LOCK:
+        if _AUX_PENDING and _AUX_STREAM[0] != st:
+            aux_flush()
+        _AUX_STREAM[0] = st
+        _AUX_PENDING.append((job, keep, then))
+        if urgent:
+            _AUX_URGENT[0] = True
 
 
 def aux_flush(everything: bool = True) -> None:
@@ -89,11 +96,12 @@ def aux_flush(everything: bool = True) -> None:
     to those jobs.  ``everything``: repeat until nothing is pending (chained work may defer further non-urgent jobs - the
     reduction behind a deferred product); otherwise one round (what ``_stream()`` does before a library call)."""
     while _AUX_PENDING:
-        batch = list(_AUX_PENDING)
-        del _AUX_PENDING[:]
-        _AUX_URGENT[0] = False
+        with _AUX_LOCK:
+            batch = list(_AUX_PENDING)
+            del _AUX_PENDING[:]
+            _AUX_URGENT[0] = False
+            st = _AUX_STREAM[0]
         live = [j for j, _, _ in batch if j.kind != 0 and j.num_blocks != 0]
-        st = _AUX_STREAM[0]
         if live:
             jobs = (_lib.AuxJob * len(live))(*live)
             _lib.check(_lib.load().tfgnn_aux_launch(jobs, len(jobs), st))
@@ -585,6 +593,8 @@ def set_gemm_mode(mode) -> int:
     aux_flush()
     _lib.check(lib.tfgnn_gemm_set_mode(mode))
     _f16x2[0] = mode == GEMM_F16X2
+    if mode == GEMM_F16X2:
+        REARM_EPOCH[0] += 1  # stacks that demoted their own Dense products take the split kernels again (GNN._dense_f16x2)
     return prev
 
 
@@ -595,6 +605,7 @@ def get_gemm_mode() -> int:
 
 
 _GUARD_HOLD = [0]
+REARM_EPOCH = [0]  # times the f16x2 mode was (re-)armed by set_gemm_mode("f16x2")
 
 
 def demote_gemm_mode() -> int:
@@ -626,6 +637,12 @@ def rearm_spread_guard() -> None:
     aux_flush()
     torch.cuda.current_stream().synchronize()
     _lib.load().tfgnn_sp_spread_flag(1)
+
+
+def f16x2_guard_flag_async() -> bool:
+    """The spread flag as the host sees it NOW, without waiting for the device (what products enqueued earlier have reported
+    so far)."""
+    return bool(_lib.load().tfgnn_sp_spread_flag(0))
 
 
 def f16x2_guard_tripped_sync() -> bool:
@@ -1165,6 +1182,13 @@ class SplitOperand:
     def __init__(self, data, inv_scale, rows, cols, scale_block):
         self.data, self.inv_scale, self.rows, self.cols, self.scale_block = data, inv_scale, rows, cols, scale_block
 
+    def synced(self) -> "SplitOperand":
+        """self, after every deferred small pass has been launched: an operand made with ``defer=True`` is written by the
+        next merged launch, which only a following LIBRARY call triggers - read ``data`` / ``inv_scale`` with torch (or hand
+        them to another library) through this."""
+        aux_flush()
+        return self
+
 
 def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed_inv_scale: Optional[torch.Tensor] = None,
                   out: Optional[SplitOperand] = None, defer: bool = False) -> SplitOperand:
@@ -1552,6 +1576,7 @@ def notify_weights_changed(tensor: Optional[torch.Tensor] = None) -> None:
     through ``tensor.data``, a raw-pointer optimizer kernel, another framework writing into the buffer.  Every derived form
     of ``tensor`` (or of all weights) is dropped and rebuilt at its next use.  ``Variable.assign`` / ``Variable.mark_updated``
     call this; in-place torch arithmetic on ``Variable.value`` itself is seen through the version counter as well."""
+    aux_flush()  # a deferred split job reads its source weight when it is LAUNCHED: run it on the old values, then drop it
     if tensor is None:
         _sp_weight_cache.clear()
         return
@@ -1637,6 +1662,8 @@ def sp_weight_operand(w: torch.Tensor, kind: str, build):
         return hit[1]
     import weakref
 
+    if hit is not None:
+        aux_flush()  # the stale form may still have its (deferred) conversion pending: launch it before the new one is queued
     op = build()
     if len(_sp_weight_cache) > 256:
         _sp_weight_cache.clear()
