@@ -60,7 +60,7 @@ const char* tfgnn_version(void);
 /* Bumped whenever an existing entry point changes its signature or meaning (round 4: 2 - tfgnn_gemm_grad_epilogue gained
  * `accumulate` in round 3, tfgnn_gemm_get_mode can return TFGNN_GEMM_F16X2, the bucketing keeps list order inside a bucket).
  * A binding compares tfgnn_abi_version() with the TFGNN_ABI_VERSION it was written against (tf2_gnn_amd/_lib.py does). */
-#define TFGNN_ABI_VERSION 2
+#define TFGNN_ABI_VERSION 3
 int tfgnn_abi_version(void);
 
 /* Diagnostics (no reference counterpart): number of launches of each product-kernel family this process has enqueued
@@ -587,6 +587,17 @@ int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask, int64_t n
  * cols % 16 == 0, cols <= 512; d_out_sp 64-byte aligned rows of ld_out_sp_bytes >= 4 * cols; d_inv_scale [rows]. */
 int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_mask, int64_t rows, int64_t cols, float rate,
                              uint64_t seed, void* d_out_sp, int64_t ld_out_sp_bytes, float* d_inv_scale, void* stream);
+/* The dropout EPOCH (round 5).  Every mask this library draws - tfgnn_dropout_forward / _sp, the epilogues of
+ * tfgnn_sp_gemm_nt_dropout, the recomputed mask of tfgnn_gru_gates_backward_sp_dropout - is a function of (seed, element,
+ * epoch), the epoch being one word of DEVICE memory the kernels read when they start.  It exists for steps replayed from a
+ * captured hipGraph (tf2_gnn_amd.capture.CapturedStep): a replay re-launches the same kernels with the same seeds, so the
+ * first node of the captured step is tfgnn_dropout_epoch_advance (a one-thread kernel: epoch += 1) and every replay draws
+ * fresh masks, forward and backward kernels of one replay the same ones.  Epoch 0 - the state of a process that never
+ * advances it - gives exactly the masks of (seed, element) alone.  _set stores a value (a kernel on `stream`), _get reads it
+ * back (synchronises `stream`).  [ext] tf.nn.dropout draws new random numbers per call: gnn.py:285-288. */
+int tfgnn_dropout_epoch_advance(void* stream);
+int tfgnn_dropout_epoch_set(uint32_t value, void* stream);
+int tfgnn_dropout_epoch_get(uint32_t* h_value, void* stream);
 int tfgnn_mul(const float* d_a, const float* d_b, float* d_out, int64_t n, void* stream);
 
 /* Inter-layer LayerNormalization of the GNN stack (gnn.py:157-161,318-321; [ext] Keras defaults

@@ -21,6 +21,7 @@ from .layers import (  # noqa: F401
     WeightedSumGraphRepresentation,
 )
 
+from .capture import CapturedStep  # noqa: F401,E402
 from .autograd import TorchGNN, TorchGraphTaskModel, TorchMessagePassing, TorchNodesToGraphRepresentation  # noqa: F401,E402
 
 __version__ = "0.2.0"

@@ -179,6 +179,9 @@ _SIGNATURES = [
     ("tfgnn_film_edge_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     ("tfgnn_film_edge_backward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                          c_void_p]),
+    ("tfgnn_dropout_epoch_advance", c_int, [c_void_p]),
+    ("tfgnn_dropout_epoch_set", c_int, [ctypes.c_uint32, c_void_p]),
+    ("tfgnn_dropout_epoch_get", c_int, [c_void_p, c_void_p]),
     ("tfgnn_dropout_forward_sp", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_int64,
                                          c_void_p, c_void_p]),
     ("tfgnn_transpose_batched", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
@@ -288,7 +291,7 @@ _SIGNATURES = [
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
-ABI_VERSION = 2  # include/tfgnn.h TFGNN_ABI_VERSION
+ABI_VERSION = 3  # include/tfgnn.h TFGNN_ABI_VERSION
 
 
 class AuxJob(ctypes.Structure):

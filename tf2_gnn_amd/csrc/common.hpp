@@ -70,11 +70,19 @@ static inline int64_t splitk_want(int64_t tiles, int64_t K) {
 // splitmix finaliser of rounds 1-3 cost ~200 VALU cycles per element - fine in a bandwidth-bound kernel, not in a product's
 // epilogue): the host turns the call's seed into two well-mixed words (splitmix64), the element hashes its index xor the first
 // with the "lowbias32" finaliser and xors the second; 24 bits of the word are the uniform number compared with rate * 2^24.
+//
+// Epoch (round 5): a step REPLAYED from a captured hipGraph launches the same kernels with the same arguments - the same
+// seeds - every time.  The mask is therefore a function of (seed, i, epoch), where the epoch is a word in DEVICE memory that
+// every kernel drawing a mask reads once at its start (dropout_resolve); tfgnn_dropout_epoch_advance - a one-thread kernel,
+// the first node of a captured step - bumps it per replay.  Epoch 0 (never advanced: every eager caller) leaves the key
+// untouched, so the masks of rounds 1-4 are unchanged; forward and backward kernels of one step see the same epoch.
 struct DropoutKey {
   uint32_t s0, s1;
   uint32_t threshold;  // keep iff u24 >= threshold, threshold = ceil(rate * 2^24)
   float scale;         // 1 / (1 - rate)
+  const uint32_t* epoch;  // device word (elementwise.hip dropout_epoch_word), or NULL
 };
+uint32_t* dropout_epoch_word();  // the library's epoch word in device memory, allocated (zero) at first use; NULL on failure
 static inline DropoutKey dropout_key(uint64_t seed, float rate) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -88,6 +96,7 @@ static inline DropoutKey dropout_key(uint64_t seed, float rate) {
   if ((double)th < t) ++th;
   k.threshold = th;
   k.scale = 1.f / (1.f - rate);
+  k.epoch = rate > 0.f ? dropout_epoch_word() : nullptr;
   return k;
 }
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
@@ -97,6 +106,17 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
   x *= 0x846ca68bu;
   x ^= x >> 16;
   return x;
+}
+// the key of the current epoch: once per kernel, before the first mask is drawn
+__device__ __forceinline__ DropoutKey dropout_resolve(DropoutKey k) {
+  if (k.epoch) {
+    const uint32_t e = *k.epoch;
+    if (e) {
+      k.s0 ^= lowbias32(e * 0x9E3779B9u + 0x7F4A7C15u);
+      k.s1 += e * 0x85EBCA6Bu;
+    }
+  }
+  return k;
 }
 // One hash serves the FOUR elements of an aligned group (idx / 4): element e takes the word rotated left by 8 e bits, i.e. its
 // decision hangs on a byte of its own (the top byte of its 24-bit number; the lower 16 bits are shared with neighbours and

@@ -137,8 +137,9 @@ gru_gates_backward_sp_kernel(const float* __restrict__ dh_new, const float* __re
                              const float* __restrict__ h, uint8_t* __restrict__ dmx_sp, float* __restrict__ dmx_inv,
                              uint8_t* __restrict__ dmh_sp, float* __restrict__ dmh_inv, float* __restrict__ dh_direct,
                              const float* __restrict__ out_mul, float* __restrict__ partial, int64_t V, int drop_on,
-                             DropoutKey drop) {
+                             DropoutKey drop_arg) {
   constexpr int H = 64 * UPL;
+  const DropoutKey drop = drop_on ? dropout_resolve(drop_arg) : drop_arg;
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), W = (int64_t)gridDim.x * 4;
   float cs[6][UPL];
@@ -298,7 +299,8 @@ add_scale_kernel(const float* __restrict__ x, const float* __restrict__ y, float
 // a given seed, independent of the launch geometry, and identical in every kernel that draws them (this file, the epilogue of
 // the split-operand product).  The mask (0 or 1/(1-rate)) is stored for the backward pass when the caller asks for it.
 __global__ void __launch_bounds__(256)
-dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n, DropoutKey key) {
+dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n, DropoutKey key_arg) {
+  const DropoutKey key = dropout_resolve(key_arg);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float m = dropout_mask_at(key, (uint64_t)i);
     if (mask) mask[i] = m;
@@ -313,7 +315,8 @@ dropout_forward_kernel(const float* __restrict__ x, float* __restrict__ y, float
 template <int VPL>
 __global__ void __launch_bounds__(256)
 dropout_forward_sp_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t rows, int cols,
-                          DropoutKey key, uint8_t* __restrict__ out_sp, int64_t ld_sp, float* __restrict__ inv_out) {
+                          DropoutKey key_arg, uint8_t* __restrict__ out_sp, int64_t ld_sp, float* __restrict__ inv_out) {
+  const DropoutKey key = dropout_resolve(key_arg);
   const int sub = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (r >= rows) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
@@ -601,6 +604,57 @@ extern "C" int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, 
   TFGNN_REQUIRE(d_x && d_y && d_out, "NULL pointer");
   hipLaunchKernelGGL(add_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, alpha, d_out, n);
   TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+// ---- the dropout epoch (common.hpp DropoutKey): one word of device memory, bumped by a kernel so that the bump can be a
+// node of a captured hipGraph ----
+namespace tfgnn {
+static uint32_t* g_dropout_epoch = nullptr;
+uint32_t* dropout_epoch_word() {
+  if (!g_dropout_epoch) {
+    uint32_t* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess) {  // (never inside a stream capture: CapturedStep touches it first)
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (hipMemset(p, 0, 256) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_dropout_epoch = p;
+  }
+  return g_dropout_epoch;
+}
+__global__ void dropout_epoch_kernel(uint32_t* word, uint32_t value, int add) { *word = add ? *word + value : value; }
+}  // namespace tfgnn
+
+extern "C" int tfgnn_dropout_epoch_advance(void* stream) {
+  using namespace tfgnn;
+  uint32_t* w = dropout_epoch_word();
+  TFGNN_REQUIRE(w, "tfgnn_dropout_epoch_advance: no device memory for the epoch word");
+  hipLaunchKernelGGL(dropout_epoch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, 1u, 1);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_dropout_epoch_set(uint32_t value, void* stream) {
+  using namespace tfgnn;
+  uint32_t* w = dropout_epoch_word();
+  TFGNN_REQUIRE(w, "tfgnn_dropout_epoch_set: no device memory for the epoch word");
+  hipLaunchKernelGGL(dropout_epoch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, value, 0);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
+extern "C" int tfgnn_dropout_epoch_get(uint32_t* h_value, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(h_value, "NULL pointer");
+  uint32_t* w = dropout_epoch_word();
+  TFGNN_REQUIRE(w, "tfgnn_dropout_epoch_get: no device memory for the epoch word");
+  TFGNN_HIP_CHECK(hipMemcpyAsync(h_value, w, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  TFGNN_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return TFGNN_OK;
 }
 

@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   // accumulate operand are fetched four float4 ahead of their use.
   float* patch = reinterpret_cast<float*>(lds) + wave * 32 * G::PATCH_LD;
   const int64_t wcol0 = col0 + wn * 32 * TNW;
+  const DropoutKey dkey = g.drop_on == 1 ? dropout_resolve(g.drop) : g.drop;  // the mask of the current epoch (common.hpp)
   constexpr int C4 = 8 * TNW;             // float4 per patch row
   constexpr int NIT = 32 * C4 / 64;       // float4 per lane and row tile
   static_assert(NIT % 4 == 0, "epilogue chunking");
@@ -576,7 +577,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
             if (savp) { w[q][j].x *= sv[j].x; w[q][j].y *= sv[j].y; w[q][j].z *= sv[j].z; w[q][j].w *= sv[j].w; }
           }
           if (g.drop_on == 1) {
-            const float4 dm = dropout_mask4(g.drop, (uint64_t)(rowq[q] * g.drop_ld + wcol0 + (l8 + 8 * j) * 4));  // N % 4 == 0
+            const float4 dm = dropout_mask4(dkey, (uint64_t)(rowq[q] * g.drop_ld + wcol0 + (l8 + 8 * j) * 4));  // N % 4 == 0
             w[q][j].x *= dm.x; w[q][j].y *= dm.y; w[q][j].z *= dm.z; w[q][j].w *= dm.w;
           } else if (g.drop_on == 2) {  // the mask is in the saved tensor (see SpArgs)
             w[q][j].x *= g.drop.scale; w[q][j].y *= g.drop.scale; w[q][j].z *= g.drop.scale; w[q][j].w *= g.drop.scale;
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
           if (savp) { w.x *= sv[j].x; w.y *= sv[j].y; w.z *= sv[j].z; w.w *= sv[j].w; }
         }
         if (g.drop_on == 1) {
-          const float4 dm = dropout_mask4(g.drop, (uint64_t)doff[j]);
+          const float4 dm = dropout_mask4(dkey, (uint64_t)doff[j]);
           w.x *= dm.x; w.y *= dm.y; w.z *= dm.z; w.w *= dm.w;
         } else if (g.drop_on == 2) {
           w.x *= g.drop.scale; w.y *= g.drop.scale; w.z *= g.drop.scale; w.w *= g.drop.scale;

@@ -450,6 +450,12 @@ class GNN:
             was_f16x2 = ops.get_gemm_mode() == ops.GEMM_F16X2
             self._backward_passes += 1
             periodic = self.guard_check_every > 0 and self._backward_passes % self.guard_check_every == 0
+            if ops.capturing():  # a step being captured into a hipGraph cannot wait for the device: never a checked pass
+                if was_f16x2 and self._guard_sync_passes > 0:
+                    raise RuntimeError("tf2_gnn_amd: this GNN's first backward passes are checked synchronously "
+                                       f"(TFGNN_GUARD_SYNC_PASSES, {self._guard_sync_passes} left); run them eagerly before "
+                                       "capturing the step (capture.CapturedStep warmup)")
+                periodic = False
             if not (was_f16x2 and (self._guard_sync_passes > 0 or periodic)):
                 self.guard_tripped_last_backward = bool(was_f16x2 and ops.f16x2_guard_flag_async())
                 return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)

@@ -254,6 +254,9 @@ class Graph:
     def wait(self):
         """Block the host until the bucketing has finished; raises ValueError for bad node indices."""
         if self._pending:
+            if capturing():
+                raise RuntimeError("tf2_gnn_amd: a batch's edges cannot be bucketed inside a hipGraph capture (the build reads "
+                                   "sizes back); run the step eagerly once on the same adjacency tensors first (CapturedStep warmup)")
             self._pending = False
             self._keep = None
             try:
@@ -950,6 +953,29 @@ def dropout_forward(x: torch.Tensor, rate: float, seed: int, want_mask: bool = T
         lib.tfgnn_dropout_forward(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & (2**64 - 1), _stream())
     )
     return y, mask
+
+
+def dropout_epoch() -> int:
+    """The dropout epoch (include/tfgnn.h: masks are a function of (seed, element, epoch); 0 unless something advanced it).
+    Waits for the current stream."""
+    v = ctypes.c_uint32()
+    aux_flush()
+    _lib.check(_lib.load().tfgnn_dropout_epoch_get(ctypes.byref(v), _raw_stream()))
+    return int(v.value)
+
+
+def dropout_epoch_advance() -> None:
+    """epoch += 1 by a kernel on the current stream (capturable: the first node of ``capture.CapturedStep``)."""
+    _lib.check(_lib.load().tfgnn_dropout_epoch_advance(_stream()))
+
+
+def dropout_epoch_set(value: int) -> None:
+    _lib.check(_lib.load().tfgnn_dropout_epoch_set(int(value) & 0xFFFFFFFF, _stream()))
+
+
+def capturing() -> bool:
+    """Is the current stream being captured into a hipGraph (``capture.CapturedStep``)?  Host synchronisation is illegal then."""
+    return bool(torch.cuda.is_current_stream_capturing())
 
 
 def dropout_mask(shape, rate: float, seed: int, device=None) -> torch.Tensor:
