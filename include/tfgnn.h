@@ -662,6 +662,22 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
                         int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
                         const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                         float* d_out_inv_scale, void* stream);
+/* K split INSIDE the launch of the NT product, for few row tiles (round 5; BASELINE configs[0]: a PPI batch of 7 110 nodes is 56
+ * row tiles - 56 workgroups each streaming the whole weight operand while 200 CUs idle, and the product takes as long as at
+ * 30 000 nodes).  With a workspace registered here, products of at most 112 output tiles and K >= 480 launch S = 2..4
+ * workgroups per tile (S * tiles <= 232: all resident at once); splits 1 .. S-1 hand their raw accumulators to split 0
+ * through the workspace (write-through stores + one flag word each), split 0 adds them in split order - the result is
+ * bit-reproducible, though not bit-equal to the unsplit product's (another summation order; same error class) - and runs
+ * the epilogue.  No extra launch, no extra pass.  Layout: [64 KB of flags][slabs of 128 x tile-width floats]; 32 MB cover
+ * every eligible shape.  The library keeps the flags zero between launches (each reducer clears what it consumed), which is
+ * what makes a product captured in a hipGraph replayable.  ONE workspace per process: products that may run CONCURRENTLY (two
+ * streams) must not both be eligible.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
+ * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = 1 if a reducer ever gave
+ * up waiting for a producer (~1 s; never expected - the product it belongs to is wrong); *split_launches (may be NULL) = products
+ * launched with a split so far (tests assert that the path under test really ran); returns 1 if splits can happen. */
+int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes);
+int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches);
+
 /* The superset: tfgnn_sp_gemm_nt / _sp (d_out_sp may be NULL) with the layer-input dropout of the NEXT op in the epilogue
  * (gnn.py:285-288 - the producer of a layer's input drops it, so the stand-alone pass over [V, H], its mask tensor and the
  * split pass disappear): the result, after bias / activation / the gradient factors, is multiplied by the mask

@@ -127,7 +127,7 @@ def test_node_multiclass_training_step_replayed(dev):
     X = torch.from_numpy(feats).to(dev)
     adjs, _ = process_adjacency_lists([torch.from_numpy(fwd).to(dev)], V, add_self_loop_edges=True, tied_fwd_bkwd_edge_types=set())
     params = NodeMulticlassTask.get_default_hyperparameters("rgcn")
-    params.update({"gnn_hidden_dim": 128, "gnn_num_layers": 2, "gnn_layer_input_dropout_rate": 0.0})
+    params.update({"gnn_hidden_dim": 320, "gnn_num_layers": 2, "gnn_layer_input_dropout_rate": 0.0})  # (H = 320, 3 types: the products split K in their launch)
     set_seed(1)
     model = NodeMulticlassTask(params, num_edge_types=3, num_node_target_labels=121)
     batch = {"node_features": X, "node_to_graph_map": torch.from_numpy(n2g).to(dev), "num_graphs_in_batch": 2,

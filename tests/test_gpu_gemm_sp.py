@@ -524,6 +524,43 @@ def test_product_over_pattern_ordered_rows_skipping_empty_blocks_equals_the_plai
     g.close()
 
 
+@pytest.mark.parametrize("M,N,K,sb", [(7110, 320, 960, 320), (300, 320, 1280, 0), (129, 128, 512, 0), (1000, 256, 1280, 320), (700, 640, 960, 0),
+                                      (14000, 320, 480, 0)])
+def test_gemm_nt_k_split_inside_the_launch(dev, M, N, K, sb):
+    """Round 5: products over few row tiles split K inside their launch (include/tfgnn.h
+    tfgnn_sp_gemm_nt_set_splitk_workspace): splits 1.. hand their accumulators to split 0, which adds them in split order.
+    Same bound against fp64 as the unsplit product, within fp32 rounding of it, bit-reproducible over launches (the flags go
+    back to zero), no reducer ever timed out - with every epilogue form."""
+    from tf2_gnn_amd import ops
+
+    def products(**kw):
+        return _run(dev, M, N, K, sb=sb, **kw)
+
+    ops.sp_gemm_nt_splitk(True)
+    _, _, before = ops.sp_gemm_nt_splitk()
+    res, ref, _, _ = products()
+    on, timed_out, after = ops.sp_gemm_nt_splitk()
+    assert on and not timed_out and after == before + 1, "the product under test did not split"
+    scale = max(1.0, 0.05 * float(K) ** 0.5)
+    assert_close(res / scale, (ref / scale).float(), tol=1e-5, what=f"sp nt k-split {M}x{N}x{K}")
+    for _ in range(3):
+        again, _, _, _ = products()
+        assert torch.equal(again, res)
+    full = dict(bias=True, act="tanh", acc=True, grad=True)
+    res_e, ref_e, _, _ = products(**full)
+    assert_close(res_e, ref_e.float(), tol=2e-5, what=f"sp nt k-split epilogue {M}x{N}x{K}")
+    try:
+        ops.sp_gemm_nt_splitk(False)
+        plain, _, _, _ = products()
+        plain_e, _, _, _ = products(**full)
+        assert ops.sp_gemm_nt_splitk()[2] == after + 4  # (3 repeats + the epilogue run; none since the switch)
+    finally:
+        ops.sp_gemm_nt_splitk(True)
+    assert float((res.double() - plain.double()).abs().max()) <= 2e-6 * scale * max(1.0, float(ref.abs().max()) / scale)
+    assert float((res_e.double() - plain_e.double()).abs().max()) <= 4e-6 * max(1.0, float(ref_e.abs().max()))
+    assert not ops.sp_gemm_nt_splitk()[1]
+
+
 def test_tile_mask_needs_block_scales_that_tile_k(dev):
     from tf2_gnn_amd import ops
 

@@ -179,6 +179,8 @@ _SIGNATURES = [
     ("tfgnn_film_edge_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     ("tfgnn_film_edge_backward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                          c_void_p]),
+    ("tfgnn_sp_gemm_nt_set_splitk_workspace", c_int, [c_void_p, ctypes.c_size_t]),
+    ("tfgnn_sp_gemm_nt_splitk_status", c_int, [c_int, c_void_p, c_void_p]),
     ("tfgnn_dropout_epoch_advance", c_int, [c_void_p]),
     ("tfgnn_dropout_epoch_set", c_int, [ctypes.c_uint32, c_void_p]),
     ("tfgnn_dropout_epoch_get", c_int, [c_void_p, c_void_p]),

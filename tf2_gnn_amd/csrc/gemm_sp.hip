@@ -93,6 +93,14 @@ struct SpArgs {
   // blocks' k16 steps are not executed.  row_map: output row of product row r (the operand's rows are in pattern order)
   const uint8_t* tile_kmask;
   const int32_t* row_map;
+  // K split inside the launch (round 5, few row tiles: a batch of some thousand nodes leaves most CUs idle while 56
+  // workgroups each stream the whole weight operand).  ksplit = S > 1: the grid holds S workgroups per output tile, each
+  // multiplies 1/S of the tile's k16 steps; splits 1 .. S-1 publish their raw accumulators (write-through stores into
+  // ws_partial + a flag word), split 0 adds them IN SPLIT ORDER (bit-reproducible) and runs the one epilogue.
+  int ksplit;
+  float* ws_partial;    // [tiles][S - 1][4 waves x 2 x TNW x 16 x 64 floats]
+  unsigned* ws_flags;   // [tiles][S - 1], zero when the kernel starts (split 0 clears what it consumed)
+  int* ws_timeout;      // host-mapped: set to 1 if a reducer gave up waiting (never expected; the result is then wrong)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -226,7 +234,9 @@ struct SpLoop {
   // physical step blk[q] * bsteps + r (blk: 4 bits each).  bsteps == 0: identity.  brecip = ceil(2^16 / bsteps): s / bsteps
   // for s < 8 * bsteps, bsteps <= 64
   unsigned blkmap, bsteps, brecip;
+  unsigned step0;  // first logical step of this workgroup's share of K (K split inside the launch; 0 otherwise)
   __device__ __forceinline__ unsigned phys_step(unsigned s) const {
+    s += step0;
     if (!bsteps) return s;
     const unsigned q = (s * brecip) >> 16;
     return ((blkmap >> (4u * q)) & 15u) * bsteps + (s - q * bsteps);
@@ -294,8 +304,9 @@ struct SpLoop {
   template <int SET>
   __device__ __forceinline__ void scale_frags(int step) {  // plain VALU on the freshly read A fragments
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (step % a_blk_steps == 0) {
-      const int q = step < nsteps ? step / a_blk_steps : 0;
+    const int lstep = step + (int)step0;  // logical step of the tile (a K split starts inside a block)
+    if (lstep % a_blk_steps == 0 || step == 0) {
+      const int q = step < nsteps ? lstep / a_blk_steps : 0;
       const int b = bsteps ? (int)((blkmap >> (4u * (unsigned)q)) & 15u) : q;
       if (step < nsteps && b < a_nblk) {
 #pragma unroll
@@ -361,8 +372,21 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const unsigned tile_n = blockIdx.x % g.n_tiles;
-  const unsigned tile_m = blockIdx.x / g.n_tiles;
+  // K split: the producers (splits S-1 .. 1) take the low block ids - they are dispatched first -, the reducers (split 0) last
+  unsigned bid = blockIdx.x;
+  int split = 0;
+  const int S = g.ksplit;
+  if (S > 1) {
+    const unsigned nt_all = gridDim.x / (unsigned)S;
+    if (bid < nt_all * (unsigned)(S - 1)) {
+      split = 1 + (int)(bid / nt_all);
+      bid -= (unsigned)(split - 1) * nt_all;
+    } else {
+      bid -= nt_all * (unsigned)(S - 1);
+    }
+  }
+  const unsigned tile_n = bid % g.n_tiles;
+  const unsigned tile_m = bid / g.n_tiles;
   const int64_t row0 = (int64_t)tile_m * SP_BM;
   const int64_t col0 = (int64_t)tile_n * G::BN;
   int nsteps = (int)(g.K >> 4);
@@ -375,6 +399,33 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
       if (m & (1u << b)) blkmap |= (unsigned)b << (4 * n++);
     bsteps = (unsigned)g.a_blk_steps;
     nsteps = n * g.a_blk_steps;
+  }
+  unsigned step0 = 0;
+  if (S > 1) {
+    // This workgroup's share of K: the PHYSICAL k16 steps [p0, p1) - the same range with and without a tile mask, so that a
+    // product that skips all-zero blocks groups its non-zero terms exactly like the one that multiplies them (bit-equal
+    // results, tests/test_gpu_gemm_sp.py) - of which the tile's non-empty blocks hold a contiguous run of logical steps.
+    const int P = (int)(g.K >> 4);
+    const int per = (P + S - 1) / S;
+    const int p0 = split * per, p1 = p0 + per < P ? p0 + per : P;
+    if (!bsteps) {
+      step0 = (unsigned)p0;
+      nsteps = p1 > p0 ? p1 - p0 : 0;
+    } else {
+      int first = -1, cnt = 0;
+      const int nb = nsteps / (int)bsteps;
+      for (int q = 0; q < nb; ++q) {
+        const int b = (int)((blkmap >> (4u * (unsigned)q)) & 15u);
+        const int lo = p0 > b * (int)bsteps ? p0 : b * (int)bsteps;
+        const int hi = p1 < (b + 1) * (int)bsteps ? p1 : (b + 1) * (int)bsteps;
+        if (hi > lo) {
+          if (first < 0) first = q * (int)bsteps + (lo - b * (int)bsteps);
+          cnt += hi - lo;
+        }
+      }
+      step0 = first < 0 ? 0u : (unsigned)first;
+      nsteps = cnt;
+    }
   }
 
   // ---- DMA setup: buffer descriptors over this tile's rows (rows past M / N read as zeros) -------------------
@@ -401,6 +452,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   L.m0_b = __builtin_amdgcn_readfirstlane(lds_base + wave * G::ND_B * 1024);
   L.nsteps = nsteps;
   L.blkmap = blkmap;
+  L.step0 = step0;
   L.bsteps = bsteps;
   L.brecip = bsteps ? (65536u + bsteps - 1u) / bsteps : 0u;
   // lane j of a DMA instruction fills LDS slot j of 16 rows x 64 bytes: row j / 4, slot q' = j % 4 holds source
@@ -454,18 +506,89 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
 
   // ---- prologue: three steps in flight, fragments of step 0 in set 0 ----------------------------------------
   constexpr int NR = SpLoop<TNW>::NR;
-  L.template dma_prologue<0>();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::VMW) : "memory");  // steps 0 and 1 have landed
-  __builtin_amdgcn_s_barrier();
-  L.template read_all<0, NR, 0, 0>();
-  if (ABLK) L.template scale_frags<0>(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (nsteps > 0) {  // (a late K split of a short tile has nothing to multiply: its accumulators stay zero)
+    L.template dma_prologue<0>();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::VMW) : "memory");  // steps 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();
+    L.template read_all<0, NR, 0, 0>();
+    if (ABLK) L.template scale_frags<0>(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0, ABLK>(s);
+    for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0, ABLK>(s);
+  }
   // the re-loads of the last steps must not land in the patch; the accumulators of the last MFMAs must be
   // readable by plain VALU (the compiler does not see the MFMAs inside the asm statements)
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_s_barrier();
+
+  // ---- K split inside the launch: hand the raw accumulators to split 0 ------------------------------------------
+  // (cdna_hip_programming.md guideline 16: write-through 16-byte stores, every storing wave drains, one barrier, ONE lane
+  // publishes the flag with an agent-scope store; the reducer polls that one word relaxed, then reads the slab with sc1
+  // loads.)  A slab is stored in the accumulator layout, lane-major - float4 q of accumulator (t, c) of lane l at
+  // [wave][t][c][q][l] - so every store / load instruction moves 1 KB of consecutive bytes and split 0 adds register to
+  // register.  Sum order: own share, then splits 1, 2, ..: fixed, so the result is bit-reproducible.
+  if (S > 1) {
+    constexpr int WAVE_F4 = 2 * TNW * 4 * 64;  // float4 per wave and slab
+    const unsigned tile_lin = bid;
+    auto make_rsrc_ws = [](const float* ptr, int bytes) {  // raw buffer over one wave's share of a slab
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), (short)0, bytes, 0x00020000);
+    };
+    unsigned* flags = g.ws_flags + (size_t)tile_lin * (unsigned)(S - 1);
+    if (split != 0) {
+      float* slab = g.ws_partial + ((size_t)(tile_lin * (unsigned)(S - 1) + (unsigned)(split - 1)) * 4 + wave) * (WAVE_F4 * 4);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc_ws(slab, WAVE_F4 * 16);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < TNW; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint4v v{__float_as_uint(L.acc[t][c][4 * q]), __float_as_uint(L.acc[t][c][4 * q + 1]),
+                           __float_as_uint(L.acc[t][c][4 * q + 2]), __float_as_uint(L.acc[t][c][4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)((((t * TNW + c) * 4 + q) * 64 + lane) * 16), 0, 16 /* sc1 */);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + (split - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid < S - 1) {  // lane i of wave 0 polls the flag of split i + 1: one word each, relaxed; bounded (a producer that
+      unsigned spins = 0;  // never arrives must not hang the device)
+      while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 24)) {
+          if (g.ws_timeout) *g.ws_timeout = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    for (int sp = 1; sp < S; ++sp) {
+      const float* slab = g.ws_partial + ((size_t)(tile_lin * (unsigned)(S - 1) + (unsigned)(sp - 1)) * 4 + wave) * (WAVE_F4 * 4);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc_ws(slab, WAVE_F4 * 16);
+      // the whole slab in flight at once (2 TNW x 4 loads of 16 bytes per lane: the fragment registers are dead here) - a
+      // first version waited for four loads at a time and spent ~25 us per launch on 30 dependent round trips
+      uint4v v[2 * TNW * 4];
+#pragma unroll
+      for (int i = 0; i < 2 * TNW * 4; ++i)
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((i * 64 + lane) * 16), 0, 16 /* sc1 */);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < TNW; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint4v w = v[(t * TNW + c) * 4 + q];
+            L.acc[t][c][4 * q] += __uint_as_float(w.x);
+            L.acc[t][c][4 * q + 1] += __uint_as_float(w.y);
+            L.acc[t][c][4 * q + 2] += __uint_as_float(w.z);
+            L.acc[t][c][4 * q + 3] += __uint_as_float(w.w);
+          }
+    }
+    // the flags this tile consumed go back to zero for the next launch (also the next replay of a captured step)
+    __syncthreads();
+    if (tid < S - 1) __hip_atomic_store(flags + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   // Scales, bias and activation are applied in the accumulator layout (their operands were fetched before the main
@@ -1226,6 +1349,18 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
 #undef SP_LAUNCH
 }
 
+// Workspace of the in-launch K split of the NT product (tfgnn_sp_gemm_nt_set_splitk_workspace): [flags 64 KB][slabs].
+constexpr size_t kSplitkFlagBytes = 65536;
+struct SplitkWorkspace {
+  void* base = nullptr;
+  size_t bytes = 0;
+  bool enabled = true;
+  long long split_launches = 0;
+  int* timeout_host = nullptr;
+  int* timeout_dev = nullptr;
+};
+static SplitkWorkspace g_splitk;
+
 static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
 // one int in host memory mapped into the device's address space: the factor pass of the weight-gradient product stores 1
@@ -1390,7 +1525,26 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   }
   const int64_t tiles = ceil_div(M, SP_BM) * g.n_tiles;
   TFGNN_REQUIRE(tiles <= 0x7fffffff, "tfgnn_sp_gemm_nt: too many tiles");
-  dim3 grid((unsigned)tiles);
+  // K split inside the launch (SpArgs::ksplit): only where one wave of workgroups leaves most of the chip idle - every
+  // workgroup of a split launch must be RESIDENT (the reducers wait for the producers), one per CU
+  g.ksplit = 1;
+  {
+    const int64_t steps = K >> 4;
+    int S = (int)std::min<int64_t>(4, steps / 15);  // (K = 320 split in two measured slower: 52 vs 51 us at 56 tiles - the hand-off costs what 10 steps do)
+    while (S > 1 && tiles * S > 232) --S;
+    if (g_splitk.enabled && g_splitk.base && S > 1 && tiles <= 112) {
+      const size_t slab = (size_t)SP_BM * bn * 4;
+      const size_t need = kSplitkFlagBytes + (size_t)tiles * (S - 1) * slab;
+      if (need <= g_splitk.bytes && (size_t)tiles * (S - 1) * 4 <= kSplitkFlagBytes) {
+        g.ksplit = S;
+        ++g_splitk.split_launches;
+        g.ws_flags = (unsigned*)g_splitk.base;
+        g.ws_partial = (float*)((char*)g_splitk.base + kSplitkFlagBytes);
+        g.ws_timeout = g_splitk.timeout_dev;
+      }
+    }
+  }
+  dim3 grid((unsigned)(tiles * g.ksplit));
   hipStream_t s = (hipStream_t)stream;
   if (bn == 320) launch_sp_nt<5>(g, grid, s);
   else if (bn == 256) launch_sp_nt<4>(g, grid, s);
@@ -1399,6 +1553,39 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   return TFGNN_OK;
 }
 
+
+int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes) {
+  // (waits for the device: nothing in flight may still be using the previous workspace)
+  TFGNN_HIP_CHECK(hipDeviceSynchronize());
+  if (!d_workspace || bytes <= kSplitkFlagBytes) {
+    g_splitk.base = nullptr;
+    g_splitk.bytes = 0;
+    return TFGNN_OK;
+  }
+  TFGNN_REQUIRE((uintptr_t)d_workspace % 256 == 0, "tfgnn_sp_gemm_nt_set_splitk_workspace: the workspace must be 256-byte aligned");
+  if (!g_splitk.timeout_host) {
+    int* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      *h = 0;
+      g_splitk.timeout_host = h;
+      g_splitk.timeout_dev = (int*)d;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  TFGNN_HIP_CHECK(hipMemset(d_workspace, 0, kSplitkFlagBytes));  // the flags are zero between launches from here on
+  g_splitk.base = d_workspace;
+  g_splitk.bytes = bytes;
+  return TFGNN_OK;
+}
+
+int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches) {
+  if (enable >= 0) g_splitk.enabled = enable != 0;
+  if (split_launches) *split_launches = g_splitk.split_launches;
+  if (timed_out) *timed_out = g_splitk.timeout_host ? __atomic_load_n(g_splitk.timeout_host, __ATOMIC_RELAXED) : 0;
+  return (g_splitk.enabled && g_splitk.base) ? 1 : 0;
+}
 
 int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
                      int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,

@@ -1301,6 +1301,33 @@ def _row_map(t, M):
     return t
 
 
+_SPLITK_WS = {}  # "ws": the workspace tensor of the in-launch K split (tfgnn_sp_gemm_nt_set_splitk_workspace), once per process
+_SPLITK_BYTES = 32 << 20
+
+
+def _ensure_splitk_workspace(device, rows: int) -> None:
+    """Products over few row tiles (a batch of some thousand nodes) split K inside their launch so that more than one
+    workgroup per tile works (include/tfgnn.h): the workspace is registered the first time such a product is issued - one
+    per process, on that product's device (one process drives one GPU).  TFGNN_NT_SPLITK=0 keeps the unsplit product."""
+    if rows > 112 * 128 or "done" in _SPLITK_WS or capturing():
+        return
+    _SPLITK_WS["done"] = True
+    if os.environ.get("TFGNN_NT_SPLITK", "1") == "0":
+        return
+    ws = torch.empty(_SPLITK_BYTES, dtype=torch.uint8, device=device)
+    aux_flush()
+    _lib.check(_lib.load().tfgnn_sp_gemm_nt_set_splitk_workspace(_ptr(ws), _SPLITK_BYTES))
+    _SPLITK_WS["ws"] = ws
+
+
+def sp_gemm_nt_splitk(enable: Optional[bool] = None):
+    """-> (splits can happen, a reducer ever timed out, products launched with a split so far).  enable: switch the in-launch
+    K split of products over few row tiles on / off (include/tfgnn.h tfgnn_sp_gemm_nt_set_splitk_workspace)."""
+    t, n = ctypes.c_int(0), ctypes.c_int64(0)
+    on = _lib.load().tfgnn_sp_gemm_nt_splitk_status(-1 if enable is None else int(bool(enable)), ctypes.byref(t), ctypes.byref(n))
+    return bool(on), bool(t.value), int(n.value)
+
+
 @_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
                act_grad=None, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None) -> torch.Tensor:
@@ -1328,6 +1355,7 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
     if bias is not None:
         bias = bias.contiguous()
     rate, seed = dropout if dropout is not None else (0.0, 0)
+    _ensure_splitk_workspace(a.data.device, M)
     _lib.check(
         lib.tfgnn_sp_gemm_nt_dropout(
             M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
@@ -1362,6 +1390,7 @@ def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NON
     if bias is not None:
         bias = bias.contiguous()
     rate, seed = dropout if dropout is not None else (0.0, 0)
+    _ensure_splitk_workspace(dev, M)
     _lib.check(
         lib.tfgnn_sp_gemm_nt_dropout(
             M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
