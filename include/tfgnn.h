@@ -175,7 +175,11 @@ typedef enum {
   /* part DST_PATTERN (at most 8 edge types; count 0 beyond): nodes ordered by the emptiness pattern of their by-target buckets */
   TFGNN_G_PATTERN_POS_BY_DST = 27,      /* int32 [V]: node -> position                                  */
   TFGNN_G_PATTERN_NODE_BY_DST = 28,     /* int32 [V]: position -> node (the row map of a product's output) */
-  TFGNN_G_PATTERN_TILEMASK_BY_DST = 29  /* uint8 [ceil(V/128)]: union of the patterns of 128 positions (bit l: type l non-empty) */
+  TFGNN_G_PATTERN_TILEMASK_BY_DST = 29, /* uint8 [ceil(V/128)]: union of the patterns of 128 positions (bit l: type l non-empty) */
+  /* the same order for the by-SOURCE buckets (also part DST_PATTERN; round 5): the input-gradient product over the by-source
+   * sums reads its operand rows through NODE_BY_SRC (tfgnn_sp_gemm_nt_rows d_a_rows) and skips a tile's all-zero blocks */
+  TFGNN_G_PATTERN_NODE_BY_SRC = 30,     /* int32 [V]: position -> node */
+  TFGNN_G_PATTERN_TILEMASK_BY_SRC = 31  /* uint8 [ceil(V/128)] */
 } tfgnn_graph_array_id;
 
 /* Borrow a device array owned by the handle (valid until tfgnn_graph_destroy). */
@@ -662,6 +666,19 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
                         int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
                         const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                         float* d_out_inv_scale, void* stream);
+/* tfgnn_sp_gemm_nt_dropout with the rows of A read through an index (round 5): product row r multiplies operand row
+ * d_a_rows[r] (int32 [M], every entry in [0, M); NULL: row r) and takes that row's scales; the operand must be below 4 GB.
+ * The input-gradient product dX = [G_0|..|G_{L-1}] W^T of the aggregate-first layers walks the by-source sums in the order of
+ * their emptiness patterns this way (d_a_rows = d_row_map = TFGNN_G_PATTERN_NODE_BY_SRC, d_tile_kmask =
+ * TFGNN_G_PATTERN_TILEMASK_BY_SRC) and skips the all-zero type blocks of a row tile, while the sums themselves stay in node
+ * order, as the weight-gradient product needs them.  Skipped products are exact zeros: bit-equal to the unindexed call. */
+int tfgnn_sp_gemm_nt_rows(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                          int a_scale_block, const int32_t* d_a_rows, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale,
+                          float* d_C, int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                          int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
+                          int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
+                          const uint8_t* d_tile_kmask, const int32_t* d_row_map, void* stream);
+
 /* K split INSIDE the launch of the NT product, for few row tiles (round 5; BASELINE configs[0]: a PPI batch of 7 110 nodes is 56
  * row tiles - 56 workgroups each streaming the whole weight operand while 200 CUs idle, and the product takes as long as at
  * 30 000 nodes).  With a workspace registered here, products of at most 112 output tiles and K >= 480 launch S = 2..4
@@ -669,7 +686,7 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
  * through the workspace (write-through stores + one flag word each), split 0 adds them in split order - the result is
  * bit-reproducible, though not bit-equal to the unsplit product's (another summation order; same error class) - and runs
  * the epilogue.  No extra launch, no extra pass.  Layout: [64 KB of flags][slabs of 128 x tile-width floats]; 32 MB cover
- * every eligible shape.  The library keeps the flags zero between launches (each reducer clears what it consumed), which is
+ * every shape eligible for the K split (the helper workgroups of tfgnn_sp_gemm_nt_balance take one slab per tile).  The library keeps the flags zero between launches (each reducer clears what it consumed), which is
  * what makes a product captured in a hipGraph replayable.  ONE workspace per process: products that may run CONCURRENTLY (two
  * streams) must not both be eligible.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
  * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = 1 if a reducer ever gave
@@ -677,6 +694,12 @@ int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int
  * launched with a split so far (tests assert that the path under test really ran); returns 1 if splits can happen. */
 int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes);
 int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches);
+/* Helper workgroups for the heavy tiles of a MASKED product (d_tile_kmask, >= 128 row tiles, the workspace above): a tile
+ * with at least min_blocks non-empty K blocks is multiplied by two workgroups (halves of K, the same hand-off).  0 = off, the
+ * default: measured a LOSS on the benchmark batch (DESIGN.md / gemm_sp.hip: 112 vs 90 us per forward product) - kept for
+ * re-measurement.  min_blocks < 0 only queries.  Returns the previous value.  Results with helpers are reproducible but not
+ * bit-equal to the unmasked product's (a heavy tile's sum is grouped in two halves). */
+int tfgnn_sp_gemm_nt_balance(int min_blocks);
 
 /* The superset: tfgnn_sp_gemm_nt / _sp (d_out_sp may be NULL) with the layer-input dropout of the NEXT op in the epilogue
  * (gnn.py:285-288 - the producer of a layer's input drops it, so the stand-alone pass over [V, H], its mask tensor and the

@@ -181,6 +181,7 @@ _SIGNATURES = [
                                          c_void_p]),
     ("tfgnn_sp_gemm_nt_set_splitk_workspace", c_int, [c_void_p, ctypes.c_size_t]),
     ("tfgnn_sp_gemm_nt_splitk_status", c_int, [c_int, c_void_p, c_void_p]),
+    ("tfgnn_sp_gemm_nt_balance", c_int, [c_int]),
     ("tfgnn_dropout_epoch_advance", c_int, [c_void_p]),
     ("tfgnn_dropout_epoch_set", c_int, [ctypes.c_uint32, c_void_p]),
     ("tfgnn_dropout_epoch_get", c_int, [c_void_p, c_void_p]),
@@ -287,6 +288,13 @@ _SIGNATURES = [
         "tfgnn_sp_gemm_nt_dropout",
         c_int,
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_float,
+         ctypes.c_uint64, c_void_p, c_void_p, c_void_p],
+    ),
+    (
+        "tfgnn_sp_gemm_nt_rows",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_float,
          ctypes.c_uint64, c_void_p, c_void_p, c_void_p],
     ),

@@ -93,11 +93,20 @@ struct SpArgs {
   // blocks' k16 steps are not executed.  row_map: output row of product row r (the operand's rows are in pattern order)
   const uint8_t* tile_kmask;
   const int32_t* row_map;
+  // operand rows through an index (round 5): product row r multiplies row a_rows[r] of A (and takes that row's scales) - the
+  // by-source sums stay in node order for the weight-gradient product while the input-gradient product walks them in the
+  // order of the by-source emptiness patterns (tile_kmask of THAT order) and writes node order again through row_map
+  const int32_t* a_rows;
   // K split inside the launch (round 5, few row tiles: a batch of some thousand nodes leaves most CUs idle while 56
   // workgroups each stream the whole weight operand).  ksplit = S > 1: the grid holds S workgroups per output tile, each
   // multiplies 1/S of the tile's k16 steps; splits 1 .. S-1 publish their raw accumulators (write-through stores into
   // ws_partial + a flag word), split 0 adds them IN SPLIT ORDER (bit-reproducible) and runs the one epilogue.
   int ksplit;
+  // balance > 0 (with tile_kmask; round 5): the grid holds TWO workgroups per tile - ids [0, tiles) are helper candidates,
+  // dispatched first, ids [tiles, 2 tiles) the tiles themselves.  A tile whose mask has at least `balance` non-empty blocks
+  // is split in two halves of K (helper = split 1, the tile's own workgroup = split 0, the reducer); the helper of any other
+  // tile exits at once.  The launch then lasts about as long as its three-block tiles instead of its four-block ones.
+  int balance;
   float* ws_partial;    // [tiles][S - 1][4 waves x 2 x TNW x 16 x 64 floats]
   unsigned* ws_flags;   // [tiles][S - 1], zero when the kernel starts (split 0 clears what it consumed)
   int* ws_timeout;      // host-mapped: set to 1 if a reducer gave up waiting (never expected; the result is then wrong)
@@ -375,8 +384,13 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   // K split: the producers (splits S-1 .. 1) take the low block ids - they are dispatched first -, the reducers (split 0) last
   unsigned bid = blockIdx.x;
   int split = 0;
-  const int S = g.ksplit;
-  if (S > 1) {
+  int S = g.ksplit;
+  bool helper = false;
+  if (g.balance > 0) {
+    const unsigned nt_all = gridDim.x / 2u;
+    helper = bid < nt_all;
+    if (!helper) bid -= nt_all;
+  } else if (S > 1) {
     const unsigned nt_all = gridDim.x / (unsigned)S;
     if (bid < nt_all * (unsigned)(S - 1)) {
       split = 1 + (int)(bid / nt_all);
@@ -393,6 +407,12 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   unsigned blkmap = 0, bsteps = 0;
   if (g.tile_kmask) {  // only the blocks of K that hold anything in this row tile (wave-uniform: one byte per tile)
     unsigned m = __builtin_amdgcn_readfirstlane((int)g.tile_kmask[tile_m]) & ((1u << g.a_nblk) - 1u);
+    if (g.balance > 0) {  // heavy tile: two workgroups share it; light tile: its helper candidate has nothing to do
+      const bool heavy = __builtin_popcount(m) >= g.balance;
+      if (helper && !heavy) return;
+      S = heavy ? 2 : 1;
+      split = helper ? 1 : 0;
+    }
     if (!m) m = 1u;  // an all-empty tile still runs one (zero) block: the epilogue needs defined accumulators and scales
     int n = 0;
     for (int b = 0; b < g.a_nblk; ++b)
@@ -438,7 +458,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
                   (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
   };
-  const uint4v rs_a = make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
+  // (a_rows: the descriptor spans the whole operand - its rows come from anywhere; host: M * lda < 2^32)
+  const uint4v rs_a = g.a_rows ? make_rsrc(g.A, g.M * g.lda) : make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
   const uint4v rs_b = make_rsrc(g.B + col0 * g.ldb, rows_b * g.ldb);
   half8 r_fa[2][2][2];
   half8 r_fb[2][TNW][2];
@@ -460,7 +481,15 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   const int drow = lane >> 2;
   const int dq = (lane & 3) ^ ((drow >> 2) & 3);
 #pragma unroll
-  for (int i = 0; i < G::ND_A; ++i) L.voff_a[i] = (unsigned)(((wave * G::ND_A + i) * 16 + drow) * g.lda + dq * 16);
+  for (int i = 0; i < G::ND_A; ++i) {
+    const int tr = (wave * G::ND_A + i) * 16 + drow;  // row of the tile this lane fetches
+    if (g.a_rows) {  // rows past M: an offset outside the descriptor reads zeros
+      const int64_t pr = row0 + tr;
+      L.voff_a[i] = pr < g.M ? (unsigned)((int64_t)g.a_rows[pr] * g.lda + dq * 16) : 0xfffffff0u;
+    } else {
+      L.voff_a[i] = (unsigned)(tr * g.lda + dq * 16);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < G::ND_B; ++i) L.voff_b[i] = (unsigned)(((wave * G::ND_B + i) * 16 + drow) * g.ldb + dq * 16);
 
@@ -487,6 +516,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   for (int t = 0; t < 2; ++t) {
     int64_t r = row0 + wm * 64 + t * 32 + fi;
     L.a_row[t] = r < g.M ? r : g.M - 1;
+    if (g.a_rows) L.a_row[t] = g.a_rows[L.a_row[t]];  // the scales of the operand row this product row reads
     float m = 1.f;
     if (ABLK) {
       m = 0.f;
@@ -1360,6 +1390,18 @@ struct SplitkWorkspace {
   int* timeout_dev = nullptr;
 };
 static SplitkWorkspace g_splitk;
+// Helper workgroups for the heavy tiles of a masked product (SpArgs::balance): tiles with at least this many non-empty K
+// blocks get a second workgroup; 0 = off, the DEFAULT - measured a loss on the benchmark batch (rmat30k, 235 tiles on 256
+// CUs: forward product 112 us with helpers for the 90 four-block tiles, 101 us with helpers for three-block tiles too, 90 us
+// without; step 2.50 / 2.48 / 2.38 ms, same box, two runs each): the 90 + 235 workgroups no longer fit one wave, the
+// light tiles that start late set the launch time, and all 256 CUs keep contending for L2 -> LDS bandwidth until then
+// (without helpers the heavy tiles speed up once the light ones are done).  TFGNN_NT_BALANCE_MIN_BLOCKS /
+// tfgnn_sp_gemm_nt_balance switch it on for re-measurement.
+static int balance_min_blocks_from_env() {
+  const char* e = std::getenv("TFGNN_NT_BALANCE_MIN_BLOCKS");
+  return e ? std::atoi(e) : 0;
+}
+static int g_balance_min_blocks = balance_min_blocks_from_env();
 
 static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
@@ -1473,8 +1515,10 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
                            int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
                            int act_of_saved, const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                            float* d_out_inv_scale, void* stream, float dropout_rate = 0.f, uint64_t dropout_seed = 0,
-                           float saved_scale = 1.f, const uint8_t* d_tile_kmask = nullptr, const int32_t* d_row_map = nullptr) {
+                           float saved_scale = 1.f, const uint8_t* d_tile_kmask = nullptr, const int32_t* d_row_map = nullptr,
+                           const int32_t* d_a_rows = nullptr) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && (d_C || d_out_sp), "tfgnn_sp_gemm_nt: null pointer");
+  TFGNN_REQUIRE(!d_a_rows || M * lda_bytes < (1ll << 32) - 65536, "tfgnn_sp_gemm_nt_rows: the operand read through a row index must be below 4 GB");
   TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "tfgnn_sp_gemm_nt: dropout rate must be in [0, 1), got %f", (double)dropout_rate);
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
   const int bn = sp_tile_width(N);
@@ -1510,6 +1554,7 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
     g.tile_kmask = d_tile_kmask;
   }
   g.row_map = d_row_map;
+  g.a_rows = d_a_rows;
   g.drop_on = dropout_rate > 0.f ? (dropout_seed == ~0ull ? 2 : 1) : 0;
   if (g.drop_on == 2)
     TFGNN_REQUIRE(d_saved && act_of_saved == TFGNN_ACT_RELU, "tfgnn_sp_gemm_nt_dropout: the mask-from-saved form needs a relu saved tensor");
@@ -1544,7 +1589,17 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
       }
     }
   }
-  dim3 grid((unsigned)(tiles * g.ksplit));
+  // heavy-tile balancing of a masked product (SpArgs::balance): one slab and one flag per tile
+  g.balance = 0;
+  if (g.ksplit == 1 && d_tile_kmask && g_splitk.enabled && g_splitk.base && g_balance_min_blocks > 0 && g.a_nblk >= 2 && tiles >= 128 &&
+      (size_t)tiles * 4 <= kSplitkFlagBytes && kSplitkFlagBytes + (size_t)tiles * SP_BM * bn * 4 <= g_splitk.bytes) {
+    g.balance = std::min(g_balance_min_blocks, g.a_nblk);
+    g.ws_flags = (unsigned*)g_splitk.base;
+    g.ws_partial = (float*)((char*)g_splitk.base + kSplitkFlagBytes);
+    g.ws_timeout = g_splitk.timeout_dev;
+    ++g_splitk.split_launches;
+  }
+  dim3 grid((unsigned)(tiles * (g.balance > 0 ? 2 : g.ksplit)));
   hipStream_t s = (hipStream_t)stream;
   if (bn == 320) launch_sp_nt<5>(g, grid, s);
   else if (bn == 256) launch_sp_nt<4>(g, grid, s);
@@ -1587,6 +1642,12 @@ int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_la
   return (g_splitk.enabled && g_splitk.base) ? 1 : 0;
 }
 
+int tfgnn_sp_gemm_nt_balance(int min_blocks) {
+  const int prev = g_balance_min_blocks;
+  if (min_blocks >= 0) g_balance_min_blocks = min_blocks;
+  return prev;
+}
+
 int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
                      int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                      int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
@@ -1615,6 +1676,17 @@ int tfgnn_sp_gemm_nt_dropout(int64_t M, int64_t N, int64_t K, const void* d_A_sp
   return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
                          act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale,
                          stream, dropout_rate, dropout_seed, saved_scale, d_tile_kmask, d_row_map);
+}
+
+int tfgnn_sp_gemm_nt_rows(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                          int a_scale_block, const int32_t* d_a_rows, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale,
+                          float* d_C, int64_t ldc, const float* d_bias, int act, int accumulate, const float* d_mul, int64_t ld_mul,
+                          int act_of_saved, const float* d_saved, int64_t ld_saved, float saved_scale, void* d_out_sp,
+                          int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
+                          const uint8_t* d_tile_kmask, const int32_t* d_row_map, void* stream) {
+  return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
+                         act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale,
+                         stream, dropout_rate, dropout_seed, saved_scale, d_tile_kmask, d_row_map, d_a_rows);
 }
 
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {

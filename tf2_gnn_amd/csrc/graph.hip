@@ -616,9 +616,10 @@ __global__ void __launch_bounds__(256) pattern_place_kernel(const int32_t* __res
     __syncthreads();
     if (v < V) {
       const int32_t p = base[m] + slot0[m] + rank;
-      pos[v] = p;
+      if (pos) pos[v] = p;
       node_at[p] = (int32_t)v;
-      for (int l = 0; l < L; ++l) rowmap[v * L + l] = p * L + l;
+      if (rowmap)
+        for (int l = 0; l < L; ++l) rowmap[v * L + l] = p * L + l;
     }
     __syncthreads();
   }
@@ -908,6 +909,15 @@ int build_dst_pattern(tfgnn_graph* g, int32_t* pat, hipStream_t s) {
                      pat + 256, g->pat_pos_d, g->pat_node_d, g->pat_rowmap_d);
   hipLaunchKernelGGL(pattern_tilemask_kernel, dim3((unsigned)ceil_div(g->V, 128)), dim3(128), 0, s, (const int32_t*)g->rowptr_d,
                      (const int32_t*)g->pat_node_d, g->V, g->L, g->pat_tilemask_d);
+  // the same for the by-SOURCE buckets (round 5: the input-gradient product over [G_0|..|G_{L-1}] reads its rows through
+  // node_at and skips the all-zero blocks of a tile; the gather keeps writing node order, which the weight-gradient
+  // product needs) - no position / row-map arrays on this side
+  int32_t* pat_s = pat + 512;
+  hipLaunchKernelGGL(pattern_count_kernel, dim3(blocks), dim3(256), 0, s, (const int32_t*)g->rowptr_s, g->V, g->L, pat_s);
+  hipLaunchKernelGGL(pattern_place_kernel, dim3(blocks), dim3(256), 0, s, (const int32_t*)g->rowptr_s, g->V, g->L, (const int32_t*)pat_s,
+                     pat_s + 256, (int32_t*)nullptr, g->pat_node_s, (int32_t*)nullptr);
+  hipLaunchKernelGGL(pattern_tilemask_kernel, dim3((unsigned)ceil_div(g->V, 128)), dim3(128), 0, s, (const int32_t*)g->rowptr_s,
+                     (const int32_t*)g->pat_node_s, g->V, g->L, g->pat_tilemask_s);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -976,7 +986,7 @@ CoreScratch core_scratch(int64_t E, int L, bool pay) {
   c.keys = tmp.take((size_t)E * 8 * 4);
   c.pays = tmp.take(pay ? (size_t)E * 4 * 4 : 0);
   c.hist = tmp.take((size_t)2 * RS_RADIX * c.nblk_ld * 4 + 16);
-  c.counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4);  // counters, the bins, the pattern bins: one memset
+  c.counters = tmp.take((size_t)(64 + 4 * 2 * SHORT_BINS + 1024) * 4);  // counters, the bins, the pattern bins: one memset
   c.ptrs = tmp.take((size_t)(L + 1) * 8);
   c.off = tmp.take((size_t)(L + 1) * 8);
   c.total = tmp.total;
@@ -1058,6 +1068,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   const size_t o_tgt_d = plan.take(E * 4), o_eid2pos = plan.take(E * 4);
   const size_t o_pat_pos = plan.take((V + 1) * 4), o_pat_node = plan.take((V + 1) * 4), o_pat_rowmap = plan.take((R + 1) * 4);
   const size_t o_pat_mask = plan.take((size_t)ceil_div(V > 0 ? V : 1, 128) + 16);
+  const size_t o_pat_node_s = plan.take((V + 1) * 4), o_pat_mask_s = plan.take((size_t)ceil_div(V > 0 ? V : 1, 128) + 16);
   const size_t o_invdeg_d = plan.take((R + 1) * 4);
   const size_t o_invdeg_es = plan.take(E * 4), o_invdeg_ed = plan.take(E * 4);
   size_t o_cb[2][6];
@@ -1140,6 +1151,8 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   g->pat_node_d = (int32_t*)(slab + o_pat_node);
   g->pat_rowmap_d = (int32_t*)(slab + o_pat_rowmap);
   g->pat_tilemask_d = (uint8_t*)(slab + o_pat_mask);
+  g->pat_node_s = (int32_t*)(slab + o_pat_node_s);
+  g->pat_tilemask_s = (uint8_t*)(slab + o_pat_mask_s);
   g->invdeg_d = (float*)(slab + o_invdeg_d);
   g->invdeg_edge_s = (float*)(slab + o_invdeg_es);
   g->invdeg_edge_d = (float*)(slab + o_invdeg_ed);
@@ -1188,7 +1201,7 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
     }                                                                                          \
   } while (0)
 
-  G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4, s));
+  G_CHECK(hipMemsetAsync(counters, 0, (size_t)(64 + 4 * 2 * SHORT_BINS + 1024) * 4, s));
   // sort the edges into bucket order for both bucketings, then everything per edge and per row
   if (E > 0) {
     rc = run_core(g, with_ids, scratch, cs, s);
@@ -1285,7 +1298,7 @@ extern "C" int tfgnn_graph_ensure(tfgnn_graph* g, unsigned parts, void* stream) 
   // the edge ids were not carried through the sort: run it again with the payload (same order, same arrays - the adjacency
   // lists of tfgnn_graph_create* are read again and must still be alive)
   const CoreScratch cs = core_scratch(redo_core ? g->E : 0, g->L, true);
-  const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS + 512) * 4;
+  const size_t c_bytes = (size_t)(64 + 4 * 2 * SHORT_BINS + 1024) * 4;
   const size_t core_take = (cs.total + 255) & ~(size_t)255;
   const size_t need = core_take + ((missing & TFGNN_GRAPH_PART_COMPACT) ? compact_scratch_bytes(g->R, g->V) : 0);
   char* scratch = nullptr;
@@ -1469,7 +1482,7 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     unsigned need = 0;
     if (array_id == TFGNN_G_SRC2DST_POS) need = TFGNN_GRAPH_PART_EDGE_MAPS;
     if (array_id == TFGNN_G_EID_BY_DST || array_id == TFGNN_G_EID_BY_SRC) need = TFGNN_GRAPH_PART_EDGE_IDS;
-    if (array_id >= TFGNN_G_PATTERN_POS_BY_DST && array_id <= TFGNN_G_PATTERN_TILEMASK_BY_DST) need = TFGNN_GRAPH_PART_DST_PATTERN;
+    if (array_id >= TFGNN_G_PATTERN_POS_BY_DST && array_id <= TFGNN_G_PATTERN_TILEMASK_BY_SRC) need = TFGNN_GRAPH_PART_DST_PATTERN;
     if (array_id >= TFGNN_G_NZ_CPOS_BY_DST && array_id <= TFGNN_G_NZ_COL_BY_SRC) need = TFGNN_GRAPH_PART_COMPACT;
     if (need) {
       const int rc = tfgnn::graph_require_parts(g, need, "tfgnn_graph_array");
@@ -1495,6 +1508,8 @@ extern "C" int tfgnn_graph_array(const tfgnn_graph* g, int array_id, const void*
     case TFGNN_G_PATTERN_POS_BY_DST: *d_ptr = g->L <= 8 ? g->pat_pos_d : nullptr; *count = g->L <= 8 ? g->V : 0; break;
     case TFGNN_G_PATTERN_NODE_BY_DST: *d_ptr = g->L <= 8 ? g->pat_node_d : nullptr; *count = g->L <= 8 ? g->V : 0; break;
     case TFGNN_G_PATTERN_TILEMASK_BY_DST: *d_ptr = g->L <= 8 ? (const void*)g->pat_tilemask_d : nullptr; *count = g->L <= 8 ? ceil_div(g->V, 128) : 0; break;
+    case TFGNN_G_PATTERN_NODE_BY_SRC: *d_ptr = g->L <= 8 ? g->pat_node_s : nullptr; *count = g->L <= 8 ? g->V : 0; break;
+    case TFGNN_G_PATTERN_TILEMASK_BY_SRC: *d_ptr = g->L <= 8 ? (const void*)g->pat_tilemask_s : nullptr; *count = g->L <= 8 ? ceil_div(g->V, 128) : 0; break;
     case TFGNN_G_NZ_CPOS_BY_DST: case TFGNN_G_NZ_CPOS_BY_SRC:
       *d_ptr = g->compact[array_id >= TFGNN_G_NZ_CPOS_BY_SRC].cpos; *count = g->R; break;
     case TFGNN_G_NZ_ROW_BY_DST: case TFGNN_G_NZ_ROW_BY_SRC:

@@ -66,6 +66,8 @@ struct tfgnn_graph {
   // part DST_PATTERN: nodes ordered by which of their by-target buckets are empty (graph.hip)
   int32_t *pat_pos_d = nullptr, *pat_node_d = nullptr, *pat_rowmap_d = nullptr;
   uint8_t* pat_tilemask_d = nullptr;
+  int32_t* pat_node_s = nullptr;  // ... and of their by-source buckets (position -> node, tile masks; round 5)
+  uint8_t* pat_tilemask_s = nullptr;
   unsigned parts = 0;          // TFGNN_GRAPH_PART_* bits that have been built (the sort and the per-edge arrays always are)
   int sec_bits = 0, total_bits = 0;        // composite key: (bucket << sec_bits) | column
   std::vector<const int32_t*> h_adj;       // the adjacency lists of the creation call (device pointers) and their

@@ -184,9 +184,9 @@ class _DevArray:
  G_INVDEG_EDGE_BY_DST, G_SRC2DST_POS, G_TARGET_BY_DST, G_NZ_CPOS_BY_DST, G_NZ_ROW_BY_DST, G_NZ_NODE_BY_DST,
  G_NZ_OFF_BY_DST, G_NZ_NODEPTR_BY_DST, G_NZ_COL_BY_DST, G_NZ_CPOS_BY_SRC, G_NZ_ROW_BY_SRC, G_NZ_NODE_BY_SRC,
  G_NZ_OFF_BY_SRC, G_NZ_NODEPTR_BY_SRC, G_NZ_COL_BY_SRC, G_PATTERN_POS_BY_DST, G_PATTERN_NODE_BY_DST,
- G_PATTERN_TILEMASK_BY_DST) = range(30)
+ G_PATTERN_TILEMASK_BY_DST, G_PATTERN_NODE_BY_SRC, G_PATTERN_TILEMASK_BY_SRC) = range(32)
 _FLOAT_ARRAYS = {G_INVDEG_BY_DST, G_INVDEG_EDGE_BY_SRC, G_INVDEG_EDGE_BY_DST}
-_BYTE_ARRAYS = {G_PATTERN_TILEMASK_BY_DST}
+_BYTE_ARRAYS = {G_PATTERN_TILEMASK_BY_DST, G_PATTERN_TILEMASK_BY_SRC}
 # parts of a graph handle beyond the two sorted edge orders (include/tfgnn.h tfgnn_graph_part)
 G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_EDGE_IDS, G_PART_DST_PATTERN, G_PARTS_ALL = 1, 2, 4, 8, 16, 32, 63
 G_PARTS_DEFAULT = G_PARTS_ALL & ~G_PART_DST_PATTERN  # the pattern order is built for the layers that ask for it
@@ -200,7 +200,7 @@ def _array_parts(array_id: int) -> int:
         return G_PART_EDGE_MAPS | G_PART_EDGE_IDS
     if array_id in (G_EID_BY_DST, G_EID_BY_SRC):
         return G_PART_EDGE_IDS
-    if G_PATTERN_POS_BY_DST <= array_id <= G_PATTERN_TILEMASK_BY_DST:
+    if G_PATTERN_POS_BY_DST <= array_id <= G_PATTERN_TILEMASK_BY_SRC:
         return G_PART_DST_PATTERN
     return G_PART_COMPACT if G_NZ_CPOS_BY_DST <= array_id <= G_NZ_COL_BY_SRC else 0
 
@@ -1302,14 +1302,14 @@ def _row_map(t, M):
 
 
 _SPLITK_WS = {}  # "ws": the workspace tensor of the in-launch K split (tfgnn_sp_gemm_nt_set_splitk_workspace), once per process
-_SPLITK_BYTES = 32 << 20
+_SPLITK_BYTES = 80 << 20
 
 
 def _ensure_splitk_workspace(device, rows: int) -> None:
     """Products over few row tiles (a batch of some thousand nodes) split K inside their launch so that more than one
     workgroup per tile works (include/tfgnn.h): the workspace is registered the first time such a product is issued - one
     per process, on that product's device (one process drives one GPU).  TFGNN_NT_SPLITK=0 keeps the unsplit product."""
-    if rows > 112 * 128 or "done" in _SPLITK_WS or capturing():
+    if rows > 56000 or "done" in _SPLITK_WS or capturing():  # (few row tiles: K split; masked products up to ~430 tiles: helpers)
         return
     _SPLITK_WS["done"] = True
     if os.environ.get("TFGNN_NT_SPLITK", "1") == "0":
@@ -1328,15 +1328,22 @@ def sp_gemm_nt_splitk(enable: Optional[bool] = None):
     return bool(on), bool(t.value), int(n.value)
 
 
+def sp_gemm_nt_balance(min_blocks: int = -1) -> int:
+    """Helper workgroups for the heavy tiles of masked products (tfgnn_sp_gemm_nt_balance; 0 = off, the default - a measured
+    loss on the benchmark batch).  -> the previous setting."""
+    return int(_lib.load().tfgnn_sp_gemm_nt_balance(int(min_blocks)))
+
+
 @_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
-               act_grad=None, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None) -> torch.Tensor:
+               act_grad=None, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None, a_rows=None) -> torch.Tensor:
     """out [M, N] = epilogue(a [M, K] @ b [N, K]^T) from SP16 operands (tfgnn_sp_gemm_nt / tfgnn_sp_gemm_nt_dropout).
     tile_kmask (uint8 [ceil(M / 128)]): bit b = scale block b of ``a`` holds non-zeros in that row tile, the other blocks are
     skipped; row_map (int32 [M]): product row r is written at out[row_map[r]] (Graph pattern order, graph_gather_sp).
     dropout = (rate, seed): the result times the mask ``dropout_forward`` draws for that seed, applied in the epilogue
     (forward: the next layer's input dropout; gradient product: the recomputed forward mask).  saved_scale: the derivative
-    of ``act_grad`` is taken at saved * saved_scale (saved is a dropped activation)."""
+    of ``act_grad`` is taken at saved * saved_scale (saved is a dropped activation).  a_rows (int32 [M]): product row r reads
+    row a_rows[r] of ``a`` (tfgnn_sp_gemm_nt_rows: the by-source pattern order of the input-gradient product)."""
     lib = _lib.load()
     M, K, N = a.rows, a.cols, b.rows
     if b.cols != K:
@@ -1357,9 +1364,9 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
     rate, seed = dropout if dropout is not None else (0.0, 0)
     _ensure_splitk_workspace(a.data.device, M)
     _lib.check(
-        lib.tfgnn_sp_gemm_nt_dropout(
-            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
-            b.data.stride(0),
+        lib.tfgnn_sp_gemm_nt_rows(
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1,
+            _ptr(_row_map(a_rows, M)), _ptr(b.data), b.data.stride(0),
             _ptr(b.inv_scale), _ptr(out), ldc, _ptr(bias), act_id(act), int(accumulate), _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
             saved.stride(0) if saved is not None else 0, float(saved_scale), None, 0, None, float(rate),
@@ -1370,7 +1377,7 @@ def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out
 
 
 def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out_mul=None, act_grad=None,
-                     want_fp32: bool = True, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None):
+                     want_fp32: bool = True, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None, a_rows=None):
     """As sp_gemm_nt, with the result ALSO (or only: want_fp32=False) written as an SP16 operand with one scale per row
     by the product's epilogue (tfgnn_sp_gemm_nt_sp): the next product's operand without a split pass.  N must be one
     column tile (128, 256 or 320).  -> (fp32 [M, N] | None, SplitOperand); the fp32 tensor remembers its split form
@@ -1392,8 +1399,9 @@ def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NON
     rate, seed = dropout if dropout is not None else (0.0, 0)
     _ensure_splitk_workspace(dev, M)
     _lib.check(
-        lib.tfgnn_sp_gemm_nt_dropout(
-            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(b.data),
+        lib.tfgnn_sp_gemm_nt_rows(
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1,
+            _ptr(_row_map(a_rows, M)), _ptr(b.data),
             b.data.stride(0), _ptr(b.inv_scale), _ptr(out), N, _ptr(bias), act_id(act), 0, _ptr(out_mul),
             out_mul.stride(0) if out_mul is not None else 0, act_id(act_name), _ptr(saved),
             saved.stride(0) if saved is not None else 0, float(saved_scale), _ptr(op.data), op.data.stride(0), _ptr(op.inv_scale),
