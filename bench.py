@@ -231,12 +231,12 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
     t_layer_full = 2.0 * run(1.0 / 2, 1) if sweep[threads] / cal > 1.0 else sweep[threads] / cal
     # the sample: whole stack on the whole batch if a warm-up and two timed runs fit the budget, else fewer layers, then a
     # fraction of the batch
-    per_run = budget_seconds / 3.0
+    per_run = budget_seconds / 4.5  # a warm-up and at least THREE timed runs ("median of 1 runs")
     layers = NL if t_layer_full * NL <= per_run else max(1, min(NL, int(per_run / max(t_layer_full, 1e-6))))
     frac = float(min(1.0, max(cal, per_run / max(t_layer_full * layers, 1e-6))))
     t_used = run(frac, layers)  # warm-up at the sample size
     times = []
-    while len(times) < 5 and (not times or t_used + times[-1] < budget_seconds):
+    while len(times) < 5 and (len(times) < 3 or t_used + times[-1] < budget_seconds):
         times.append(run(frac, layers))
         t_used += times[-1]
     t = float(np.median(times))
@@ -246,10 +246,11 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
         "value": E / t_full,
         "unit": "edges/s",
         "cores": threads,
+        "host_cpu_count": cores_all,  # os.cpu_count() of the box the line was measured on (north_star: "core count stated")
         "kind": "port",
         "thread_sweep_seconds": {str(k): v for k, v in sweep.items()},
         "sample": f"{layers} of {NL} {model.upper()} layers (+ projection / Dense{' / WeightedSum pooling' if pooled else ''}) fwd+bwd on "
-        f"{frac:.3f} of the batch ({what}{', all nodes' if not pooled else ''}), {threads} threads (fastest of a sweep up to {cores_all}): "
+        f"{frac:.3f} of the batch ({what}{', all nodes' if not pooled else ''}), {threads} threads (fastest of a sweep up to the host's {cores_all}): "
         f"1 warm-up, median of {len(times)} runs = {t:.2f} s, scaled to the full batch and stack; torch-CPU fp32 restatement of the "
         "reference op sequence (TensorFlow unavailable offline)",
         "seconds_per_step": t_full,
@@ -259,21 +260,21 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
 # --------------------------------------------------------------------------------------------------------------------
 # workload construction / launch
 # --------------------------------------------------------------------------------------------------------------------
-def build_batch(wl, rank, world):
-    """-> dict(feats, adjs, n2g, num_graphs)"""
+def build_batch(wl, rank, world, variant=0):
+    """-> dict(feats, adjs, n2g, num_graphs).  variant > 0: another draw of the same shape (--distinct-batches)"""
     from tf2_gnn_amd import parallel
     from tf2_gnn_amd.data import make_qm9_shaped_batch, make_synthetic_batch, make_zipf_typed_batch
 
     if wl.get("sharded"):
-        feats, adjs, n2g, _ = make_qm9_shaped_batch(wl["num_graphs"], seed=1, feature_dim=wl["feature_dim"])  # same on every rank
+        feats, adjs, n2g, _ = make_qm9_shaped_batch(wl["num_graphs"], seed=1 + 1000 * variant, feature_dim=wl["feature_dim"])  # same on every rank
         G = wl["num_graphs"]
         if world > 1:
             feats, adjs, n2g, G, _, _ = parallel.shard_batch(feats, adjs, n2g, G, world, rank)
         return dict(feats=feats, adjs=adjs, n2g=np.ascontiguousarray(n2g, dtype=np.int32), num_graphs=G)
     if wl["model"] == "rgin":
-        feats, adjs = make_zipf_typed_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank)
+        feats, adjs = make_zipf_typed_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank + 1000 * variant)
     else:  # timing seeds 1.. (SURVEY 8d)
-        feats, adjs = make_synthetic_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank)
+        feats, adjs = make_synthetic_batch(wl["num_nodes"], wl["num_edges"], wl["num_edge_types"], wl["feature_dim"], seed=1 + rank + 1000 * variant)
     return dict(feats=feats, adjs=adjs, n2g=np.zeros(feats.shape[0], dtype=np.int32), num_graphs=1)
 
 
@@ -478,6 +479,9 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="N > 1: add the training-step exchange (one bucketed RCCL all-reduce of the weight gradients) to every "
                          "step; off by default - the fwd+bwd metric itself has no collective")
+    ap.add_argument("--distinct-batches", type=int, default=1,
+                    help="cycle K different batches of the workload's shape through the steps (default 1: the same batch every step, "
+                         "whose source rows are then warm in the Infinity Cache - the optimistic case)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle loop (launch-path tests)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short timings of the other BASELINE workloads that the default run reports under `other_configs`")
@@ -570,23 +574,39 @@ def main():
     # never touches what step i reads.
     f16_features = args.gemm_mode == "f16x2" and D % 16 == 0 and D >= 32
     feats_dev = [X, X.clone()] if (f16_features and graph is None and not args.serial_bucketing) else [X]
+    adjs_dev = [adj_dev]
+    K_batches = max(1, int(args.distinct_batches))
+    if K_batches > 1:
+        # --distinct-batches K: K draws of the workload's shape (same V, E, L; other seeds) take turns, so a step's source rows,
+        # edge lists and saved tensors are NOT the ones the previous step left in the 256 MB Infinity Cache
+        if graph is not None or sharded:
+            print("--distinct-batches needs per-step bucketing of an unsharded workload", file=sys.stderr)
+            sys.exit(2)
+        feats_dev, adjs_dev = [X], [adj_dev]
+        for k in range(1, K_batches):
+            bk = build_batch(wl, rank, world, variant=k)
+            assert bk["feats"].shape == feats.shape and sum(a.shape[0] for a in bk["adjs"]) == E
+            feats_dev.append(torch.from_numpy(bk["feats"]).to(dev))
+            adjs_dev.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in bk["adjs"]))
     prepared = [0]
 
     def prepare_batch():
         """-> (Graph, features): bucket the edges and (f16x2) split the node features for the first product"""
         x = feats_dev[prepared[0] % len(feats_dev)]
+        adj = adjs_dev[prepared[0] % len(adjs_dev)]
+        ept = edges_per_type if len(adjs_dev) == 1 else [int(a.shape[0]) for a in adj]
         prepared[0] += 1
         if side is None:
             if f16_features:
                 ops.split_rows_remembered(x)
-            return ops.Graph(adj_dev, V, parts=gnn.graph_parts(V, edges_per_type)), x
+            return ops.Graph(adj, V, parts=gnn.graph_parts(V, ept)), x
         # the preparation may start once the steps enqueued so far are done (the step before last used this copy of the
         # features); it then runs under the step that is enqueued next
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if f16_features:
                 ops.split_rows_remembered(x)
-            return ops.Graph(adj_dev, V, wait=False, parts=gnn.graph_parts(V, edges_per_type)), x  # only the tables this stack reads
+            return ops.Graph(adj, V, wait=False, parts=gnn.graph_parts(V, ept)), x  # only the tables this stack reads
 
     allreduce_events = []
 
@@ -717,6 +737,9 @@ def main():
             f"step = edge bucketing{bucketing} + forward (training mode) + full backward",
             "per_layer_traversal_rate_edges_per_s": value * NL,
             "gemm_mode": GEMM_MODE_NOTES[args.gemm_mode],
+            "batches": (f"{K_batches} distinct batches of this shape take turns (--distinct-batches)" if K_batches > 1 else
+                        "the same batch every step (re-bucketed per step; its rows stay warm in the Infinity Cache: the optimistic "
+                        "case - see --distinct-batches)"),
             "collectives_per_step": ("1 bucketed all-reduce of the weight gradients (--allreduce-grads)"
                                      if (args.allreduce_grads and world > 1) else "none (graph-sharded batches / replicas)"),
             "edges_per_rank": gathered[:, 0].tolist(),
@@ -779,7 +802,7 @@ def other_configs(args):
     out = {}
     for name, steps in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "1", "--no-alt-mode",
-               "--no-other-configs", "--gemm-mode", args.gemm_mode, "--cpu-baseline-seconds", "8"]
+               "--no-other-configs", "--gemm-mode", args.gemm_mode, "--cpu-baseline-seconds", "10"]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         if args.no_roofline:
@@ -813,7 +836,7 @@ def other_configs(args):
                                        "top": [{k: e[k] for k in ("op", "shapes", "launches_per_step", "ms_per_launch", "share_of_step", "bound", "frac")}
                                                for e in sb["top"][:8]]}
         if "cpu_baseline" in r:
-            entry["cpu_baseline"] = {k: r["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+            entry["cpu_baseline"] = {k: r["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "host_cpu_count", "kind", "sample")}
         out[name] = entry
     return out
 
@@ -821,7 +844,7 @@ def other_configs(args):
 # --------------------------------------------------------------------------------------------------------------------
 # step breakdown: every library op of ONE real step between HIP events (launch stream), aggregated by (op, shapes)
 # --------------------------------------------------------------------------------------------------------------------
-_TIMED_OPS = ("gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
+_TIMED_OPS = ("graph_gather_dot", "aux_flush", "dropout_mask", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
               "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
               "activation_backward", "dropout_forward", "mul", "add_scale", "colsum", "layernorm_forward", "layernorm_backward",
               "permute_021", "transpose_batched", "edge_aggregate_backward", "sp_split_rows", "sp_split_cols", "clip", "clip_backward")
@@ -900,6 +923,30 @@ def step_breakdown(step, ops, steps=2, top=12):
         if hasattr(ops, name):
             real[name] = getattr(ops, name)
             setattr(ops, name, wrap(name, real[name]))
+
+    class Scope:  # regions the layers mark with ops.op_scope (library calls that bypass the wrappers: RGAT's attention kernels)
+        def __init__(self, name, tensors):
+            self.name, self.tensors, self.e0 = name, tensors, None
+
+        def __enter__(self):
+            if depth[0] == 0:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            depth[0] += 1
+            return self
+
+        def __exit__(self, *exc):
+            depth[0] -= 1
+            if self.e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                ts = [t for t in self.tensors if isinstance(t, torch.Tensor)]
+                shapes = ["x".join(map(str, t.shape)) for t in ts if t.numel() * t.element_size() >= 1 << 16]
+                records.append((self.name, " ".join(shapes[:4]), self.e0, e1, sum(t.numel() * t.element_size() for t in ts), 0.0))
+            return False
+
+    real["op_scope"] = ops.op_scope
+    ops.op_scope = lambda name, *tensors: Scope(name, tensors)
     try:
         step()
         torch.cuda.synchronize()

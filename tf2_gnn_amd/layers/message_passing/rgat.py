@@ -103,11 +103,12 @@ class RGAT(MessagePassing):
             Y = ops.gemm(X, self._kernels)  # [V, L*H] == rows (v, l) of width H
         s_src = torch.empty((V * L, K), dtype=torch.float32, device=dev)
         s_tgt = torch.empty((V * L, K), dtype=torch.float32, device=dev)
-        _lib.check(
-            lib.tfgnn_rgat_node_scores(
-                ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
+        with ops.op_scope("rgat_node_scores", Y, s_src, s_tgt):
+            _lib.check(
+                lib.tfgnn_rgat_node_scores(
+                    ops._ptr(Y), ops._ptr(self._attn), V, L, K, H, ops._ptr(s_src), ops._ptr(s_tgt), ops._stream()
+                )
             )
-        )
         att, att_by_src = self._edge_attention(g, s_src, s_tgt, K, training)
         act = self._activation_name
         fused = None if act == "gelu" else act
@@ -157,8 +158,9 @@ class RGAT(MessagePassing):
         g.ensure(ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_MAPS)
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
-        rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(att_by_src),
-                                              ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
+        with ops.op_scope("rgat_attention_forward", s_src, s_tgt, att, att_by_src):
+            rc = lib.tfgnn_rgat_attention_forward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), K, ops._ptr(att), ops._ptr(att_by_src),
+                                                  ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
         if rc == 0:
             return att, att_by_src
         if rc != -4:
@@ -246,8 +248,9 @@ class RGAT(MessagePassing):
         g.ensure(ops.G_PART_PLAN_NODE | ops.G_PART_EDGE_MAPS)
         ws_bytes = lib.tfgnn_rgat_attention_workspace_bytes(g._h, K)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
-        rc = lib.tfgnn_rgat_attention_backward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), K, ops._ptr(dz),
-                                               ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
+        with ops.op_scope("rgat_attention_backward", s_src, s_tgt, att, da, dz):
+            rc = lib.tfgnn_rgat_attention_backward(g._h, ops._ptr(s_src), ops._ptr(s_tgt), ops._ptr(att), ops._ptr(da), K, ops._ptr(dz),
+                                                   ops._ptr(ws), ws.numel() if ws is not None else 0, ops._stream())
         if rc == -4:  # head count not a power of two: the piecewise form
             t = ops.graph_gather(g, ops.VIEW_BY_DST_NODE, ops.mul(att, da), col=ident_e[:E])  # [V, K] sum of a * da
             _lib.check(
@@ -268,10 +271,11 @@ class RGAT(MessagePassing):
         d_attn = torch.empty_like(self._attn)
         ws_bytes = lib.tfgnn_rgat_alpha_grad_workspace_bytes(V, L, H)
         ws = ops._workspace(dev, ws_bytes) if ws_bytes else None
-        _lib.check(
-            lib.tfgnn_rgat_alpha_grad(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(Y), V, L, K, H, ops._ptr(d_attn), ops._ptr(ws),
-                                      ws.numel() if ws is not None else 0, ops._stream())
-        )
+        with ops.op_scope("rgat_alpha_grad", ds_src, ds_tgt, Y):
+            _lib.check(
+                lib.tfgnn_rgat_alpha_grad(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(Y), V, L, K, H, ops._ptr(d_attn), ops._ptr(ws),
+                                          ws.numel() if ws is not None else 0, ops._stream())
+            )
         d_kernels = dX = None
         if ctx.get("f16x2") and ops.get_gemm_mode() == ops.GEMM_F16X2:
             # the score terms are added while dY is ALSO written as the split operand of dX = dY W^T.  The weight gradient stays
@@ -279,8 +283,9 @@ class RGAT(MessagePassing):
             # split-operand TN product (measured: it trips on the first step of the rgat workload)
             dY_sp = ops.SplitOperand(torch.empty((V, L * H * 4), dtype=torch.uint8, device=dev),
                                      torch.empty((V, 1), dtype=torch.float32, device=dev), V, L * H, L * H)
-            rc = lib.tfgnn_rgat_scores_backward_sp(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), ops._ptr(dY), 1, V, L, K, H,
-                                                   ops._ptr(dY_sp.data), ops._ptr(dY_sp.inv_scale), ops._stream())
+            with ops.op_scope("rgat_scores_backward", ds_src, ds_tgt, dY, dY_sp.data):
+                rc = lib.tfgnn_rgat_scores_backward_sp(ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), ops._ptr(dY), 1, V, L, K, H,
+                                                       ops._ptr(dY_sp.data), ops._ptr(dY_sp.inv_scale), ops._stream())
             if rc == 0:
                 d_kernels = ops.gemm(X, dY.view(V, L * H), trans_a=True)  # X^T dY  [D, L*H]
                 Wr = ops.sp_weight_operand(self._kernels, "rows", lambda: ops.sp_split_rows(self._kernels, defer=True))
@@ -292,11 +297,12 @@ class RGAT(MessagePassing):
             elif rc != -4:
                 _lib.check(rc)
         if dX is None:
-            _lib.check(
-                lib.tfgnn_rgat_scores_backward(
-                    ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
+            with ops.op_scope("rgat_scores_backward", ds_src, ds_tgt, dY):
+                _lib.check(
+                    lib.tfgnn_rgat_scores_backward(
+                        ops._ptr(ds_src), ops._ptr(ds_tgt), ops._ptr(self._attn), V, L, K, H, ops._ptr(dY), ops._stream()
+                    )
                 )
-            )
             # (5) Y = X @ W
             dYv = dY.view(V, L * H)
             d_kernels = ops.gemm(X, dYv, trans_a=True)  # [D, L*H]

@@ -40,6 +40,26 @@ def act_id(name_or_id) -> int:
         raise ValueError(f"Unknown activation function: {name_or_id}")
 
 
+class _NullScope:
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_SCOPE = _NullScope()
+
+
+def op_scope(name: str, *tensors):
+    """Marks a group of library launches that is not a wrapper of this module (the attention kernels of the RGAT layer call
+    the C ABI directly): ``with ops.op_scope("rgat_attention_forward", s_src, att): ...``.  Does nothing; a profiler replaces
+    this function with one that brackets the region with events (bench.py step_breakdown), like it wraps the wrappers."""
+    return _NULL_SCOPE
+
+
 def _raw_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
