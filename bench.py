@@ -844,11 +844,11 @@ def other_configs(args):
 # --------------------------------------------------------------------------------------------------------------------
 # step breakdown: every library op of ONE real step between HIP events (launch stream), aggregated by (op, shapes)
 # --------------------------------------------------------------------------------------------------------------------
-_TIMED_OPS = ("graph_gather_dot", "aux_flush", "dropout_mask", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
+_TIMED_OPS = ("graph_gather_dot", "aux_flush", "dropout_mask", "sp_gemm_nt_grouped", "sp_gather_rows", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
               "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
               "activation_backward", "dropout_forward", "mul", "add_scale", "colsum", "layernorm_forward", "layernorm_backward",
               "permute_021", "transpose_batched", "edge_aggregate_backward", "sp_split_rows", "sp_split_cols", "clip", "clip_backward")
-_PRODUCT_OPS = {"gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
+_PRODUCT_OPS = {"sp_gemm_nt_grouped", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
 
 
 def step_breakdown(step, ops, steps=2, top=12):
@@ -899,7 +899,9 @@ def step_breakdown(step, ops, steps=2, top=12):
             flops = 0.0
             if name in _PRODUCT_OPS:
                 big = sorted((t for t in ts if t.dim() >= 2), key=lambda t: -t.numel())[:3]
-                if name in ("sp_gemm_nt", "sp_gemm_nt_split") and isinstance(a[0], ops.SplitOperand):
+                if name == "sp_gemm_nt_grouped":
+                    flops = 2.0 * a[2].num_rows * a[0].cols * (a[1].rows // max(a[2].num_groups, 1))
+                elif name in ("sp_gemm_nt", "sp_gemm_nt_split") and isinstance(a[0], ops.SplitOperand):
                     flops = 2.0 * a[0].rows * a[0].cols * a[1].rows
                 elif name == "sp_gemm_tn" and isinstance(a[0], ops.SplitOperand):
                     M = (k.get("a_cols") or (0, a[0].cols))[1]

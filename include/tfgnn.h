@@ -679,6 +679,30 @@ int tfgnn_sp_gemm_nt_rows(int64_t M, int64_t N, int64_t K, const void* d_A_sp, i
                           int64_t ld_out_sp_bytes, float* d_out_inv_scale, float dropout_rate, uint64_t dropout_seed,
                           const uint8_t* d_tile_kmask, const int32_t* d_row_map, void* stream);
 
+/* Grouped rows (round 5; BASELINE configs[4]: the per-relation MLPs of RGIN / GNN_Edge_MLP over the non-empty (source, type)
+ * rows, rgin.py:77-106, gnn_edge_mlp.py:84-107): the M product rows fall into num_groups consecutive groups, group g multiplies
+ * ITS OWN [N, K] weight operand: group g's starts b_group_stride_bytes behind group g-1's, its column scales / bias
+ * b_scale_group_stride elements behind (stacked operands: N * ldb_bytes and N; column blocks of ONE operand [N, G * K] - what
+ * tfgnn_sp_split_cols makes of G stacked Keras kernels [G * K, N], one scale per row shared by the groups: 4 * K and 0).
+ * d_tile_table: int32 [num_tiles][4] = {first row, rows (1..128), group, 0} - every row tile lies inside one group (the host
+ * cuts each group into tiles of 128 rows; a binder builds it from the group offsets).  d_a_rows / a_src_rows as in
+ * tfgnn_sp_gemm_nt_rows, with the source operand having a_src_rows rows (the first MLP layer reads the node states through the
+ * row -> node index: no expanded copy of them is made).  The split-form result (d_out_sp) carries one scale per row and column
+ * tile: N = 512 gives scale blocks of 256 columns - what the next grouped product takes as a_scale_block = 256.
+ * 3 piece products per fp32 product where the bf16x3 grouped kernels (tfgnn_gemm_grouped_rows) spend 6. */
+int tfgnn_sp_gemm_nt_grouped(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int a_scale_block, const int32_t* d_a_rows, int64_t a_src_rows, const int32_t* d_tile_table,
+                             int64_t num_tiles, int num_groups, const void* d_B_sp, int64_t ldb_bytes, int64_t b_group_stride_bytes,
+                             const float* d_b_inv_scale, int64_t b_scale_group_stride, float* d_C, int64_t ldc, const float* d_bias,
+                             int act, const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved, int64_t ld_saved,
+                             void* d_out_sp, int64_t ld_out_sp_bytes, float* d_out_inv_scale, void* stream);
+/* dst row r = src row d_index[r] of an SP16 operand, with its scales_per_row scales (an index outside [0, src_rows) gives a
+ * zero row).  The expanded operand of the grouped weight-gradient products: the K dimension of tfgnn_sp_gemm_tn cannot be
+ * read through an index. */
+int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, const float* d_src_inv_scale, int scales_per_row,
+                         const int32_t* d_index, int64_t rows, int64_t src_rows, int64_t cols, void* d_dst_sp, int64_t ld_dst_bytes,
+                         float* d_dst_inv_scale, void* stream);
+
 /* K split INSIDE the launch of the NT product, for few row tiles (round 5; BASELINE configs[0]: a PPI batch of 7 110 nodes is 56
  * row tiles - 56 workgroups each streaming the whole weight operand while 200 CUs idle, and the product takes as long as at
  * 30 000 nodes).  With a workspace registered here, products of at most 112 output tiles and K >= 480 launch S = 2..4

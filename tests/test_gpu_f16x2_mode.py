@@ -376,3 +376,40 @@ def test_gnn_stack_gradients_are_linear_in_the_loss_gradient_magnitude(dev, mp_s
         for name, g1, gs in zip(["d node_features"] + [v.name for v in gnn.trainable_variables], base, grads(scale)):
             top = float(g1.abs().max())
             assert float((gs - g1).abs().max()) <= 1e-5 * top, (mp_style, scale, name, float((gs - g1).abs().max()) / top)
+
+
+@pytest.mark.parametrize("H,over", [(128, {}), (256, {"num_edge_MLP_hidden_layers": 2}), (128, {"message_activation_function": "tanh",
+                                                                                             "aggregation_function": "mean"})],
+                         ids=["h128", "h256_two_hidden", "h128_tanh_mean"])
+def test_rgin_compact_rows_on_grouped_split_operand_products(dev, monkeypatch, H, over):
+    """Round 5 (BASELINE configs[4]): where most (source, type) pairs have no edge, RGIN's per-relation MLPs run over the non-empty
+    rows as grouped products on split operands - tfgnn_sp_gemm_nt_grouped forward and input gradients (first layer through the
+    row -> node index, hidden layers writing the next operand), one split-operand TN product per relation for the kernel
+    gradients - where the bf16x3 grouped kernels ran before.  Forward, dX and every kernel gradient against fp64 autograd through
+    the oracle; ragged relation sizes (a hub among the targets).  Then the same with the kernel gradients demoted to the exact
+    grouped kernel, as the stack's guard policy does for un-normalised sums spread over more than 2^20."""
+    from tests.helpers import KernelsUsed
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers.message_passing import RGIN
+
+    import numpy as np
+
+    L, V = 8, 400
+    # few distinct sources (most (source, type) pairs have no edge: the compact-row path), every node a target of ~10 edges (a node
+    # without incoming edges would sit exactly at the kink of the output activation); ragged relation sizes
+    rng = np.random.default_rng(5)
+    hubs = rng.choice(V, size=70, replace=False)
+    adjs = []
+    for l in range(L):
+        e = 900 if l < 2 else (40 if l == 5 else 350)
+        adjs.append(np.stack([rng.choice(hubs[: 70 if l % 2 else 25], size=e), rng.integers(0, V, size=e)], axis=1).astype(np.int32))
+    monkeypatch.setattr(RGIN, "GROUPED_SPLIT_MIN_ROWS", 64)
+    with KernelsUsed() as k:
+        check_layer_backward(dev, f"rgin_grouped_split_h{H}", "RGIN", over, V=V, E=0, L=L, H=H, adjs=adjs)
+    layers = 2 + (1 if over.get("num_edge_MLP_hidden_layers") == 2 else 0)
+    assert k.delta["sp_nt"] >= 2 * layers and k.delta["sp_tn"] >= layers * L, k.delta
+    assert ops.get_gemm_mode() == ops.GEMM_F16X2 and not ops.f16x2_guard_tripped_sync()
+    monkeypatch.setattr(RGIN, "_grouped_tn_split_ok", False, raising=False)
+    with KernelsUsed() as k:
+        check_layer_backward(dev, f"rgin_grouped_split_exact_tn_h{H}", "RGIN", over, V=V, E=0, L=L, H=H, adjs=adjs)
+    assert k.delta["sp_nt"] >= 2 * layers and k.delta["sp_tn"] == 0 and k.delta["gemm_bf16x3"] >= layers, k.delta

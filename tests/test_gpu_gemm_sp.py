@@ -328,13 +328,91 @@ def test_gemm_nt_split_result_equals_a_split_pass_over_the_fp32_result(dev, M, N
     assert np.array_equal(decode_sp16(op), decode_sp16(ref))
 
 
-def test_gemm_nt_split_result_needs_a_single_column_tile(dev):
+def test_gemm_nt_split_result_over_several_column_tiles_carries_one_scale_per_tile(dev):
+    """Round 5: N = 512 = two column tiles of 256 - the split form of the result has scale blocks of 256 columns and equals a
+    split pass over the fp32 result with that block size; it feeds the next product as an operand with per-block scales."""
     from tf2_gnn_amd import ops
 
-    a_op = ops.sp_split_rows(torch.randn((64, 64), device=dev))
-    b_op = ops.sp_split_rows(torch.randn((640, 64), device=dev))
-    with pytest.raises(ValueError, match="split result needs N"):
-        ops.sp_gemm_nt_split(a_op, b_op)
+    gen = torch.Generator().manual_seed(4)
+    A = torch.randn((700, 512), generator=gen).to(dev)
+    W = (torch.randn((512, 512), generator=gen) * 0.05).to(dev)
+    out, op = ops.sp_gemm_nt_split(ops.sp_split_rows(A), ops.sp_split_rows(W), act="relu")
+    assert op.scale_block == 256 and tuple(op.inv_scale.shape) == (700, 2)
+    ref = ops.sp_split_rows(out, scale_block=256)
+    assert torch.equal(op.data, ref.data) and torch.equal(op.inv_scale, ref.inv_scale)
+    nxt = ops.sp_gemm_nt(op, ops.sp_split_rows(W))
+    exact = torch.relu(A.double() @ W.double().t()) @ W.double().t()
+    assert float((nxt.double() - exact).abs().max()) <= 1e-5 * max(1.0, float(exact.abs().max()))
+
+
+@pytest.mark.parametrize("sizes", [[300, 5, 128, 0, 1000, 129], [4000], [1, 1, 1]])
+@pytest.mark.parametrize("H", [512, 128])
+def test_grouped_products_on_split_operands(dev, sizes, H):
+    """tfgnn_sp_gemm_nt_grouped (configs[4]: the per-relation MLP of RGIN over the non-empty (source, type) rows): every group
+    multiplies its own weight operand; rows read through a row -> node index; relu + split-form output of the hidden layer,
+    the second layer on that operand, the input-gradient product with relu' of the saved hidden activations - against fp64,
+    and the grouped form equals the per-group calls of the plain product bit for bit."""
+    from tf2_gnn_amd import ops
+
+    G = len(sizes)
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    R, V = off[-1], 900
+    gen = torch.Generator().manual_seed(R + H)
+    X = torch.randn((V, H), generator=gen)
+    node = torch.randint(0, V, (R,), generator=gen).int()
+    W1 = torch.randn((G, H, H), generator=gen) * 0.06
+    W2 = torch.randn((G, H, H), generator=gen) * 0.06
+    groups = ops.RowGroups(off, dev)
+    assert groups.num_tiles == sum((n + 127) // 128 for n in sizes)
+    x_sp = ops.sp_split_rows(X.to(dev))
+    w1t = ops.sp_split_rows(W1.transpose(1, 2).contiguous().view(G * H, H).to(dev))  # group g: W1_g^T [out, in]
+    w2t = ops.sp_split_rows(W2.transpose(1, 2).contiguous().view(G * H, H).to(dev))
+    hid32, hid_sp = ops.sp_gemm_nt_grouped(x_sp, w1t, groups, a_rows=node.to(dev), act="relu", want_split=True)
+    # the weight operand as column blocks of ONE transposed split of the stacked kernels (one launch; scales shared by groups)
+    w1c = ops.sp_split_cols(W1.contiguous().view(G * H, H).to(dev))
+    hid32_c, _ = ops.sp_gemm_nt_grouped(x_sp, w1c, groups, a_rows=node.to(dev), act="relu", b_column_blocks=True)
+    y32, _ = ops.sp_gemm_nt_grouped(hid_sp, w2t, groups)
+    Xc = X.double()[node.long()]
+    hid_ref = torch.cat([torch.relu(Xc[off[g]:off[g + 1]] @ W1[g].double()) for g in range(G)])
+    y_ref = torch.cat([hid_ref[off[g]:off[g + 1]] @ W2[g].double() for g in range(G)])
+    assert_close(hid32.cpu(), hid_ref.float(), tol=1e-5, what="grouped sp nt hidden")
+    assert_close(hid32_c.cpu(), hid_ref.float(), tol=1e-5, what="grouped sp nt hidden (column-block weights)")
+    assert_close(y32.cpu(), y_ref.float(), tol=2e-5, what="grouped sp nt output")
+    bn = ops.sp_tile_width(H)
+    ref_sp = ops.sp_split_rows(hid32, scale_block=bn)
+    assert torch.equal(hid_sp.data, ref_sp.data) and torch.equal(hid_sp.inv_scale, ref_sp.inv_scale)
+    # input gradient of the second layer with relu'(hidden): dH = (dY @ W2_g^T) * (hidden > 0), split form only
+    dY = torch.randn((R, H), generator=gen)
+    w2r = ops.sp_split_rows(W2.contiguous().view(G * H, H).to(dev))  # group g: W2_g [in, out] = the [N = in, K = out] operand
+    _, dh_sp_only = ops.sp_gemm_nt_grouped(ops.sp_split_rows(dY.to(dev)), w2r, groups, act_grad=("relu", hid32), want_fp32=False,
+                                           want_split=True)
+    dh32, dh_sp = ops.sp_gemm_nt_grouped(ops.sp_split_rows(dY.to(dev)), w2r, groups, act_grad=("relu", hid32), want_split=True)
+    assert torch.equal(dh_sp_only.data, dh_sp.data) and torch.equal(dh_sp_only.inv_scale, dh_sp.inv_scale)
+    dh_ref = torch.cat([(dY.double()[off[g]:off[g + 1]] @ W2[g].double().t()) for g in range(G)]) * (hid_ref > 0)
+    flips = (hid32.cpu() > 0) != (hid_ref > 0)  # (units at the relu kink may decide differently in fp32)
+    err = ((dh32.cpu().double() - dh_ref).abs() / dh_ref.abs().clamp(min=1.0))[~flips]
+    assert float(err.max()) <= 1e-5 if err.numel() else True
+    ref_sp = ops.sp_split_rows(dh32, scale_block=bn)
+    # (relu' makes exact zeros with either sign - (negative) x 0 - and the two kernels round the low piece of a -0 to different
+    # zeros: compare the fp16 VALUES)
+    assert torch.equal(dh_sp.data.view(torch.float16).float(), ref_sp.data.view(torch.float16).float())
+    assert torch.equal(dh_sp.inv_scale, ref_sp.inv_scale)
+    # group by group with the plain product: the same bits
+    xc_sp = ops.sp_gather_rows(x_sp, node.to(dev))
+    assert torch.equal(xc_sp.data, x_sp.data[node.long().to(dev)]) and torch.equal(xc_sp.inv_scale, x_sp.inv_scale[node.long().to(dev)])
+    for g in range(G):
+        if sizes[g] == 0:
+            continue
+        sl = slice(off[g], off[g + 1])
+        part = ops.SplitOperand(xc_sp.data[sl], xc_sp.inv_scale[sl], sizes[g], H, xc_sp.scale_block)
+        wg = ops.SplitOperand(w1t.data[g * H:(g + 1) * H], w1t.inv_scale[g * H:(g + 1) * H], H, H, H)
+        try:
+            ops.sp_gemm_nt_splitk(False)  # (a stand-alone product of few tiles would split K in its launch)
+            assert torch.equal(ops.sp_gemm_nt(part, wg, act="relu"), hid32[sl])
+        finally:
+            ops.sp_gemm_nt_splitk(True)
 
 
 @pytest.mark.parametrize("K,M,N", [(3000, 320, 320), (777, 64, 128), (2000, 336, 256), (30000, 320, 320), (29999, 128, 128)])

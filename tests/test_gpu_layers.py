@@ -204,13 +204,14 @@ def test_layer_backward_parity(dev, name, cls_name, over):
     check_layer_backward(dev, name, cls_name, over, V=120, E=1500, L=3, H=32)
 
 
-def check_layer_backward(dev, name, cls_name, over, V, E, L, H, dout_scale=1.0):
+def check_layer_backward(dev, name, cls_name, over, V, E, L, H, dout_scale=1.0, adjs=None):
     """dout_scale: the HIP backward pass gets dOut * dout_scale (a real loss gradient is 1e-9, not N(0,1))
     and its gradients are scaled back before the comparison - the reference gradients are linear in dOut, so every bound
     stays relative to the gradient's OWN magnitude."""
     from tf2_gnn_amd.layers import MessagePassingInput
 
-    adjs = random_graph(V, E, L, seed=4, hub=(2, min(150, V // 2)))
+    if adjs is None:
+        adjs = random_graph(V, E, L, seed=4, hub=(2, min(150, V // 2)))
     adj_t = [torch.from_numpy(a) for a in adjs]
     layer, p = _build(cls_name, dict(over, hidden_dim=H), H, L)
     w32 = mp_weights_from_layer(layer)

@@ -292,6 +292,15 @@ _SIGNATURES = [
          ctypes.c_uint64, c_void_p, c_void_p, c_void_p],
     ),
     (
+        "tfgnn_sp_gemm_nt_grouped",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
+         c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
+         c_void_p, c_void_p],
+    ),
+    ("tfgnn_sp_gather_rows", c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                     c_void_p, c_void_p]),
+    (
         "tfgnn_sp_gemm_nt_rows",
         c_int,
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,

@@ -607,6 +607,49 @@ extern "C" int tfgnn_add_scale(const float* d_x, const float* d_y, float alpha, 
   return TFGNN_OK;
 }
 
+// ---- rows of an SP16 operand through an index (round 5): dst row r = src row index[r], with its scales.  The expanded operand
+// of the per-relation weight-gradient products (the K dimension of a TN product cannot be read through an index: its rows
+// change every k step).  16 bytes per lane, a row of `row_bytes` (multiple of 64) by row_bytes / 16 consecutive lanes.
+namespace tfgnn {
+__global__ void __launch_bounds__(256) sp_gather_rows_kernel(const uint8_t* __restrict__ src, int64_t ld_src, const float* __restrict__ src_inv,
+                                                             int inv_per_row, const int32_t* __restrict__ index, int64_t rows,
+                                                             int64_t src_rows, int row_bytes, uint8_t* __restrict__ dst, int64_t ld_dst,
+                                                             float* __restrict__ dst_inv) {
+  const int lanes_per_row = row_bytes >> 4;
+  const int64_t total = rows * lanes_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / lanes_per_row;
+    const int c = (int)(i - r * lanes_per_row);
+    const int64_t sr = index[r];
+    const bool ok = sr >= 0 && sr < src_rows;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (ok) v = *reinterpret_cast<const uint4*>(src + sr * ld_src + (int64_t)c * 16);
+    *reinterpret_cast<uint4*>(dst + r * ld_dst + (int64_t)c * 16) = v;
+    if (c < inv_per_row) dst_inv[r * inv_per_row + c] = ok ? src_inv[sr * inv_per_row + c] : 1.1754943508222875e-38f;
+  }
+}
+}  // namespace tfgnn
+
+extern "C" int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, const float* d_src_inv_scale, int scales_per_row,
+                                    const int32_t* d_index, int64_t rows, int64_t src_rows, int64_t cols, void* d_dst_sp,
+                                    int64_t ld_dst_bytes, float* d_dst_inv_scale, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(rows >= 0 && src_rows >= 0 && cols > 0 && cols % 16 == 0 && scales_per_row >= 1 && scales_per_row <= cols / 16,
+                "tfgnn_sp_gather_rows: cols must be a positive multiple of 16");
+  if (rows == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_src_sp && d_src_inv_scale && d_index && d_dst_sp && d_dst_inv_scale, "NULL pointer");
+  TFGNN_REQUIRE(ld_src_bytes >= cols * 4 && ld_dst_bytes >= cols * 4 && ld_src_bytes % 16 == 0 && ld_dst_bytes % 16 == 0 &&
+                    (uintptr_t)d_src_sp % 16 == 0 && (uintptr_t)d_dst_sp % 16 == 0,
+                "tfgnn_sp_gather_rows: SP16 rows must be 16-byte aligned");
+  const int64_t total = rows * (cols / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 64);
+  hipLaunchKernelGGL(sp_gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_src_sp, ld_src_bytes,
+                     d_src_inv_scale, scales_per_row, d_index, rows, src_rows, (int)(cols * 4), (uint8_t*)d_dst_sp, ld_dst_bytes,
+                     d_dst_inv_scale);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
+}
+
 // ---- the dropout epoch (common.hpp DropoutKey): one word of device memory, bumped by a kernel so that the bump can be a
 // node of a captured hipGraph ----
 namespace tfgnn {

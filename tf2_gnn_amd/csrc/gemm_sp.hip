@@ -97,6 +97,13 @@ struct SpArgs {
   // by-source sums stay in node order for the weight-gradient product while the input-gradient product walks them in the
   // order of the by-source emptiness patterns (tile_kmask of THAT order) and writes node order again through row_map
   const int32_t* a_rows;
+  int64_t a_src_rows;  // rows of the operand a_rows points into (its descriptor spans them); = M without a_rows
+  // grouped rows (round 5; the per-relation products of RGIN / GNN_Edge_MLP over the non-empty (source, type) rows, grouped by
+  // type): tile_table[tile] = {first row, rows (<= 128), group, -}; group gr multiplies B + gr * group_stride_b (its own
+  // [N, K] weight operand) with column scales / bias at offset gr * N.  A row tile never straddles two groups.
+  const int32_t* tile_table;
+  int64_t group_stride_b;      // bytes between the weight operands of consecutive groups
+  int64_t group_stride_scale;  // elements between their column scales / biases (0: shared)
   // K split inside the launch (round 5, few row tiles: a batch of some thousand nodes leaves most CUs idle while 56
   // workgroups each stream the whole weight operand).  ksplit = S > 1: the grid holds S workgroups per output tile, each
   // multiplies 1/S of the tile's k16 steps; splits 1 .. S-1 publish their raw accumulators (write-through stores into
@@ -401,7 +408,14 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   }
   const unsigned tile_n = bid % g.n_tiles;
   const unsigned tile_m = bid / g.n_tiles;
-  const int64_t row0 = (int64_t)tile_m * SP_BM;
+  int64_t row0 = (int64_t)tile_m * SP_BM, m_end = g.M;  // this tile's rows: [row0, min(row0 + 128, m_end))
+  int64_t grp = 0;
+  if (g.tile_table) {
+    const int32_t* e = g.tile_table + 4 * (int64_t)tile_m;
+    row0 = __builtin_amdgcn_readfirstlane(e[0]);
+    m_end = row0 + __builtin_amdgcn_readfirstlane(e[1]);
+    grp = __builtin_amdgcn_readfirstlane(e[2]);
+  }
   const int64_t col0 = (int64_t)tile_n * G::BN;
   int nsteps = (int)(g.K >> 4);
   unsigned blkmap = 0, bsteps = 0;
@@ -449,7 +463,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
   }
 
   // ---- DMA setup: buffer descriptors over this tile's rows (rows past M / N read as zeros) -------------------
-  const int64_t rows_a = g.M - row0 < SP_BM ? g.M - row0 : SP_BM;
+  const int64_t rows_a = m_end - row0 < SP_BM ? m_end - row0 : SP_BM;
   const int64_t rows_b = g.N - col0 < G::BN ? g.N - col0 : G::BN;
   // raw buffer descriptors: {base[31:0], base[47:32] (stride 0), bytes, 0x00020000}
   auto make_rsrc = [](const uint8_t* p, int64_t bytes) {
@@ -459,8 +473,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
                   (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
   };
   // (a_rows: the descriptor spans the whole operand - its rows come from anywhere; host: M * lda < 2^32)
-  const uint4v rs_a = g.a_rows ? make_rsrc(g.A, g.M * g.lda) : make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
-  const uint4v rs_b = make_rsrc(g.B + col0 * g.ldb, rows_b * g.ldb);
+  const uint4v rs_a = g.a_rows ? make_rsrc(g.A, g.a_src_rows * g.lda) : make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
+  const uint4v rs_b = make_rsrc(g.B + grp * g.group_stride_b + col0 * g.ldb, rows_b * g.ldb);
   half8 r_fa[2][2][2];
   half8 r_fb[2][TNW][2];
   floatx16 r_acc[2][TNW];
@@ -485,7 +499,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
     const int tr = (wave * G::ND_A + i) * 16 + drow;  // row of the tile this lane fetches
     if (g.a_rows) {  // rows past M: an offset outside the descriptor reads zeros
       const int64_t pr = row0 + tr;
-      L.voff_a[i] = pr < g.M ? (unsigned)((int64_t)g.a_rows[pr] * g.lda + dq * 16) : 0xfffffff0u;
+      L.voff_a[i] = pr < m_end ? (unsigned)((int64_t)g.a_rows[pr] * g.lda + dq * 16) : 0xfffffff0u;
     } else {
       L.voff_a[i] = (unsigned)(tr * g.lda + dq * 16);
     }
@@ -515,7 +529,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     int64_t r = row0 + wm * 64 + t * 32 + fi;
-    L.a_row[t] = r < g.M ? r : g.M - 1;
+    L.a_row[t] = r < m_end ? r : m_end - 1;
     if (g.a_rows) L.a_row[t] = g.a_rows[L.a_row[t]];  // the scales of the operand row this product row reads
     float m = 1.f;
     if (ABLK) {
@@ -530,8 +544,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
 #pragma unroll
   for (int c = 0; c < TNW; ++c) {
     const int64_t col = col0 + wn * 32 * TNW + c * 32 + fi;
-    cfac[c] = g.b_inv ? g.b_inv[col] : 1.f;
-    cbias[c] = g.bias ? g.bias[col] : 0.f;
+    cfac[c] = g.b_inv ? g.b_inv[grp * g.group_stride_scale + col] : 1.f;
+    cbias[c] = g.bias ? g.bias[grp * g.group_stride_scale + col] : 0.f;
   }
 
   // ---- prologue: three steps in flight, fragments of step 0 in set 0 ----------------------------------------
@@ -685,8 +699,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
       for (int q = 0; q < 4; ++q) {
         const int pr = q * 8 + rgrp;
         const int64_t row = wrow0 + pr;
-        okq[q] = row < g.M;
-        rowq[q] = okq[q] ? row : g.M - 1;
+        okq[q] = row < m_end;
+        rowq[q] = okq[q] ? row : m_end - 1;
         if (g.row_map) rowq[q] = g.row_map[rowq[q]];
         float4 m[TNW], sv[TNW];
 #pragma unroll
@@ -753,7 +767,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         float iv;
         const float sc = sp_scale_for_max(full, &iv);
         if (okq[q]) {
-          if (wn == 0 && l8 == 0) g.out_inv[rowq[q]] = iv;
+          if (wn == 0 && l8 == 0) g.out_inv[rowq[q] * g.n_tiles + tile_n] = iv;  // one scale per row and column tile
           uint8_t* drow = g.out_sp + rowq[q] * g.ld_out_sp;
 #pragma unroll
           for (int j = 0; j < TNW; ++j) {
@@ -776,8 +790,8 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
         const int idx = lane + (it0 + j) * 64;
         const int pr = idx / C4, c4 = idx - pr * C4;
         const int64_t row = wrow0 + pr, col = wcol0 + c4 * 4;
-        ok[j] = row < g.M;
-        int64_t rr = ok[j] ? row : g.M - 1;
+        ok[j] = row < m_end;
+        int64_t rr = ok[j] ? row : m_end - 1;
         if (g.row_map) rr = g.row_map[rr];
         coff[j] = rr * g.ldc + col;
         doff[j] = rr * g.drop_ld + col;
@@ -1516,9 +1530,14 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
                            int act_of_saved, const float* d_saved, int64_t ld_saved, void* d_out_sp, int64_t ld_out_sp_bytes,
                            float* d_out_inv_scale, void* stream, float dropout_rate = 0.f, uint64_t dropout_seed = 0,
                            float saved_scale = 1.f, const uint8_t* d_tile_kmask = nullptr, const int32_t* d_row_map = nullptr,
-                           const int32_t* d_a_rows = nullptr) {
+                           const int32_t* d_a_rows = nullptr, int64_t a_src_rows = 0, const int32_t* d_tile_table = nullptr,
+                           int64_t num_tiles_m = 0, int num_groups = 1, int64_t b_group_stride_bytes = -1,
+                           int64_t b_scale_group_stride = -1) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && (d_C || d_out_sp), "tfgnn_sp_gemm_nt: null pointer");
-  TFGNN_REQUIRE(!d_a_rows || M * lda_bytes < (1ll << 32) - 65536, "tfgnn_sp_gemm_nt_rows: the operand read through a row index must be below 4 GB");
+  if (!d_a_rows || a_src_rows <= 0) a_src_rows = M;
+  TFGNN_REQUIRE(!d_a_rows || a_src_rows * lda_bytes < (1ll << 32) - 65536, "tfgnn_sp_gemm_nt_rows: the operand read through a row index must be below 4 GB");
+  TFGNN_REQUIRE(!d_tile_table || (num_tiles_m > 0 && num_groups >= 1 && !d_tile_kmask && !d_row_map),
+                "tfgnn_sp_gemm_nt_grouped: a tile table needs its tile count and excludes the tile mask / row map");
   TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "tfgnn_sp_gemm_nt: dropout rate must be in [0, 1), got %f", (double)dropout_rate);
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "tfgnn_sp_gemm_nt: K must be a positive multiple of 16");
   const int bn = sp_tile_width(N);
@@ -1555,6 +1574,11 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   }
   g.row_map = d_row_map;
   g.a_rows = d_a_rows;
+  g.a_src_rows = a_src_rows;
+  g.tile_table = d_tile_table;
+  g.group_stride_b = b_group_stride_bytes >= 0 ? b_group_stride_bytes : N * ldb_bytes;
+  g.group_stride_scale = b_scale_group_stride >= 0 ? b_scale_group_stride : N;
+  TFGNN_REQUIRE(g.group_stride_b % 64 == 0, "tfgnn_sp_gemm_nt_grouped: group stride of B must be a multiple of 64 bytes");
   g.drop_on = dropout_rate > 0.f ? (dropout_seed == ~0ull ? 2 : 1) : 0;
   if (g.drop_on == 2)
     TFGNN_REQUIRE(d_saved && act_of_saved == TFGNN_ACT_RELU, "tfgnn_sp_gemm_nt_dropout: the mask-from-saved form needs a relu saved tensor");
@@ -1562,13 +1586,13 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
   g.drop = dropout_key(dropout_seed, dropout_rate);
   g.n_tiles = (unsigned)(N / bn);
   if (d_out_sp) {
-    TFGNN_REQUIRE(N == bn && !accumulate && d_out_inv_scale, "tfgnn_sp_gemm_nt_sp: the split result needs N = 128, 256 or 320 (one column "
-                  "tile holds whole rows), no accumulation and an inverse-scale array");
+    // one scale per row and COLUMN TILE (N = bn: one per row; N = 512 = 2 x 256: scale blocks of 256 columns - round 5)
+    TFGNN_REQUIRE(!accumulate && d_out_inv_scale, "tfgnn_sp_gemm_nt_sp: the split result needs no accumulation and an inverse-scale array");
     TFGNN_REQUIRE(ld_out_sp_bytes >= N * 4 && ld_out_sp_bytes % 64 == 0 && (uintptr_t)d_out_sp % 64 == 0,
                   "tfgnn_sp_gemm_nt_sp: SP16 result rows must be 64-byte aligned and at least 4 N bytes");
     g.out_sp = (uint8_t*)d_out_sp; g.ld_out_sp = ld_out_sp_bytes; g.out_inv = d_out_inv_scale;
   }
-  const int64_t tiles = ceil_div(M, SP_BM) * g.n_tiles;
+  const int64_t tiles = (d_tile_table ? num_tiles_m : ceil_div(M, SP_BM)) * g.n_tiles;
   TFGNN_REQUIRE(tiles <= 0x7fffffff, "tfgnn_sp_gemm_nt: too many tiles");
   // K split inside the launch (SpArgs::ksplit): only where one wave of workgroups leaves most of the chip idle - every
   // workgroup of a split launch must be RESIDENT (the reducers wait for the producers), one per CU
@@ -1577,7 +1601,7 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
     const int64_t steps = K >> 4;
     int S = (int)std::min<int64_t>(4, steps / 15);  // (K = 320 split in two measured slower: 52 vs 51 us at 56 tiles - the hand-off costs what 10 steps do)
     while (S > 1 && tiles * S > 232) --S;
-    if (g_splitk.enabled && g_splitk.base && S > 1 && tiles <= 112) {
+    if (g_splitk.enabled && g_splitk.base && S > 1 && tiles <= 112 && !d_tile_table) {
       const size_t slab = (size_t)SP_BM * bn * 4;
       const size_t need = kSplitkFlagBytes + (size_t)tiles * (S - 1) * slab;
       if (need <= g_splitk.bytes && (size_t)tiles * (S - 1) * 4 <= kSplitkFlagBytes) {
@@ -1687,6 +1711,19 @@ int tfgnn_sp_gemm_nt_rows(int64_t M, int64_t N, int64_t K, const void* d_A_sp, i
   return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
                          act, accumulate, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale,
                          stream, dropout_rate, dropout_seed, saved_scale, d_tile_kmask, d_row_map, d_a_rows);
+}
+
+int tfgnn_sp_gemm_nt_grouped(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int a_scale_block, const int32_t* d_a_rows, int64_t a_src_rows, const int32_t* d_tile_table,
+                             int64_t num_tiles, int num_groups, const void* d_B_sp, int64_t ldb_bytes, int64_t b_group_stride_bytes,
+                             const float* d_b_inv_scale, int64_t b_scale_group_stride, float* d_C, int64_t ldc, const float* d_bias,
+                             int act, const float* d_mul, int64_t ld_mul, int act_of_saved, const float* d_saved, int64_t ld_saved,
+                             void* d_out_sp, int64_t ld_out_sp_bytes, float* d_out_inv_scale, void* stream) {
+  TFGNN_REQUIRE(d_tile_table && num_tiles > 0 && num_groups >= 1, "tfgnn_sp_gemm_nt_grouped: tile table missing");
+  return sp_gemm_nt_impl(M, N, K, d_A_sp, lda_bytes, d_a_inv_scale, a_scale_block, d_B_sp, ldb_bytes, d_b_inv_scale, d_C, ldc, d_bias,
+                         act, 0, d_mul, ld_mul, act_of_saved, d_saved, ld_saved, d_out_sp, ld_out_sp_bytes, d_out_inv_scale, stream,
+                         0.f, 0, 1.f, nullptr, nullptr, d_a_rows, a_src_rows, d_tile_table, num_tiles, num_groups,
+                         b_group_stride_bytes, b_scale_group_stride);
 }
 
 size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {

@@ -477,14 +477,13 @@ class GNN:
                     if not ops.f16x2_guard_tripped_sync():
                         break
                     self.guard_tripped_last_backward = True
-                    if attempt == 0 and self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
-                        self._dense_split_ok = False
-                        self._dense_demoted_epoch = ops.REARM_EPOCH[0]
+                    if attempt == 0 and self._demote_fragile_weight_gradients():
                         ops.rearm_spread_guard()
                         import warnings
 
-                        warnings.warn("tf2_gnn_amd: the Dense / projection weight gradients of this GNN have operand rows spread over "
-                                      "more than 2^20; these products take the exact bf16x3 kernels from here on (the pass was recomputed)")
+                        warnings.warn("tf2_gnn_amd: the Dense / projection (and per-relation MLP) weight gradients of this GNN have operand "
+                                      "rows spread over more than 2^20; these products take the exact bf16x3 kernels from here on (the pass "
+                                      "was recomputed)")
                     else:
                         ops.demote_gemm_mode()  # the whole mode (sticky), with a warning
                     for v in self.trainable_variables:
@@ -497,6 +496,22 @@ class GNN:
                 mp._defer_aux_join = False
             ops.aux_flush()        # the deferred split reductions of the weight gradients: one launch for all layers
             ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
+
+    def _demote_fragile_weight_gradients(self) -> bool:
+        """First stage of the spread guard's policy: the weight-gradient products whose operand ROWS are un-normalised sums -
+        this stack's Dense / projection products and the per-relation TN products of the compact-row MLP path (RGIN,
+        GNN_Edge_MLP) - go to the exact kernels; the message products keep their split operands.  -> anything demoted?"""
+        did = False
+        if self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
+            self._dense_split_ok = False
+            self._dense_demoted_epoch = ops.REARM_EPOCH[0]
+            did = True
+        for mp in self._mp_layers:
+            if getattr(mp, "_grouped_tn_split_ok", None) is not False and hasattr(mp, "_backward_B_compact_split"):
+                if getattr(mp, "_grouped_tn_used", False):
+                    mp._grouped_tn_split_ok = False
+                    did = True
+        return did
 
     @staticmethod
     def _activation_backward_scaled(act, g, saved, saved_scale):

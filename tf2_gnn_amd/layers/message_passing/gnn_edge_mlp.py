@@ -567,7 +567,120 @@ class GNN_Edge_MLP(MessagePassing):
     # grouped GEMMs over the compact rows only.
     SPARSE_SOURCE_THRESHOLD = 0.6
 
+    # ---- path Bc on split operands (round 5; BASELINE configs[4]) ------------------------------------------------------------
+    # The per-relation MLPs over the non-empty (source, type) rows as grouped products on SP16 operands (3 piece products per
+    # fp32 product; the bf16x3 grouped kernels spend 6): the first layer reads the node states through the row -> node index
+    # (no expanded copy of X for the forward pass), a hidden layer's product writes its relu output ALSO as the operand of the
+    # next product, the input-gradient products carry relu' of the saved activations and write the operand of the next
+    # gradient product; the weight gradients are one split-operand TN product per relation over that relation's row range.
+    GROUPED_SPLIT_MIN_ROWS = 4096  # (tests lower it: below this the grouped bf16x3 kernels are as good)
+
+    def _grouped_split_ok(self, X, g) -> bool:
+        import os
+
+        if ops.get_gemm_mode() != ops.GEMM_F16X2 or os.environ.get("TFGNN_GROUPED_F16X2", "1") == "0":
+            return False
+        dims = [X.shape[1]] + [int(W.shape[2]) for W in self._edge_type_mlps.kernels]
+        # every width a column tile of the split-operand product and a multiple of its scale blocks; rows x bytes below 4 GB
+        return (all(d % 128 == 0 and d <= 1024 for d in dims) and X.shape[0] * X.shape[1] * 4 < (1 << 32) - 65536
+                and g.nonempty_offsets(True)[-1] >= self.GROUPED_SPLIT_MIN_ROWS)
+
+    @staticmethod
+    def _row_groups(g):
+        rg = g._cache.get("row_groups_by_src")
+        if rg is None:
+            rg = ops.RowGroups(g.nonempty_offsets(True), g.device)
+            g._cache["row_groups_by_src"] = rg
+        return rg
+
+    @staticmethod
+    def _stacked_transposed_operand(W):
+        """[L, in, out] kernels -> SP16 [out, L * in]: column block l is W_l^T, relation l's [N, K] operand of the forward product
+        (ONE split launch for the whole stack; a row's scale is shared by the relations)"""
+        L, K, N = W.shape
+        return ops.sp_split_cols(W.view(L * K, N), defer=True)
+
+    def _forward_B_compact_split(self, X, g, fuse_act):
+        mlps = self._edge_type_mlps
+        _, ew_d, _, node_scale = self._scales(g)
+        groups = self._row_groups(g)
+        node_of = g.array(ops.G_NZ_NODE_BY_SRC)
+        x_sp = ops.sp_rows_of(X)
+        acts, cur_sp, cur32 = [], x_sp, None
+        for j, W in enumerate(mlps.kernels):
+            last = j == mlps.num_layers - 1
+            wt = ops.sp_weight_operand(W, "grouped_cols", lambda W=W: self._stacked_transposed_operand(W))
+            cur32, nxt_sp = ops.sp_gemm_nt_grouped(cur_sp, wt, groups, a_rows=node_of if j == 0 else None,
+                                                   act=None if last else "relu", want_split=not last, b_column_blocks=True)
+            acts.append(cur32)
+            cur_sp = nxt_sp
+        colc = g._cache.get("compact_src_col_by_dst")
+        if colc is None:
+            colc = g.array(ops.G_NZ_CPOS_BY_SRC)[g.array(ops.G_COLL_BY_DST).long()].contiguous()
+            g._cache["compact_src_col_by_dst"] = colc
+        ctx = {"path": "Bc", "fused_act": fuse_act, "Xc": None, "x_sp": x_sp, "mlp_acts": acts, "colc": colc, "grouped_split": True}
+        return self._gather_messages(g, cur32, colc, ew_d, node_scale, fuse_act, ctx), ctx
+
+    def _backward_B_compact_split(self, dcur, ctx, g):
+        """d(MLP outputs) [nz, H] -> d(compact inputs) [nz, D]; fills the kernel gradients (see _forward_B_compact_split).
+        The kernel gradients dW_l = inp_l^T d_l are split-operand TN products while ``_grouped_tn_split_ok``: that product
+        applies one combined fp16 factor per operand row pair, and its spread guard trips when a relation's rows are spread over
+        more than 2^20 in scale (un-normalised RGIN sums grow by the degree per layer: the arxiv-rgin workload reaches 2^25) -
+        the stack then hands these gradients to the exact bf16x3 grouped kernel (GNN.backward, like its Dense products); the
+        row-wise products above have per-row scales and no such limit."""
+        mlps = self._edge_type_mlps
+        groups = self._row_groups(g)
+        off = groups.offsets
+        acts = ctx["mlp_acts"]
+        tn_split = getattr(self, "_grouped_tn_split_ok", True)
+        d_sp = ops.sp_split_rows(dcur)  # (the compact by-source gather has no SP16-writing form)
+        d32 = dcur
+        grads = [None] * mlps.num_layers
+        dcur32 = None
+        for j in range(mlps.num_layers - 1, -1, -1):
+            W = mlps.kernels[j]  # [L, in, out]
+            if not tn_split:
+                if j > 0:
+                    inp32 = acts[j - 1]
+                else:  # the expanded node states, as the bf16x3 path keeps them
+                    nz = groups.num_rows
+                    ident = g._cache.get(("ident_nz", nz))
+                    if ident is None:
+                        ident = torch.arange(nz + 1, dtype=torch.int32, device=dcur.device)
+                        g._cache[("ident_nz", nz)] = ident
+                    inp32 = ops.gather_reduce(ident, g.array(ops.G_NZ_NODE_BY_SRC), ctx["X"])
+                grads[j] = ops.gemm_grouped_k(inp32, d32, g.array(ops.G_NZ_OFF_BY_SRC), off, groups.num_groups)
+            else:
+                self._grouped_tn_used = True  # (what the stack's guard policy demotes if the spread guard trips: GNN.backward)
+                inp_sp = ops.sp_rows_of(acts[j - 1]) if j > 0 else ops.sp_gather_rows(ctx["x_sp"], g.array(ops.G_NZ_NODE_BY_SRC))
+                # The operand with per-block scales is the product's left one: the layer input for j > 0 (a product wrote it:
+                # blocks of a column tile), the gradient for j = 0 (then the transpose is stored)
+                dW = torch.empty_like(W)
+                left_is_input = inp_sp.scale_block != inp_sp.cols or d_sp.scale_block == d_sp.cols
+                for l in range(groups.num_groups):
+                    r0, r1 = off[l], off[l + 1]
+                    if r1 == r0:
+                        dW[l].zero_()
+                        continue
+                    a_l = ops.SplitOperand(inp_sp.data[r0:r1], inp_sp.inv_scale[r0:r1], r1 - r0, inp_sp.cols, inp_sp.scale_block)
+                    b_l = ops.SplitOperand(d_sp.data[r0:r1], d_sp.inv_scale[r0:r1], r1 - r0, d_sp.cols, d_sp.scale_block)
+                    if left_is_input:
+                        ops.sp_gemm_tn(a_l, b_l, out=dW[l], defer_reduce=True)
+                    else:  # (d_l^T inp_l)^T: element (m, n) of the product is dW_l[n, m]
+                        ops.sp_gemm_tn(b_l, a_l, out=dW[l], scatter=(b_l.cols, 0, 1, W.shape[2]), defer_reduce=True)
+                ops.aux_flush()  # the relations' split reductions, eight per launch: dW is complete from here on
+                grads[j] = dW
+            wr = ops.sp_weight_operand(W, "grouped_rows", lambda W=W: ops.sp_split_rows(W.view(W.shape[0] * W.shape[1], W.shape[2])))
+            dcur32, d_sp = ops.sp_gemm_nt_grouped(d_sp, wr, groups, act_grad=("relu", acts[j - 1]) if j > 0 else None,
+                                                  want_fp32=(j == 0 or not tn_split), want_split=(j > 0))
+            d32 = dcur32
+        mlps.grads = grads
+        mlps.publish_grads()
+        return dcur32
+
     def _forward_B_compact(self, X, g, fuse_act):
+        if self._grouped_split_ok(X, g):
+            return self._forward_B_compact_split(X, g, fuse_act)
         L, H = g.num_edge_types, self._hidden_dim
         mlps = self._edge_type_mlps
         _, ew_d, _, node_scale = self._scales(g)
@@ -607,6 +720,9 @@ class GNN_Edge_MLP(MessagePassing):
             dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, dM, col=g.array(ops.G_SRC2DST_POS))
         else:
             dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, d_agg, edge_weight=ew_s)  # d(MLP outputs) [nz, H]
+        if ctx.get("grouped_split"):
+            dxc = self._backward_B_compact_split(dcur, ctx, g)
+            return ops.gather_reduce(g.array(ops.G_NZ_NODEPTR_BY_SRC), g.array(ops.G_NZ_COL_BY_SRC), dxc)
         grads = [None] * mlps.num_layers
         for j in range(mlps.num_layers - 1, -1, -1):
             inp = ctx["Xc"] if j == 0 else acts[j - 1]

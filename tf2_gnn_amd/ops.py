@@ -1291,15 +1291,21 @@ def sp_rows_of(x: torch.Tensor) -> SplitOperand:
     return op
 
 
-def sp_split_cols(w: torch.Tensor, defer: bool = False) -> SplitOperand:
+def sp_split_cols(w: torch.Tensor, defer: bool = False, out: Optional[SplitOperand] = None) -> SplitOperand:
     """SP16 form of w^T for a row-major [K, N] matrix (a Keras kernel): rows = N, cols = K, one scale per row.
-    defer: as a job of the next merged small-pass launch (``aux_defer``)."""
+    defer: as a job of the next merged small-pass launch (``aux_defer``).  out: write into this operand (N rows of K columns:
+    a slice of a stack of per-group operands)."""
     lib = _lib.load()
     _require_dev(w, torch.float32, "w")
     w, ld = _rowmajor(w, "w")
     K, N = w.shape
-    data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
-    inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
+    if out is not None:
+        if out.rows != N or out.cols != K:
+            raise ValueError("sp_split_cols: out must hold N rows of K columns")
+        data, inv = out.data, out.inv_scale
+    else:
+        data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
+        inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
     if defer and aux_enabled():
         job = _lib.AuxJob()
         _lib.check(lib.tfgnn_sp_split_cols_job(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), ctypes.byref(job)))
@@ -1346,6 +1352,93 @@ def sp_gemm_nt_splitk(enable: Optional[bool] = None):
     t, n = ctypes.c_int(0), ctypes.c_int64(0)
     on = _lib.load().tfgnn_sp_gemm_nt_splitk_status(-1 if enable is None else int(bool(enable)), ctypes.byref(t), ctypes.byref(n))
     return bool(on), bool(t.value), int(n.value)
+
+
+def sp_tile_width(N: int) -> int:
+    """Column tile of the split-operand NT product for N output columns (gemm_sp.hip sp_tile_width); 0: unsupported."""
+    return 320 if N % 320 == 0 else (256 if N % 256 == 0 else (128 if N % 128 == 0 else 0))
+
+
+class RowGroups:
+    """Consecutive row groups (rows of group g: [offsets[g], offsets[g + 1])) cut into the row tiles of the grouped product
+    (tfgnn_sp_gemm_nt_grouped d_tile_table): int32 [tiles, 4] = (first row, rows, group, 0) on the device, built once per
+    grouping (a batch's non-empty (source, type) rows: cached on its Graph)."""
+
+    def __init__(self, offsets_host, device):
+        import numpy as np
+
+        off = [int(o) for o in offsets_host]
+        rows = []
+        for gi in range(len(off) - 1):
+            for r0 in range(off[gi], off[gi + 1], 128):
+                rows.append((r0, min(128, off[gi + 1] - r0), gi, 0))
+        self.offsets = off
+        self.num_groups = len(off) - 1
+        self.num_rows = off[-1]
+        self.num_tiles = len(rows)
+        tab = np.asarray(rows if rows else [(0, 0, 0, 0)], dtype=np.int32)
+        self.table = torch.from_numpy(tab).to(device)
+
+
+def sp_gemm_nt_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, *, a_rows=None, act=ACT_NONE, act_grad=None,
+                       want_fp32: bool = True, want_split: bool = False, b_column_blocks: bool = False):
+    """Per-group products on split operands (tfgnn_sp_gemm_nt_grouped): row r of group g -> epilogue(a_row(r) @ b_g^T).
+    b: ``groups.num_groups`` stacked [N, K] operands with one scale per row ([G * N, K]), or - b_column_blocks - ONE operand
+    [N, G * K] whose column block g is group g's (``sp_split_cols`` of G stacked Keras kernels [G * K, N]: one launch; the row
+    scales are shared by the groups).  a_rows (int32 [rows]): row r reads a[a_rows[r]] (a then has any number of rows).
+    act_grad = (name, saved [rows, N]).  -> (fp32 [rows, N] | None, SplitOperand | None)"""
+    lib = _lib.load()
+    M, K = groups.num_rows, a.cols
+    G = max(groups.num_groups, 1)
+    if b_column_blocks:
+        if b.cols != G * K or b.scale_block != b.cols:
+            raise ValueError("sp_gemm_nt_grouped: b must be [N, G * K] with one scale per row")
+        N, stride_b, stride_scale = b.rows, 4 * K, 0
+    else:
+        if b.cols != K or b.rows % G or b.scale_block != K:
+            raise ValueError("sp_gemm_nt_grouped: b must stack one [N, K] operand per group with one scale per row")
+        N = b.rows // G
+        stride_b, stride_scale = N * b.data.stride(0), N
+    if a_rows is None and a.rows != M:
+        raise ValueError(f"sp_gemm_nt_grouped: {a.rows} operand rows for {M} grouped rows")
+    if a_rows is not None:
+        a_rows = _row_map(a_rows, M)
+    dev = a.data.device
+    out = torch.empty((M, N), dtype=torch.float32, device=dev) if want_fp32 else None
+    op = None
+    if want_split:
+        bn = sp_tile_width(N)
+        op = SplitOperand(torch.empty((M, N * 4), dtype=torch.uint8, device=dev),
+                          torch.empty((M, max(1, N // max(bn, 1))), dtype=torch.float32, device=dev), M, N, bn if bn else N)
+    if M == 0:
+        return out, op
+    _, act_grad, _, _ = _native_epilogue(None, act_grad, None, 1.0)
+    act_name, saved = act_grad if act_grad is not None else (None, None)
+    _lib.check(
+        lib.tfgnn_sp_gemm_nt_grouped(
+            M, N, K, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.scale_block if a.scale_block else -1, _ptr(a_rows), a.rows,
+            _ptr(groups.table), groups.num_tiles, G, _ptr(b.data), b.data.stride(0), stride_b, _ptr(b.inv_scale), stride_scale,
+            _ptr(out), N, None, act_id(act), None, 0, act_id(act_name), _ptr(saved), saved.stride(0) if saved is not None else 0,
+            _ptr(op.data) if op is not None else None, op.data.stride(0) if op is not None else 0,
+            _ptr(op.inv_scale) if op is not None else None, _stream(),
+        )
+    )
+    if out is not None and op is not None:
+        _remember_split_rows(out, op)
+    return out, op
+
+
+def sp_gather_rows(a: SplitOperand, index: torch.Tensor) -> SplitOperand:
+    """rows ``index`` of a split operand, with their scales (tfgnn_sp_gather_rows)."""
+    lib = _lib.load()
+    _require_dev(index, torch.int32, "index")
+    n = int(index.numel())
+    per = a.inv_scale.shape[1] if a.inv_scale.dim() == 2 else 1
+    out = SplitOperand(torch.empty((n, a.cols * 4), dtype=torch.uint8, device=a.data.device),
+                       torch.empty((n, per), dtype=torch.float32, device=a.data.device), n, a.cols, a.scale_block)
+    _lib.check(lib.tfgnn_sp_gather_rows(_ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), per, _ptr(index.contiguous()), n, a.rows, a.cols,
+                                        _ptr(out.data), out.data.stride(0), _ptr(out.inv_scale), _stream()))
+    return out
 
 
 def sp_gemm_nt_balance(min_blocks: int = -1) -> int:
@@ -1410,8 +1503,9 @@ def sp_gemm_nt_split(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NON
         raise ValueError("sp_gemm_nt_split: the right operand must carry one scale per row")
     dev = a.data.device
     out = torch.empty((M, N), dtype=torch.float32, device=dev) if want_fp32 else None
-    op = SplitOperand(torch.empty((M, N * 4), dtype=torch.uint8, device=dev), torch.empty((M, 1), dtype=torch.float32, device=dev),
-                      M, N, N)
+    bn = sp_tile_width(N)  # the result carries one scale per row and COLUMN TILE (N = 512: blocks of 256 columns)
+    op = SplitOperand(torch.empty((M, N * 4), dtype=torch.uint8, device=dev),
+                      torch.empty((M, max(1, N // max(bn, 1))), dtype=torch.float32, device=dev), M, N, bn if bn else N)
     out_mul, act_grad, dropout, saved_scale = _native_epilogue(out_mul, act_grad, dropout, saved_scale)
     act_name, saved = act_grad if act_grad is not None else (None, None)
     if bias is not None:
