@@ -720,7 +720,7 @@ int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes);
 int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches);
 /* Helper workgroups for the heavy tiles of a MASKED product (d_tile_kmask, >= 128 row tiles, the workspace above): a tile
  * with at least min_blocks non-empty K blocks is multiplied by two workgroups (halves of K, the same hand-off).  0 = off, the
- * default: measured a LOSS on the benchmark batch (DESIGN.md / gemm_sp.hip: 112 vs 90 us per forward product) - kept for
+ * default: measured a LOSS on the benchmark batch (DESIGN.md 5 / gemm_sp.hip: 112 vs 90 us per forward product) - kept for
  * re-measurement.  min_blocks < 0 only queries.  Returns the previous value.  Results with helpers are reproducible but not
  * bit-equal to the unmasked product's (a heavy tile's sum is grouped in two halves). */
 int tfgnn_sp_gemm_nt_balance(int min_blocks);

@@ -16,5 +16,5 @@ own tests hold for the path (``tests/golden/reference_kats.json``; see ``tests/t
   * tf2_gnn/test/layers/test_RGCN.py / test_RGAT.py       (parameter-shape contracts)
 
 Everything the reference's tests do not pin numerically (degree normalisation, RGAT softmax, GRU,
-pooling, [ext] TensorFlow / dpu_utils semantics) is "parity unpinned": stated in DESIGN.md.
+pooling, [ext] TensorFlow / dpu_utils semantics) is "parity unpinned": stated in DESIGN.md 7.
 """

@@ -153,7 +153,7 @@ def test_sigmoid_cross_entropy_and_f1_match_independent_forms():
 
 
 def test_bucket_emptiness_patterns_hand_worked():
-    """oracle/adjacency_oracle.py: the specification of the device's pattern order on a case small enough to
+    """oracle/adjacency_oracle.py: the specification of the device's pattern order (NOTEBOOK.md 4.8) on a case small enough to
     check by hand: 5 nodes, 3 edge types."""
     import numpy as np
 

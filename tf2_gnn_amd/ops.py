@@ -1623,7 +1623,7 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
                 b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len)
         keep = (ws, out, a.data, a.inv_scale, b.data, b.inv_scale)
         rjob = _lib.AuxJob()
-        if K <= 131072 and os.environ.get("TFGNN_TN_CHAINED", "0") == "1":  # opt-in: measured slower
+        if K <= 131072 and os.environ.get("TFGNN_TN_CHAINED", "0") == "1":  # opt-in: measured slower (NOTEBOOK.md 4.7)
             # the whole product waits for the next merged launch: its factor pass rides there, the product follows it, the
             # reduction rides in a later one (a weight gradient is off the critical path of the backward pass)
             fjob = _lib.AuxJob()

@@ -7,7 +7,7 @@ of ``GraphDataset._finalise_batch``: "node_features", "adjacency_list_<i>", "nod
 "num_graphs_in_batch"; labels "node_labels" / "target_value") and result keys.  ``backward()`` stands in for the
 ``tf.GradientTape`` of ``GraphTaskModel._run_step`` (tf2_gnn/models/graph_task_model.py:327-357): it fills ``.grad``
 of every trainable variable with d loss / d variable.  The optimizer, the epoch loop, datasets and checkpoint I/O are
-the reference's control plane and stay out (DESIGN.md, out of scope).
+the reference's control plane and stay out (DESIGN.md 10, out of scope).
 
 MLP-input dropout of the heads (``regression_mlp_dropout``, ``graph_aggregation_dropout_rate``; QM9 hands
 ``out_layer_dropout_keep_prob`` over as a rate) is applied in training mode as in the pooling layers (layers/nodes_to_graph_representation.py MLP).

@@ -2,7 +2,7 @@
      python tools/tn_spread_probe.py      (on the GPU box)
 Wraps ops.sp_gemm_tn, runs one step of bench.run_ppi and prints per call and scale block: rows with an all-zero operand row
 (marker scale 2^-126), quantiles of log2(row scale product / largest), rows more than 2^14 / 2^20 below the largest.
-This is how the round-4 guard bug was found: every product showed ~25 % all-zero rows (empty buckets) and no
+This is how the round-4 guard bug was found (NOTEBOOK.md 4.8): every product showed ~25 % all-zero rows (empty buckets) and no
 real row below 2^-16, yet the guard tripped - it judged zero rows by their factor, which is not tiny when the operands are."""
 import sys, types
 import numpy as np
