@@ -244,7 +244,12 @@ typedef enum {
   TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5,
   /* the by-target typed view with its output rows in PATTERN order: bucket (v, l) is written at row pos[v] * L + l
    * (TFGNN_G_PATTERN_POS_BY_DST), every bucket has a row (part DST_PATTERN) */
-  TFGNN_VIEW_BY_DST_TYPED_PATTERN = 6
+  TFGNN_VIEW_BY_DST_TYPED_PATTERN = 6,
+  /* the same rows, for a consumer that skips the all-zero blocks of a row tile (tfgnn_sp_gemm_nt_dropout d_tile_kmask =
+   * TFGNN_G_PATTERN_TILEMASK_BY_DST over the operand [V, L * width], round 5): an EMPTY bucket in a block the consumer does not
+   * read writes only its scale, not its row of zeros - those bytes of the output stay UNDEFINED.  Split-form output only
+   * (tfgnn_graph_gather_reduce_sp, per-bucket scales). */
+  TFGNN_VIEW_BY_DST_TYPED_PATTERN_MASKED = 7
 } tfgnn_graph_view;
 size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* graph, int view, int width);
 int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t* d_col_override,

@@ -220,7 +220,15 @@ struct SpGeo {
   // steps before the step and has to have landed two steps before it: NST - 3 steps (and the rest of the issuing
   // one) cover its latency - ~1 us under load, a step is ~0.45 us (tools/sp_ablate.py: with four stages the loop
   // waited for its DMAs).
-  static constexpr int NST = (163840 / STG) < 6 ? (163840 / STG) : 6;
+  // BN = 128 (round 5): 4 stages = 64 KB, so that TWO workgroups share a CU (the kernel needs <= 228 registers there: two waves
+  // per SIMD) and one tile's epilogue / ring fill runs under the other's main loop - the 10^6-row products of configs[3]
+  // (K = 640 .. 2560, N = 128) spend a third of a tile's time outside the main loop.  TFGNN_SP_NT_NARROW_STAGES (build flag)
+  // restores 6 for A/B runs.
+#ifndef TFGNN_SP_NT_NARROW_STAGES
+#define TFGNN_SP_NT_NARROW_STAGES 4
+#endif
+  static constexpr int NST_MAX = TNW == 2 ? TFGNN_SP_NT_NARROW_STAGES : 6;
+  static constexpr int NST = (163840 / STG) < NST_MAX ? (163840 / STG) : NST_MAX;
   static constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;  // steps per unrolled loop body (register sets alternate)
   static constexpr int VMW = (NST - 3) * ND;                // DMAs that may still be in flight at the end of a step
   static constexpr int LDS_BYTES = NST * STG;
@@ -381,7 +389,7 @@ struct SpLoop {
 };
 
 template <int TNW, bool ABLK, bool GRAD, bool OUT_SP = false>
-__global__ void __launch_bounds__(SP_NT, 1) gemm_sp_nt_kernel(SpArgs g) {
+__global__ void __launch_bounds__(SP_NT, (TNW == 2 ? 2 : 1)) gemm_sp_nt_kernel(SpArgs g) {  // (BN = 128: two workgroups per CU, see SpGeo::NST)
   using G = SpGeo<TNW>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;

@@ -212,7 +212,7 @@ G_PART_PLAN_TYPED, G_PART_PLAN_NODE, G_PART_COMPACT, G_PART_EDGE_MAPS, G_PART_ED
 G_PARTS_DEFAULT = G_PARTS_ALL & ~G_PART_DST_PATTERN  # the pattern order is built for the layers that ask for it
 _VIEW_PARTS = {0: G_PART_PLAN_TYPED, 1: G_PART_PLAN_NODE, 2: G_PART_PLAN_TYPED, 3: G_PART_PLAN_NODE,
                4: G_PART_PLAN_TYPED | G_PART_COMPACT, 5: G_PART_PLAN_TYPED | G_PART_COMPACT,
-               6: G_PART_PLAN_TYPED | G_PART_DST_PATTERN}
+               6: G_PART_PLAN_TYPED | G_PART_DST_PATTERN, 7: G_PART_PLAN_TYPED | G_PART_DST_PATTERN}
 
 
 def _array_parts(array_id: int) -> int:
@@ -388,7 +388,7 @@ def gather_reduce(
 
 
 (VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE, VIEW_BY_DST_TYPED_COMPACT,
- VIEW_BY_SRC_TYPED_COMPACT, VIEW_BY_DST_TYPED_PATTERN) = range(7)
+ VIEW_BY_SRC_TYPED_COMPACT, VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED) = range(8)
 
 
 @_writes_out
@@ -1545,9 +1545,9 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     _require_dev(inp, torch.float32, "inp")
     if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
         raise ValueError("graph_gather_sp: compact views are not supported")
-    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN)
+    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED)
     num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
-    if view == VIEW_BY_DST_TYPED_PATTERN and graph.num_edge_types > 8:
+    if view in (VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED) and graph.num_edge_types > 8:
         raise ValueError("graph_gather_sp: the pattern order exists for at most 8 edge types")
     inp, ld_in = _rowmajor(inp, "inp")
     width = inp.shape[1]
