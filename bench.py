@@ -1016,7 +1016,7 @@ def _pmc_traffic(workload, name):
     if name is None:
         return None, None
     root = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r04", "r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
+    for tag in ("r05", "r04", "r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
         path = os.path.join(root, "profiles", f"{tag}_pmc_traffic_{workload}.json")
         try:
             with open(path) as f:
@@ -1147,9 +1147,24 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         Ac = torch.randn((nz, H), device=dev)
         W = torch.randn((L, H, H), device=dev) * 0.05
         off_d = g.array(ops.G_NZ_OFF_BY_SRC)
-        ms = time_kernel(lambda: ops.gemm_grouped_rows(Ac, off_d, off_h, W, act="relu"))
-        out.append(mfma_block(f"grouped GEMM over the {nz} non-empty (source, type) rows in {L} relation groups ([rows_l, H] x [H, H])", ms,
-                              2.0 * nz * H * H, nprod, split_peak, 6 * NL))
+        if args.gemm_mode == "f16x2":
+            # round 5: the forward and input-gradient products of the per-relation MLPs run on split operands
+            # (tfgnn_sp_gemm_nt_grouped: 3 piece products); the kernel gradients stay on the exact grouped kernel where the
+            # spread guard demotes them (this workload: un-normalised sums, row scales spread over 2^25)
+            groups = ops.RowGroups(off_h, dev)
+            a_sp = ops.sp_split_rows(Ac)
+            w_sp = ops.sp_split_cols(W.view(L * H, H))
+            ms = time_kernel(lambda: ops.sp_gemm_nt_grouped(a_sp, w_sp, groups, act="relu", b_column_blocks=True))
+            out.append(mfma_block(f"tfgnn_sp_gemm_nt_grouped over the {nz} non-empty (source, type) rows in {L} relation groups "
+                                  "([rows_l, H] x [H, H], split operands)", ms, 2.0 * nz * H * H, 3, MFMA_16BIT_PEAK_TFLOPS, 4 * NL))
+            G2 = torch.randn((nz, H), device=dev)
+            ms = time_kernel(lambda: ops.gemm_grouped_k(Ac, G2, off_d, off_h, L))
+            out.append(mfma_block(f"gemm_grouped_k: kernel gradients of the {L} relations (bf16x3: the spread guard keeps them exact)", ms,
+                                  2.0 * nz * H * H, 6, MFMA_16BIT_PEAK_TFLOPS, 2 * NL))
+        else:
+            ms = time_kernel(lambda: ops.gemm_grouped_rows(Ac, off_d, off_h, W, act="relu"))
+            out.append(mfma_block(f"grouped GEMM over the {nz} non-empty (source, type) rows in {L} relation groups ([rows_l, H] x [H, H])", ms,
+                                  2.0 * nz * H * H, nprod, split_peak, 6 * NL))
         colc = g.array(ops.G_NZ_CPOS_BY_SRC)[g.array(ops.G_COLL_BY_DST).long()].contiguous()
         agg = torch.empty((V, H), device=dev)
         ms = time_kernel(lambda: ops.graph_gather(g, ops.VIEW_BY_DST_NODE, Ac, col=colc, out=agg))

@@ -3,7 +3,7 @@ same launches bench.py's `roofline` section times), preceded by a streaming cali
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir>/fetch -- python tools/pmc_workload.py <workload>
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -- python tools/pmc_workload.py <workload>
-  python tools/parse_pmc.py <dir>/fetch <dir>/write profiles/r03_pmc_traffic_<workload>.json
+  python tools/parse_pmc.py <dir>/fetch <dir>/write profiles/r05_pmc_traffic_<workload>.json
 
 (tools/pmc_collect.sh does the three steps and copies the counter CSVs to profiles/.)"""
 import argparse
