@@ -802,11 +802,12 @@ def other_configs(args):
     out = {}
     for name, steps in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "1", "--no-alt-mode",
-               "--no-other-configs", "--gemm-mode", args.gemm_mode, "--cpu-baseline-seconds", "10"]
+               "--no-other-configs", "--gemm-mode", args.gemm_mode, "--cpu-baseline-seconds", "8"]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         if args.no_roofline:
             cmd.append("--no-roofline")
+        t_sub = time.perf_counter()
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -818,7 +819,7 @@ def other_configs(args):
             out[name] = {"error": str(e)[:300]}
             continue
         entry = {"workload": r["config"]["workload"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
-                 "unit": r["unit"], "scaling": r["scaling"]}
+                 "unit": r["unit"], "scaling": r["scaling"], "wall_seconds_of_this_run": round(time.perf_counter() - t_sub, 1)}
         for key in ("graphs_per_s", "host_ms_per_step", "device_ms_one_step_alone", "bound", "reference_published", "step", "replay_only",
                     "eager"):
             if key in r:  # the PPI stand-in's own fields

@@ -296,8 +296,12 @@ struct SpLoop {
     // 35 of them at BN = 320 - runs out of SGPRs, parks the buffer descriptors in VGPRs and wraps every DMA in a
     // readfirstlane waterfall loop.  Here m0 is base + immediate: two SGPRs in all.
     unsigned so = phys_step((unsigned)(step < nsteps ? step : nsteps - 1)) * 64u;
+    // (TFGNN_SP_NT_A_POLICY: cache policy of the A stream - rows one workgroup reads once - for A/B builds, e.g. " nt")
+#ifndef TFGNN_SP_NT_A_POLICY
+#define TFGNN_SP_NT_A_POLICY ""
+#endif
     if constexpr (I < G::ND_A)
-      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen" TFGNN_SP_NT_A_POLICY " lds"
                    :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(so) : "memory");
     else
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
