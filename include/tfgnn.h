@@ -663,9 +663,10 @@ int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
 /* The same product whose epilogue ALSO writes the result as an SP16 operand with one power-of-two scale per row
  * (d_out_sp rows of ld_out_sp_bytes >= 4 N, 64-byte aligned; d_out_inv_scale [M]) - the operand of the next product
  * (a Dense layer behind a message-passing layer, the weight-gradient products of the backward pass) without a split
- * pass.  The row maximum is taken over the FINAL values (after bias / activation / the gradient factors).  N must be
- * one column tile (128, 256 or 320: a workgroup holds whole rows); no accumulation; d_C may be NULL when only the
- * split form is needed. */
+ * pass.  The row maximum is taken over the FINAL values (after bias / activation / the gradient factors), per COLUMN TILE
+ * of the product (N = 128, 256 or 320: one scale per row; since round 5 also several tiles - N = 512 = 2 x 256, 640 = 2 x 320:
+ * d_out_inv_scale [M][N / tile], an operand with scale blocks of one tile, a_scale_block of the next product); no
+ * accumulation; d_C may be NULL when only the split form is needed. */
 int tfgnn_sp_gemm_nt_sp(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
                         int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale, float* d_C,
                         int64_t ldc, const float* d_bias, int act, const float* d_mul, int64_t ld_mul, int act_of_saved,
@@ -715,8 +716,9 @@ int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, const float
  * through the workspace (write-through stores + one flag word each), split 0 adds them in split order - the result is
  * bit-reproducible, though not bit-equal to the unsplit product's (another summation order; same error class) - and runs
  * the epilogue.  No extra launch, no extra pass.  Layout: [64 KB of flags][slabs of 128 x tile-width floats]; 32 MB cover
- * every shape eligible for the K split (the helper workgroups of tfgnn_sp_gemm_nt_balance take one slab per tile).  The library keeps the flags zero between launches (each reducer clears what it consumed), which is
- * what makes a product captured in a hipGraph replayable.  ONE workspace per process: products that may run CONCURRENTLY (two
+ * every shape eligible for the K split (the helper workgroups of tfgnn_sp_gemm_nt_balance take one slab per tile).  The
+ * library keeps the flags zero between launches (each reducer clears what it consumed), which is what makes a product
+ * captured in a hipGraph replayable.  ONE workspace per process: products that may run CONCURRENTLY (two
  * streams) must not both be eligible.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
  * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = 1 if a reducer ever gave
  * up waiting for a producer (~1 s; never expected - the product it belongs to is wrong); *split_launches (may be NULL) = products
