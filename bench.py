@@ -846,10 +846,10 @@ def other_configs(args):
 # step breakdown: every library op of ONE real step between HIP events (launch stream), aggregated by (op, shapes)
 # --------------------------------------------------------------------------------------------------------------------
 _TIMED_OPS = ("graph_gather_dot", "aux_flush", "dropout_mask", "sp_gemm_nt_grouped", "sp_gather_rows", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn",
-              "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
+              "sp_gemm_tn_grouped", "graph_gather", "graph_gather_sp", "gather_reduce", "gru_gates_forward", "gru_gates_backward", "activation_forward",
               "activation_backward", "dropout_forward", "mul", "add_scale", "colsum", "layernorm_forward", "layernorm_backward",
               "permute_021", "transpose_batched", "edge_aggregate_backward", "sp_split_rows", "sp_split_cols", "clip", "clip_backward")
-_PRODUCT_OPS = {"sp_gemm_nt_grouped", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn"}
+_PRODUCT_OPS = {"sp_gemm_nt_grouped", "gemm", "gemm_gathered", "gemm_grad", "gemm_gru", "gemm_grouped_rows", "gemm_grouped_k", "sp_gemm_nt", "sp_gemm_nt_split", "sp_gemm_tn", "sp_gemm_tn_grouped"}
 
 
 def step_breakdown(step, ops, steps=2, top=12):
@@ -908,6 +908,8 @@ def step_breakdown(step, ops, steps=2, top=12):
                     M = (k.get("a_cols") or (0, a[0].cols))[1]
                     N = (k.get("b_cols") or (0, a[1].cols))[1]
                     flops = 2.0 * a[0].rows * M * N
+                elif name == "sp_gemm_tn_grouped":
+                    flops = 2.0 * a[0].rows * a[0].cols * a[1].cols
                 elif name == "gemm_gru":
                     flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
                 elif name == "gemm_grouped_k":
@@ -1150,18 +1152,20 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         off_d = g.array(ops.G_NZ_OFF_BY_SRC)
         if args.gemm_mode == "f16x2":
             # round 5: the forward and input-gradient products of the per-relation MLPs run on split operands
-            # (tfgnn_sp_gemm_nt_grouped: 3 piece products); the kernel gradients stay on the exact grouped kernel where the
-            # spread guard demotes them (this workload: un-normalised sums, row scales spread over 2^25)
+            # (tfgnn_sp_gemm_nt_grouped: 3 piece products), the kernel gradients of all relations in one launch of the
+            # two-factor TN product (tfgnn_sp_gemm_tn_grouped: per-k factors on both operands' fragments, so the row scales
+            # of this workload's un-normalised sums - spread over 2^19 and 2^21 - stay below each operand's guard)
             groups = ops.RowGroups(off_h, dev)
             a_sp = ops.sp_split_rows(Ac)
             w_sp = ops.sp_split_cols(W.view(L * H, H))
             ms = time_kernel(lambda: ops.sp_gemm_nt_grouped(a_sp, w_sp, groups, act="relu", b_column_blocks=True))
             out.append(mfma_block(f"tfgnn_sp_gemm_nt_grouped over the {nz} non-empty (source, type) rows in {L} relation groups "
                                   "([rows_l, H] x [H, H], split operands)", ms, 2.0 * nz * H * H, 3, MFMA_16BIT_PEAK_TFLOPS, 4 * NL))
-            G2 = torch.randn((nz, H), device=dev)
-            ms = time_kernel(lambda: ops.gemm_grouped_k(Ac, G2, off_d, off_h, L))
-            out.append(mfma_block(f"gemm_grouped_k: kernel gradients of the {L} relations (bf16x3: the spread guard keeps them exact)", ms,
-                                  2.0 * nz * H * H, 6, MFMA_16BIT_PEAK_TFLOPS, 2 * NL))
+            g_sp = ops.sp_split_rows(torch.randn((nz, H), device=dev))
+            dWg = torch.empty((L, H, H), device=dev)
+            ms = time_kernel(lambda: ops.sp_gemm_tn_grouped(a_sp, g_sp, groups, dWg))
+            out.append(mfma_block(f"tfgnn_sp_gemm_tn_grouped: kernel gradients of the {L} relations in one launch (two-factor split-operand "
+                                  "TN product + grouped reduce)", ms, 2.0 * nz * H * H, 3, MFMA_16BIT_PEAK_TFLOPS, 2 * NL))
         else:
             ms = time_kernel(lambda: ops.gemm_grouped_rows(Ac, off_d, off_h, W, act="relu"))
             out.append(mfma_block(f"grouped GEMM over the {nz} non-empty (source, type) rows in {L} relation groups ([rows_l, H] x [H, H])", ms,

@@ -709,6 +709,32 @@ int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, const float
                          const int32_t* d_index, int64_t rows, int64_t src_rows, int64_t cols, void* d_dst_sp, int64_t ld_dst_bytes,
                          float* d_dst_inv_scale, void* stream);
 
+/* tfgnn_sp_gemm_tn with a WIDER operand range (round 5): both operands' fragments carry per-k factors of their own (inv_a /
+ * its maximum over the K range, inv_b / its maximum) instead of one combined factor on A.  A row keeps >= 16 bits while EACH of
+ * its two scales lies within 2^22 of the largest of its K range (ranges of <= 2016 rows, factors computed in the kernel), whatever
+ * their product is; the spread flag is set beyond that.  For products whose rows are un-normalised sums on both sides (the
+ * per-relation weight gradients of RGIN at arxiv scale: row scales over 2^19 and 2^21, their products over 2^25 - the combined
+ * factor of tfgnn_sp_gemm_tn trips its 2^20 guard there).  Costs 2 (N / 32) packed multiplies more per k16 step (~+25 %) and
+ * more K ranges (workspace: tfgnn_sp_gemm_tn_wide_workspace_bytes).  reduce_job non-NULL: the split reduction as a job of
+ * tfgnn_aux_launch, as tfgnn_sp_gemm_tn_deferred.  d_b_inv_scale is required.  Same result layout arguments. */
+size_t tfgnn_sp_gemm_tn_wide_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block);
+int tfgnn_sp_gemm_tn_wide(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                          const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                          int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                          int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                          size_t workspace_bytes, struct tfgnn_aux_job* reduce_job, void* stream);
+
+/* The wide-range product over ROW GROUPS of the same two operands in one launch (round 5; the kernel gradients dW_g = A_g^T B_g
+ * of the per-relation MLPs): d_split_table int32 [num_splits][2] = (first row, rows <= 2016) of every K range, ranges of a group
+ * consecutive; d_group_split_offsets int32 [num_groups + 1] = first range of every group.  Output g at d_C + g *
+ * c_group_stride, element (m, n) at m * stride_row + n * stride_col.  Workspace: 4 * 512 * (a_total_cols / a_scale_block)
+ * rounded up to 256, + num_splits * roundup(M, 128) * N * 4 bytes.  num_splits <= 512. */
+int tfgnn_sp_gemm_tn_grouped(int64_t M, int64_t N, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int64_t a_total_cols, int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale,
+                             int num_groups, const int32_t* d_group_split_offsets, int num_splits, const int32_t* d_split_table,
+                             float* d_C, int64_t c_group_stride, int64_t stride_row, int64_t stride_col, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* K split INSIDE the launch of the NT product, for few row tiles (round 5; BASELINE configs[0]: a PPI batch of 7 110 nodes is 56
  * row tiles - 56 workgroups each streaming the whole weight operand while 200 CUs idle, and the product takes as long as at
  * 30 000 nodes).  With a workspace registered here, products of at most 112 output tiles and K >= 480 launch S = 2..4

@@ -384,8 +384,8 @@ def test_gnn_stack_gradients_are_linear_in_the_loss_gradient_magnitude(dev, mp_s
 def test_rgin_compact_rows_on_grouped_split_operand_products(dev, monkeypatch, H, over):
     """Round 5 (BASELINE configs[4]): where most (source, type) pairs have no edge, RGIN's per-relation MLPs run over the non-empty
     rows as grouped products on split operands - tfgnn_sp_gemm_nt_grouped forward and input gradients (first layer through the
-    row -> node index, hidden layers writing the next operand), one split-operand TN product per relation for the kernel
-    gradients - where the bf16x3 grouped kernels ran before.  Forward, dX and every kernel gradient against fp64 autograd through
+    row -> node index, hidden layers writing the next operand), one grouped two-factor TN product per MLP layer for the kernel
+    gradients (tfgnn_sp_gemm_tn_grouped) - where the bf16x3 grouped kernels ran before.  Forward, dX and every kernel gradient against fp64 autograd through
     the oracle; ragged relation sizes (a hub among the targets).  Then the same with the kernel gradients demoted to the exact
     grouped kernel, as the stack's guard policy does for un-normalised sums spread over more than 2^20."""
     from tests.helpers import KernelsUsed
@@ -407,7 +407,8 @@ def test_rgin_compact_rows_on_grouped_split_operand_products(dev, monkeypatch, H
     with KernelsUsed() as k:
         check_layer_backward(dev, f"rgin_grouped_split_h{H}", "RGIN", over, V=V, E=0, L=L, H=H, adjs=adjs)
     layers = 2 + (1 if over.get("num_edge_MLP_hidden_layers") == 2 else 0)
-    assert k.delta["sp_nt"] >= 2 * layers and k.delta["sp_tn"] >= layers * L, k.delta
+    # (the kernel gradients of all relations of one MLP layer are ONE launch of the grouped two-factor product)
+    assert k.delta["sp_nt"] >= 2 * layers and k.delta["sp_tn"] >= layers, k.delta
     assert ops.get_gemm_mode() == ops.GEMM_F16X2 and not ops.f16x2_guard_tripped_sync()
     monkeypatch.setattr(RGIN, "_grouped_tn_split_ok", False, raising=False)
     with KernelsUsed() as k:

@@ -399,8 +399,23 @@ def test_grouped_products_on_split_operands(dev, sizes, H):
     # zeros: compare the fp16 VALUES)
     assert torch.equal(dh_sp.data.view(torch.float16).float(), ref_sp.data.view(torch.float16).float())
     assert torch.equal(dh_sp.inv_scale, ref_sp.inv_scale)
-    # group by group with the plain product: the same bits
+    # the kernel gradients of all groups in one launch (tfgnn_sp_gemm_tn_grouped): dW1_g = Xc_g^T dH_g, dW2_g = hidden_g^T dY_g
     xc_sp = ops.sp_gather_rows(x_sp, node.to(dev))
+    dY_sp = ops.sp_split_rows(dY.to(dev))
+    dW2 = ops.sp_gemm_tn_grouped(hid_sp, dY_sp, groups, torch.empty((G, H, H), device=dev)).cpu()
+    dW1 = ops.sp_gemm_tn_grouped(dh_sp, xc_sp, groups, torch.empty((G, H, H), device=dev), transposed=True).cpu()
+    # (against the fp32 values the operands were split from: in a group of one row an entry of the product is ONE a * b, and the
+    # fp32 rounding of a nearly cancelled hidden unit is not small relative to that unit)
+    dh_val, hid_val = dh32.cpu().double(), hid32.cpu().double()
+    for g in range(G):
+        sl = slice(off[g], off[g + 1])
+        for got, ref, mag in ((dW2[g], hid_val[sl].t() @ dY.double()[sl], hid_val[sl].abs().t() @ dY.double()[sl].abs()),
+                              (dW1[g], Xc[sl].t() @ dh_val[sl], Xc[sl].abs().t() @ dh_val[sl].abs())):
+            if sizes[g] == 0:
+                assert not bool(got.any())
+            else:
+                assert float(((got.double() - ref).abs() / mag.clamp(min=1e-30)).max()) <= 3e-6, g
+    # group by group with the plain product: the same bits
     assert torch.equal(xc_sp.data, x_sp.data[node.long().to(dev)]) and torch.equal(xc_sp.inv_scale, x_sp.inv_scale[node.long().to(dev)])
     for g in range(G):
         if sizes[g] == 0:
@@ -413,6 +428,58 @@ def test_grouped_products_on_split_operands(dev, sizes, H):
             assert torch.equal(ops.sp_gemm_nt(part, wg, act="relu"), hid32[sl])
         finally:
             ops.sp_gemm_nt_splitk(True)
+
+
+@pytest.mark.parametrize("K,M,N,sb", [(3000, 320, 320, 0), (777, 64, 128, 0), (5000, 512, 512, 256), (29999, 128, 128, 0), (2016 * 3 + 5, 512, 256, 128)])
+def test_gemm_tn_wide_range_form(dev, K, M, N, sb):
+    """tfgnn_sp_gemm_tn_wide (round 5): per-k factors on BOTH operands' fragments.  Same numbers as the one-factor product on
+    ordinary operands; with each operand's row scales spread over 2^18 (their products over 2^36 - the one-factor form flags
+    that and loses the small rows) the result stays within 2e-6 of sum |a||b| per entry and the guard stays quiet; a row 2^30
+    below the rest of its operand still trips it.  Also transposed scatter and accumulation."""
+    from tf2_gnn_amd import _lib, ops
+
+    lib = _lib.load()
+    ops.set_gemm_mode("f16x2")
+    gen = torch.Generator().manual_seed(K + M)
+    a = torch.randn((K, M), generator=gen)
+    b = torch.randn((K, N), generator=gen)
+
+    def run(a_, b_, **kw):
+        return ops.sp_gemm_tn(ops.sp_split_rows(a_.to(dev), scale_block=sb), ops.sp_split_rows(b_.to(dev)), wide=True, **kw).cpu()
+
+    def rel(got, a_, b_):
+        ref = a_.double().t() @ b_.double()
+        mag = a_.double().abs().t() @ b_.double().abs()
+        return float(((got.double() - ref).abs() / mag.clamp(min=1e-300)).max())
+
+    assert rel(run(a, b), a, b) <= 2e-6
+    plain = ops.sp_gemm_tn(ops.sp_split_rows(a.to(dev), scale_block=sb), ops.sp_split_rows(b.to(dev))).cpu()
+    assert float((run(a, b) - plain).abs().max()) <= 1e-5 * float(plain.abs().max())
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 0
+    # rows spread over 2^18 in EACH operand, independently
+    sa = torch.exp2(torch.randint(-18, 1, (K, 1), generator=gen).float())
+    sb_ = torch.exp2(torch.randint(-18, 1, (K, 1), generator=gen).float())
+    a2, b2 = a * sa, b * sb_
+    a2[::7] = 0.0
+    b2[3::11] = 0.0
+    assert rel(run(a2, b2), a2, b2) <= 2e-6
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 0 and ops.get_gemm_mode() == ops.GEMM_F16X2
+    out = torch.randn((N, M), generator=gen).to(dev)  # transposed, accumulating
+    base = out.clone()
+    got = ops.sp_gemm_tn(ops.sp_split_rows(a2.to(dev), scale_block=sb), ops.sp_split_rows(b2.to(dev)), wide=True, out=out,
+                         scatter=(M, 0, 1, M), accumulate=True)
+    ref = (a2.double().t() @ b2.double()).t() + base.cpu().double()
+    mag = (a2.double().abs().t() @ b2.double().abs()).t() + base.cpu().double().abs()
+    assert float(((got.cpu().double() - ref).abs() / mag).max()) <= 2e-6
+    # one operand row 2^30 below its neighbours: reported
+    a3 = a.clone()
+    a3[5] *= 2.0 ** -30
+    run(a3, b)
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 1
+    ops.set_gemm_mode("f16x2")  # re-arm
 
 
 @pytest.mark.parametrize("K,M,N", [(3000, 320, 320), (777, 64, 128), (2000, 336, 256), (30000, 320, 320), (29999, 128, 128)])

@@ -226,6 +226,19 @@ _SIGNATURES = [
     ),
     ("tfgnn_sp_gemm_tn_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int]),
     (
+        "tfgnn_sp_gemm_tn_grouped",
+        c_int,
+        [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_size_t, c_void_p],
+    ),
+    ("tfgnn_sp_gemm_tn_wide_workspace_bytes", c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int]),
+    (
+        "tfgnn_sp_gemm_tn_wide",
+        c_int,
+        [c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
+    (
         "tfgnn_sp_gemm_tn",
         c_int,
         [c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,

@@ -913,6 +913,9 @@ struct SpTnArgs {
   int64_t k_chunk;    // rows of K per split (a multiple of 16)
   unsigned n_tiles;
   unsigned tiles, splits, per_xcd;  // output tiles, K splits, workgroups per XCD (grid = 8 * per_xcd)
+  // grouped K ranges (round 5): split z multiplies rows [split_table[2 z], + split_table[2 z + 1]) - the ranges of several
+  // products over row groups of the same operands in ONE launch; the reduce pass sums each group's ranges
+  const int32_t* split_table;
 };
 
 // Per-k factors of the weight-gradient product.  Both operands carry one power-of-two scale per ROW (A one per row and
@@ -1008,9 +1011,17 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
 // stages are in flight; the ring loses the 1 KB factor slot per stage and wave 0 its extra DMA per step.
 constexpr int SP_TN_FTAB_BYTES = 20480;
 constexpr int64_t SP_TN_FIK_MAX_CHUNK = (SP_TN_FTAB_BYTES / 128 - 2) * 16;  // rows of K per split: one zeroed step + 128 B of scratch
-template <int TNW, bool FIK>
+// BSC (round 5, "wide range"): BOTH operands' fragments are scaled by per-k factors of their own - F_a[b][k] = inv_a[k, b] /
+// max_k inv_a[., b], F_b[k] = inv_b[k] / max_k inv_b - instead of ONE combined factor on the A fragments.  A row keeps >= 16
+// bits while each of its two factors is >= 2^-22, whatever their product is: the scale products of the per-relation weight
+// gradients of an un-normalised RGIN stack spread over 2^25 (2^19 and 2^21 per operand) and trip the combined-factor guard.
+// 2 TNW more packed multiplies per fragment set and step; the factor table takes 160 bytes per step (k_chunk <= 2016).
+constexpr int64_t SP_TN_BSC_MAX_CHUNK = (SP_TN_FTAB_BYTES / 160 - 2) * 16;
+template <int TNW, bool FIK, bool BSC = false>
 struct SpGeoTN : SpGeo<TNW> {
   using B0 = SpGeo<TNW>;
+  static_assert(!BSC || FIK, "the two-factor form computes its factors in the kernel");
+  static constexpr int FSTRIDE = BSC ? 160 : 128;   // bytes of factors per k16 step: [4 blocks][16 k] (+ [16 k] of B)
   static constexpr int FOFF = B0::STG;          // !FIK: per stage the factors of the step, [<= 4 blocks][16 k] fp16 (1 KB slot)
   static constexpr int STG = B0::STG + (FIK ? 0 : 1024);
   static constexpr int ND = B0::ND + (FIK ? 0 : 1);  // !FIK: wave 0 also fetches the factor slot; the other waves issue ND - 1 DMAs
@@ -1025,9 +1036,9 @@ struct SpGeoTN : SpGeo<TNW> {
   static_assert(4 * 32 * B0::PATCH_LD * 4 <= NST * STG, "epilogue patch must fit the ring");
 };
 
-template <int TNW, bool FIK>
+template <int TNW, bool FIK, bool BSC = false>
 struct SpLoopTN {
-  using G = SpGeoTN<TNW, FIK>;
+  using G = SpGeoTN<TNW, FIK, BSC>;
   static constexpr int KGB_A = 2048, KGB_B = TNW * 1024;  // bytes per 4-row group: A (4 granule pairs), B (2 TNW pairs)
   half8 (&fa)[2][2][2];
   half8 (&fb)[2][TNW][2];
@@ -1063,21 +1074,29 @@ struct SpLoopTN {
   // are read at its first item, every fragment is scaled a few MFMAs after its read was issued - VALU work in the
   // shadow of the matrix pipe (all of it after the last MFMA of the step cost 40 us of a 125 us launch).
   half8 fvA[2];
+  half8 fvB;          // BSC: the factors of B's rows (this lane's 8 k)
+  unsigned fb_addr;   // BSC: LDS address (step 0) of those
   template <int ST>
   __device__ __forceinline__ void load_factors(int step) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // FIK: the table entry of the step (128 bytes per step; steps past the end read the zeroed tail); else the stage's slot
-    const unsigned off = FIK ? (unsigned)step * 128u : (unsigned)(ST * G::STG);
+    // FIK: the table entry of the step (FSTRIDE bytes per step; steps past the end read the zeroed tail); else the stage's slot
+    const unsigned off = FIK ? (unsigned)step * (unsigned)G::FSTRIDE : (unsigned)(ST * G::STG);
     fvA[0] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[0] + off));
     fvA[1] = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(f_addr[1] + off));
+    if constexpr (BSC) fvB = *reinterpret_cast<const __attribute__((address_space(3))) half8*>((uintptr_t)(fb_addr + off));
 #else
     (void)step;
 #endif
   }
   template <int I, int SET>
-  __device__ __forceinline__ void scale_one() {  // I < 4: the A fragments
-    constexpr int t = I >> 1, p = I & 1;
-    fa[SET][t][p] = fa[SET][t][p] * fvA[t];
+  __device__ __forceinline__ void scale_one() {  // I < 4: the A fragments; BSC: I - 4 = the B fragments
+    if constexpr (I < 4) {
+      constexpr int t = I >> 1, p = I & 1;
+      fa[SET][t][p] = fa[SET][t][p] * fvA[t];
+    } else {
+      constexpr int c = (I - 4) >> 1, p = (I - 4) & 1;
+      fb[SET][c][p] = fb[SET][c][p] * fvB;
+    }
   }
   template <int I, int N, int SET>
   __device__ __forceinline__ void scale_all() {
@@ -1124,8 +1143,9 @@ struct SpLoopTN {
   }
   static constexpr int NR = 4 + 2 * TNW;  // fragments per step (two tr reads each)
   static constexpr int NM = 6 * TNW;
-  static constexpr int SLAG = NM - 4 < 10 ? NM - 4 : 10;  // an A fragment (the first four reads) is scaled SLAG items
-  static_assert(4 + SLAG <= NM, "issue pattern");          // (MFMAs) after its read was issued: the LDS round trip is over
+  static constexpr int SLAG0 = NM - 4 < 10 ? NM - 4 : 10;  // an A fragment (the first four reads) is scaled SLAG items
+  static constexpr int SLAG = BSC ? (SLAG0 < NM - NR ? SLAG0 : NM - NR) : SLAG0;  // (BSC: every fragment is scaled)
+  static_assert((BSC ? NR : 4) + SLAG <= NM, "issue pattern");  // (MFMAs) after its read was issued: the LDS round trip is over
   template <int S, int I>
   __device__ __forceinline__ void step_items(int sbase) {
     if constexpr (I < NM) {
@@ -1135,7 +1155,7 @@ struct SpLoopTN {
       else if constexpr (I < NR + G::ND) dma_one<I - NR, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
       if constexpr (I == NM - 1 && NM - NR < G::ND)  // narrow tiles: fewer bare MFMAs than DMAs - the rest goes last
         dma_all<NM - NR, G::ND, ((S + G::NST - 1) % G::NST)>(sbase + S + G::NST - 1);
-      if constexpr (I >= SLAG && I < 4 + SLAG) scale_one<I - SLAG, ((S + 1) & 1)>();
+      if constexpr (I >= SLAG && I < (BSC ? NR : 4) + SLAG) scale_one<I - SLAG, ((S + 1) & 1)>();
       __builtin_amdgcn_sched_barrier(0);
       step_items<S, I + 1>(sbase);
     }
@@ -1167,10 +1187,10 @@ struct SpLoopTN {
   }
 };
 
-template <int TNW, bool FIK>
+template <int TNW, bool FIK, bool BSC = false>
 __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
-  using G = SpGeoTN<TNW, FIK>;
-  using LP = SpLoopTN<TNW, FIK>;
+  using G = SpGeoTN<TNW, FIK, BSC>;
+  using LP = SpLoopTN<TNW, FIK, BSC>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1188,8 +1208,12 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   const unsigned tile_m = tile / g.n_tiles;
   const int64_t row0 = (int64_t)tile_m * SP_BM;   // first column of A (= output row)
   const int64_t col0 = (int64_t)tile_n * G::BN;   // first column of B (= output column)
-  const int64_t k0 = (int64_t)split * g.k_chunk;
-  const int64_t krows = g.K - k0 < g.k_chunk ? g.K - k0 : g.k_chunk;
+  int64_t k0 = (int64_t)split * g.k_chunk;
+  int64_t krows = g.K - k0 < g.k_chunk ? g.K - k0 : g.k_chunk;
+  if (g.split_table) {
+    k0 = __builtin_amdgcn_readfirstlane(g.split_table[2 * split]);
+    krows = __builtin_amdgcn_readfirstlane(g.split_table[2 * split + 1]);
+  }
   const int nsteps = (int)((krows + 15) >> 4);
 
   auto make_rsrc = [](const uint8_t* p, int64_t bytes) {
@@ -1264,6 +1288,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
       const int blk = min((int)((g.a_col0 + row0 + wm * 64 + t * 32 + fi) / g.a_sb), blk_last) - blk_first;
       L.f_addr[t] = lds_base + (unsigned)((FIK ? G::FTAB : G::FOFF) + blk * 32 + kg * 16);
     }
+    L.fb_addr = lds_base + (unsigned)(G::FTAB + 128 + kg * 16);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -1283,11 +1308,25 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
     float* fref = reinterpret_cast<float*>(lds + G::FTAB + SP_TN_FTAB_BYTES - 64);            // 1 / reference of block j
     const int64_t kpad = (int64_t)(nsteps + 1) * 16;  // one zeroed step past the end: the loop reads the factors one step ahead
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    float mxb = 0.f;  // BSC: the largest scale of B's rows (all-zero rows carry the marker 2^-126: never the maximum of a range
+                      // that holds anything)
     for (int64_t k = tid; k < krows; k += SP_NT) {
       const float ib = g.inv_b ? g.inv_b[k0 + k] : 1.f;
+      if constexpr (BSC) mxb = fmaxf(mxb, ib);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nb) mx[j] = fmaxf(mx[j], g.inv_a[(k0 + k) * g.a_nblk + blk_first + j] * ib);
+        if (j < nb) mx[j] = fmaxf(mx[j], g.inv_a[(k0 + k) * g.a_nblk + blk_first + j] * (BSC ? 1.f : ib));
+    }
+    float frefb = 1.f;
+    if constexpr (BSC) {
+      float* fmb = reinterpret_cast<float*>(lds + G::FTAB + SP_TN_FTAB_BYTES - 160);  // [4 waves]
+#pragma unroll
+      for (int o = 32; o; o >>= 1) mxb = fmaxf(mxb, __shfl_xor(mxb, o, 64));
+      if (lane == 0) fmb[wave] = mxb;
+      __syncthreads();
+      mxb = fmaxf(fmaxf(fmb[0], fmb[1]), fmaxf(fmb[2], fmb[3]));
+      if (mxb == 0.f) mxb = 1.f;
+      frefb = 1.f / mxb;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1300,23 +1339,31 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
       float m = fmaxf(fmaxf(fmx[0][tid], fmx[1][tid]), fmaxf(fmx[2][tid], fmx[3][tid]));
       if (m == 0.f) m = 1.f;
       fref[tid] = 1.f / m;  // a power of two: exact
-      // every tile of the split that touches the block writes the same value
-      if (tid < nb) g.ref_split[(int64_t)split * g.a_nblk + blk_first + tid] = m;
+      // every tile of the split that touches the block writes the same value (BSC: the product of the two references)
+      if (tid < nb) g.ref_split[(int64_t)split * g.a_nblk + blk_first + tid] = BSC ? m * mxb : m;
     }
     __syncthreads();
     bool wide = false;
+    constexpr int FH = G::FSTRIDE / 2;  // fp16 per step of the table
     for (int64_t k = tid; k < kpad; k += SP_NT) {
       const float ib = (k < krows && g.inv_b) ? g.inv_b[k0 + k] : 1.f;
+      if constexpr (BSC) {
+        const float fbv = k < krows ? ib * frefb : 0.f;
+        ftab[(k >> 4) * FH + 64 + (k & 15)] = (_Float16)fbv;
+        // a non-zero row of B more than 2^22 below the largest of the range (>= 16 bits are left above that)
+        wide |= k < krows && fbv < 2.384185791015625e-07f && ib > 1.2e-38f;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float f = 0.f, ia = 0.f;
         if (j < nb && k < krows) {
           ia = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j];
-          f = ia * ib * fref[j];  // powers of two: exact
+          f = BSC ? ia * fref[j] : ia * ib * fref[j];  // powers of two: exact
         }
-        ftab[(k >> 4) * 64 + j * 16 + (k & 15)] = (_Float16)f;
-        // the spread guard (see sp_tn_factors_kernel), relative to the largest scale product of THIS K range
-        wide |= sp_row_too_small(f, ia, ib);
+        ftab[(k >> 4) * FH + j * 16 + (k & 15)] = (_Float16)f;
+        // the spread guard (see sp_tn_factors_kernel), relative to the largest scale (product) of THIS K range
+        if constexpr (BSC) wide |= j < nb && k < krows && f < 2.384185791015625e-07f && ia > 1.2e-38f;
+        else wide |= sp_row_too_small(f, ia, ib);
       }
     }
     if (g.spread_flag && __any(wide) && lane == 0) *g.spread_flag = 1;
@@ -1326,7 +1373,7 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
   __builtin_amdgcn_sched_barrier(0);
   L.template load_factors<0>(0);
   L.template read_all<0, NR, 0, 0>();
-  L.template scale_all<0, 4, 0>();
+  L.template scale_all<0, (BSC ? NR : 4), 0>();
   __builtin_amdgcn_sched_barrier(0);
   for (int s = 0; s < nsteps; s += G::UNR) L.template steps<0>(s);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -1363,6 +1410,17 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
 }
 
 __global__ void __launch_bounds__(256) sp_tn_reduce_kernel(AuxTnReduce a) { sp_tn_reduce_body(a, blockIdx.x, gridDim.x); }
+// blockIdx.y = row group: the K ranges [split_off[g], split_off[g + 1]) of the grouped product belong to output g
+__global__ void __launch_bounds__(256) sp_tn_reduce_grouped_kernel(AuxTnReduce a, const int32_t* __restrict__ split_off,
+                                                                   int64_t c_group_stride) {
+  const int gq = blockIdx.y;
+  const int s0 = split_off[gq], s1 = split_off[gq + 1];
+  a.partial += (int64_t)s0 * a.slab;
+  a.ref += (int64_t)s0 * a.ref_ld;
+  a.splits = s1 - s0;
+  a.C += (int64_t)gq * c_group_stride;
+  sp_tn_reduce_body(a, blockIdx.x, gridDim.x);
+}
 
 static int sp_tn_splits(int64_t M, int64_t N, int64_t K, int bn) {
   const int64_t tiles = (M / SP_BM) * (N / bn);
@@ -1738,13 +1796,23 @@ int tfgnn_sp_gemm_nt_grouped(int64_t M, int64_t N, int64_t K, const void* d_A_sp
                          b_group_stride_bytes, b_scale_group_stride);
 }
 
-size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
+static size_t sp_gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block, bool wide) {
   const int bn = sp_tile_width(N);
   if (!bn || M <= 0 || a_scale_block <= 0) return 0;
   const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
   const int64_t nblk = ceil_div(a_total_cols, a_scale_block), kpad = (K + 15) & ~15ll;
   const size_t factors = (((size_t)nblk * kpad * 2 + 255) & ~(size_t)255) + (((size_t)nblk * (1 + SP_TN_MAXCHUNKS + 512) * 4 + 255) & ~(size_t)255);
-  return factors + (size_t)sp_tn_splits(Mp, N, K, bn) * (size_t)Mp * (size_t)N * 4;
+  int64_t splits = sp_tn_splits(Mp, N, K, bn);
+  if (wide) splits = std::max<int64_t>(splits, ceil_div(K, SP_TN_BSC_MAX_CHUNK));
+  return factors + (size_t)splits * (size_t)Mp * (size_t)N * 4;
+}
+
+size_t tfgnn_sp_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
+  return sp_gemm_tn_ws_bytes(M, N, K, a_total_cols, a_scale_block, false);
+}
+
+size_t tfgnn_sp_gemm_tn_wide_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t a_total_cols, int a_scale_block) {
+  return sp_gemm_tn_ws_bytes(M, N, K, a_total_cols, a_scale_block, true);
 }
 
 static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
@@ -1752,7 +1820,7 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
                            int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
                            int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
                            size_t workspace_bytes, void* stream, tfgnn_aux_job* reduce_job = nullptr,
-                           tfgnn_aux_job* factors_job = nullptr) {
+                           tfgnn_aux_job* factors_job = nullptr, bool wide = false) {
   TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale, "tfgnn_sp_gemm_tn: null pointer");
   TFGNN_REQUIRE(M > 0 && N > 0 && K > 0, "tfgnn_sp_gemm_tn: empty product");
   const int bn = sp_tile_width(N);
@@ -1772,7 +1840,12 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   TFGNN_REQUIRE(group_rows > 0, "tfgnn_sp_gemm_tn: group_rows must be positive");
   TFGNN_REQUIRE(a_scale_block >= 48 || a_first_col % a_scale_block == 0,
                 "tfgnn_sp_gemm_tn: 32-column scale blocks need a block-aligned first column (at most 4 blocks per 128-column tile)");
-  const int splits = sp_tn_splits(Mp, N, K, bn);
+  int splits = sp_tn_splits(Mp, N, K, bn);
+  if (wide) {  // two-factor form: factors in the kernel, K ranges of at most SP_TN_BSC_MAX_CHUNK rows
+    splits = (int)std::max<int64_t>(splits, ceil_div(K, SP_TN_BSC_MAX_CHUNK));
+    TFGNN_REQUIRE(splits <= 512 && (phases == (1 | 2 | 4) || phases == (1 | 2 | 8)) && d_b_inv_scale,
+                  "tfgnn_sp_gemm_tn_wide: K too large (more than 512 ranges of 2016 rows), or no scales of B");
+  }
   const int64_t nblk = a_total_cols / a_scale_block, kpad = (K + 15) & ~15ll;
   const size_t f_bytes = ((size_t)nblk * kpad * 2 + 255) & ~(size_t)255, r_bytes = ((size_t)nblk * (1 + SP_TN_MAXCHUNKS + 512) * 4 + 255) & ~(size_t)255;
   const size_t need = f_bytes + r_bytes + (size_t)splits * (size_t)Mp * (size_t)N * 4;
@@ -1785,7 +1858,8 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   static const bool fik_env = [] { const char* e = getenv("TFGNN_TN_FIK"); return !e || atoi(e) != 0; }();
   const int64_t steps_all = (K + 15) / 16;
   const int64_t k_chunk_all = ((steps_all + splits - 1) / splits) * 16;
-  const bool fik = fik_env && k_chunk_all <= SP_TN_FIK_MAX_CHUNK && splits <= 512;
+  const bool fik = wide || (fik_env && k_chunk_all <= SP_TN_FIK_MAX_CHUNK && splits <= 512);
+  TFGNN_REQUIRE(!wide || k_chunk_all <= SP_TN_BSC_MAX_CHUNK, "tfgnn_sp_gemm_tn_wide: K range too long");
   float* ref_split = ref + nblk * (1 + SP_TN_MAXCHUNKS);  // [splits][nblk]
   if (fik) phases &= ~(1 | 16);
   if ((phases & 16) && factors_job) factors_job->kind = 0, factors_job->num_blocks = 0;
@@ -1822,21 +1896,25 @@ static int sp_gemm_tn_impl(int phases, int64_t M, int64_t N, int64_t K, const vo
   g.splits = (unsigned)splits_used;
   g.per_xcd = (g.tiles * g.splits + 7) / 8;
   dim3 grid(8 * g.per_xcd);
-#define SP_LAUNCH_TN(T, FK)                                                                                        \
+#define SP_LAUNCH_TN(T, FK, ...)                                                                                   \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
-    using TnGeo = SpGeoTN<T, FK>;                                                                                  \
+    using TnGeo = SpGeoTN<T, FK, ##__VA_ARGS__>;                                                                   \
     constexpr int tn_lds = TnGeo::LDS_BYTES;                                                                       \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                tn_lds);                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T, FK, ##__VA_ARGS__>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, tn_lds);                               \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_sp_tn_kernel<T, FK>), grid, dim3(SP_NT), tn_lds, s, g);                               \
+    hipLaunchKernelGGL((gemm_sp_tn_kernel<T, FK, ##__VA_ARGS__>), grid, dim3(SP_NT), tn_lds, s, g);                \
   } while (0)
   if (phases & 2) {
     count_launch(TFGNN_KFAM_SP_TN);
-    if (fik) {
+    if (wide) {
+      if (bn == 320) SP_LAUNCH_TN(5, true, true);
+      else if (bn == 256) SP_LAUNCH_TN(4, true, true);
+      else SP_LAUNCH_TN(2, true, true);
+    } else if (fik) {
       if (bn == 320) SP_LAUNCH_TN(5, true);
       else if (bn == 256) SP_LAUNCH_TN(4, true);
       else SP_LAUNCH_TN(2, true);
@@ -1874,6 +1952,86 @@ int tfgnn_sp_gemm_tn(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_
   return sp_gemm_tn_impl(7, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block, d_B_sp, ldb_bytes,
                          b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate, d_workspace,
                          workspace_bytes, stream);
+}
+
+int tfgnn_sp_gemm_tn_wide(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,
+                          const float* d_a_inv_scale, int64_t a_total_cols, int a_scale_block, const void* d_B_sp,
+                          int64_t ldb_bytes, int64_t b_first_col, const float* d_b_inv_scale, float* d_C, int64_t group_rows,
+                          int64_t stride_group, int64_t stride_row, int64_t stride_col, int accumulate, void* d_workspace,
+                          size_t workspace_bytes, tfgnn_aux_job* reduce_job, void* stream) {
+  return sp_gemm_tn_impl(reduce_job ? (1 | 2 | 8) : 7, M, N, K, d_A_sp, lda_bytes, a_first_col, d_a_inv_scale, a_total_cols, a_scale_block,
+                         d_B_sp, ldb_bytes, b_first_col, d_b_inv_scale, d_C, group_rows, stride_group, stride_row, stride_col, accumulate,
+                         d_workspace, workspace_bytes, stream, reduce_job, nullptr, true);
+}
+
+int tfgnn_sp_gemm_tn_grouped(int64_t M, int64_t N, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,
+                             int64_t a_total_cols, int a_scale_block, const void* d_B_sp, int64_t ldb_bytes, const float* d_b_inv_scale,
+                             int num_groups, const int32_t* d_group_split_offsets, int num_splits, const int32_t* d_split_table,
+                             float* d_C, int64_t c_group_stride, int64_t stride_row, int64_t stride_col, void* d_workspace,
+                             size_t workspace_bytes, void* stream) {
+  TFGNN_REQUIRE(d_A_sp && d_B_sp && d_C && d_a_inv_scale && d_b_inv_scale && d_group_split_offsets && d_split_table,
+                "tfgnn_sp_gemm_tn_grouped: null pointer");
+  TFGNN_REQUIRE(M > 0 && N > 0 && num_groups >= 1 && num_splits >= 0 && num_splits <= 512, "tfgnn_sp_gemm_tn_grouped: 1.. groups, at most 512 K ranges");
+  const int bn = sp_tile_width(N);
+  if (!bn || M % 16 || a_scale_block < 32) {
+    set_error("tfgnn_sp_gemm_tn_grouped: M = %lld must be a multiple of 16, N = %lld of 128, scale blocks of A >= 32 columns",
+              (long long)M, (long long)N);
+    return TFGNN_ERR_UNSUPPORTED;
+  }
+  const int64_t Mp = ceil_div(M, SP_BM) * SP_BM;
+  TFGNN_REQUIRE(lda_bytes % 64 == 0 && ldb_bytes % 64 == 0 && (uintptr_t)d_A_sp % 64 == 0 && (uintptr_t)d_B_sp % 64 == 0 &&
+                    lda_bytes >= M * 4 && ldb_bytes >= N * 4 && a_total_cols >= M && a_total_cols % a_scale_block == 0,
+                "tfgnn_sp_gemm_tn_grouped: SP16 operands must be 64-byte aligned with rows wide enough");
+  const int64_t nblk = a_total_cols / a_scale_block;
+  const size_t r_bytes = ((size_t)nblk * 512 * 4 + 255) & ~(size_t)255;
+  const size_t need = r_bytes + (size_t)num_splits * (size_t)Mp * (size_t)N * 4;
+  TFGNN_REQUIRE(d_workspace && workspace_bytes >= need && (uintptr_t)d_workspace % 256 == 0,
+                "tfgnn_sp_gemm_tn_grouped: workspace too small or unaligned (need %zu bytes)", need);
+  hipStream_t s = (hipStream_t)stream;
+  float* ref_split = (float*)d_workspace;  // [num_splits][nblk]
+  SpTnArgs g{};
+  g.M = Mp; g.N = N; g.K = 0;
+  g.A = (const uint8_t*)d_A_sp; g.lda = lda_bytes;
+  g.B = (const uint8_t*)d_B_sp; g.ldb = ldb_bytes;
+  g.a_sb = a_scale_block; g.a_col0 = 0; g.a_nblk = (int)nblk;
+  g.inv_a = d_a_inv_scale; g.inv_b = d_b_inv_scale; g.ref_split = ref_split; g.spread_flag = sp_spread_flag_device();
+  g.partial = (float*)((uint8_t*)d_workspace + r_bytes);
+  g.k_chunk = SP_TN_BSC_MAX_CHUNK;
+  g.split_table = d_split_table;
+  g.n_tiles = (unsigned)(N / bn);
+  g.tiles = (unsigned)((Mp / SP_BM) * g.n_tiles);
+  g.splits = (unsigned)num_splits;
+  g.per_xcd = (g.tiles * g.splits + 7) / 8;
+  if (num_splits > 0) {
+    dim3 grid(8 * g.per_xcd);
+    count_launch(TFGNN_KFAM_SP_TN);
+#define SP_LAUNCH_TNG(T)                                                                                             \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    using TnGeo = SpGeoTN<T, true, true>;                                                                            \
+    constexpr int tn_lds = TnGeo::LDS_BYTES;                                                                         \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_sp_tn_kernel<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, tn_lds); \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_sp_tn_kernel<T, true, true>), grid, dim3(SP_NT), tn_lds, s, g);                         \
+  } while (0)
+    if (bn == 320) SP_LAUNCH_TNG(5);
+    else if (bn == 256) SP_LAUNCH_TNG(4);
+    else SP_LAUNCH_TNG(2);
+#undef SP_LAUNCH_TNG
+    TFGNN_LAUNCH_CHECK();
+  }
+  AuxTnReduce ra{};
+  ra.partial = g.partial; ra.splits = 0; ra.M = M; ra.N = N; ra.ref = ref_split; ra.a_col0 = 0; ra.a_sb = a_scale_block;
+  ra.ref_ld = (int)nblk;
+  ra.C = d_C; ra.group_rows = M; ra.stride_group = 0; ra.stride_row = stride_row; ra.stride_col = stride_col;
+  ra.accumulate = 0; ra.slab = Mp * N;
+  const unsigned rblocks = (unsigned)std::min<int64_t>(ceil_div(M * N, 256), 512);
+  hipLaunchKernelGGL(sp_tn_reduce_grouped_kernel, dim3(rblocks, (unsigned)num_groups), dim3(256), 0, s, ra, d_group_split_offsets,
+                     c_group_stride);
+  TFGNN_LAUNCH_CHECK();
+  return TFGNN_OK;
 }
 
 int tfgnn_sp_gemm_tn_phase(int phases, int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, int64_t a_first_col,

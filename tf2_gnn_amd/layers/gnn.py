@@ -473,17 +473,17 @@ class GNN:
             self.guard_tripped_last_backward = False
             with ops.hold_spread_guard():
                 result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
-                for attempt in range(2):
+                for attempt in range(3):
                     if not ops.f16x2_guard_tripped_sync():
                         break
                     self.guard_tripped_last_backward = True
-                    if attempt == 0 and self._demote_fragile_weight_gradients():
+                    what = self._demote_fragile_weight_gradients() if attempt < 2 else None
+                    if what:
                         ops.rearm_spread_guard()
                         import warnings
 
-                        warnings.warn("tf2_gnn_amd: the Dense / projection (and per-relation MLP) weight gradients of this GNN have operand "
-                                      "rows spread over more than 2^20; these products take the exact bf16x3 kernels from here on (the pass "
-                                      "was recomputed)")
+                        warnings.warn(f"tf2_gnn_amd: {what} of this GNN have operand rows spread beyond the range of the "
+                                      "split-operand product; they take the exact bf16x3 kernels from here on (the pass was recomputed)")
                     else:
                         ops.demote_gemm_mode()  # the whole mode (sticky), with a warning
                     for v in self.trainable_variables:
@@ -497,21 +497,22 @@ class GNN:
             ops.aux_flush()        # the deferred split reductions of the weight gradients: one launch for all layers
             ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
 
-    def _demote_fragile_weight_gradients(self) -> bool:
-        """First stage of the spread guard's policy: the weight-gradient products whose operand ROWS are un-normalised sums -
-        this stack's Dense / projection products and the per-relation TN products of the compact-row MLP path (RGIN,
-        GNN_Edge_MLP) - go to the exact kernels; the message products keep their split operands.  -> anything demoted?"""
-        did = False
+    def _demote_fragile_weight_gradients(self) -> Optional[str]:
+        """The stages of the spread guard's policy before the whole mode is demoted: the weight-gradient products whose operand
+        ROWS are un-normalised sums go to the exact kernels, one family per call - first this stack's Dense / projection
+        products (combined-factor TN product, range 2^20), then the per-relation TN products of the compact-row MLP path
+        (RGIN, GNN_Edge_MLP: the two-factor product, range 2^22 per operand); the message products keep their split operands.
+        -> what was demoted, or None when nothing is left to demote."""
         if self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
             self._dense_split_ok = False
             self._dense_demoted_epoch = ops.REARM_EPOCH[0]
-            did = True
+            return "the Dense / projection weight gradients"
+        did = False
         for mp in self._mp_layers:
-            if getattr(mp, "_grouped_tn_split_ok", None) is not False and hasattr(mp, "_backward_B_compact_split"):
-                if getattr(mp, "_grouped_tn_used", False):
-                    mp._grouped_tn_split_ok = False
-                    did = True
-        return did
+            if getattr(mp, "_grouped_tn_used", False) and getattr(mp, "_grouped_tn_split_ok", True):
+                mp._grouped_tn_split_ok = False
+                did = True
+        return "the per-relation MLP weight gradients" if did else None
 
     @staticmethod
     def _activation_backward_scaled(act, g, saved, saved_scale):

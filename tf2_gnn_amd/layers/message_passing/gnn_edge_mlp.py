@@ -664,18 +664,13 @@ class GNN_Edge_MLP(MessagePassing):
                 # blocks of a column tile), the gradient for j = 0 (then the transpose is stored)
                 dW = torch.empty_like(W)
                 left_is_input = inp_sp.scale_block != inp_sp.cols or d_sp.scale_block == d_sp.cols
-                for l in range(groups.num_groups):
-                    r0, r1 = off[l], off[l + 1]
-                    if r1 == r0:
-                        dW[l].zero_()
-                        continue
-                    a_l = ops.SplitOperand(inp_sp.data[r0:r1], inp_sp.inv_scale[r0:r1], r1 - r0, inp_sp.cols, inp_sp.scale_block)
-                    b_l = ops.SplitOperand(d_sp.data[r0:r1], d_sp.inv_scale[r0:r1], r1 - r0, d_sp.cols, d_sp.scale_block)
-                    if left_is_input:
-                        ops.sp_gemm_tn(a_l, b_l, out=dW[l], defer_reduce=True)
-                    else:  # (d_l^T inp_l)^T: element (m, n) of the product is dW_l[n, m]
-                        ops.sp_gemm_tn(b_l, a_l, out=dW[l], scatter=(b_l.cols, 0, 1, W.shape[2]), defer_reduce=True)
-                ops.aux_flush()  # the relations' split reductions, eight per launch: dW is complete from here on
+                # all relations in ONE launch of the two-factor ("wide range") product: both operands' rows are un-normalised
+                # sums, the guard looks at each operand's own spread inside a K range of <= 2016 rows (a launch per relation
+                # cost as much as the exact grouped kernel: 40 small products, 40 reductions)
+                if left_is_input:
+                    ops.sp_gemm_tn_grouped(inp_sp, d_sp, groups, dW)
+                else:  # (d_l^T inp_l)^T: element (m, n) of the product is dW_l[n, m]
+                    ops.sp_gemm_tn_grouped(d_sp, inp_sp, groups, dW, transposed=True)
                 grads[j] = dW
             wr = ops.sp_weight_operand(W, "grouped_rows", lambda W=W: ops.sp_split_rows(W.view(W.shape[0] * W.shape[1], W.shape[2])))
             dcur32, d_sp = ops.sp_gemm_nt_grouped(d_sp, wr, groups, act_grad=("relu", acts[j - 1]) if j > 0 else None,

@@ -1378,6 +1378,27 @@ class RowGroups:
         self.num_tiles = len(rows)
         tab = np.asarray(rows if rows else [(0, 0, 0, 0)], dtype=np.int32)
         self.table = torch.from_numpy(tab).to(device)
+        self._tn = None
+
+    def tn_tables(self):
+        """-> (K ranges int32 [S, 2] = (first row, rows <= TN_GROUPED_MAX_CHUNK), first range of every group int32 [G + 1], S):
+        the row groups cut into the K ranges of the grouped weight-gradient product (tfgnn_sp_gemm_tn_grouped)"""
+        if self._tn is None:
+            import numpy as np
+
+            ranges, first = [], [0]
+            for gi in range(self.num_groups):
+                r0, r1 = self.offsets[gi], self.offsets[gi + 1]
+                n = -(-(r1 - r0) // TN_GROUPED_MAX_CHUNK)
+                if n:
+                    chunk = -(-(-(-(r1 - r0) // n)) // 16) * 16  # equal shares, whole k16 steps
+                    for r in range(r0, r1, chunk):
+                        ranges.append((r, min(chunk, r1 - r)))
+                first.append(len(ranges))
+            dev = self.table.device
+            self._tn = (torch.from_numpy(np.asarray(ranges if ranges else [(0, 0)], dtype=np.int32)).to(dev),
+                        torch.from_numpy(np.asarray(first, dtype=np.int32)).to(dev), len(ranges))
+        return self._tn
 
 
 def sp_gemm_nt_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, *, a_rows=None, act=ACT_NONE, act_grad=None,
@@ -1426,6 +1447,31 @@ def sp_gemm_nt_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, *, a
     if out is not None and op is not None:
         _remember_split_rows(out, op)
     return out, op
+
+
+TN_GROUPED_MAX_CHUNK = 2016  # rows of a K range of the wide-range product (gemm_sp.hip SP_TN_BSC_MAX_CHUNK)
+
+
+def sp_gemm_tn_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, out: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """out[g] = a_g^T b_g over the rows of group g, all groups in ONE launch of the wide-range product (tfgnn_sp_gemm_tn_grouped):
+    ``a`` [rows, M] with per-(row, block) scales, ``b`` [rows, N] with one scale per row, out [G, M, N] (transposed: [G, N, M],
+    element (m, n) of product g at out[g, n, m])."""
+    lib = _lib.load()
+    if a.scale_block <= 0 or b.scale_block != b.cols or a.rows != b.rows or a.rows != groups.num_rows:
+        raise ValueError("sp_gemm_tn_grouped: operands must share the grouped rows; b needs one scale per row")
+    M, N, G = a.cols, b.cols, groups.num_groups
+    if not out.is_contiguous() or out.numel() != G * M * N:
+        raise ValueError("sp_gemm_tn_grouped: out must be contiguous [G, M, N]")
+    tab = groups.tn_tables()
+    nblk = a.cols // a.scale_block
+    ws_bytes = ((nblk * 512 * 4 + 255) & ~255) + tab[2] * ((M + 127) // 128 * 128) * N * 4 + 256
+    ws = _workspace(a.data.device, ws_bytes)
+    off = (-ws.data_ptr()) % 256
+    sr, sc = (1, M) if transposed else (N, 1)
+    _lib.check(lib.tfgnn_sp_gemm_tn_grouped(M, N, _ptr(a.data), a.data.stride(0), _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
+                                            b.data.stride(0), _ptr(b.inv_scale), G, _ptr(tab[1]), tab[2], _ptr(tab[0]), _ptr(out), M * N, sr, sc,
+                                            ctypes.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()))
+    return out
 
 
 def sp_gather_rows(a: SplitOperand, index: torch.Tensor) -> SplitOperand:
@@ -1586,11 +1632,13 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
 
 @_writes_out
 def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
-               scatter=None, accumulate: bool = False, defer_reduce: bool = False) -> torch.Tensor:
+               scatter=None, accumulate: bool = False, defer_reduce: bool = False, wide: bool = False) -> torch.Tensor:
     """C[m, n] = sum_k a[k, a0 + m] * b[k, b0 + n] (tfgnn_sp_gemm_tn).  ``a`` carries one scale per (row, block),
     ``b`` one per row - what sp_split_rows / graph_gather_sp write.  ``a_cols`` / ``b_cols`` = (first column, count)
     select column ranges.  ``scatter`` = (group_rows, stride_group, stride_row, stride_col) writes element (m, n) at
-    out.flatten()[(m // group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col]; default: row-major."""
+    out.flatten()[(m // group_rows) * stride_group + (m % group_rows) * stride_row + n * stride_col]; default: row-major.
+    wide: the two-factor form (tfgnn_sp_gemm_tn_wide) - each operand's row scales may spread over 2^22 within a K range,
+    whatever their products do (rows that are un-normalised sums on both sides)."""
     lib = _lib.load()
     if a.scale_block <= 0 or b.scale_block != b.cols:
         raise ValueError("sp_gemm_tn: the left operand needs per-(row, block) scales, the right one one scale per row")
@@ -1606,7 +1654,7 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
     if not out.is_contiguous() or out.numel() != M * N:
         raise ValueError(f"out must be contiguous with {M * N} elements")
     gr, sg, sr, sc = scatter if scatter is not None else (M, 0, N, 1)
-    ws_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(M, N, K, a.cols, a.scale_block)
+    ws_bytes = (lib.tfgnn_sp_gemm_tn_wide_workspace_bytes if wide else lib.tfgnn_sp_gemm_tn_workspace_bytes)(M, N, K, a.cols, a.scale_block)
     defer_reduce = bool(defer_reduce) and aux_enabled() and ws_bytes > 0
     if defer_reduce:
         # ``out`` is complete only after the next aux_flush(): a weight gradient is not read before the end of the backward pass,
@@ -1618,6 +1666,16 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
     if ws is not None:
         off = (-ws.data_ptr()) % 256
         ws_ptr, ws_len = ctypes.c_void_p(ws.data_ptr() + off), ws.numel() - off
+    if wide:
+        args = (M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
+                b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len)
+        if defer_reduce:
+            rjob = _lib.AuxJob()
+            _lib.check(lib.tfgnn_sp_gemm_tn_wide(*args, ctypes.byref(rjob), _stream()))
+            aux_defer(rjob, keep=(ws, out, a.data, a.inv_scale, b.data, b.inv_scale), urgent=False)
+        else:
+            _lib.check(lib.tfgnn_sp_gemm_tn_wide(*args, None, _stream()))
+        return out
     if defer_reduce:
         args = (M, N, K, _ptr(a.data), a.data.stride(0), a0, _ptr(a.inv_scale), a.cols, a.scale_block, _ptr(b.data),
                 b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len)
