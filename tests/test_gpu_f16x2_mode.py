@@ -326,6 +326,23 @@ def test_layer_training_step_at_loss_gradient_magnitudes(dev, name, cls_name, ov
     _assert_mode_kept()
 
 
+def test_edge_mlp_first_layer_gradients_run_on_split_operands(dev, monkeypatch):
+    """Round 5 (BASELINE configs[3], GNN_Edge_MLP with target states): the gradients of the first per-edge MLP layer - both halves,
+    source and target states - as SP16-writing typed gathers + split-operand NT / two-factor TN products where two fp32 gathers
+    and four bf16x3 products ran; same fp64 parity bound as the route it replaces (TFGNN_EDGE_FIRST_LAYER_F16X2=0)."""
+    from tests.helpers import KernelsUsed
+    from tf2_gnn_amd import ops
+
+    with KernelsUsed() as k:
+        check_layer_backward(dev, "edge_mlp_first_layer_split", "GNN_Edge_MLP", {}, V=384, E=4200, L=5, H=128)
+    assert k.delta["gather_sp"] >= 2 and k.delta["sp_tn"] >= 2 and k.delta["sp_nt"] >= 2, k.delta
+    assert ops.get_gemm_mode() == ops.GEMM_F16X2 and not ops.f16x2_guard_tripped_sync()
+    monkeypatch.setenv("TFGNN_EDGE_FIRST_LAYER_F16X2", "0")
+    with KernelsUsed() as k:
+        check_layer_backward(dev, "edge_mlp_first_layer_exact", "GNN_Edge_MLP", {}, V=384, E=4200, L=5, H=128)
+    assert k.delta["gather_sp"] == 0 and k.delta["sp_tn"] == 0, k.delta
+
+
 @pytest.mark.parametrize("dout_scale", [1e-9, 1e4])
 def test_rgat_training_step_at_loss_gradient_magnitudes(dev, dout_scale):
     check_rgat_backward(dev, 8, "tanh", V=300, E=3200, L=4, H=256, dout_scale=dout_scale)

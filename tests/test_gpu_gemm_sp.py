@@ -262,6 +262,35 @@ def test_gather_sp_matches_fp32_gather(dev, width, fixed):
         assert np.all(np.abs(rec - ref) <= bound), (view, float(np.max(np.abs(rec - ref) / np.maximum(bound, 1e-300))))
 
 
+@pytest.mark.parametrize("width", [64, 128, 512])
+def test_gather_sp_compact_views_equal_a_split_pass_over_the_fp32_gather(dev, width):
+    """Compact views (one row per NON-EMPTY bucket, type-major) written as a split operand - RGIN's d(MLP outputs) at configs[4]:
+    the same bytes and scales as sp_split_rows over the fp32 gather of the view (same sums in the same order, same scale rule);
+    edge weights, hub buckets (item and multi-item rows), empty buckets."""
+    from tests.helpers import random_graph, to_dev
+    from tf2_gnn_amd import ops
+
+    V, L = 900, 6
+    adjs = random_graph(V, 7000, L, seed=width, hub=(3, 3000))
+    gr = ops.Graph(to_dev(adjs, dev), V, parts=ops.G_PARTS_DEFAULT)
+    g = torch.Generator().manual_seed(width)
+    X = (torch.randn((V, width), generator=g) * torch.exp(torch.randn((V, 1), generator=g) * 3)).to(dev)
+    ew = torch.rand(gr.num_edges, generator=g).to(dev)
+    for view, by_src in ((ops.VIEW_BY_SRC_TYPED_COMPACT, True), (ops.VIEW_BY_DST_TYPED_COMPACT, False)):
+        nz = int(gr.nonempty_offsets(by_src)[-1])
+        assert 0 < nz < V * L
+        for w in (None, ew):
+            ref32 = ops.graph_gather(gr, view, X, edge_weight=w)
+            assert tuple(ref32.shape) == (nz, width)
+            ref = ops.sp_split_rows(ref32)
+            op = ops.graph_gather_sp(gr, view, X, edge_weight=w)
+            assert (op.rows, op.cols, op.scale_block) == (nz, width, width)
+            assert torch.equal(op.inv_scale.view(-1), ref.inv_scale.view(-1))
+            assert torch.equal(op.data.view(torch.float16).float(), ref.data.view(torch.float16).float())  # (+0 == -0)
+    with pytest.raises(ValueError):
+        ops.graph_gather_sp(gr, ops.VIEW_BY_SRC_TYPED_COMPACT, X, rows_per_operand_row=L)
+
+
 def test_absmax(dev):
     from tf2_gnn_amd import ops
 
@@ -473,6 +502,16 @@ def test_gemm_tn_wide_range_form(dev, K, M, N, sb):
     ref = (a2.double().t() @ b2.double()).t() + base.cpu().double()
     mag = (a2.double().abs().t() @ b2.double().abs()).t() + base.cpu().double().abs()
     assert float(((got.cpu().double() - ref).abs() / mag).max()) <= 2e-6
+    # operands longer than one launch covers (512 K ranges: 10^6 node rows) run as consecutive row ranges adding into out
+    if K > 2500:
+        out2 = base.clone().to(dev)
+        try:
+            ops.TN_WIDE_MAX_ROWS, keep = 2016, ops.TN_WIDE_MAX_ROWS
+            ops.sp_gemm_tn(ops.sp_split_rows(a2.to(dev), scale_block=sb), ops.sp_split_rows(b2.to(dev)), wide=True, out=out2,
+                           scatter=(M, 0, 1, M), accumulate=True)
+        finally:
+            ops.TN_WIDE_MAX_ROWS = keep
+        assert float(((out2.cpu().double() - ref).abs() / mag).max()) <= 2e-6
     # one operand row 2^30 below its neighbours: reported
     a3 = a.clone()
     a3[5] *= 2.0 ** -30

@@ -409,6 +409,24 @@ def test_layernorm_forward_backward(dev):
     assert_close(dbet.cpu(), gb.float(), tol=1e-5, what="ln dbeta")
 
 
+@pytest.mark.parametrize("M", [1, 200, 256, 257, 4097, 7110, 150001])
+@pytest.mark.parametrize("N", [7, 121, 320])
+def test_colsum_bias_gradient_sums(dev, M, N):
+    """tfgnn_colsum (Dense / GRUCell bias gradients, the sums of LayerNorm's d gamma / d beta): both kernels (16-byte rows and
+    odd widths), one slab and many, a ragged last slab, rows of a wider matrix - against the fp64 sum, relative to sum |x|; the
+    same call twice gives the same bits (fixed slab order)."""
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    wide = torch.randn((M, N + 5), generator=g).to(dev)
+    for x in (wide[:, :N].contiguous(), wide[:, 1:N + 1]):
+        got = ops.colsum(x)
+        ref = x.double().sum(dim=0)
+        mag = x.double().abs().sum(dim=0).clamp(min=1e-30)
+        assert float(((got.double() - ref).abs() / mag).max()) <= 2e-6
+        assert torch.equal(got, ops.colsum(x))
+
+
 def test_dropout_mask_statistics_and_scaling(dev):
     from tf2_gnn_amd import ops
 

@@ -845,15 +845,21 @@ def gru_gates_forward(mx, mh, h, save_gates: bool = True):
     return h_new, gates
 
 
+_gru_perm = {}
+
+
 def gru_kernel_regrouped(kernel: torch.Tensor, bias: Optional[torch.Tensor]):
     """Keras GRUCell kernel [K, 3H] (+ bias [3H]) -> the operand form of tfgnn_gemm_gru: [3H, K], K contiguous, rows
     regrouped per 192-row block as [z | r | h] of the same 64 units (an index gather on a small weight matrix)."""
     K, H3 = kernel.shape
     H = H3 // 3
-    t = torch.arange(H // 64, device=kernel.device).view(-1, 1, 1)
-    g = torch.arange(3, device=kernel.device).view(1, -1, 1)
-    c = torch.arange(64, device=kernel.device).view(1, 1, -1)
-    perm = (g * H + t * 64 + c).reshape(-1)
+    key = (H, kernel.device)
+    perm = _gru_perm.get(key)
+    if perm is None:  # (seven tiny launches per call otherwise: once per width and device)
+        t = torch.arange(H // 64, device=kernel.device).view(-1, 1, 1)
+        g = torch.arange(3, device=kernel.device).view(1, -1, 1)
+        c = torch.arange(64, device=kernel.device).view(1, 1, -1)
+        perm = _gru_perm[key] = (g * H + t * 64 + c).reshape(-1)
     return transpose_batched(kernel.index_select(1, perm)), (None if bias is None else bias.index_select(0, perm).contiguous())
 
 
@@ -1449,6 +1455,7 @@ def sp_gemm_nt_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, *, a
     return out, op
 
 
+TN_WIDE_MAX_ROWS = 512 * 2016  # rows one launch of the two-factor TN product covers (512 K ranges)
 TN_GROUPED_MAX_CHUNK = 2016  # rows of a K range of the wide-range product (gemm_sp.hip SP_TN_BSC_MAX_CHUNK)
 
 
@@ -1586,13 +1593,16 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
                     defer_combine: bool = False) -> SplitOperand:
     """graph_gather (plain sums) with the result written as an SP16 operand (tfgnn_graph_gather_reduce_sp).
     ``rows_per_operand_row`` = L folds the rows (v, l) of a typed view into the [V, L * width] operand with one scale
-    block per edge type."""
+    block per edge type.  Compact views: one operand row (and scale) per non-empty bucket."""
     lib = _lib.load()
     _require_dev(inp, torch.float32, "inp")
-    if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
-        raise ValueError("graph_gather_sp: compact views are not supported")
     typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED)
-    num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
+    if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
+        if rows_per_operand_row != 1:
+            raise ValueError("graph_gather_sp: compact rows are operand rows (rows_per_operand_row = 1)")
+        num_rows = int(graph.nonempty_offsets(view == VIEW_BY_SRC_TYPED_COMPACT)[-1])
+    else:
+        num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
     if view in (VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED) and graph.num_edge_types > 8:
         raise ValueError("graph_gather_sp: the pattern order exists for at most 8 edge types")
     inp, ld_in = _rowmajor(inp, "inp")
@@ -1644,6 +1654,17 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
         raise ValueError("sp_gemm_tn: the left operand needs per-(row, block) scales, the right one one scale per row")
     if a.rows != b.rows:
         raise ValueError(f"sp_gemm_tn: K differs ({a.rows} vs {b.rows})")
+    if wide and a.rows > TN_WIDE_MAX_ROWS:
+        # the two-factor product takes at most 512 K ranges of 2016 rows per launch: longer operands (10^6 node rows) run as
+        # consecutive row ranges, each adding into ``out``
+        if out is None or defer_reduce:
+            raise ValueError("sp_gemm_tn(wide=True) over more than %d rows needs out and no deferred reduction" % TN_WIDE_MAX_ROWS)
+        for r0 in range(0, a.rows, TN_WIDE_MAX_ROWS):
+            r1 = min(a.rows, r0 + TN_WIDE_MAX_ROWS)
+            sp_gemm_tn(SplitOperand(a.data[r0:r1], a.inv_scale[r0:r1], r1 - r0, a.cols, a.scale_block),
+                       SplitOperand(b.data[r0:r1], b.inv_scale[r0:r1], r1 - r0, b.cols, b.scale_block),
+                       a_cols=a_cols, b_cols=b_cols, out=out, scatter=scatter, accumulate=accumulate or r0 > 0, wide=True)
+        return out
     a0, M = a_cols if a_cols is not None else (0, a.cols)
     b0, N = b_cols if b_cols is not None else (0, b.cols)
     K = a.rows
