@@ -219,7 +219,8 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
     cal = 1.0 / 64
     run(cal, 1)  # first-touch / thread-pool warm-up
     sweep = {}
-    for nt in sorted({n for n in (8, 16, 32, 64, 128, cores_all) if n <= cores_all}):
+    candidates = (8, 16, 32, 64, 128, cores_all) if budget_seconds >= 20 else (16, 32)  # (a short budget: a short sweep)
+    for nt in sorted({n for n in candidates if n <= cores_all} or {cores_all}):
         torch.set_num_threads(nt)
         sweep[nt] = min(run(cal, 1), run(cal, 1))
         if sweep[nt] > 2.0 * min(sweep.values()):
@@ -228,7 +229,11 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
     torch.set_num_threads(threads)
     # one layer (+ projection / Dense / pooling) on the whole batch, extrapolated from HALF the batch (the 1/64 runs of the
     # sweep are dominated by fixed costs: they over-estimate a full layer several times)
-    t_layer_full = 2.0 * run(1.0 / 2, 1) if sweep[threads] / cal > 1.0 else sweep[threads] / cal
+    # - or from the fraction that takes about a sixth of the budget at that pessimistic estimate: half of an arxiv-sized RGIN
+    # layer with 40 edge types is minutes of host time)
+    est_full = sweep[threads] / cal
+    f_cal = float(min(0.5, max(2 * cal, (budget_seconds / 6.0) / max(est_full, 1e-6))))
+    t_layer_full = run(f_cal, 1) / f_cal if est_full > 1.0 else est_full
     # the sample: whole stack on the whole batch if a warm-up and two timed runs fit the budget, else fewer layers, then a
     # fraction of the batch
     per_run = budget_seconds / 4.5  # a warm-up and at least THREE timed runs ("median of 1 runs")
