@@ -239,7 +239,9 @@ typedef enum {
   TFGNN_VIEW_BY_SRC_TYPED = 2,
   TFGNN_VIEW_BY_SRC_NODE = 3,
   /* the two typed views with COMPACT output: row c of the output belongs to the c-th non-empty
-   * bucket in type-major order (TFGNN_G_NZ_* arrays); empty buckets produce no row */
+   * bucket in type-major order (TFGNN_G_NZ_* arrays); empty buckets produce no row (and, since round 5, no work: the
+   * launch covers the non-empty buckets only).  tfgnn_graph_gather_reduce_sp takes them too: one operand row and one
+   * scale per non-empty bucket */
   TFGNN_VIEW_BY_DST_TYPED_COMPACT = 4,
   TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5,
   /* the by-target typed view with its output rows in PATTERN order: bucket (v, l) is written at row pos[v] * L + l
