@@ -326,6 +326,46 @@ def test_layer_training_step_at_loss_gradient_magnitudes(dev, name, cls_name, ov
     _assert_mode_kept()
 
 
+def test_rearming_the_mode_restores_both_demotion_stages_of_a_stack(dev, monkeypatch):
+    """ADVICE r4 (guard policy re-armable), extended to stage 2: a stack that handed its Dense AND its per-relation weight
+    gradients back to the exact kernels takes the split-operand routes again after ops.set_gemm_mode("f16x2"), under the
+    synchronous check of the first passes."""
+    from tests.helpers import random_graph, to_dev
+    from tf2_gnn_amd import ops
+    from tf2_gnn_amd.layers import GNN, GNNInput
+    from tf2_gnn_amd.layers.message_passing import RGIN, set_seed
+
+    monkeypatch.setattr(RGIN, "GROUPED_SPLIT_MIN_ROWS", 64)
+    params = GNN.get_default_hyperparameters("rgin")
+    params.update({"hidden_dim": 128, "num_layers": 2, "global_exchange_every_num_layers": 10000, "layer_input_dropout_rate": 0.0,
+                   "dense_every_num_layers": 2, "residual_every_num_layers": 2})
+    set_seed(3)
+    gnn = GNN(params)
+    V, L = 600, 8
+    gen = torch.Generator().manual_seed(2)
+    X = torch.randn((V, 128), generator=gen).to(dev)
+    dOut = torch.randn((V, 128), generator=gen).to(dev)
+    inp = GNNInput(X, to_dev(random_graph(V, 900, L, seed=6), dev), torch.zeros(V, dtype=torch.int32, device=dev), 1)
+    gnn(inp, training=True)
+    gnn.backward(dOut)
+    assert any(getattr(mp, "_grouped_tn_used", False) for mp in gnn._mp_layers)
+    stages = []
+    while True:
+        what = gnn._demote_fragile_weight_gradients()
+        if what is None:
+            break
+        stages.append(what)
+    assert stages[-1] == "the per-relation MLP weight gradients" and len(stages) <= 2
+    assert all(mp._grouped_tn_split_ok is False for mp in gnn._mp_layers if getattr(mp, "_grouped_tn_used", False))
+    gnn._guard_sync_passes = 0
+    ops.set_gemm_mode("f16x2")  # re-arm
+    gnn(inp, training=True)
+    assert gnn._tn_demoted_epoch is None and gnn._guard_sync_passes == gnn._guard_sync_passes_init
+    assert all(getattr(mp, "_grouped_tn_split_ok", True) for mp in gnn._mp_layers)
+    gnn.backward(dOut)
+    _assert_mode_kept()
+
+
 def test_edge_mlp_first_layer_gradients_run_on_split_operands(dev, monkeypatch):
     """Round 5 (BASELINE configs[3], GNN_Edge_MLP with target states): the gradients of the first per-edge MLP layer - both halves,
     source and target states - as SP16-writing typed gathers + split-operand NT / two-factor TN products where two fp32 gathers

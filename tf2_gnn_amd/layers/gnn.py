@@ -114,6 +114,7 @@ class GNN:
         self._backward_passes = 0
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
         self._dense_demoted_epoch = -1  # ops.REARM_EPOCH at that moment: set_gemm_mode("f16x2") re-arms this stack as well
+        self._tn_demoted_epoch = None   # the same for stage 2 (per-relation weight gradients of the message-passing layers)
 
     # ---- Keras-like plumbing ----------------------------------------------------------------
     @property
@@ -295,6 +296,14 @@ class GNN:
         X = inputs.node_features
         V = X.shape[0]
         adj = inputs.adjacency_lists
+        if self._tn_demoted_epoch is not None and ops.REARM_EPOCH[0] != self._tn_demoted_epoch:
+            # the mode was re-armed (ops.set_gemm_mode("f16x2")) after stage 2 of the guard policy took the per-relation weight
+            # gradients of this stack's layers off the split operands: they try again, under the synchronous check
+            for mp in self._mp_layers:
+                if getattr(mp, "_grouped_tn_split_ok", True) is False:
+                    mp._grouped_tn_split_ok = True
+            self._tn_demoted_epoch = None
+            self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
         graph = adj if isinstance(adj, ops.Graph) else get_graph(
             adj, V, parts=self.graph_parts(V, [int(a.shape[0]) if a.numel() else 0 for a in adj]))
         graph = get_graph(graph, V)
@@ -512,6 +521,8 @@ class GNN:
             if getattr(mp, "_grouped_tn_used", False) and getattr(mp, "_grouped_tn_split_ok", True):
                 mp._grouped_tn_split_ok = False
                 did = True
+        if did:
+            self._tn_demoted_epoch = ops.REARM_EPOCH[0]
         return "the per-relation MLP weight gradients" if did else None
 
     @staticmethod
