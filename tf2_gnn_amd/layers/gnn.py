@@ -115,6 +115,9 @@ class GNN:
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
         self._dense_demoted_epoch = -1  # ops.REARM_EPOCH at that moment: set_gemm_mode("f16x2") re-arms this stack as well
         self._tn_demoted_epoch = None   # the same for stage 2 (per-relation weight gradients of the message-passing layers)
+        # stage 1a: the Dense / projection weight gradients on the TWO-FACTOR product (each operand's rows guarded on their own,
+        # 2^22) before they leave the split operands altogether (stage 1b)
+        self._dense_tn_wide = False
 
     # ---- Keras-like plumbing ----------------------------------------------------------------
     @property
@@ -227,6 +230,7 @@ class GNN:
             # the mode was re-armed (ops.set_gemm_mode("f16x2")) after this stack demoted its Dense products: try again, with
             # the synchronous check of the first passes
             self._dense_split_ok = True
+            self._dense_tn_wide = False
             self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
         if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0" or not self._dense_split_ok:
             return False
@@ -255,7 +259,10 @@ class GNN:
         d_in, d_out = w.value.shape
         if x.shape[0] > 0 and self._dense_f16x2(d_in, d_out):
             g_sp = ops.sp_rows_of(gpre)  # written by the epilogue of the product above when that is a split-operand product
-            w.grad = ops.sp_gemm_tn(ops.sp_rows_of(x), g_sp)  # [in, out] = x^T gpre
+            if self._dense_tn_wide:  # (guard policy stage 1a: both operands' rows are un-normalised sums)
+                w.grad = ops.sp_gemm_tn(ops.sp_rows_of(x), g_sp, out=torch.empty_like(w.value), wide=True)
+            else:
+                w.grad = ops.sp_gemm_tn(ops.sp_rows_of(x), g_sp)  # [in, out] = x^T gpre
             if not need_input_grad:
                 return None
             if self._tiles(d_in):
@@ -482,17 +489,17 @@ class GNN:
             self.guard_tripped_last_backward = False
             with ops.hold_spread_guard():
                 result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
-                for attempt in range(3):
+                for attempt in range(4):
                     if not ops.f16x2_guard_tripped_sync():
                         break
                     self.guard_tripped_last_backward = True
-                    what = self._demote_fragile_weight_gradients() if attempt < 2 else None
+                    what = self._demote_fragile_weight_gradients() if attempt < 3 else None
                     if what:
                         ops.rearm_spread_guard()
                         import warnings
 
-                        warnings.warn(f"tf2_gnn_amd: {what} of this GNN have operand rows spread beyond the range of the "
-                                      "split-operand product; they take the exact bf16x3 kernels from here on (the pass was recomputed)")
+                        warnings.warn(f"tf2_gnn_amd: operand rows of a weight-gradient product of this GNN are spread beyond the range "
+                                      f"of the split-operand product that ran: {what}; the pass was recomputed")
                     else:
                         ops.demote_gemm_mode()  # the whole mode (sticky), with a warning
                     for v in self.trainable_variables:
@@ -508,14 +515,18 @@ class GNN:
 
     def _demote_fragile_weight_gradients(self) -> Optional[str]:
         """The stages of the spread guard's policy before the whole mode is demoted: the weight-gradient products whose operand
-        ROWS are un-normalised sums go to the exact kernels, one family per call - first this stack's Dense / projection
-        products (combined-factor TN product, range 2^20), then the per-relation TN products of the compact-row MLP path
-        (RGIN, GNN_Edge_MLP: the two-factor product, range 2^22 per operand); the message products keep their split operands.
+        ROWS are un-normalised sums change kernels, one step per call - first this stack's Dense / projection weight gradients
+        go from the combined-factor TN product (range 2^20) to the two-factor one (2^22 per operand), then these products leave
+        the split operands, then the per-relation TN products of the compact-row MLP path (RGIN, GNN_Edge_MLP: the two-factor
+        product) go to the exact kernels; the message products keep their split operands.
         -> what was demoted, or None when nothing is left to demote."""
         if self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
-            self._dense_split_ok = False
             self._dense_demoted_epoch = ops.REARM_EPOCH[0]
-            return "the Dense / projection weight gradients"
+            if not self._dense_tn_wide and os.environ.get("TFGNN_DENSE_TN_WIDE", "1") == "1":
+                self._dense_tn_wide = True
+                return "the Dense / projection weight gradients (now on the two-factor split-operand product)"
+            self._dense_split_ok = False
+            return "the Dense / projection products (now on the exact bf16x3 kernels)"
         did = False
         for mp in self._mp_layers:
             if getattr(mp, "_grouped_tn_used", False) and getattr(mp, "_grouped_tn_split_ok", True):
@@ -523,7 +534,7 @@ class GNN:
                 did = True
         if did:
             self._tn_demoted_epoch = ops.REARM_EPOCH[0]
-        return "the per-relation MLP weight gradients" if did else None
+        return "the per-relation MLP weight gradients (now on the exact bf16x3 kernels)" if did else None
 
     @staticmethod
     def _activation_backward_scaled(act, g, saved, saved_scale):
