@@ -228,3 +228,38 @@ def test_layers_answer_the_stack_queries_of_round4_before_and_after_build():
     assert ops.G_PARTS_DEFAULT == 31 and ops.G_PARTS_ALL == 63 and not ops.G_PARTS_DEFAULT & ops.G_PART_DST_PATTERN
     assert ops._VIEW_PARTS[ops.VIEW_BY_DST_TYPED_PATTERN] == ops.G_PART_PLAN_TYPED | ops.G_PART_DST_PATTERN
     assert ops._array_parts(ops.G_PATTERN_TILEMASK_BY_DST) == ops.G_PART_DST_PATTERN
+
+
+def test_round5_host_side_queries_and_validation_without_gpu():
+    """Round 5 entry points that decide or validate on the host: the slab count of the column sums, the workspace of the two-factor
+    TN product, the K-split switch, the argument checks of the grouped products (rejected before any HIP call), and the row limit
+    above which the host mirror runs the two-factor product as row ranges."""
+    from tf2_gnn_amd import _lib, ops
+
+    lib = _lib.load()
+    assert _lib.ABI_VERSION == 3 and lib.tfgnn_abi_version() == 3
+    # column sums: one slab per 64 rows above 256 rows, at most 2048 slabs; no workspace for a single slab
+    assert lib.tfgnn_colsum_workspace_bytes(256, 121) == 0 and lib.tfgnn_colsum_workspace_bytes(100, 0) == 0
+    assert lib.tfgnn_colsum_workspace_bytes(7110, 121) == 112 * 121 * 4
+    assert lib.tfgnn_colsum_workspace_bytes(10 ** 7, 320) == 2048 * 320 * 4
+    # the two-factor TN product needs the split partials plus its factor tables; more than the one-factor form never less
+    one = lib.tfgnn_sp_gemm_tn_workspace_bytes(1280, 320, 30000, 1280, 320)
+    two = lib.tfgnn_sp_gemm_tn_wide_workspace_bytes(1280, 320, 30000, 1280, 320)
+    assert one > 1280 * 320 * 4 and two > 1280 * 320 * 4
+    assert ops.TN_WIDE_MAX_ROWS == 512 * ops.TN_GROUPED_MAX_CHUNK == 512 * 2016
+    # the in-launch K split is a host-side switch with counters (no device needed to flip and read it)
+    import ctypes
+
+    timed_out, launches = ctypes.c_int(-1), ctypes.c_int64(-1)
+    assert lib.tfgnn_sp_gemm_nt_splitk_status(-1, ctypes.byref(timed_out), ctypes.byref(launches)) == 0  # no workspace set: no splits
+    assert timed_out.value == 0 and launches.value == 0
+    assert lib.tfgnn_sp_gemm_nt_splitk_status(0, None, None) == 0 and lib.tfgnn_sp_gemm_nt_splitk_status(1, None, None) == 0
+    prev = lib.tfgnn_sp_gemm_nt_balance(3)
+    assert lib.tfgnn_sp_gemm_nt_balance(prev) == 3  # -> the previous setting
+    # grouped TN: null operands, then an unsupported width (N must tile: 128 / 256 / 320 columns)
+    args = [512, 512, None, 2048, None, 512, 512, None, 2048, None, 2, None, 4, None, None, 512 * 512, 512, 1, None, 0, None]
+    assert lib.tfgnn_sp_gemm_tn_grouped(*args) == -1
+    assert "null pointer" in lib.tfgnn_last_error().decode()
+    # compact views take the split-form gather since round 5; what they need from the handle
+    assert ops._VIEW_PARTS[ops.VIEW_BY_SRC_TYPED_COMPACT] == ops.G_PART_PLAN_TYPED | ops.G_PART_COMPACT
+    assert ops.sp_tile_width(512) == 256 and ops.sp_tile_width(320) == 320 and ops.sp_tile_width(121) == 0
