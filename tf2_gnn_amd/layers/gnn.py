@@ -226,9 +226,10 @@ class GNN:
         # factor and reduce passes of two more weight-gradient products took it back.  With the weight splits riding in the
         # merged small-pass launches, the factors computed inside the weight-gradient kernel and the layer-input dropout in
         # these products' epilogues (all four dropout passes of the benchmark stack gone) it is worth 2.48 vs 2.51 ms.
-        if not self._dense_split_ok and ops.REARM_EPOCH[0] != self._dense_demoted_epoch:
-            # the mode was re-armed (ops.set_gemm_mode("f16x2")) after this stack demoted its Dense products: try again, with
-            # the synchronous check of the first passes
+        if (not self._dense_split_ok or self._dense_tn_wide) and ops.REARM_EPOCH[0] != self._dense_demoted_epoch:
+            # the mode was re-armed (ops.set_gemm_mode("f16x2")) after this stack moved its Dense weight gradients to the
+            # two-factor product or its Dense products off the split operands: try again, with the synchronous check of the
+            # first passes
             self._dense_split_ok = True
             self._dense_tn_wide = False
             self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
@@ -479,9 +480,10 @@ class GNN:
             # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
             # first passes of a model (TFGNN_GUARD_SYNC_PASSES, default 3: whether a model's gradient rows are spread
             # that far shows at once - RGAT's attention-weighted rows trip it on the first step) wait for the pass and,
-            # if it tripped, run it again on exact kernels: first with only this stack's Dense / projection products
-            # demoted (their operand rows - un-normalised sums, attention-weighted gradients - are the usual culprit; the
-            # message products keep their split operands), then, if it trips again, with the whole mode demoted.  Later
+            # if it tripped, run it again on sturdier kernels, one step per attempt (_demote_fragile_weight_gradients): this
+            # stack's Dense / projection weight gradients on the two-factor product, then its Dense products off the split
+            # operands (their operand rows - un-normalised sums, attention-weighted gradients - are the usual culprit; the
+            # message products keep their split operands), then the per-relation MLP weight gradients, then the whole mode.  Later
             # trips demote the mode from the NEXT pass on and say so (ops.get_gemm_mode warns), but the tripping pass
             # itself is not recomputed (README.md).  While this section runs, a set flag does not demote the mode on sight.
             if self._guard_sync_passes > 0:
