@@ -263,3 +263,30 @@ def test_round5_host_side_queries_and_validation_without_gpu():
     # compact views take the split-form gather since round 5; what they need from the handle
     assert ops._VIEW_PARTS[ops.VIEW_BY_SRC_TYPED_COMPACT] == ops.G_PART_PLAN_TYPED | ops.G_PART_COMPACT
     assert ops.sp_tile_width(512) == 256 and ops.sp_tile_width(320) == 320 and ops.sp_tile_width(121) == 0
+
+
+def test_row_groups_tables_of_the_grouped_products():
+    """ops.RowGroups is host logic: row tiles never straddle two groups; the K ranges of the grouped weight-gradient product are
+    whole k16 steps, at most TN_GROUPED_MAX_CHUNK rows, equal shares of a group, and cover every row exactly once."""
+    from tf2_gnn_amd import ops
+
+    off = [0, 300, 305, 305, 5000, 5129, 12000]
+    rg = ops.RowGroups(off, "cpu")
+    assert rg.num_groups == 6 and rg.num_rows == 12000 and rg.num_tiles == sum(-(-(b - a) // 128) for a, b in zip(off, off[1:]))
+    tab = rg.table.tolist()
+    for r0, n, gi, _ in tab:
+        assert off[gi] <= r0 and r0 + n <= off[gi + 1] and 0 < n <= 128
+    ranges, first, S = rg.tn_tables()
+    ranges, first = ranges.tolist(), first.tolist()
+    assert S == len(ranges) == first[-1] and len(first) == 7 and first[3] == first[2]  # (the empty group has no range)
+    covered = 0
+    for gi in range(6):
+        rows = 0
+        for r0, n in ranges[first[gi]:first[gi + 1]]:
+            assert off[gi] <= r0 and r0 + n <= off[gi + 1] and 0 < n <= ops.TN_GROUPED_MAX_CHUNK
+            assert (r0 - off[gi]) % 16 == 0
+            rows += n
+        assert rows == off[gi + 1] - off[gi]
+        covered += rows
+    assert covered == 12000 and S <= ops.TN_GROUPED_MAX_RANGES
+    assert ops.RowGroups([0, 0], "cpu").tn_tables()[2] == 0

@@ -611,6 +611,11 @@ class GNN_Edge_MLP(MessagePassing):
             g._cache["row_groups_by_src"] = rg
         return rg
 
+    def _grouped_tn_route(self, g) -> bool:
+        """kernel gradients of the compact-row MLPs on the grouped two-factor TN product?  Not after the stack's guard policy
+        handed them back (``_grouped_tn_split_ok``), and not for more K ranges than one launch takes (~10^6 compact rows)."""
+        return bool(getattr(self, "_grouped_tn_split_ok", True)) and self._row_groups(g).tn_tables()[2] <= ops.TN_GROUPED_MAX_RANGES
+
     @staticmethod
     def _stacked_transposed_operand(W):
         """[L, in, out] kernels -> SP16 [out, L * in]: column block l is W_l^T, relation l's [N, K] operand of the forward product
@@ -650,7 +655,7 @@ class GNN_Edge_MLP(MessagePassing):
         groups = self._row_groups(g)
         off = groups.offsets
         acts = ctx["mlp_acts"]
-        tn_split = getattr(self, "_grouped_tn_split_ok", True)
+        tn_split = self._grouped_tn_route(g)
         if isinstance(dcur, ops.SplitOperand):  # written by the compact by-source gather
             d_sp, d32 = dcur, None
         else:
@@ -734,7 +739,7 @@ class GNN_Edge_MLP(MessagePassing):
             dM = self._message_grads(g, d_agg, ctx, acts[-1], ctx["colc"], g.array(ops.G_TARGET_BY_DST), ew_d, node_scale,
                                      self._ident_e(g)[: g.num_edges])
             dcur = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED_COMPACT, dM, col=g.array(ops.G_SRC2DST_POS))
-        elif ctx.get("grouped_split") and getattr(self, "_grouped_tn_split_ok", True) and d_agg.shape[1] % 16 == 0:
+        elif ctx.get("grouped_split") and self._grouped_tn_route(g) and d_agg.shape[1] % 16 == 0:
             # every consumer of d(MLP outputs) takes the split form: the gather writes it (no fp32 [nz, H], no split pass)
             dcur = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED_COMPACT, d_agg.contiguous(), edge_weight=ew_s)
         else:

@@ -1456,6 +1456,7 @@ def sp_gemm_nt_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, *, a
 
 
 TN_WIDE_MAX_ROWS = 512 * 2016  # rows one launch of the two-factor TN product covers (512 K ranges)
+TN_GROUPED_MAX_RANGES = 512  # K ranges one launch of the grouped two-factor product takes (tfgnn_sp_gemm_tn_grouped)
 TN_GROUPED_MAX_CHUNK = 2016  # rows of a K range of the wide-range product (gemm_sp.hip SP_TN_BSC_MAX_CHUNK)
 
 
@@ -1470,6 +1471,8 @@ def sp_gemm_tn_grouped(a: SplitOperand, b: SplitOperand, groups: RowGroups, out:
     if not out.is_contiguous() or out.numel() != G * M * N:
         raise ValueError("sp_gemm_tn_grouped: out must be contiguous [G, M, N]")
     tab = groups.tn_tables()
+    if tab[2] > TN_GROUPED_MAX_RANGES:
+        raise ValueError(f"sp_gemm_tn_grouped: {tab[2]} K ranges, at most {TN_GROUPED_MAX_RANGES} per launch (callers take another route)")
     nblk = a.cols // a.scale_block
     ws_bytes = ((nblk * 512 * 4 + 255) & ~255) + tab[2] * ((M + 127) // 128 * 128) * N * 4 + 256
     ws = _workspace(a.data.device, ws_bytes)
