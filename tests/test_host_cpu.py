@@ -290,3 +290,58 @@ def test_row_groups_tables_of_the_grouped_products():
         covered += rows
     assert covered == 12000 and S <= ops.TN_GROUPED_MAX_RANGES
     assert ops.RowGroups([0, 0], "cpu").tn_tables()[2] == 0
+
+
+def test_device_tanh_formula_is_relatively_accurate_restated_in_numpy():
+    """csrc/common.hpp fast_tanh (TFGNN_ACT_TANH, and inside GELU, in every kernel epilogue), restated with the coefficients
+    parsed from the source: the odd polynomial branch below 0.625 (fused multiply-adds emulated in float64, rounded once) and
+    the 1 - 2 / (e^{2|x|} + 1) branch above it, against float64 tanh over log-spaced 1e-7 .. 10, both signs: <= 4 ulp - the
+    algorithm-level pin of tests/test_gpu_ops.py::test_tanh_relative_accuracy (which measures the device, native exp included)."""
+    import os
+    import re
+
+    import numpy as np
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf2_gnn_amd", "csrc", "common.hpp")).read()
+    body = src[src.index("float fast_tanh(float x)"):]
+    body = body[: body.index("}")]
+    coef = [np.float32(c) for c in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
+    assert len(coef) == 5 and "0.625f" in body
+    f32 = np.float32
+
+    def fma(a, b, c):  # one rounding
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    x = np.concatenate([np.logspace(-7, 1, 4001), -np.logspace(-7, 1, 4001)]).astype(np.float32)
+    u = (x * x).astype(f32)
+    q = fma(u, np.full_like(u, coef[0]), np.full_like(u, coef[1]))
+    for c in coef[2:]:
+        q = fma(u, q, np.full_like(u, c))
+    small = fma((x * u).astype(f32), q, x)
+    t = np.exp((f32(2.0) * np.abs(x)).astype(np.float64)).astype(f32)  # (a correctly rounded exp; the device's native one: GPU test)
+    with np.errstate(over="ignore"):
+        big = np.copysign(f32(1.0) - f32(2.0) / (t + f32(1.0)), x).astype(f32)
+    got = np.where(np.abs(x) < f32(0.625), small, big)
+    ref = np.tanh(x.astype(np.float64))
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - ref) / ulp
+    assert float(err.max()) <= 4.0, (float(err.max()), float(x[int(err.argmax())]))
+    assert float(np.abs(got[np.abs(x) < 1e-4] - x[np.abs(x) < 1e-4]).max()) == 0.0  # tanh(x) == x to fp32 down there
+
+
+def test_captured_step_fails_loudly_without_a_device():
+    """capture.CapturedStep is host plumbing around the HIP path: without a ROCm device it raises (no CPU fallback), a second
+    capture of the same object is refused, and nothing runs at construction."""
+    import torch
+
+    from tf2_gnn_amd import CapturedStep
+
+    calls = []
+    step = CapturedStep(lambda: calls.append(1), warmup=2)
+    assert not step.captured and step.replays == 0 and calls == []
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            step.capture()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            step.replay()
+        assert calls == []
