@@ -263,8 +263,160 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# output: the full record on an EARLIER line (and in gpurun_out/), the driver's line LAST and short
+# --------------------------------------------------------------------------------------------------------------------
+FINAL_LINE_LIMIT = 4096  # bytes: the driver keeps an 8 KB tail of stdout and parses its last line
+DETAIL_PREFIX = "BENCH_DETAIL "
+GEMM_MODE_SHORT = {
+    "fp32": "fp32 (fp32 MFMA)",
+    "bf16x3": "bf16x3 (fp32 in/out, exact 3-way bf16 split, 6 piece products, fp32 accumulate)",
+    "bf16x3_9": "bf16x3_9 (fp32 in/out, exact 3-way bf16 split, 9 piece products)",
+    "f16x2": "f16x2 (fp32 in/out/accumulate; operands as 2 fp16 pieces per value under a power-of-two block scale, 3 piece products)",
+}
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_boundary", "compulsory_frac", "ms_per_launch",
+              "launches_per_step", "share_of_step", "achieved_basis", "mfma_busy_counter")
+_CPU_KEYS = ("value", "unit", "cores", "host_cpu_count", "kind", "seconds_per_step", "sample")
+
+
+def _round(x, digits=5):
+    """floats to ``digits`` significant digits (the short line only; the detail record keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, digits) for v in x]
+    return x
+
+
+def _short_roofline(b, kernel_chars=90):
+    if not b:
+        return None
+    out = {k: b[k] for k in _ROOF_KEYS if b.get(k) is not None}
+    if "kernel" in out and len(out["kernel"]) > kernel_chars:
+        out["kernel"] = out["kernel"][:kernel_chars].rstrip() + "..."
+    if "achieved_basis" in out and len(out["achieved_basis"]) > 70:
+        out["achieved_basis"] = out["achieved_basis"][:70].rstrip() + "..."
+    return out
+
+
+def compact_line(result, detail_path=None):
+    """The driver's line: the contract's keys, ``roofline`` / ``cpu_baseline`` objects and a one-row summary of every other
+    BASELINE workload - everything else (step breakdowns, secondary rooflines, prose) stays in the detail record.
+    Always shorter than FINAL_LINE_LIMIT: optional parts are dropped, in a fixed order, until it is."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "graphs_per_s", "host_ms_per_step", "plumbing_only", "edges_per_rank", "nodes_per_rank", "graphs_per_rank",
+            "max_time", "batches")
+    line = {k: result[k] for k in keep if k in result}
+    cfg = result.get("config", {})
+    c = {}
+    for k in ("workload", "gemm_mode", "per_layer_traversal_rate_edges_per_s", "products_per_step", "guard", "collectives_per_step",
+              "ms_per_step_per_rank", "allreduce_ms_per_step_per_rank", "rccl", "loss"):
+        if cfg.get(k) is not None:
+            c[k] = cfg[k]
+    if cfg.get("gemm_mode_name") in GEMM_MODE_SHORT:
+        c["gemm_mode"] = GEMM_MODE_SHORT[cfg["gemm_mode_name"]]
+    alt = cfg.get("alt_gemm_mode")
+    if alt:
+        c["alt_gemm_mode"] = {"gemm_mode": alt.get("gemm_mode_name", alt.get("gemm_mode", ""))[:24], "ms_per_step": alt["ms_per_step"],
+                              "value": alt["value"]}
+    line["config"] = c
+    if result.get("roofline"):
+        line["roofline"] = _short_roofline(result["roofline"])
+    if result.get("roofline_secondary"):
+        line["roofline_secondary"] = _short_roofline(result["roofline_secondary"], 60)
+    if result.get("cpu_baseline"):
+        cb = {k: result["cpu_baseline"][k] for k in _CPU_KEYS if k in result["cpu_baseline"]}
+        if len(cb.get("sample", "")) > 200:
+            cb["sample"] = cb["sample"][:200].rstrip() + "..."
+        line["cpu_baseline"] = cb
+    for k in ("eager", "replay_only", "replay_static_batch"):
+        if isinstance(result.get(k), dict):
+            line[k] = {kk: vv for kk, vv in result[k].items() if kk in ("ms_per_step", "host_ms_per_step", "edges_per_s", "graphs_per_s", "batches")}
+    if result.get("other_configs"):
+        oc = {}
+        for name, e in result["other_configs"].items():
+            if "error" in e:
+                oc[name] = {"error": str(e["error"])[-80:]}
+                continue
+            row = {"ms_per_step": e.get("ms_per_step"), "value": e.get("value")}
+            if e.get("roofline"):
+                r = e["roofline"]
+                row["roofline"] = {"bound": r.get("bound"), "frac": r.get("frac"), "share_of_step": r.get("share_of_step")}
+            if e.get("cpu_baseline"):
+                row["cpu_value"] = e["cpu_baseline"].get("value")
+            if e.get("products_per_step"):
+                row["products_per_step"] = {k: v for k, v in e["products_per_step"].items() if v}
+            if e.get("guard"):
+                row["guard_stage"] = e["guard"].get("stage")
+            if e.get("host_ms_per_step") is not None:
+                row["host_ms_per_step"] = e["host_ms_per_step"]
+            if isinstance(e.get("replay_static_batch"), dict):
+                row["replay_static_batch_ms"] = e["replay_static_batch"].get("ms_per_step")
+            oc[name] = row
+        line["other_configs"] = oc
+    if detail_path:
+        line["detail"] = detail_path
+    line = _round(line)
+    # shrink, in this order, until the line fits
+    for drop in (("roofline_secondary",), ("config", "alt_gemm_mode"), ("cpu_baseline", "sample"), ("other_configs",), ("data",),
+                 ("config", "ms_per_step_per_rank"), ("config", "allreduce_ms_per_step_per_rank"), ("edges_per_rank",),
+                 ("nodes_per_rank",), ("graphs_per_rank",), ("roofline", "achieved_basis"), ("roofline", "kernel")):
+        if len(json.dumps(line)) < FINAL_LINE_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return line
+
+
+def emit(result, workload, write_file=True):
+    """Rank 0's output: the complete record as ``BENCH_DETAIL {...}`` on an earlier line and, where the directory can be
+    written, in gpurun_out/bench_detail_<workload>.json; then ONE short JSON line - the last line of stdout."""
+    detail_path = None
+    try:
+        if not write_file:
+            raise OSError("no file asked for")
+        root = os.path.dirname(os.path.abspath(__file__))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        rel = os.path.join("gpurun_out", f"bench_detail_{workload}.json")
+        with open(os.path.join(root, rel), "w") as f:
+            json.dump(result, f, indent=1)
+        detail_path = rel
+    except OSError:
+        pass
+    print(DETAIL_PREFIX + json.dumps(result), flush=True)
+    text = json.dumps(compact_line(result, detail_path))
+    assert len(text) < FINAL_LINE_LIMIT and "\n" not in text
+    print(text, flush=True)
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # workload construction / launch
 # --------------------------------------------------------------------------------------------------------------------
+def products_from_counts(c0, c1, steps):
+    """tfgnn_launch_counts differences -> launches per step by product family.  ``x3`` = the exact bf16x3 kernels (gemm_x3s /
+    x3p / x3k; ``x3_stream`` is the x3k share), ``fp32`` = gemm_mfma_kernel, ``sp_nt`` / ``sp_tn`` = the split-operand products."""
+    d = {k: (c1[k] - c0[k]) / float(steps) for k in c1}
+    return {"sp_nt": d["sp_nt"], "sp_tn": d["sp_tn"], "x3": d["gemm_bf16x3"], "x3_stream": d["gemm_stream"], "fp32": d["gemm_fp32"],
+            "gather_sp": d["gather_sp"], "gather": d["gather"]}
+
+
+def rccl_info(dist, dev, world):
+    """What the communicator of an N > 1 run is made of: backend, the world size IT reports, the RCCL
+    version torch was built against, the device name.  None at N == 1."""
+    if dist is None or world == 1:
+        return None
+    info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
+            "device": torch.cuda.get_device_name(dev) if dev is not None else "cpu"}
+    try:
+        info["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as e:  # a torch build without the binding
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    return info
+
+
 def build_batch(wl, rank, world, variant=0):
     """-> dict(feats, adjs, n2g, num_graphs).  variant > 0: another draw of the same shape (--distinct-batches)"""
     from tf2_gnn_amd import parallel
@@ -343,11 +495,13 @@ def run_ppi(args, wl):
         step()
     torch.cuda.synchronize()
     # device-bound step time: K steps between synchronisations (the host runs ahead where it can)
+    c0 = ops.launch_counts()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    products = products_from_counts(c0, ops.launch_counts(), args.steps)
     # host time: how long the enqueue of a step takes (each step timed on an idle queue, then waited for)
     host = []
     for _ in range(min(args.steps, 10)):
@@ -437,22 +591,29 @@ def run_ppi(args, wl):
     m, _ = cap.replay()
     torch.cuda.synchronize()
     assert not cap.guard_tripped(), "the spread guard tripped during the replayed steps"
+    # The line's `value` is the EAGER step: a stream of distinct batches - what PPI training is and what the reference's
+    # tf.function step serves (layers/gnn.py:220-232) - cannot be replayed from a graph frozen to one adjacency.
+    # The replayed step of a static batch (full-batch training, revisited batches, inference) is reported beside it.
     result = {
         "metric": "graphs/sec and edges/sec (batch finalisation + fwd + loss + bwd) RGCN H=320 L=4 + NodeMulticlassTask, PPI stand-in (BASELINE configs[0])",
-        "value": E[0] / dt_cap,
+        "value": E[0] / dt,
         "unit": "edges/s",
-        "graphs_per_s": G / dt_cap,
+        "graphs_per_s": G / dt,
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1000.0 * dt_cap,
-        "host_ms_per_step": host_cap,
-        "step": "finalisation + bucketing of the next batch (eager, second stream) + forward + loss + backward replayed from one hipGraph",
+        "ms_per_step": 1000.0 * dt,
+        "host_ms_per_step": host_ms,
+        "step": "every step a new batch: finalisation + bucketing + forward + loss + backward driven from Python (eager)",
+        "eager": eager,
+        "replay_static_batch": {"ms_per_step": 1000.0 * dt_cap, "host_ms_per_step": host_cap, "edges_per_s": E[0] / dt_cap,
+                                "graphs_per_s": G / dt_cap,
+                                "what": "the SAME batch every step: forward + loss + backward replayed from one hipGraph (CapturedStep) + "
+                                        "finalisation and bucketing of a next batch on a second stream (built, not trained on)"},
         "replay_only": {"ms_per_step": 1000.0 * dt_replay, "host_ms_per_step": host_replay, "edges_per_s": E[0] / dt_replay,
                         "graphs_per_s": G / dt_replay,
                         "what": "forward + loss + backward of the finalised, bucketed batch: one hipGraphLaunch per step"},
-        "eager": eager,
-        "bound": "host" if host_cap > 0.9 * 1000.0 * dt_cap else "device",
+        "bound": "host" if host_ms > 0.9 * 1000.0 * dt else "device",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -461,9 +622,10 @@ def run_ppi(args, wl):
         "dtype": "f32",
         "data": "synthetic: 3 R-MAT graphs x 2370 nodes, 14 forward edges per node, N(0,1) features [V, 50], Bernoulli(0.3) labels [V, 121], Glorot weights",
         "config": {"workload": f"ppi: V={V} E={E[0]} (3 edge types after finalisation) D_in=50 H=320 L=4 labels=121",
-                   "gemm_mode": args.gemm_mode, "loss": float(m["loss"])},
+                   "gemm_mode": args.gemm_mode, "gemm_mode_name": args.gemm_mode, "products_per_step": products,
+                   "guard": model._gnn.guard_state(), "loss": float(m["loss"])},
     }
-    print(json.dumps(result))
+    emit(result, "ppi")
 
 
 def main():
@@ -519,10 +681,10 @@ def main():
         gathered = parallel.all_gather_scalars([float(sum(a.shape[0] for a in batch["adjs"])), float(batch["feats"].shape[0]),
                                                 float(batch["num_graphs"])], dist)
         if rank == 0:
-            print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "edges/s", "n_gpus": world, "plumbing_only": True,
-                              "edges_per_rank": gathered[:, 0].tolist(), "nodes_per_rank": gathered[:, 1].tolist(),
-                              "graphs_per_rank": gathered[:, 2].tolist(), "max_time": dt,
-                              "scaling": "strong" if sharded else "weak"}), flush=True)
+            emit({"metric": baseline_metric(), "value": None, "unit": "edges/s", "n_gpus": world, "plumbing_only": True,
+                  "edges_per_rank": gathered[:, 0].tolist(), "nodes_per_rank": gathered[:, 1].tolist(),
+                  "graphs_per_rank": gathered[:, 2].tolist(), "max_time": dt, "scaling": "strong" if sharded else "weak",
+                  "config": {"workload": args.workload, "rccl": rccl_info(dist, None, world)}}, args.workload, write_file=False)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -654,6 +816,7 @@ def main():
 
     ms_guess = [3.0]
     per_rank_seconds = []
+    products_per_step = {}
 
     def settle(max_batches=40, tol=0.03, min_batches=8):
         """Untimed extra warm-up: short batches of steps until two consecutive ones take the same time (clock ramp,
@@ -683,11 +846,15 @@ def main():
         if not args.no_settle:
             settle()
         barrier()
+        c0 = ops.launch_counts()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
+        c1 = ops.launch_counts()
+        products_per_step.clear()
+        products_per_step.update(products_from_counts(c0, c1, steps))
         for g_, _x in pending:  # the batch prepared for the step after the last one
             g_.wait()
             g_.close()
@@ -742,6 +909,12 @@ def main():
             f"step = edge bucketing{bucketing} + forward (training mode) + full backward",
             "per_layer_traversal_rate_edges_per_s": value * NL,
             "gemm_mode": GEMM_MODE_NOTES[args.gemm_mode],
+            "gemm_mode_name": args.gemm_mode,
+            # which product kernels the TIMED steps launched (tfgnn_launch_counts, per step, rank 0) and what the spread guard's
+            # staged policy has taken off the split operands: the global mode does not say
+            "products_per_step": dict(products_per_step),
+            "guard": gnn.guard_state(),
+            "rccl": rccl_info(dist, dev, world),
             "batches": (f"{K_batches} distinct batches of this shape take turns (--distinct-batches)" if K_batches > 1 else
                         "the same batch every step (re-bucketed per step; its rows stay warm in the Infinity Cache: the optimistic "
                         "case - see --distinct-batches)"),
@@ -760,7 +933,7 @@ def main():
         alt_elapsed = timed(2, alt_steps)
         ops.set_gemm_mode(args.gemm_mode)
         result["config"]["alt_gemm_mode"] = {
-            "gemm_mode": GEMM_MODE_NOTES[alt], "steps": alt_steps, "ms_per_step": 1000.0 * alt_elapsed / alt_steps,
+            "gemm_mode": GEMM_MODE_NOTES[alt], "gemm_mode_name": alt, "products_per_step": dict(products_per_step), "steps": alt_steps, "ms_per_step": 1000.0 * alt_elapsed / alt_steps,
             "value": total_edges_per_step * alt_steps / alt_elapsed,
         }
 
@@ -791,7 +964,7 @@ def main():
         result["other_configs"] = other_configs(args)
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result, args.workload)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -815,7 +988,7 @@ def other_configs(args):
         t_sub = time.perf_counter()
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            line = [l[len(DETAIL_PREFIX):] for l in res.stdout.splitlines() if l.startswith(DETAIL_PREFIX)]
             if res.returncode != 0 or not line:
                 out[name] = {"error": (res.stderr or res.stdout)[-300:]}
                 continue
@@ -826,14 +999,18 @@ def other_configs(args):
         entry = {"workload": r["config"]["workload"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
                  "unit": r["unit"], "scaling": r["scaling"], "wall_seconds_of_this_run": round(time.perf_counter() - t_sub, 1)}
         for key in ("graphs_per_s", "host_ms_per_step", "device_ms_one_step_alone", "bound", "reference_published", "step", "replay_only",
-                    "eager"):
+                    "replay_static_batch", "eager"):
             if key in r:  # the PPI stand-in's own fields
                 entry[key] = r[key]
         for key in ("roofline", "roofline_secondary"):
             if key in r:
                 b = r[key]
-                entry[key] = {k: b.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch",
-                                                    "launches_per_step", "share_of_step", "achieved_basis")}
+                entry[key] = {k: b.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_boundary",
+                                                    "compulsory_frac", "ms_per_launch", "launches_per_step", "share_of_step",
+                                                    "achieved_basis")}
+        for key in ("products_per_step", "guard"):
+            if r["config"].get(key) is not None:
+                entry[key] = r["config"][key]
         if "roofline_blocks_share_of_step" in r:
             entry["roofline_blocks_share_of_step"] = r["roofline_blocks_share_of_step"]
         if "step_breakdown" in r:
@@ -1042,6 +1219,23 @@ def _pmc_traffic(workload, name):
     return None, None
 
 
+def _pmc_mfma_busy(workload, kernel_substring):
+    """matrix-pipe busy fraction of a kernel from the newest committed counter pass (tools/pmc_mfma.sh) -> float | None"""
+    if not kernel_substring:
+        return None
+    root = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r06", "r05"):
+        try:
+            with open(os.path.join(root, "profiles", f"{tag}_pmc_mfma.json")) as f:
+                doc = json.load(f).get(workload, {})
+        except (OSError, ValueError):
+            continue
+        for name, e in doc.items():
+            if kernel_substring in name and e.get("mfma_busy_fraction_all_simds") is not None:
+                return {"value": e["mfma_busy_fraction_all_simds"], "file": f"profiles/{tag}_pmc_mfma.json", "kernel": name[:80]}
+    return None
+
+
 def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
     g = ops.Graph(adj_dev, V)
     out = []
@@ -1066,17 +1260,31 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
                "traffic": traffic, "traffic_from": traffic_from, "ms_per_launch": ms, "algorithmic_bytes_per_launch": alg_bytes,
                "no_reuse_model_rate_GBs": alg_bytes / (ms * 1e-3) / 1e9, "launches_per_step": launches,
                "share_of_step": launches * ms / ms_per_step}
+        if traffic:
+            # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count requests leaving L2 for the fabric - Infinity-Cache (MALL) hits
+            # included - so the fraction is taken at the L2 <-> fabric boundary against the HBM peak; DRAM traffic itself lies
+            # between the compulsory bytes and this figure
+            blk["traffic_boundary"] = "L2<->fabric (Infinity-Cache hits included)"
         if compulsory_bytes:
             blk["compulsory_bytes_per_launch"] = compulsory_bytes
+            blk["compulsory_frac"] = compulsory_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         return blk
 
-    def mfma_block(kernel, ms, flops, executed_factor, peak, launches, traffic_key=None):
+    def mfma_block(kernel, ms, flops, executed_factor, peak, launches, traffic_key=None, executed_fraction=1.0, busy_key=None):
+        """``achieved`` counts the MFMA work the launch EXECUTES: piece products per fp32 product x the share of the operand's
+        type blocks the kernel does not skip (``executed_block_fraction``; VERDICT r5 weak 4: skipped all-zero blocks are not
+        work).  ``mfma_busy_counter`` is the hardware's own figure where a counter pass of this kernel is committed
+        (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/<tag>_pmc_mfma.json)."""
         tf = flops / (ms * 1e-3) / 1e12
         traffic, traffic_from = _pmc_traffic(args.workload, traffic_key)
-        blk = {"kernel": kernel, "bound": "mfma", "achieved": tf * executed_factor, "peak": peak, "unit": "TFLOP/s",
-               "frac": tf * executed_factor / peak, "traffic": traffic, "traffic_from": traffic_from, "ms_per_launch": ms,
+        blk = {"kernel": kernel, "bound": "mfma", "achieved": tf * executed_factor * executed_fraction, "peak": peak, "unit": "TFLOP/s",
+               "frac": tf * executed_factor * executed_fraction / peak, "traffic": traffic, "traffic_from": traffic_from, "ms_per_launch": ms,
                "algorithmic_flops_per_launch": flops, "algorithmic_tflops": tf, "piece_products_per_fp32_product": executed_factor,
+               "executed_block_fraction": executed_fraction,
                "launches_per_step": launches, "share_of_step": launches * ms / ms_per_step}
+        busy = _pmc_mfma_busy(args.workload, busy_key)
+        if busy is not None:
+            blk["mfma_busy_counter"] = busy
         if peak == MFMA_16BIT_PEAK_TFLOPS:
             # tools/mfma_dep_probe.hip: back-to-back 32x32x16 16-bit MFMAs sustain 2.47 PFLOP/s on smooth operands and
             # 1.87 PFLOP/s on operands with random significands (the clock drops to 1.78 GHz)
@@ -1102,18 +1310,31 @@ def roofline_blocks(args, wl, ops, dev, adj_dev, V, E, L, H, NL, ms_per_step):
         res = torch.empty((V, H), device=dev)
         flops = 2.0 * V * (L * H) * H
         if mode == "f16x2":
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED, Hx, row_scale=g.array(ops.G_INVDEG_BY_DST), rows_per_operand_row=L)
+            # the product as the layer launches it (gnn_edge_mlp._forward_A): operand rows in the order of their emptiness
+            # patterns, all-zero type blocks of a row tile skipped, rows written back in node order
+            from tf2_gnn_amd.layers.message_passing.gnn_edge_mlp import _skip_empty_blocks
+
+            skip = _skip_empty_blocks(L, H)
+            kmask = g.array(ops.G_PATTERN_TILEMASK_BY_DST) if skip else None
+            rmap = g.array(ops.G_PATTERN_NODE_BY_DST) if skip else None
+            executed = 1.0
+            if skip:
+                m = kmask.cpu().numpy().astype(np.uint32)
+                executed = float(sum(int(((m >> b) & 1).sum()) for b in range(L))) / float(m.size * L)
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED, Hx,
+                                       row_scale=g.array(ops.G_INVDEG_BY_DST), rows_per_operand_row=L)
             Wt_sp = ops.sp_split_cols(W)
-            ms = time_kernel(lambda: ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=res))
-            out.append(mfma_block("gemm_sp_nt_kernel 128 x N tile, LDS-DMA ring, pinned MFMA stream ([V, L*H] x [H, L*H]^T + relu: 3 x "
-                                  "v_mfma_f32_32x32x16_f16 per fp32 k16 step on SP16 operands written by the gather); forward + dX launches",
-                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, 2 * NL, "gemm_sp_nt"))
+            ms = time_kernel(lambda: ops.sp_gemm_nt(A_sp, Wt_sp, act="relu", out=res, tile_kmask=kmask, row_map=rmap))
+            out.append(mfma_block("gemm_sp_nt_kernel ([V, L*H] x [H, L*H]^T + relu on SP16 operands written by the gather: 3 x "
+                                  "v_mfma_f32_32x32x16_f16 per fp32 k16 step, all-zero type blocks skipped); forward + dX launches",
+                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, 2 * NL, "gemm_sp_nt", executed_fraction=executed,
+                                  busy_key="gemm_sp_nt_kernel"))
             Xs = ops.sp_split_rows(Hx)
             Gs = ops.sp_split_rows(torch.randn((V, L * H), device=dev) * 1e-3, scale_block=H)
             dW = torch.empty((L, H, H), device=dev)
             ms = time_kernel(lambda: ops.sp_gemm_tn(Gs, Xs, out=dW, scatter=(H, H * H, 1, H)))
             out.append(mfma_block("gemm_sp_tn_kernel (per-k factors computed in the kernel, round 4) + split-K reduce (dW = X^T G over K = V rows, transposing LDS reads)",
-                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, NL, "gemm_sp_tn"))
+                                  ms, flops, 3, MFMA_16BIT_PEAK_TFLOPS, NL, "gemm_sp_tn", busy_key="gemm_sp_tn_kernel"))
         elif mode == "fp32":
             A = torch.randn((V, L * H), device=dev)
             ms = time_kernel(lambda: ops.gemm(A, W, act="relu", out=res))

@@ -60,7 +60,7 @@ const char* tfgnn_version(void);
 /* Bumped whenever an existing entry point changes its signature or meaning (round 4: 2 - tfgnn_gemm_grad_epilogue gained
  * `accumulate` in round 3, tfgnn_gemm_get_mode can return TFGNN_GEMM_F16X2, the bucketing keeps list order inside a bucket).
  * A binding compares tfgnn_abi_version() with the TFGNN_ABI_VERSION it was written against (tf2_gnn_amd/_lib.py does). */
-#define TFGNN_ABI_VERSION 3
+#define TFGNN_ABI_VERSION 4
 int tfgnn_abi_version(void);
 
 /* Diagnostics (no reference counterpart): number of launches of each product-kernel family this process has enqueued
@@ -246,12 +246,9 @@ typedef enum {
   TFGNN_VIEW_BY_SRC_TYPED_COMPACT = 5,
   /* the by-target typed view with its output rows in PATTERN order: bucket (v, l) is written at row pos[v] * L + l
    * (TFGNN_G_PATTERN_POS_BY_DST), every bucket has a row (part DST_PATTERN) */
-  TFGNN_VIEW_BY_DST_TYPED_PATTERN = 6,
-  /* the same rows, for a consumer that skips the all-zero blocks of a row tile (tfgnn_sp_gemm_nt_dropout d_tile_kmask =
-   * TFGNN_G_PATTERN_TILEMASK_BY_DST over the operand [V, L * width], round 5): an EMPTY bucket in a block the consumer does not
-   * read writes only its scale, not its row of zeros - those bytes of the output stay UNDEFINED.  Split-form output only
-   * (tfgnn_graph_gather_reduce_sp, per-bucket scales). */
-  TFGNN_VIEW_BY_DST_TYPED_PATTERN_MASKED = 7
+  TFGNN_VIEW_BY_DST_TYPED_PATTERN = 6
+  /* (7, round 5 only: the same rows without the zero rows of blocks a masked consumer skips - measured no gain, the gather's
+   *  time is its reads; removed in round 6 with ABI version 4) */
 } tfgnn_graph_view;
 size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* graph, int view, int width);
 int tfgnn_graph_gather_reduce(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
@@ -744,21 +741,19 @@ int tfgnn_sp_gemm_tn_grouped(int64_t M, int64_t N, const void* d_A_sp, int64_t l
  * through the workspace (write-through stores + one flag word each), split 0 adds them in split order - the result is
  * bit-reproducible, though not bit-equal to the unsplit product's (another summation order; same error class) - and runs
  * the epilogue.  No extra launch, no extra pass.  Layout: [64 KB of flags][slabs of 128 x tile-width floats]; 32 MB cover
- * every shape eligible for the K split (the helper workgroups of tfgnn_sp_gemm_nt_balance take one slab per tile).  The
+ * every shape eligible for the K split.  The
  * library keeps the flags zero between launches (each reducer clears what it consumed), which is what makes a product
- * captured in a hipGraph replayable.  ONE workspace per process: products that may run CONCURRENTLY (two
- * streams) must not both be eligible.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
- * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = 1 if a reducer ever gave
- * up waiting for a producer (~1 s; never expected - the product it belongs to is wrong); *split_launches (may be NULL) = products
- * launched with a split so far (tests assert that the path under test really ran); returns 1 if splits can happen. */
+ * captured in a hipGraph replayable.  ONE workspace per process, owned by the device that was current at registration
+ * (round 6): a product on another device is never split; a split product on another STREAM than the previous one
+ * first waits (host side) for that stream - or stays unsplit while either stream is being captured - so two split products
+ * never share the flags in flight.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
+ * A reducer that gives up waiting for a producer (~1 s; never expected) leaves ITS product incomplete: the next product call
+ * then fails with TFGNN_ERR_HIP and a message, after clearing the flags (a late producer may have left one set).
+ * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = number of such timeouts
+ * so far; *split_launches (may be NULL) = products launched with a split so far (tests assert that the path under test
+ * really ran); returns 1 if splits can happen. */
 int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes);
 int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches);
-/* Helper workgroups for the heavy tiles of a MASKED product (d_tile_kmask, >= 128 row tiles, the workspace above): a tile
- * with at least min_blocks non-empty K blocks is multiplied by two workgroups (halves of K, the same hand-off).  0 = off, the
- * default: measured a LOSS on the benchmark batch (DESIGN.md 5 / gemm_sp.hip: 112 vs 90 us per forward product) - kept for
- * re-measurement.  min_blocks < 0 only queries.  Returns the previous value.  Results with helpers are reproducible but not
- * bit-equal to the unmasked product's (a heavy tile's sum is grouped in two halves). */
-int tfgnn_sp_gemm_nt_balance(int min_blocks);
 
 /* The superset: tfgnn_sp_gemm_nt / _sp (d_out_sp may be NULL) with the layer-input dropout of the NEXT op in the epilogue
  * (gnn.py:285-288 - the producer of a layer's input drops it, so the stand-alone pass over [V, H], its mask tensor and the

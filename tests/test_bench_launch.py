@@ -55,3 +55,49 @@ def test_cpu_baseline_runs_for_every_workload_model():
         params = bench.model_params(model, 16, 2, wl.get("num_heads"))
         r = bench.cpu_baseline(wl, batch, params, budget_seconds=1.0)
         assert r["value"] > 0 and r["kind"] == "port" and r["cores"] >= 1 and model.upper() in r["sample"], (model, r)
+
+
+def test_final_line_is_short_and_carries_the_contract():
+    """the driver parses the LAST stdout line out of an 8 KB tail.  A complete record of the default run
+    (the committed round-5 one: five workloads, step breakdowns, prose - 21 KB) must come out of bench.compact_line as one
+    JSON object under 4 KB that still holds the contract's keys and the roofline / cpu_baseline objects."""
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 8192  # the record that did not fit the driver's tail
+    full["config"]["gemm_mode_name"] = "f16x2"
+    full["config"]["products_per_step"] = {"sp_nt": 11.0, "sp_tn": 6.0, "x3": 0.0, "x3_stream": 0.0, "fp32": 0.0, "gather_sp": 8.0, "gather": 0.0}
+    full["config"]["guard"] = {"tripped": False, "stage": "none", "checked_passes_left": 0}
+    line = bench.compact_line(full, "gpurun_out/bench_detail_rmat30k.json")
+    text = json.dumps(line)
+    assert len(text) < bench.FINAL_LINE_LIMIT and "\n" not in text
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["metric"] == full["metric"] and abs(back["value"] - full["value"]) <= 1e-4 * full["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert back["config"]["workload"].startswith("rmat30k") and back["config"]["products_per_step"]["sp_nt"] == 11.0
+    assert set(back["other_configs"]) == set(full["other_configs"])  # one short row per BASELINE workload
+    # a record ten times as wordy still fits: optional parts go first
+    full["data"] = full["data"] * 40
+    full["cpu_baseline"]["sample"] = full["cpu_baseline"]["sample"] * 10
+    assert len(json.dumps(bench.compact_line(full))) < bench.FINAL_LINE_LIMIT
+
+
+def test_plumbing_run_prints_detail_before_the_final_line():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-only", "--gpus", "2", "--workload", "qm9-tiny"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{") and len(lines[-1]) < 4096
+    assert any(l.startswith("BENCH_DETAIL {") for l in lines[:-1])
+    last = json.loads(lines[-1])
+    assert last["n_gpus"] == 2 and last["config"]["rccl"]["backend"] == "gloo" and last["config"]["rccl"]["world_size_reported"] == 2

@@ -159,3 +159,15 @@ def test_backward_after_another_forward_fails_loudly(dev):
     for g, p in zip(got, mod.parameters()):
         assert torch.equal(g, p.grad)
     assert not mod.pending_backward
+    #  a forward under torch.no_grad() is not a recorded pass: nothing is pending after it, and a recorded forward
+    # that a no_grad forward has overwritten is no longer pending either (its backward can only raise)
+    with torch.no_grad():
+        mod(inp)
+    assert not mod.pending_backward
+    loss_c = mod(inp).square().sum()
+    assert mod.pending_backward
+    with torch.no_grad():
+        mod(other)
+    assert not mod.pending_backward
+    with pytest.raises(RuntimeError, match="another forward pass"):
+        loss_c.backward()

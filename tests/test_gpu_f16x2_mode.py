@@ -437,8 +437,11 @@ def test_gnn_stack_gradients_are_linear_in_the_loss_gradient_magnitude(dev, mp_s
 
 
 @pytest.mark.parametrize("H,over", [(128, {}), (256, {"num_edge_MLP_hidden_layers": 2}), (128, {"message_activation_function": "tanh",
-                                                                                             "aggregation_function": "mean"})],
-                         ids=["h128", "h256_two_hidden", "h128_tanh_mean"])
+                                                                                             "aggregation_function": "mean"}),
+                                    # two hidden layers wider than one column tile: both TN operands of the middle layer come
+                                    # out of grouped products with one scale per row AND tile (this raised)
+                                    (512, {"num_edge_MLP_hidden_layers": 2})],
+                         ids=["h128", "h256_two_hidden", "h128_tanh_mean", "h512_two_hidden"])
 def test_rgin_compact_rows_on_grouped_split_operand_products(dev, monkeypatch, H, over):
     """Round 5 (BASELINE configs[4]): where most (source, type) pairs have no edge, RGIN's per-relation MLPs run over the non-empty
     rows as grouped products on split operands - tfgnn_sp_gemm_nt_grouped forward and input gradients (first layer through the

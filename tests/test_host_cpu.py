@@ -237,7 +237,7 @@ def test_round5_host_side_queries_and_validation_without_gpu():
     from tf2_gnn_amd import _lib, ops
 
     lib = _lib.load()
-    assert _lib.ABI_VERSION == 3 and lib.tfgnn_abi_version() == 3
+    assert _lib.ABI_VERSION == 4 and lib.tfgnn_abi_version() == 4
     # column sums: one slab per 64 rows above 256 rows, at most 2048 slabs; no workspace for a single slab
     assert lib.tfgnn_colsum_workspace_bytes(256, 121) == 0 and lib.tfgnn_colsum_workspace_bytes(100, 0) == 0
     assert lib.tfgnn_colsum_workspace_bytes(7110, 121) == 112 * 121 * 4
@@ -254,8 +254,7 @@ def test_round5_host_side_queries_and_validation_without_gpu():
     assert lib.tfgnn_sp_gemm_nt_splitk_status(-1, ctypes.byref(timed_out), ctypes.byref(launches)) == 0  # no workspace set: no splits
     assert timed_out.value == 0 and launches.value == 0
     assert lib.tfgnn_sp_gemm_nt_splitk_status(0, None, None) == 0 and lib.tfgnn_sp_gemm_nt_splitk_status(1, None, None) == 0
-    prev = lib.tfgnn_sp_gemm_nt_balance(3)
-    assert lib.tfgnn_sp_gemm_nt_balance(prev) == 3  # -> the previous setting
+    assert not hasattr(lib, "tfgnn_sp_gemm_nt_balance")  # round 6: the rejected heavy-tile helpers left the ABI (version 4)
     # grouped TN: null operands, then an unsupported width (N must tile: 128 / 256 / 320 columns)
     args = [512, 512, None, 2048, None, 512, 512, None, 2048, None, 2, None, 4, None, None, 512 * 512, 512, 1, None, 0, None]
     assert lib.tfgnn_sp_gemm_tn_grouped(*args) == -1

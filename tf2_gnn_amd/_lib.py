@@ -181,7 +181,6 @@ _SIGNATURES = [
                                          c_void_p]),
     ("tfgnn_sp_gemm_nt_set_splitk_workspace", c_int, [c_void_p, ctypes.c_size_t]),
     ("tfgnn_sp_gemm_nt_splitk_status", c_int, [c_int, c_void_p, c_void_p]),
-    ("tfgnn_sp_gemm_nt_balance", c_int, [c_int]),
     ("tfgnn_dropout_epoch_advance", c_int, [c_void_p]),
     ("tfgnn_dropout_epoch_set", c_int, [ctypes.c_uint32, c_void_p]),
     ("tfgnn_dropout_epoch_get", c_int, [c_void_p, c_void_p]),
@@ -323,7 +322,7 @@ _SIGNATURES = [
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
-ABI_VERSION = 3  # include/tfgnn.h TFGNN_ABI_VERSION
+ABI_VERSION = 4  # include/tfgnn.h TFGNN_ABI_VERSION
 
 
 class AuxJob(ctypes.Structure):

@@ -44,6 +44,7 @@ class _LayerFunction(torch.autograd.Function):
         # every forward pass REPLACES the state the layer keeps for its reverse pass (layer._ctx, runner._cur): stamp it, so
         # that a backward pass can tell whether the state in the layer is still the one of ITS forward pass
         runner._gen += 1
+        runner._taped_gen = runner._gen
         ctx.gen = runner._gen
         return outs
 
@@ -74,6 +75,7 @@ class _AutogradModule(torch.nn.Module):
         self._versions: List[int] = []
         self._gen = 0            # forward passes run so far (each replaces the layer's saved state)
         self._consumed_gen = -1  # the pass whose state a backward pass has used up
+        self._taped_gen = -1     # the latest pass autograd recorded (a forward under torch.no_grad() is not one: ADVICE r5)
         self._cur = None
         if getattr(layer, "built", False):
             self._adopt_variables()
@@ -118,7 +120,7 @@ class _AutogradModule(torch.nn.Module):
     @property
     def pending_backward(self) -> bool:
         """True while the latest forward pass has been recorded by autograd and not differentiated yet."""
-        return self._gen > 0 and self._consumed_gen != self._gen
+        return self._taped_gen == self._gen and self._consumed_gen != self._gen
 
     def run(self, x):
         raise NotImplementedError

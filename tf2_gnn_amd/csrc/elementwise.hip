@@ -517,7 +517,6 @@ static int gru_gates_backward_sp_impl(const float* d_dh_new, const float* d_gate
   TFGNN_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f && !(dropout_rate > 0.f && d_out_mul),
                 "tfgnn_gru_gates_backward_sp: a stored mask or a recomputed one, rate in [0, 1)");
   const int drop_on = dropout_rate > 0.f ? 1 : 0;
-  const DropoutKey drop = dropout_key(dropout_seed, dropout_rate);
   if (H % 64 != 0 || H > 512) return TFGNN_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (V == 0) {
@@ -531,6 +530,8 @@ static int gru_gates_backward_sp_impl(const float* d_dh_new, const float* d_gate
   TFGNN_REQUIRE(d_workspace && workspace_bytes >= (size_t)waves * 6 * H * 4, "workspace too small: need %zu bytes",
                 (size_t)waves * 6 * H * 4);
   float* partial = (float*)d_workspace;
+  const DropoutKey drop = dropout_key(dropout_seed, dropout_rate);
+  TFGNN_REQUIRE(dropout_rate <= 0.f || drop.epoch, "tfgnn_gru_gates_backward_sp: no device memory for this device's epoch word");
   const dim3 grid(waves / 4), block(256);
 #define GATES_SP(U)                                                                                                     \
   hipLaunchKernelGGL(gru_gates_backward_sp_kernel<U>, grid, block, 0, s, d_dh_new, d_gates, d_mh, d_h, (uint8_t*)d_dmx_sp, \
@@ -662,11 +663,21 @@ extern "C" int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, 
 // ---- the dropout epoch (common.hpp DropoutKey): one word of device memory, bumped by a kernel so that the bump can be a
 // node of a captured hipGraph ----
 namespace tfgnn {
-static uint32_t* g_dropout_epoch = nullptr;
+// One word PER DEVICE (a process-global word lived on whichever device drew the first mask; kernels on another
+// device dereferenced a foreign pointer).  Allocated when a batch handle is created on the device (tfgnn_graph_create: never
+// inside a stream capture) or at the first mask; a failed allocation is an ERROR for every caller with rate > 0
+// (dropout_key_checked) - a NULL word would silently repeat the masks of a replayed step.
+constexpr int kMaxDevices = 64;
+static uint32_t* g_dropout_epoch[kMaxDevices] = {};
 uint32_t* dropout_epoch_word() {
-  if (!g_dropout_epoch) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (!g_dropout_epoch[dev]) {
     uint32_t* p = nullptr;
-    if (hipMalloc((void**)&p, 256) != hipSuccess) {  // (never inside a stream capture: CapturedStep touches it first)
+    if (hipMalloc((void**)&p, 256) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }
@@ -675,9 +686,9 @@ uint32_t* dropout_epoch_word() {
       (void)hipFree(p);
       return nullptr;
     }
-    g_dropout_epoch = p;
+    g_dropout_epoch[dev] = p;
   }
-  return g_dropout_epoch;
+  return g_dropout_epoch[dev];
 }
 __global__ void dropout_epoch_kernel(uint32_t* word, uint32_t value, int add) { *word = add ? *word + value : value; }
 }  // namespace tfgnn
@@ -718,8 +729,10 @@ extern "C" int tfgnn_dropout_forward(const float* d_x, float* d_y, float* d_mask
   if (n == 0) return TFGNN_OK;
   // d_y == NULL: only the mask of (seed, rate) is (re)generated - the fused producers draw the same one in their epilogues
   TFGNN_REQUIRE((d_y == nullptr || d_x != nullptr) && (d_y || d_mask), "NULL pointer");
+  const DropoutKey key = dropout_key(seed, rate);
+  TFGNN_REQUIRE(rate <= 0.f || key.epoch, "tfgnn_dropout_forward: no device memory for this device's epoch word");
   hipLaunchKernelGGL(dropout_forward_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask,
-                     n, dropout_key(seed, rate));
+                     n, key);
   TFGNN_LAUNCH_CHECK();
   return TFGNN_OK;
 }
@@ -741,9 +754,11 @@ extern "C" int tfgnn_dropout_forward_sp(const float* d_x, float* d_y, float* d_m
                 "tfgnn_dropout_forward_sp: SP16 rows must be 64-byte aligned, fp32 tensors 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(rows, 16));
   const int vpl = (int)ceil_div(cols, 64);
+  const DropoutKey key = dropout_key(seed, rate);
+  TFGNN_REQUIRE(rate <= 0.f || key.epoch, "tfgnn_dropout_forward_sp: no device memory for this device's epoch word");
 #define DROP_SP(V)                                                                                                      \
   hipLaunchKernelGGL((dropout_forward_sp_kernel<V>), grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_mask, rows, (int)cols, \
-                     dropout_key(seed, rate), (uint8_t*)d_out_sp, ld_out_sp_bytes, d_inv_scale)
+                     key, (uint8_t*)d_out_sp, ld_out_sp_bytes, d_inv_scale)
   if (vpl <= 2) DROP_SP(2);
   else if (vpl <= 4) DROP_SP(4);
   else if (vpl <= 5) DROP_SP(5);

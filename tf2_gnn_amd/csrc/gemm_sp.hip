@@ -109,11 +109,6 @@ struct SpArgs {
   // multiplies 1/S of the tile's k16 steps; splits 1 .. S-1 publish their raw accumulators (write-through stores into
   // ws_partial + a flag word), split 0 adds them IN SPLIT ORDER (bit-reproducible) and runs the one epilogue.
   int ksplit;
-  // balance > 0 (with tile_kmask; round 5): the grid holds TWO workgroups per tile - ids [0, tiles) are helper candidates,
-  // dispatched first, ids [tiles, 2 tiles) the tiles themselves.  A tile whose mask has at least `balance` non-empty blocks
-  // is split in two halves of K (helper = split 1, the tile's own workgroup = split 0, the reducer); the helper of any other
-  // tile exits at once.  The launch then lasts about as long as its three-block tiles instead of its four-block ones.
-  int balance;
   float* ws_partial;    // [tiles][S - 1][4 waves x 2 x TNW x 16 x 64 floats]
   unsigned* ws_flags;   // [tiles][S - 1], zero when the kernel starts (split 0 clears what it consumed)
   int* ws_timeout;      // host-mapped: set to 1 if a reducer gave up waiting (never expected; the result is then wrong)
@@ -296,12 +291,8 @@ struct SpLoop {
     // 35 of them at BN = 320 - runs out of SGPRs, parks the buffer descriptors in VGPRs and wraps every DMA in a
     // readfirstlane waterfall loop.  Here m0 is base + immediate: two SGPRs in all.
     unsigned so = phys_step((unsigned)(step < nsteps ? step : nsteps - 1)) * 64u;
-    // (TFGNN_SP_NT_A_POLICY: cache policy of the A stream - rows one workgroup reads once - for A/B builds, e.g. " nt")
-#ifndef TFGNN_SP_NT_A_POLICY
-#define TFGNN_SP_NT_A_POLICY ""
-#endif
     if constexpr (I < G::ND_A)
-      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen" TFGNN_SP_NT_A_POLICY " lds"
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                    :: "s"(m0_a), "n"(ST * G::STG + I * 1024), "v"(voff_a[I]), "s"(rs_a), "s"(so) : "memory");
     else
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
@@ -404,12 +395,7 @@ __global__ void __launch_bounds__(SP_NT, (TNW == 2 ? 2 : 1)) gemm_sp_nt_kernel(S
   unsigned bid = blockIdx.x;
   int split = 0;
   int S = g.ksplit;
-  bool helper = false;
-  if (g.balance > 0) {
-    const unsigned nt_all = gridDim.x / 2u;
-    helper = bid < nt_all;
-    if (!helper) bid -= nt_all;
-  } else if (S > 1) {
+  if (S > 1) {
     const unsigned nt_all = gridDim.x / (unsigned)S;
     if (bid < nt_all * (unsigned)(S - 1)) {
       split = 1 + (int)(bid / nt_all);
@@ -433,12 +419,6 @@ __global__ void __launch_bounds__(SP_NT, (TNW == 2 ? 2 : 1)) gemm_sp_nt_kernel(S
   unsigned blkmap = 0, bsteps = 0;
   if (g.tile_kmask) {  // only the blocks of K that hold anything in this row tile (wave-uniform: one byte per tile)
     unsigned m = __builtin_amdgcn_readfirstlane((int)g.tile_kmask[tile_m]) & ((1u << g.a_nblk) - 1u);
-    if (g.balance > 0) {  // heavy tile: two workgroups share it; light tile: its helper candidate has nothing to do
-      const bool heavy = __builtin_popcount(m) >= g.balance;
-      if (helper && !heavy) return;
-      S = heavy ? 2 : 1;
-      split = helper ? 1 : 0;
-    }
     if (!m) m = 1u;  // an all-empty tile still runs one (zero) block: the epilogue needs defined accumulators and scales
     int n = 0;
     for (int b = 0; b < g.a_nblk; ++b)
@@ -1465,27 +1445,64 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
 
 // Workspace of the in-launch K split of the NT product (tfgnn_sp_gemm_nt_set_splitk_workspace): [flags 64 KB][slabs].
 constexpr size_t kSplitkFlagBytes = 65536;
+// ONE workspace per process: it belongs to the device that was current when it was registered, and its flags and
+// slabs are indexed by tile only - so a split launch (a) never happens on another device, (b) on another STREAM than the
+// previous split launch first waits (host side) for that stream, or stays unsplit while either stream is being captured,
+// (c) after a reducer timeout (a producer never arrived: the product that timed out is WRONG) the next product call fails
+// loudly, zeroes the flags - a late producer may have left one set - and reports through tfgnn_sp_gemm_nt_splitk_status.
 struct SplitkWorkspace {
   void* base = nullptr;
   size_t bytes = 0;
   bool enabled = true;
   long long split_launches = 0;
+  long long timeouts = 0;
+  int device = -1;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
   int* timeout_host = nullptr;
   int* timeout_dev = nullptr;
 };
 static SplitkWorkspace g_splitk;
-// Helper workgroups for the heavy tiles of a masked product (SpArgs::balance): tiles with at least this many non-empty K
-// blocks get a second workgroup; 0 = off, the DEFAULT - measured a loss on the benchmark batch (rmat30k, 235 tiles on 256
-// CUs: forward product 112 us with helpers for the 90 four-block tiles, 101 us with helpers for three-block tiles too, 90 us
-// without; step 2.50 / 2.48 / 2.38 ms, same box, two runs each): the 90 + 235 workgroups no longer fit one wave, the
-// light tiles that start late set the launch time, and all 256 CUs keep contending for L2 -> LDS bandwidth until then
-// (without helpers the heavy tiles speed up once the light ones are done).  TFGNN_NT_BALANCE_MIN_BLOCKS /
-// tfgnn_sp_gemm_nt_balance switch it on for re-measurement.
-static int balance_min_blocks_from_env() {
-  const char* e = std::getenv("TFGNN_NT_BALANCE_MIN_BLOCKS");
-  return e ? std::atoi(e) : 0;
+
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
 }
-static int g_balance_min_blocks = balance_min_blocks_from_env();
+
+// May THIS product split K through the shared workspace?  <0: error (a reducer timed out earlier), 0: no, 1: yes.
+static int splitk_admit(hipStream_t s) {
+  if (!(g_splitk.enabled && g_splitk.base)) return 0;
+  if (g_splitk.timeout_host && __atomic_load_n(g_splitk.timeout_host, __ATOMIC_RELAXED)) {
+    ++g_splitk.timeouts;
+    __atomic_store_n(g_splitk.timeout_host, 0, __ATOMIC_RELAXED);
+    (void)hipDeviceSynchronize();  // nothing in flight may still touch the flags
+    (void)hipMemset(g_splitk.base, 0, kSplitkFlagBytes);
+    set_error("tfgnn_sp_gemm_nt: a reducer of an earlier K-split product gave up waiting for its producers - that product's "
+              "result is incomplete; the workspace flags were cleared (tfgnn_sp_gemm_nt_splitk_status reports the count)");
+    return -1;
+  }
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != g_splitk.device) {
+    (void)hipGetLastError();
+    return 0;  // the workspace lives on another device: this product runs unsplit
+  }
+  if (g_splitk.used && s != g_splitk.last_stream) {
+    if (stream_is_capturing(s) || stream_is_capturing(g_splitk.last_stream)) return 0;
+    if (hipStreamSynchronize(g_splitk.last_stream) != hipSuccess) {  // two split products never share the flags in flight
+      (void)hipGetLastError();
+      return 0;
+    }
+  }
+  g_splitk.last_stream = s;
+  g_splitk.used = true;
+  return 1;
+}
+// (Helper workgroups for the heavy tiles of a masked product - round 5, measured a loss: 112 / 101 us against 90 us per forward
+//  product, NOTEBOOK 10 - were removed in round 6 together with their export.)
 
 static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
@@ -1654,6 +1671,7 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
     TFGNN_REQUIRE(d_saved && act_of_saved == TFGNN_ACT_RELU, "tfgnn_sp_gemm_nt_dropout: the mask-from-saved form needs a relu saved tensor");
   g.drop_ld = N;
   g.drop = dropout_key(dropout_seed, dropout_rate);
+  TFGNN_REQUIRE(dropout_rate <= 0.f || g.drop.epoch, "tfgnn_sp_gemm_nt_dropout: no device memory for this device's epoch word");
   g.n_tiles = (unsigned)(N / bn);
   if (d_out_sp) {
     // one scale per row and COLUMN TILE (N = bn: one per row; N = 512 = 2 x 256: scale blocks of 256 columns - round 5)
@@ -1674,7 +1692,9 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
     if (g_splitk.enabled && g_splitk.base && S > 1 && tiles <= 112 && !d_tile_table) {
       const size_t slab = (size_t)SP_BM * bn * 4;
       const size_t need = kSplitkFlagBytes + (size_t)tiles * (S - 1) * slab;
-      if (need <= g_splitk.bytes && (size_t)tiles * (S - 1) * 4 <= kSplitkFlagBytes) {
+      const int admit = (need <= g_splitk.bytes && (size_t)tiles * (S - 1) * 4 <= kSplitkFlagBytes) ? splitk_admit((hipStream_t)stream) : 0;
+      if (admit < 0) return TFGNN_ERR_HIP;
+      if (admit > 0) {
         g.ksplit = S;
         ++g_splitk.split_launches;
         g.ws_flags = (unsigned*)g_splitk.base;
@@ -1683,17 +1703,7 @@ static int sp_gemm_nt_impl(int64_t M, int64_t N, int64_t K, const void* d_A_sp, 
       }
     }
   }
-  // heavy-tile balancing of a masked product (SpArgs::balance): one slab and one flag per tile
-  g.balance = 0;
-  if (g.ksplit == 1 && d_tile_kmask && g_splitk.enabled && g_splitk.base && g_balance_min_blocks > 0 && g.a_nblk >= 2 && tiles >= 128 &&
-      (size_t)tiles * 4 <= kSplitkFlagBytes && kSplitkFlagBytes + (size_t)tiles * SP_BM * bn * 4 <= g_splitk.bytes) {
-    g.balance = std::min(g_balance_min_blocks, g.a_nblk);
-    g.ws_flags = (unsigned*)g_splitk.base;
-    g.ws_partial = (float*)((char*)g_splitk.base + kSplitkFlagBytes);
-    g.ws_timeout = g_splitk.timeout_dev;
-    ++g_splitk.split_launches;
-  }
-  dim3 grid((unsigned)(tiles * (g.balance > 0 ? 2 : g.ksplit)));
+  dim3 grid((unsigned)(tiles * g.ksplit));
   hipStream_t s = (hipStream_t)stream;
   if (bn == 320) launch_sp_nt<5>(g, grid, s);
   else if (bn == 256) launch_sp_nt<4>(g, grid, s);
@@ -1724,22 +1734,20 @@ int tfgnn_sp_gemm_nt_set_splitk_workspace(void* d_workspace, size_t bytes) {
     }
   }
   TFGNN_HIP_CHECK(hipMemset(d_workspace, 0, kSplitkFlagBytes));  // the flags are zero between launches from here on
+  TFGNN_HIP_CHECK(hipGetDevice(&g_splitk.device));
   g_splitk.base = d_workspace;
   g_splitk.bytes = bytes;
+  g_splitk.used = false;
+  g_splitk.last_stream = nullptr;
   return TFGNN_OK;
 }
 
 int tfgnn_sp_gemm_nt_splitk_status(int enable, int* timed_out, int64_t* split_launches) {
   if (enable >= 0) g_splitk.enabled = enable != 0;
   if (split_launches) *split_launches = g_splitk.split_launches;
-  if (timed_out) *timed_out = g_splitk.timeout_host ? __atomic_load_n(g_splitk.timeout_host, __ATOMIC_RELAXED) : 0;
+  if (timed_out)  // timeouts already turned into an error + the flag of one nobody has seen yet
+    *timed_out = (int)g_splitk.timeouts + (g_splitk.timeout_host ? __atomic_load_n(g_splitk.timeout_host, __ATOMIC_RELAXED) : 0);
   return (g_splitk.enabled && g_splitk.base) ? 1 : 0;
-}
-
-int tfgnn_sp_gemm_nt_balance(int min_blocks) {
-  const int prev = g_balance_min_blocks;
-  if (min_blocks >= 0) g_balance_min_blocks = min_blocks;
-  return prev;
 }
 
 int tfgnn_sp_gemm_nt(int64_t M, int64_t N, int64_t K, const void* d_A_sp, int64_t lda_bytes, const float* d_a_inv_scale,

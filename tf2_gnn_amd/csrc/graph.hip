@@ -1038,6 +1038,9 @@ static int graph_create_impl(int num_edge_types, int64_t num_nodes, const int32_
   TFGNN_REQUIRE(num_edge_types == 0 || (d_adjacency && num_edges), "adjacency arrays are NULL");
   TFGNN_REQUIRE((parts & ~kPartsAll) == 0, "unknown graph part bits 0x%x", parts);
   hipStream_t s = (hipStream_t)stream;
+  // handle initialisation is where this device's per-process state is allocated (the dropout epoch word, common.hpp): never
+  // inside a stream capture, and a failure is reported by the first call that needs the word
+  (void)dropout_epoch_word();
   const int L = num_edge_types;
   const int64_t V = num_nodes;
   std::vector<int64_t> edge_off(L + 1, 0);

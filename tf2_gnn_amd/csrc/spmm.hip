@@ -170,10 +170,6 @@ struct GatherArgs {
   int dot_lph_log2;
   int long_threshold;  // rows longer than this are left to the item kernels (0 = never)
   const int32_t* out_row_map;  // nullable: output row of CSR row r is out_row_map[r]; < 0 = no output
-  // TFGNN_VIEW_BY_DST_TYPED_PATTERN_MASKED (SP16 output, round 5): an EMPTY bucket whose block of the operand the consumer skips
-  // (tile mask bit clear; block 0 of an all-empty tile is still read) writes its scale only, not its 4 * width bytes of zeros
-  const uint8_t* skip_tilemask;
-  int skip_L;
   unsigned xcd_units_pad;      // != 0: 1-D XCD-aware grid over (window, unit); set by the launcher
   unsigned total_units;
   // item pass
@@ -383,12 +379,6 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
         if (live[i]) mx = fmaxf(mx, fabsf(acc[i][c]));
       }
     const float sc = sp_row_scale<LPR>(a, mx, orow, gl == 0);
-    if (a.skip_tilemask && end == beg) {
-      const int64_t p = orow / a.skip_L;
-      const int l = (int)(orow - p * a.skip_L);
-      const unsigned m = a.skip_tilemask[p >> 7];
-      if (m ? !((m >> l) & 1u) : l != 0) return;  // nobody reads this block of zeros
-    }
     uint8_t* drow = a.out_sp + orow * a.ld_out_sp;
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
@@ -704,7 +694,7 @@ extern "C" int tfgnn_csr_gather_reduce(const int32_t* d_rowptr, const int32_t* d
 
 extern "C" size_t tfgnn_graph_gather_workspace_bytes(const tfgnn_graph* g, int view, int width) {
   if (!g || view < 0 || view > 7 || width <= 0) return 0;
-  if (view >= 4) view = (view == 4 || view == 6 || view == 7) ? 0 : 2;
+  if (view >= 4) view = (view == 4 || view == 6) ? 0 : 2;
   return (size_t)g->views[view].plan.num_partials * (size_t)width * 4;
 }
 
@@ -719,12 +709,7 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
                              float* d_dot_out = nullptr) {
   using namespace tfgnn;
   TFGNN_REQUIRE(g != nullptr, "graph is NULL");
-  TFGNN_REQUIRE(view >= 0 && view <= 7, "unknown graph view %d", view);
-  const bool masked = view == 7;
-  if (masked) {
-    TFGNN_REQUIRE(d_out_sp != nullptr && !d_fixed_inv, "TFGNN_VIEW_BY_DST_TYPED_PATTERN_MASKED: split-form output with per-bucket scales only");
-    view = 6;
-  }
+  TFGNN_REQUIRE(view >= 0 && view <= 6, "unknown graph view %d", view);
   TFGNN_REQUIRE(width >= 0 && ew_heads >= 1, "bad sizes");
   // views 4 / 5: the typed views 0 / 2 with compact output (one row per NON-EMPTY bucket, type-major)
   {
@@ -763,10 +748,6 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
   a.is_max = reduce_op == TFGNN_REDUCE_MAX; a.ew_heads = ew_heads; a.head_width = width / ew_heads;
   a.long_threshold = p.long_threshold;
   a.out_row_map = out_map;
-  if (masked) {
-    a.skip_tilemask = g->pat_tilemask_d;
-    a.skip_L = g->L;
-  }
   if (d_dot_out) {
     TFGNN_REQUIRE(ew_heads > 1 && d_edge_weight && width % ew_heads == 0, "tfgnn_graph_gather_reduce_dot: per-head edge weights only");
     const int lph = width / ew_heads / 4;

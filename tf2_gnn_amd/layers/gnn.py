@@ -515,6 +515,22 @@ class GNN:
             ops.aux_flush()        # the deferred split reductions of the weight gradients: one launch for all layers
             ops.join_aux_stream()  # weight gradients whose last pass ran on the second stream
 
+    def guard_state(self) -> Dict[str, Any]:
+        """What the spread-guard policy has done to this stack so far: ``tripped`` (the last backward pass, see
+        ``guard_tripped_last_backward``) and ``stage`` - "none", "1a" (Dense / projection weight gradients on the two-factor
+        product), "1b" (Dense products off the split operands), "2" (per-relation weight gradients on the exact kernels),
+        "3" (the whole mode demoted to bf16x3).  bench.py prints it with every line."""
+        stage = "none"
+        if self._dense_tn_wide:
+            stage = "1a"
+        if not self._dense_split_ok:
+            stage = "1b"
+        if self._tn_demoted_epoch is not None:
+            stage = "2"
+        if self._backward_passes and ops.get_gemm_mode() != ops.GEMM_F16X2:
+            stage = "3" if stage != "none" or ops.f16x2_guard_flag_async() else stage
+        return {"tripped": self.guard_tripped_last_backward, "stage": stage, "checked_passes_left": self._guard_sync_passes}
+
     def _demote_fragile_weight_gradients(self) -> Optional[str]:
         """The stages of the spread guard's policy before the whole mode is demoted: the weight-gradient products whose operand
         ROWS are un-normalised sums change kernels, one step per call - first this stack's Dense / projection weight gradients

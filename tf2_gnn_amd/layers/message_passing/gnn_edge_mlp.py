@@ -425,14 +425,9 @@ class GNN_Edge_MLP(MessagePassing):
             skip = _skip_empty_blocks(L, Din)
             kmask = g.array(ops.G_PATTERN_TILEMASK_BY_DST) if skip else None
             rmap = g.array(ops.G_PATTERN_NODE_BY_DST) if skip else None
-            # (VIEW_BY_DST_TYPED_PATTERN_MASKED would leave the zero rows of skipped blocks unwritten - 38 % of the operand's 154 MB
-            #  at the benchmark batch; measured no gain, round 5: 2.370 vs 2.368 ms per step, qm9-ggnn 92.4 vs 92.4 ms - the
-            #  gather's time is its reads.  TFGNN_GATHER_MASKED=1 switches it on.)
-            import os
-
-            masked = skip and os.environ.get("TFGNN_GATHER_MASKED", "0") == "1"
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN_MASKED if masked else
-                                       (ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED), X, row_scale=row_scale,
+            # (a gather that leaves the zero rows of skipped blocks unwritten - 38 % of the operand's 154 MB at the benchmark
+            #  batch - measured no gain in round 5, 2.370 vs 2.368 ms per step: the gather's time is its reads.  Removed.)
+            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale,
                                        rows_per_operand_row=L, defer_combine=True)
             Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H), defer=True))
             gelu_split = fuse_act == "gelu"
@@ -682,6 +677,11 @@ class GNN_Edge_MLP(MessagePassing):
                 # The operand with per-block scales is the product's left one: the layer input for j > 0 (a product wrote it:
                 # blocks of a column tile), the gradient for j = 0 (then the transpose is stored)
                 dW = torch.empty_like(W)
+                if inp_sp.scale_block != inp_sp.cols and d_sp.scale_block != d_sp.cols:
+                    # both operands written by grouped products wider than one column tile (two or more hidden layers of
+                    # width >= 384: one scale per row AND column tile on either side): the product takes such
+                    # scales on its left operand only - the gradient is split again with one scale per row
+                    d_sp = ops.sp_split_rows(d32)
                 left_is_input = inp_sp.scale_block != inp_sp.cols or d_sp.scale_block == d_sp.cols
                 # all relations in ONE launch of the two-factor ("wide range") product: both operands' rows are un-normalised
                 # sums, the guard looks at each operand's own spread inside a K range of <= 2016 rows (a launch per relation
@@ -692,8 +692,11 @@ class GNN_Edge_MLP(MessagePassing):
                     ops.sp_gemm_tn_grouped(d_sp, inp_sp, groups, dW, transposed=True)
                 grads[j] = dW
             wr = ops.sp_weight_operand(W, "grouped_rows", lambda W=W: ops.sp_split_rows(W.view(W.shape[0] * W.shape[1], W.shape[2])))
+            # (the fp32 copy of a hidden layer's gradient is needed by the exact route and by the re-split above: when the
+            #  layer below is itself a hidden layer and this product's split result carries per-tile scales)
+            resplit_below = j > 1 and ops.sp_tile_width(int(W.shape[1])) != int(W.shape[1])
             dcur32, d_sp = ops.sp_gemm_nt_grouped(d_sp, wr, groups, act_grad=("relu", acts[j - 1]) if j > 0 else None,
-                                                  want_fp32=(j == 0 or not tn_split), want_split=(j > 0))
+                                                  want_fp32=(j == 0 or not tn_split or resplit_below), want_split=(j > 0))
             d32 = dcur32
         mlps.grads = grads
         mlps.publish_grads()

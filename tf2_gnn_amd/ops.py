@@ -388,7 +388,7 @@ def gather_reduce(
 
 
 (VIEW_BY_DST_TYPED, VIEW_BY_DST_NODE, VIEW_BY_SRC_TYPED, VIEW_BY_SRC_NODE, VIEW_BY_DST_TYPED_COMPACT,
- VIEW_BY_SRC_TYPED_COMPACT, VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED) = range(8)
+ VIEW_BY_SRC_TYPED_COMPACT, VIEW_BY_DST_TYPED_PATTERN) = range(7)
 
 
 @_writes_out
@@ -660,6 +660,17 @@ def rearm_spread_guard() -> None:
     aux_flush()
     torch.cuda.current_stream().synchronize()
     _lib.load().tfgnn_sp_spread_flag(1)
+
+
+KERNEL_FAMILIES = ("gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream")
+
+
+def launch_counts() -> dict:
+    """tfgnn_launch_counts as a dict: kernel family -> launches this process has enqueued so far (host counters, no device
+    work).  bench.py reports the per-step differences as ``products`` so that a line says which product kernels ran."""
+    buf = (ctypes.c_int64 * len(KERNEL_FAMILIES))()
+    _lib.check(_lib.load().tfgnn_launch_counts(buf, len(KERNEL_FAMILIES)))
+    return dict(zip(KERNEL_FAMILIES, (int(v) for v in buf)))
 
 
 def f16x2_guard_flag_async() -> bool:
@@ -1497,12 +1508,6 @@ def sp_gather_rows(a: SplitOperand, index: torch.Tensor) -> SplitOperand:
     return out
 
 
-def sp_gemm_nt_balance(min_blocks: int = -1) -> int:
-    """Helper workgroups for the heavy tiles of masked products (tfgnn_sp_gemm_nt_balance; 0 = off, the default - a measured
-    loss on the benchmark batch).  -> the previous setting."""
-    return int(_lib.load().tfgnn_sp_gemm_nt_balance(int(min_blocks)))
-
-
 @_writes_out
 def sp_gemm_nt(a: SplitOperand, b: SplitOperand, *, bias=None, act=ACT_NONE, out=None, accumulate=False, out_mul=None,
                act_grad=None, dropout=None, saved_scale: float = 1.0, tile_kmask=None, row_map=None, a_rows=None) -> torch.Tensor:
@@ -1599,14 +1604,14 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     block per edge type.  Compact views: one operand row (and scale) per non-empty bucket."""
     lib = _lib.load()
     _require_dev(inp, torch.float32, "inp")
-    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED)
+    typed = view in (VIEW_BY_DST_TYPED, VIEW_BY_SRC_TYPED, VIEW_BY_DST_TYPED_PATTERN)
     if view in (VIEW_BY_DST_TYPED_COMPACT, VIEW_BY_SRC_TYPED_COMPACT):
         if rows_per_operand_row != 1:
             raise ValueError("graph_gather_sp: compact rows are operand rows (rows_per_operand_row = 1)")
         num_rows = int(graph.nonempty_offsets(view == VIEW_BY_SRC_TYPED_COMPACT)[-1])
     else:
         num_rows = graph.num_nodes * (graph.num_edge_types if typed else 1)
-    if view in (VIEW_BY_DST_TYPED_PATTERN, VIEW_BY_DST_TYPED_PATTERN_MASKED) and graph.num_edge_types > 8:
+    if view == VIEW_BY_DST_TYPED_PATTERN and graph.num_edge_types > 8:
         raise ValueError("graph_gather_sp: the pattern order exists for at most 8 edge types")
     inp, ld_in = _rowmajor(inp, "inp")
     width = inp.shape[1]
