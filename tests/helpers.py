@@ -102,11 +102,11 @@ class KernelsUsed:
         return False
 
 
-PARITY_LOG_NAME = "parity_r05.json"
+PARITY_LOG_NAME = "parity_r06.json"
 
 
 def record_parity(key: str, **numbers):
-    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r05.json (copied to profiles/ after a
+    """Measured parity numbers of the GPU tests, merged into gpurun_out/parity_r06.json (copied to profiles/ after a
     run on the GPU box), keyed by GEMM MODE first: {mode: {check: {max error, bound, test id}}}.  A check that runs
     several times in one mode (parametrised tests sharing a label) keeps its worst case."""
     import json
@@ -143,7 +143,7 @@ def _worse(a: dict, b: dict) -> dict:
 
 
 def _flush_parity_log():
-    """MERGES this process's records into gpurun_out/parity_r05.json (a partial re-run used to
+    """MERGES this process's records into gpurun_out/parity_r06.json (a partial re-run used to
     overwrite the snapshot of the full suite).  Idempotent: per (mode, check) the record with the larger error stays."""
     import json
     import os
