@@ -265,13 +265,13 @@ def cpu_baseline(wl, batch, params, budget_seconds=30.0):
 # --------------------------------------------------------------------------------------------------------------------
 # output: the full record on an EARLIER line (and in gpurun_out/), the driver's line LAST and short
 # --------------------------------------------------------------------------------------------------------------------
-FINAL_LINE_LIMIT = 4096  # bytes: the driver keeps an 8 KB tail of stdout and parses its last line
+FINAL_LINE_LIMIT = 3800  # bytes (< 4 KB with headroom): the driver keeps an 8 KB tail of stdout and parses its last line
 DETAIL_PREFIX = "BENCH_DETAIL "
 GEMM_MODE_SHORT = {
     "fp32": "fp32 (fp32 MFMA)",
     "bf16x3": "bf16x3 (fp32 in/out, exact 3-way bf16 split, 6 piece products, fp32 accumulate)",
     "bf16x3_9": "bf16x3_9 (fp32 in/out, exact 3-way bf16 split, 9 piece products)",
-    "f16x2": "f16x2 (fp32 in/out/accumulate; operands as 2 fp16 pieces per value under a power-of-two block scale, 3 piece products)",
+    "f16x2": "f16x2 (fp32 in/out/accumulate; operands = 2 fp16 pieces per value under a power-of-two block scale, 3 piece products)",
 }
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_boundary", "compulsory_frac", "ms_per_launch",
               "launches_per_step", "share_of_step", "achieved_basis", "mfma_busy_counter")
@@ -295,8 +295,10 @@ def _short_roofline(b, kernel_chars=90):
     out = {k: b[k] for k in _ROOF_KEYS if b.get(k) is not None}
     if "kernel" in out and len(out["kernel"]) > kernel_chars:
         out["kernel"] = out["kernel"][:kernel_chars].rstrip() + "..."
-    if "achieved_basis" in out and len(out["achieved_basis"]) > 70:
-        out["achieved_basis"] = out["achieved_basis"][:70].rstrip() + "..."
+    if "achieved_basis" in out and len(out["achieved_basis"]) > 48:
+        out["achieved_basis"] = out["achieved_basis"][:48].rstrip() + "..."
+    if isinstance(out.get("mfma_busy_counter"), dict):
+        out["mfma_busy_counter"] = {k: out["mfma_busy_counter"].get(k) for k in ("value", "file")}
     return out
 
 
@@ -311,11 +313,15 @@ def compact_line(result, detail_path=None):
     cfg = result.get("config", {})
     c = {}
     for k in ("workload", "gemm_mode", "per_layer_traversal_rate_edges_per_s", "products_per_step", "guard", "collectives_per_step",
-              "ms_per_step_per_rank", "allreduce_ms_per_step_per_rank", "rccl", "loss"):
+              "edges_per_rank", "ms_per_step_per_rank", "allreduce_ms_per_step_per_rank", "rccl", "loss"):
         if cfg.get(k) is not None:
             c[k] = cfg[k]
     if cfg.get("gemm_mode_name") in GEMM_MODE_SHORT:
         c["gemm_mode"] = GEMM_MODE_SHORT[cfg["gemm_mode_name"]]
+    if isinstance(c.get("guard"), dict):
+        c["guard"] = {k: c["guard"].get(k) for k in ("tripped", "stage")}
+    if isinstance(c.get("workload"), str) and len(c["workload"]) > 230:
+        c["workload"] = c["workload"][:230].rstrip() + "..."
     alt = cfg.get("alt_gemm_mode")
     if alt:
         c["alt_gemm_mode"] = {"gemm_mode": alt.get("gemm_mode_name", alt.get("gemm_mode", ""))[:24], "ms_per_step": alt["ms_per_step"],
@@ -327,8 +333,8 @@ def compact_line(result, detail_path=None):
         line["roofline_secondary"] = _short_roofline(result["roofline_secondary"], 60)
     if result.get("cpu_baseline"):
         cb = {k: result["cpu_baseline"][k] for k in _CPU_KEYS if k in result["cpu_baseline"]}
-        if len(cb.get("sample", "")) > 200:
-            cb["sample"] = cb["sample"][:200].rstrip() + "..."
+        if len(cb.get("sample", "")) > 160:
+            cb["sample"] = cb["sample"][:160].rstrip() + "..."
         line["cpu_baseline"] = cb
     for k in ("eager", "replay_only", "replay_static_batch"):
         if isinstance(result.get(k), dict):
@@ -342,11 +348,11 @@ def compact_line(result, detail_path=None):
             row = {"ms_per_step": e.get("ms_per_step"), "value": e.get("value")}
             if e.get("roofline"):
                 r = e["roofline"]
-                row["roofline"] = {"bound": r.get("bound"), "frac": r.get("frac"), "share_of_step": r.get("share_of_step")}
+                row["roofline"] = {"bound": r.get("bound"), "frac": r.get("frac")}
             if e.get("cpu_baseline"):
                 row["cpu_value"] = e["cpu_baseline"].get("value")
             if e.get("products_per_step"):
-                row["products_per_step"] = {k: v for k, v in e["products_per_step"].items() if v}
+                row["products_per_step"] = {k: v for k, v in e["products_per_step"].items() if v and k in ("sp_nt", "sp_tn", "x3", "fp32")}
             if e.get("guard"):
                 row["guard_stage"] = e["guard"].get("stage")
             if e.get("host_ms_per_step") is not None:
@@ -360,7 +366,7 @@ def compact_line(result, detail_path=None):
     line = _round(line)
     # shrink, in this order, until the line fits
     for drop in (("roofline_secondary",), ("config", "alt_gemm_mode"), ("cpu_baseline", "sample"), ("other_configs",), ("data",),
-                 ("config", "ms_per_step_per_rank"), ("config", "allreduce_ms_per_step_per_rank"), ("edges_per_rank",),
+                 ("config", "ms_per_step_per_rank"), ("config", "allreduce_ms_per_step_per_rank"), ("config", "edges_per_rank"), ("edges_per_rank",),
                  ("nodes_per_rank",), ("graphs_per_rank",), ("roofline", "achieved_basis"), ("roofline", "kernel")):
         if len(json.dumps(line)) < FINAL_LINE_LIMIT:
             break
