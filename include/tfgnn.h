@@ -745,8 +745,9 @@ int tfgnn_sp_gemm_tn_grouped(int64_t M, int64_t N, const void* d_A_sp, int64_t l
  * library keeps the flags zero between launches (each reducer clears what it consumed), which is what makes a product
  * captured in a hipGraph replayable.  ONE workspace per process, owned by the device that was current at registration
  * (round 6): a product on another device is never split; a split product on another STREAM than the previous one
- * first waits (host side) for that stream - or stays unsplit while either stream is being captured - so two split products
- * never share the flags in flight.  d_workspace NULL / too small: no split (the default).  The call waits for the device.
+ * first waits (host side) for that stream, so two split products never share the flags in flight (a stream under capture
+ * cannot wait: synchronise the device before capturing, as capture.CapturedStep does; while another stream is capturing split
+ * products, a product stays unsplit).  d_workspace NULL / too small: no split (the default).  The call waits for the device.
  * A reducer that gives up waiting for a producer (~1 s; never expected) leaves ITS product incomplete: the next product call
  * then fails with TFGNN_ERR_HIP and a message, after clearing the flags (a late producer may have left one set).
  * _status: enable >= 0 switches the split on / off (the workspace stays); *timed_out (may be NULL) = number of such timeouts

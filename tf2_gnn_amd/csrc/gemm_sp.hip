@@ -1447,7 +1447,8 @@ static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
 constexpr size_t kSplitkFlagBytes = 65536;
 // ONE workspace per process: it belongs to the device that was current when it was registered, and its flags and
 // slabs are indexed by tile only - so a split launch (a) never happens on another device, (b) on another STREAM than the
-// previous split launch first waits (host side) for that stream, or stays unsplit while either stream is being captured,
+// previous split launch first waits (host side) for that stream (a stream that is being captured cannot wait: its owner
+// synchronises the device before the capture; while ANOTHER stream is capturing split products, this one stays unsplit),
 // (c) after a reducer timeout (a producer never arrived: the product that timed out is WRONG) the next product call fails
 // loudly, zeroes the flags - a late producer may have left one set - and reports through tfgnn_sp_gemm_nt_splitk_status.
 struct SplitkWorkspace {
@@ -1491,11 +1492,16 @@ static int splitk_admit(hipStream_t s) {
     return 0;  // the workspace lives on another device: this product runs unsplit
   }
   if (g_splitk.used && s != g_splitk.last_stream) {
-    if (stream_is_capturing(s) || stream_is_capturing(g_splitk.last_stream)) return 0;
-    if (hipStreamSynchronize(g_splitk.last_stream) != hipSuccess) {  // two split products never share the flags in flight
-      (void)hipGetLastError();
-      return 0;
+    if (stream_is_capturing(g_splitk.last_stream)) return 0;  // somebody else's capture is recording split products
+    if (!stream_is_capturing(s)) {
+      // two split products never share the flags in flight: wait for the stream that launched the previous one
+      if (hipStreamSynchronize(g_splitk.last_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+      }
     }
+    // (a CAPTURING stream cannot wait for another one; whoever captures a step synchronises the device first -
+    //  capture.CapturedStep does - and replays then run on the stream the caller launches them on, like any product)
   }
   g_splitk.last_stream = s;
   g_splitk.used = true;

@@ -225,27 +225,31 @@ __global__ void __launch_bounds__(kThreads<TM>, 1) nt_probe_kernel(Args g) {
       }
 }
 
+
+// (A fourth shape - 256 x 320 tile, 8 waves x 64 x 160 with ONE fragment set, 36 KB per k16 step for twice the flops - was
+//  written and does not build at two waves per SIMD: it needs 160 accumulator registers + ~90 others of the 256 a wave may
+//  have, and hipcc (ROCm 7.2) splits that budget evenly - 128 VGPRs + 128 AGPRs: 712 spilled dwords in the main loop;
+//  amdgpu_num_vgpr(96) makes it 96 + 96 and 1220.  At one wave per SIMD a 256-row tile needs 320 accumulators.  NOTEBOOK 11.)
+
 // ---------------------------------------------------------------------------------------------------------------------
-static void pack_sp16(const std::vector<float>& x, int64_t rows, int K, std::vector<uint8_t>& out) {
-  out.assign((size_t)rows * K * 4, 0);
+static void pack_sp16(const std::vector<float>& x, int64_t rows, int K, std::vector<uint8_t>& out, int64_t pitch) {
+  out.assign((size_t)rows * pitch, 0);
   for (int64_t r = 0; r < rows; ++r)
     for (int k = 0; k < K; ++k) {
       const float v = x[(size_t)r * K + k];
       const _Float16 h = (_Float16)v;
       const _Float16 l = (_Float16)(v - (float)h);
-      uint8_t* gr = out.data() + (size_t)r * K * 4 + (k >> 4) * 64 + (k & 15) * 2;
+      uint8_t* gr = out.data() + (size_t)r * pitch + (k >> 4) * 64 + (k & 15) * 2;
       *reinterpret_cast<_Float16*>(gr) = h;
       *reinterpret_cast<_Float16*>(gr + 32) = l;
     }
 }
 
-template <int TM, bool PAIR>
-static double run(const char* name, const Args& a, int iters, const std::vector<float>& hA, const std::vector<float>& hB, bool check) {
-  using G = Geo<TM, PAIR>;
-  auto kern = nt_probe_kernel<TM, PAIR>;
-  const int lds_bytes = NST * STG;
+template <class K>
+static double run_kernel(K kern, int lds_bytes, int bm, int threads, const char* name, const Args& a, int iters, const std::vector<float>& hA,
+                         const std::vector<float>& hB, bool check) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  const dim3 grid((unsigned)((a.M + BM - 1) / BM)), block(64 * G::NW);
+  const dim3 grid((unsigned)((a.M + bm - 1) / bm)), block(threads);
   hipMemset(a.C, 0, (size_t)a.M * a.ldc * 4);
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, grid, block, lds_bytes, 0, a);
   hipEvent_t e0, e1;
@@ -284,17 +288,26 @@ static double run(const char* name, const Args& a, int iters, const std::vector<
   return us;
 }
 
+template <int TM, bool PAIR>
+static double run(const char* name, const Args& a, int iters, const std::vector<float>& hA, const std::vector<float>& hB, bool check) {
+  return run_kernel(nt_probe_kernel<TM, PAIR>, NST * STG, BM, 64 * Geo<TM, PAIR>::NW, name, a, iters, hA, hB, check);
+}
+
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 30000;
   const int KMAX = 1280;
+  // row pitch of both operands = 4 K + pad bytes (argv[2]): does the L2 -> LDS stream depend on how rows alias in the L2 channels?
+  const int64_t pad = argc > 2 ? atoll(argv[2]) : 0;
+  const int64_t pitch = (int64_t)KMAX * 4 + pad;
+  printf("M = %lld, row pitch %lld bytes (pad %lld)\n", (long long)M, (long long)pitch, (long long)pad);
   std::vector<float> hA((size_t)M * KMAX), hB((size_t)BN * KMAX);
   uint64_t s = 88172645463325252ull;
   auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); };
   for (auto& v : hA) v = rnd() * 3.f;
   for (auto& v : hB) v = rnd() * 0.1f;
   std::vector<uint8_t> pA, pB;
-  pack_sp16(hA, M, KMAX, pA);
-  pack_sp16(hB, BN, KMAX, pB);
+  pack_sp16(hA, M, KMAX, pA, pitch);
+  pack_sp16(hB, BN, KMAX, pB, pitch);
   uint8_t *dA, *dB;
   float* dC;
   hipMalloc(&dA, pA.size());
@@ -307,7 +320,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 2; ++rep)
     for (int ki = 0; ki < 3; ++ki) {
       // (the operands keep their K = 1280 layout: a shorter product reads a prefix of every row)
-      Args a{dA, (int64_t)KMAX * 4, dB, (int64_t)KMAX * 4, dC, BN, M, Ks[ki]};
+      Args a{dA, pitch, dB, pitch, dC, BN, M, Ks[ki]};
       const bool check = rep == 0;
       // the host check multiplies the first K columns of the K = 1280 rows: give it matrices with that row pitch
       std::vector<float> cA, cB;
