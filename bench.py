@@ -472,28 +472,34 @@ def run_ppi(args, wl):
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    feats, fwd, n2g, labels = make_ppi_shaped_batch(wl["num_graphs"], wl["nodes_per_graph"], wl["avg_in_degree"], wl["feature_dim"],
-                                                    wl["num_labels"], seed=1)
-    V = feats.shape[0]
-    X = torch.from_numpy(feats).to(dev)
-    fwd_dev = torch.from_numpy(fwd).to(dev)
-    n2g_dev = torch.from_numpy(n2g).to(dev)
-    labels_dev = torch.from_numpy(labels).to(dev)
+    # --distinct-batches K (default here: 8): K different draws of the stand-in take turns - every eager step finalises, buckets
+    # and trains on a batch it has not seen in the previous K - 1 steps, as a training epoch over PPI does
+    K_batches = max(1, int(args.distinct_batches)) if args.distinct_batches != 1 else 8
+    batches = []
+    for k in range(K_batches):
+        feats, fwd, n2g, labels = make_ppi_shaped_batch(wl["num_graphs"], wl["nodes_per_graph"], wl["avg_in_degree"], wl["feature_dim"],
+                                                        wl["num_labels"], seed=1 + 1000 * k)
+        batches.append(tuple(torch.from_numpy(a).to(dev) for a in (feats, fwd, n2g, labels)))
+    X, fwd_dev, n2g_dev, labels_dev = batches[0]
+    V = X.shape[0]
     params = NodeMulticlassTask.get_default_hyperparameters("rgcn")
     params.update({f"gnn_{k}": v for k, v in model_params("rgcn", wl["hidden_dim"], wl["num_layers"]).items()})
     set_seed(0)
     model = NodeMulticlassTask(params, num_edge_types=3, num_node_target_labels=wl["num_labels"])
     ops.set_gemm_mode(args.gemm_mode)
     E = [0]
+    calls = [0]
 
     def step():
         ops.clear_weight_operand_cache()  # an optimizer update invalidates the split forms of the weights
-        adjs, _ = process_adjacency_lists([fwd_dev], V, add_self_loop_edges=True, tied_fwd_bkwd_edge_types=set())
+        Xb, fwd_b, n2g_b, labels_b = batches[calls[0] % K_batches]
+        calls[0] += 1
+        adjs, _ = process_adjacency_lists([fwd_b], V, add_self_loop_edges=True, tied_fwd_bkwd_edge_types=set())
         E[0] = int(sum(a.shape[0] for a in adjs))
-        batch = {"node_features": X, "node_to_graph_map": n2g_dev, "num_graphs_in_batch": wl["num_graphs"],
+        batch = {"node_features": Xb, "node_to_graph_map": n2g_b, "num_graphs_in_batch": wl["num_graphs"],
                  **{f"adjacency_list_{i}": a for i, a in enumerate(adjs)}}
         out = model(batch, training=True)
-        metrics = model.compute_task_metrics(batch, out, {"node_labels": labels_dev})
+        metrics = model.compute_task_metrics(batch, out, {"node_labels": labels_b})
         model.backward()
         return metrics
 
@@ -610,7 +616,9 @@ def run_ppi(args, wl):
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt,
         "host_ms_per_step": host_ms,
-        "step": "every step a new batch: finalisation + bucketing + forward + loss + backward driven from Python (eager)",
+        "step": f"every step another batch ({K_batches} distinct batches take turns): finalisation + bucketing + forward + loss + backward "
+                "driven from Python (eager)",
+        "batches": K_batches,
         "eager": eager,
         "replay_static_batch": {"ms_per_step": 1000.0 * dt_cap, "host_ms_per_step": host_cap, "edges_per_s": E[0] / dt_cap,
                                 "graphs_per_s": G / dt_cap,

@@ -107,9 +107,9 @@ class GNN:
         # tells the caller what the last pass saw: False / True after a checked pass (True: recomputed on exact kernels),
         # for an unchecked pass the asynchronous flag as it stood when the pass was enqueued (a trip of that very pass shows
         # one pass later, together with the demotion warning) - a training loop that must not consume such gradients tests it.
-        self._guard_sync_passes_init = int(os.environ.get("TFGNN_GUARD_SYNC_PASSES", "3"))
+        self._guard_sync_passes_init = int(ops.env("TFGNN_GUARD_SYNC_PASSES", "3"))
         self._guard_sync_passes = self._guard_sync_passes_init
-        self.guard_check_every = int(os.environ.get("TFGNN_GUARD_CHECK_EVERY", "0"))
+        self.guard_check_every = int(ops.env("TFGNN_GUARD_CHECK_EVERY", "0"))
         self.guard_tripped_last_backward: Optional[bool] = None
         self._backward_passes = 0
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
@@ -233,7 +233,7 @@ class GNN:
             self._dense_split_ok = True
             self._dense_tn_wide = False
             self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
-        if os.environ.get("TFGNN_DENSE_F16X2", "1") == "0" or not self._dense_split_ok:
+        if ops.env("TFGNN_DENSE_F16X2", "1") == "0" or not self._dense_split_ok:
             return False
         return ops.get_gemm_mode() == ops.GEMM_F16X2 and in_dim % 16 == 0 and in_dim >= 32 and self._tiles(out_dim)
 
@@ -277,7 +277,7 @@ class GNN:
         """May the dropout at the input of layer ``layer_idx`` be applied by the op that produces that input?  Only where the
         backward pass hands the mask to an input-gradient product as well (no residual sum at this layer) and nothing but a
         Dense / the projection / a message passing layer precedes it."""
-        if os.environ.get("TFGNN_FUSED_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
+        if ops.env("TFGNN_FUSED_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
             return False
         if layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and self._residual_every_num_layers >= self._num_layers):
             return False
@@ -290,7 +290,7 @@ class GNN:
         """Drop the input of layer ``layer_idx`` WITHOUT storing the mask?  Where the backward pass hands the mask to the layer
         (no residual sum here) and the layer recomputes it in a product epilogue (MessagePassing.recomputes_input_dropout).
         TFGNN_RECOMPUTE_DROPOUT=0: always store it."""
-        if os.environ.get("TFGNN_RECOMPUTE_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
+        if ops.env("TFGNN_RECOMPUTE_DROPOUT", "1") == "0" or ops.get_gemm_mode() != ops.GEMM_F16X2:
             return False
         if layer_idx % self._residual_every_num_layers == 0 and not (layer_idx == 0 and self._residual_every_num_layers >= self._num_layers):
             return False
@@ -319,7 +319,7 @@ class GNN:
         steps = []
         NL = self._num_layers
 
-        if training and ops.get_gemm_mode() == ops.GEMM_F16X2 and os.environ.get("TFGNN_BATCHED_WEIGHT_SPLIT", "0") == "1":
+        if training and ops.get_gemm_mode() == ops.GEMM_F16X2 and ops.env("TFGNN_BATCHED_WEIGHT_SPLIT", "0") == "1":
             # Opt-in: both split forms of every layer's kernel stack in ONE launch at the start of the step instead of two
             # small launches per layer.  Measured a LOSS (2.67 vs 2.62 ms per step): the batched launch is 59 us less
             # split-kernel time, but every layer product then starts on a weight operand that is no longer in L2 and takes
@@ -540,7 +540,7 @@ class GNN:
         -> what was demoted, or None when nothing is left to demote."""
         if self._dense_split_ok and self._dense_f16x2(self._hidden_dim, self._hidden_dim):
             self._dense_demoted_epoch = ops.REARM_EPOCH[0]
-            if not self._dense_tn_wide and os.environ.get("TFGNN_DENSE_TN_WIDE", "1") == "1":
+            if not self._dense_tn_wide and ops.env("TFGNN_DENSE_TN_WIDE", "1") == "1":
                 self._dense_tn_wide = True
                 return "the Dense / projection weight gradients (now on the two-factor split-operand product)"
             self._dense_split_ok = False

@@ -52,7 +52,7 @@ def _skip_empty_blocks(L: int, Din: int) -> bool:
     most 1024 columns.  TFGNN_NT_SKIP_EMPTY=0 keeps the node order (A/B measurements)."""
     import os
 
-    return 2 <= L <= 8 and Din % 16 == 0 and Din <= 1024 and os.environ.get("TFGNN_NT_SKIP_EMPTY", "1") == "1"
+    return 2 <= L <= 8 and Din % 16 == 0 and Din <= 1024 and ops.env("TFGNN_NT_SKIP_EMPTY", "1") == "1"
 
 
 def messages_per_edge(layer, g, D, H) -> bool:
@@ -195,7 +195,7 @@ class GNN_Edge_MLP(MessagePassing):
             if self._first_layer_grads_split_ok(int(num_nodes), int(in_dim), L, H0) and _skip_empty_blocks(L, H0):
                 return ops.G_PARTS_DEFAULT | ops.G_PART_DST_PATTERN
         if (self._user_message_function() or self._path() != "A" or self._use_target_state_as_input or self._compact_opt_in
-                or os.environ.get("TFGNN_COMPACT_BUCKETS") == "1"):
+                or ops.env("TFGNN_COMPACT_BUCKETS") == "1"):
             return ops.G_PARTS_DEFAULT
         shape = SimpleNamespace(num_edge_types=len(edges_per_type), num_edges=int(sum(edges_per_type)), num_nodes=int(num_nodes),
                                 edges_per_type=tuple(int(c) for c in edges_per_type))
@@ -334,7 +334,7 @@ class GNN_Edge_MLP(MessagePassing):
     def _use_compact_buckets(self, g) -> bool:
         import os
 
-        if not (self._compact_opt_in or os.environ.get("TFGNN_COMPACT_BUCKETS") == "1"):
+        if not (self._compact_opt_in or ops.env("TFGNN_COMPACT_BUCKETS") == "1"):
             return False
         if self._use_target_state_as_input or g.num_edge_types == 0 or g.num_edges == 0:
             return False
@@ -487,7 +487,7 @@ class GNN_Edge_MLP(MessagePassing):
                                    defer_combine=True)
         # the weight gradient dW = X^T G is off the critical path of the backward pass: its two small passes (per-k factors,
         # split reduction) run on the library's second stream beside the big kernels around them
-        overlap = os.environ.get("TFGNN_TN_OVERLAP", "0") == "1"
+        overlap = ops.env("TFGNN_TN_OVERLAP", "0") == "1"
         tn = None
         if overlap:
             dW = torch.empty_like(W)
@@ -591,7 +591,7 @@ class GNN_Edge_MLP(MessagePassing):
     def _grouped_split_ok(self, X, g) -> bool:
         import os
 
-        if ops.get_gemm_mode() != ops.GEMM_F16X2 or os.environ.get("TFGNN_GROUPED_F16X2", "1") == "0":
+        if ops.get_gemm_mode() != ops.GEMM_F16X2 or ops.env("TFGNN_GROUPED_F16X2", "1") == "0":
             return False
         dims = [X.shape[1]] + [int(W.shape[2]) for W in self._edge_type_mlps.kernels]
         # every width a column tile of the split-operand product and a multiple of its scale blocks; rows x bytes below 4 GB
@@ -972,7 +972,7 @@ class GNN_Edge_MLP(MessagePassing):
         def tiles(n):
             return n % 128 == 0 or n % 320 == 0
 
-        return (ops.get_gemm_mode() == ops.GEMM_F16X2 and os.environ.get("TFGNN_EDGE_FIRST_LAYER_F16X2", "1") == "1"
+        return (ops.get_gemm_mode() == ops.GEMM_F16X2 and ops.env("TFGNN_EDGE_FIRST_LAYER_F16X2", "1") == "1"
                 and getattr(self, "_grouped_tn_split_ok", True) and V > 0 and L > 0 and H0 % 16 == 0 and H0 <= 512
                 and 32 <= D <= 512 and tiles(D) and tiles(H0))
 

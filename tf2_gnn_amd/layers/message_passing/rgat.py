@@ -232,7 +232,7 @@ class RGAT(MessagePassing):
         # (2) gradient w.r.t. the attention values: da[e,k] = <Y[(src_e, l_e)], d_agg[tgt_e]>_k.  The gather of (1) reads
         #     d_agg[tgt_e] for every out-edge of (u, l) with Y[(u, l)] fixed per row: the products ride on it and land in
         #     by-target order through the edge map (round 4; a pass of its own over the edges before, 112 us at configs[2])
-        if K > 1 and ops.graph_gather_dot_supported(H, K) and os.environ.get("TFGNN_RGAT_FUSED_DOT", "1") == "1":
+        if K > 1 and ops.graph_gather_dot_supported(H, K) and ops.env("TFGNN_RGAT_FUSED_DOT", "1") == "1":
             dY, da = ops.graph_gather_dot(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s, dot_rows=Y.view(V * L, H), dot_pos=s2d)
         else:
             dY = ops.graph_gather(g, ops.VIEW_BY_SRC_TYPED, d_agg, edge_weight=att_s)  # [V*L, H]

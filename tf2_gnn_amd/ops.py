@@ -60,7 +60,32 @@ def op_scope(name: str, *tensors):
     return _NULL_SCOPE
 
 
+_ENV_DATA = getattr(os.environ, "_data", None)  # posix: {bytes: bytes}, the dict behind os.environ (sees every later setenv)
+_ENV_KEYS = {}
+
+
+def env(name: str, default: Optional[str] = None) -> Optional[str]:
+    """os.environ.get for the switches the layers consult on every call: the Mapping protocol of os.environ costs ~1 us per
+    lookup (129 lookups per PPI-sized step, profiles/r06_ppi_host_profile_before.txt); its backing dict a tenth of that."""
+    if _ENV_DATA is None:
+        return os.environ.get(name, default)
+    key = _ENV_KEYS.get(name)
+    if key is None:
+        key = _ENV_KEYS[name] = os.fsencode(name)
+    v = _ENV_DATA.get(key)
+    return default if v is None else os.fsdecode(v)
+
+
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _raw_stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object per
+    call (~4 us: 74 calls = 0.3 ms of the 1.5 ms a PPI-sized step spends on the host, profiles/r06_ppi_host_profile_before.txt);
+    the two private accessors it is made of cost ~0.3 us."""
+    if _get_raw_stream is not None and _get_device is not None:
+        return _get_raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -92,7 +117,7 @@ _AUX_LOCK = threading.RLock()
 def aux_enabled() -> bool:
     import os
 
-    return os.environ.get("TFGNN_AUX_MERGE", "1") != "0"
+    return env("TFGNN_AUX_MERGE", "1") != "0"
 
 
 def aux_defer(job, keep=(), urgent: bool = True, then=None) -> None:
@@ -343,7 +368,7 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.type, device.index, _raw_stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -1253,6 +1278,20 @@ class SplitOperand:
         return self
 
 
+def _sp_weight_rows(rows: int, row_bytes: int, device) -> torch.Tensor:
+    """[rows, row_bytes] uint8 buffer of an SP16 operand.  Small operands that every workgroup of a product streams again and
+    again (weights: <= 4096 rows) get a row PITCH of row_bytes + 256 when row_bytes is a multiple of 1 KB: with a power-of-two-ish
+    pitch (5120 bytes at K = 1280) the rows of a tile fall into a quarter of the L2 channels, and the L2 -> LDS stream of the
+    NT product - the bound of its main loop with every CU busy - runs 0.84 instead of 0.78 us per k16 step
+    (tools/nt8_probe.hip, profiles/r06_nt_geometry_probe.txt).  TFGNN_SP_PITCH_PAD=0 restores the dense pitch."""
+    pad = 0
+    if rows <= 4096 and row_bytes % 1024 == 0:
+        pad = int(env("TFGNN_SP_PITCH_PAD", "256"))
+    if pad <= 0 or pad % 64:
+        return torch.empty((rows, row_bytes), dtype=torch.uint8, device=device)
+    return torch.empty((rows, row_bytes + pad), dtype=torch.uint8, device=device)[:, :row_bytes]
+
+
 def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed_inv_scale: Optional[torch.Tensor] = None,
                   out: Optional[SplitOperand] = None, defer: bool = False) -> SplitOperand:
     """SP16 form of the rows of ``x`` [R, C] (unit inner stride).  ``segments = (seg_len, seg_stride, cols)``: row r is
@@ -1268,7 +1307,7 @@ def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed
         seg_len, seg_stride, cols = (int(v) for v in segments)
     sb = int(scale_block) if scale_block and scale_block > 0 else cols
     if out is None:
-        data = torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device)
+        data = _sp_weight_rows(rows, cols * 4, x.device)
         if fixed_inv_scale is not None:
             out = SplitOperand(data, fixed_inv_scale, rows, cols, 0)  # one scale for the whole tensor
         else:
@@ -1321,7 +1360,7 @@ def sp_split_cols(w: torch.Tensor, defer: bool = False, out: Optional[SplitOpera
             raise ValueError("sp_split_cols: out must hold N rows of K columns")
         data, inv = out.data, out.inv_scale
     else:
-        data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
+        data = _sp_weight_rows(N, K * 4, w.device)
         inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
     if defer and aux_enabled():
         job = _lib.AuxJob()
@@ -1355,7 +1394,7 @@ def _ensure_splitk_workspace(device, rows: int) -> None:
     if rows > 56000 or "done" in _SPLITK_WS or capturing():  # (few row tiles: K split; masked products up to ~430 tiles: helpers)
         return
     _SPLITK_WS["done"] = True
-    if os.environ.get("TFGNN_NT_SPLITK", "1") == "0":
+    if env("TFGNN_NT_SPLITK", "1") == "0":
         return
     ws = torch.empty(_SPLITK_BYTES, dtype=torch.uint8, device=device)
     aux_flush()
@@ -1710,7 +1749,7 @@ def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, ou
                 b.data.stride(0), b0, _ptr(b.inv_scale), _ptr(out), gr, sg, sr, sc, int(accumulate), ws_ptr, ws_len)
         keep = (ws, out, a.data, a.inv_scale, b.data, b.inv_scale)
         rjob = _lib.AuxJob()
-        if K <= 131072 and os.environ.get("TFGNN_TN_CHAINED", "0") == "1":  # opt-in: measured slower (NOTEBOOK.md 4.7)
+        if K <= 131072 and env("TFGNN_TN_CHAINED", "0") == "1":  # opt-in: measured slower (NOTEBOOK.md 4.7)
             # the whole product waits for the next merged launch: its factor pass rides there, the product follows it, the
             # reduction rides in a later one (a weight gradient is off the critical path of the backward pass)
             fjob = _lib.AuxJob()
