@@ -490,17 +490,45 @@ def run_ppi(args, wl):
     E = [0]
     calls = [0]
 
-    def step():
-        ops.clear_weight_operand_cache()  # an optimizer update invalidates the split forms of the weights
-        Xb, fwd_b, n2g_b, labels_b = batches[calls[0] % K_batches]
-        calls[0] += 1
+    # Input pipeline: like the headline workload (and the reference's background batching thread + tf.data prefetch,
+    # data/graph_dataset.py:292-295), the finalisation + bucketing of batch i+1 is enqueued on a second stream at the start of
+    # step i; --serial-bucketing keeps it on the compute stream.
+    side_eager = None if args.serial_bucketing else torch.cuda.Stream()
+    ready = []
+
+    def prepare(k):
+        Xb, fwd_b, n2g_b, labels_b = batches[k % K_batches]
         adjs, _ = process_adjacency_lists([fwd_b], V, add_self_loop_edges=True, tied_fwd_bkwd_edge_types=set())
         E[0] = int(sum(a.shape[0] for a in adjs))
         batch = {"node_features": Xb, "node_to_graph_map": n2g_b, "num_graphs_in_batch": wl["num_graphs"],
                  **{f"adjacency_list_{i}": a for i, a in enumerate(adjs)}}
+        if side_eager is not None and model.built:
+            batch["bucketed_graph"] = ops.Graph(adjs, V, wait=False, parts=model._gnn.graph_parts(V, [int(a.shape[0]) for a in adjs]))
+        return batch, labels_b
+
+    def prepare_async(k):
+        if side_eager is None or not model.built:
+            return prepare(k)
+        side_eager.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_eager):
+            return prepare(k)
+
+    def step():
+        ops.clear_weight_operand_cache()  # an optimizer update invalidates the split forms of the weights
+        if not ready:
+            ready.append(prepare_async(calls[0]))
+        batch, labels_b = ready.pop(0)
+        calls[0] += 1
+        g_ = batch.get("bucketed_graph")
+        if g_ is not None:
+            torch.cuda.current_stream().wait_stream(side_eager)  # compute waits for THIS batch's preparation
+            g_.wait()
+        ready.append(prepare_async(calls[0]))  # the next batch, under this step
         out = model(batch, training=True)
         metrics = model.compute_task_metrics(batch, out, {"node_labels": labels_b})
         model.backward()
+        if g_ is not None:
+            g_.close()
         return metrics
 
     for _ in range(max(args.warmup, 3)):
@@ -534,6 +562,14 @@ def run_ppi(args, wl):
     eager = {"ms_per_step": 1000.0 * dt, "host_ms_per_step": host_ms, "device_ms_one_step_alone": a.elapsed_time(b),
              "edges_per_s": E[0] / dt, "graphs_per_s": G / dt,
              "what": "every step driven from Python: finalisation + bucketing + forward + loss + backward (~190 launches through ctypes)"}
+
+    for b_, _ in ready:  # the batch prepared for the step after the last one
+        g_ = b_.get("bucketed_graph")
+        if g_ is not None:
+            g_.wait()
+            g_.close()
+    ready.clear()
+    torch.cuda.synchronize()
 
     # ---- the same training step replayed from ONE hipGraph (tf2_gnn_amd.capture.CapturedStep; the reference traces its step
     # into one tf.function graph: models/graph_task_model.py:327-357).  The forward + loss + backward of the finalised, bucketed
@@ -616,8 +652,8 @@ def run_ppi(args, wl):
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt,
         "host_ms_per_step": host_ms,
-        "step": f"every step another batch ({K_batches} distinct batches take turns): finalisation + bucketing + forward + loss + backward "
-                "driven from Python (eager)",
+        "step": f"every step another batch ({K_batches} distinct batches take turns): finalisation + bucketing of the next batch "
+                f"{'on the compute stream' if args.serial_bucketing else '(2nd stream, overlapped)'} + forward + loss + backward, driven from Python (eager)",
         "batches": K_batches,
         "eager": eager,
         "replay_static_batch": {"ms_per_step": 1000.0 * dt_cap, "host_ms_per_step": host_cap, "edges_per_s": E[0] / dt_cap,

@@ -1278,20 +1278,6 @@ class SplitOperand:
         return self
 
 
-def _sp_weight_rows(rows: int, row_bytes: int, device) -> torch.Tensor:
-    """[rows, row_bytes] uint8 buffer of an SP16 operand.  Small operands that every workgroup of a product streams again and
-    again (weights: <= 4096 rows) get a row PITCH of row_bytes + 256 when row_bytes is a multiple of 1 KB: with a power-of-two-ish
-    pitch (5120 bytes at K = 1280) the rows of a tile fall into a quarter of the L2 channels, and the L2 -> LDS stream of the
-    NT product - the bound of its main loop with every CU busy - runs 0.84 instead of 0.78 us per k16 step
-    (tools/nt8_probe.hip, profiles/r06_nt_geometry_probe.txt).  TFGNN_SP_PITCH_PAD=0 restores the dense pitch."""
-    pad = 0
-    if rows <= 4096 and row_bytes % 1024 == 0:
-        pad = int(env("TFGNN_SP_PITCH_PAD", "256"))
-    if pad <= 0 or pad % 64:
-        return torch.empty((rows, row_bytes), dtype=torch.uint8, device=device)
-    return torch.empty((rows, row_bytes + pad), dtype=torch.uint8, device=device)[:, :row_bytes]
-
-
 def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed_inv_scale: Optional[torch.Tensor] = None,
                   out: Optional[SplitOperand] = None, defer: bool = False) -> SplitOperand:
     """SP16 form of the rows of ``x`` [R, C] (unit inner stride).  ``segments = (seg_len, seg_stride, cols)``: row r is
@@ -1307,7 +1293,7 @@ def sp_split_rows(x: torch.Tensor, *, scale_block: int = 0, segments=None, fixed
         seg_len, seg_stride, cols = (int(v) for v in segments)
     sb = int(scale_block) if scale_block and scale_block > 0 else cols
     if out is None:
-        data = _sp_weight_rows(rows, cols * 4, x.device)
+        data = torch.empty((rows, cols * 4), dtype=torch.uint8, device=x.device)
         if fixed_inv_scale is not None:
             out = SplitOperand(data, fixed_inv_scale, rows, cols, 0)  # one scale for the whole tensor
         else:
@@ -1360,7 +1346,7 @@ def sp_split_cols(w: torch.Tensor, defer: bool = False, out: Optional[SplitOpera
             raise ValueError("sp_split_cols: out must hold N rows of K columns")
         data, inv = out.data, out.inv_scale
     else:
-        data = _sp_weight_rows(N, K * 4, w.device)
+        data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
         inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
     if defer and aux_enabled():
         job = _lib.AuxJob()

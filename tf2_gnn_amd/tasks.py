@@ -107,7 +107,12 @@ class GraphTaskModel:
 
     # ---- forward (graph_task_model.py:158-183) -----------------------------------------------------------------
     def compute_final_node_representations(self, inputs, training: bool):
-        adjacency_lists = tuple(inputs[f"adjacency_list_{i}"] for i in range(self._num_edge_types))
+        # An input pipeline may hand over the batch already bucketed - ``bucketed_graph``: the ops.Graph of these adjacency
+        # lists, built on a prefetch stream while the previous step trained (the reference prepares batches in a background
+        # thread + tf.data prefetch: data/graph_dataset.py:292-295); the caller has ordered the compute stream after it.
+        adjacency_lists = inputs.get("bucketed_graph") if hasattr(inputs, "get") else None
+        if adjacency_lists is None:
+            adjacency_lists = tuple(inputs[f"adjacency_list_{i}"] for i in range(self._num_edge_types))
         gnn_input = GNNInput(
             node_features=self.compute_initial_node_features(inputs, training),
             adjacency_lists=adjacency_lists,
