@@ -915,6 +915,109 @@ int tfgnn_sigmoid_ce_metrics(const float* d_logits, int64_t ld_logits, const flo
 int tfgnn_regression_metrics(const float* d_pred, const float* d_target, int64_t G, float* d_metrics,
                              float* d_dpred, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Layer-level entry points (round 6): one call per message-passing layer and pass.
+ * Replaces, for one layer, MessagePassing.call (message_passing.py:95-133) with
+ * _calculate_messages_per_type (:181-218), GNN_Edge_MLP._message_function (gnn_edge_mlp.py:84-107) and
+ * _compute_new_node_embeddings (message_passing.py:135-179) - and their share of tape.gradient
+ * (models/graph_task_model.py:347-357) - in the aggregate-first formulation on split operands, the route of RGCN, of
+ * GGNN's message part and of GNN_Edge_MLP without hidden layers / target states (sum, mean or sqrt_n aggregation, activation
+ * after aggregation; hidden_dim and in_dim multiples of 128 or of 320).  Each function enqueues, on `stream`, exactly the
+ * kernels the op-level calls named below would: results are bit-identical to that route.
+ *
+ * All pointers are device pointers unless named h_*; buffers are the caller's (sizes in comments, V = nodes, L = edge types
+ * of the graph handle, D = in_dim, H = hidden_dim).  `struct_size` = sizeof of the struct (a binding built against another
+ * header is rejected).  `extra_jobs`: small passes the caller has pending (tfgnn_*_job / *_deferred), launched with this
+ * call's own in ONE tfgnn_aux_launch.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum {
+  TFGNN_MP_AGGREGATE_FIRST = 0 /* linear message per edge type, aggregated before the per-relation product */
+} tfgnn_mp_kind;
+
+typedef struct tfgnn_mp_forward_args {
+  size_t struct_size;
+  int kind; /* tfgnn_mp_kind */
+  const tfgnn_graph* graph;
+  int view;                 /* TFGNN_VIEW_BY_DST_TYPED, or ..._PATTERN with tile_kmask / row_map of the handle */
+  const float* x;           /* node states [V, D], row pitch ldx floats */
+  int64_t ldx;
+  int in_dim, hidden_dim;
+  const float* row_scale;   /* [V * L] factor per (node, type) bucket - 1 / (c + 1e-7), tfgnn_graph_scales - or NULL */
+  const float* w;           /* stacked kernels [L * D, H] row-major: non-NULL = (re)build the operand below from them */
+  void* wt_sp;              /* W^T as SP16 [H, L * D] (row pitch ld_wt_sp_bytes) + wt_inv_scale [H]: kept by the caller */
+  int64_t ld_wt_sp_bytes;   /*   across calls while the kernels do not change                                          */
+  float* wt_inv_scale;
+  void* agg_sp;             /* scratch: the aggregate [V, L * D] SP16 (V * L * D * 4 bytes) + agg_inv_scale [V * L] */
+  float* agg_inv_scale;
+  const float* bias;        /* [H] or NULL */
+  int act;                  /* tfgnn_activation applied to the sum (message_passing.py:176-177) */
+  float dropout_rate;       /* > 0: the NEXT op's input dropout applied to the result (tfgnn_sp_gemm_nt_dropout) */
+  uint64_t dropout_seed;
+  const uint8_t* tile_kmask; /* TFGNN_G_PATTERN_TILEMASK_BY_DST with the PATTERN view, else NULL */
+  const int32_t* row_map;    /* TFGNN_G_PATTERN_NODE_BY_DST with the PATTERN view, else NULL */
+  float* out;               /* [V, H] fp32, row pitch ld_out floats (may be NULL when out_sp is given) */
+  int64_t ld_out;
+  void* out_sp;             /* optional: the result as a split operand [V, H] + out_inv_scale [V * (H / tile width)] */
+  int64_t ld_out_sp_bytes;
+  float* out_inv_scale;
+  const struct tfgnn_aux_job* extra_jobs;
+  int num_extra_jobs;
+  void* workspace;          /* tfgnn_graph_gather_workspace_bytes(graph, view, D) bytes */
+  size_t workspace_bytes;
+} tfgnn_mp_forward_args;
+
+typedef struct tfgnn_mp_backward_args {
+  size_t struct_size;
+  int kind;
+  const tfgnn_graph* graph;
+  const float* d_pre;       /* gradient w.r.t. the layer's pre-activation sums [V, H], row pitch ld_d_pre floats */
+  int64_t ld_d_pre;
+  int in_dim, hidden_dim;
+  const float* edge_weight; /* [E] factor per edge in by-source order (tfgnn_graph_scales d_edge_weight_by_src) or NULL */
+  const float* w;           /* stacked kernels [L, D, H]: non-NULL = (re)build the operand below */
+  void* wh_sp;              /* rows [W_0[d, :] | W_1[d, :] | ..] as SP16 [D, L * H] + wh_inv_scale [D] */
+  int64_t ld_wh_sp_bytes;
+  float* wh_inv_scale;
+  void* g_sp;               /* scratch: G [V, L * H] SP16 + g_inv_scale [V * L] */
+  float* g_inv_scale;
+  /* d(node states) = epilogue(G W^T): fp32 result dx [V, D] (added into when accumulate), times mul [V, D] (NULL: 1), times
+   * act'(saved * saved_scale) of activation act_of_saved (saved NULL: 1), times the dropout mask of (rate, seed) (rate 0: none);
+   * optionally also as a split operand */
+  float* dx;
+  int64_t ld_dx;
+  int accumulate;
+  const float* mul;
+  int64_t ld_mul;
+  int act_of_saved;
+  const float* saved;
+  int64_t ld_saved;
+  float saved_scale;
+  float dropout_rate;
+  uint64_t dropout_seed;
+  void* dx_sp;
+  int64_t ld_dx_sp_bytes;
+  float* dx_inv_scale;
+  const uint8_t* tile_kmask; /* TFGNN_G_PATTERN_TILEMASK_BY_SRC + a_rows = row_map = TFGNN_G_PATTERN_NODE_BY_SRC, or all NULL */
+  const int32_t* a_rows;
+  const int32_t* row_map;
+  /* kernel gradients dW [L, D, H] = X^T G_l (dw NULL: skipped): the layer input as a split operand [V, D], one scale per row */
+  float* dw;
+  const void* x_sp;
+  int64_t ld_x_sp_bytes;
+  const float* x_inv_scale;
+  void* tn_workspace;       /* tfgnn_sp_gemm_tn_workspace_bytes(L * H, D, V, L * H, H) bytes, 256-byte aligned */
+  size_t tn_workspace_bytes;
+  const struct tfgnn_aux_job* extra_jobs;
+  int num_extra_jobs;
+  void* workspace;          /* tfgnn_graph_gather_workspace_bytes(graph, TFGNN_VIEW_BY_SRC_TYPED, H) bytes */
+  size_t workspace_bytes;
+} tfgnn_mp_backward_args;
+
+/* = tfgnn_graph_gather_reduce_sp_deferred + tfgnn_sp_split_cols_job + tfgnn_aux_launch + tfgnn_sp_gemm_nt_rows */
+int tfgnn_mp_forward(const tfgnn_mp_forward_args* args, void* stream);
+/* = tfgnn_graph_gather_reduce_sp_deferred + tfgnn_sp_split_rows_job + tfgnn_aux_launch + tfgnn_sp_gemm_nt_rows + tfgnn_sp_gemm_tn */
+int tfgnn_mp_backward(const tfgnn_mp_backward_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

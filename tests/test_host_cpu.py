@@ -344,3 +344,23 @@ def test_captured_step_fails_loudly_without_a_device():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             step.replay()
         assert calls == []
+
+
+def test_layer_entry_points_validate_their_arguments_without_a_gpu():
+    """tfgnn_mp_forward / tfgnn_mp_backward (round 6, include/tfgnn.h): the argument structs of the binding have the library's
+    size (the call checks struct_size first), NULL handles are rejected before any HIP call."""
+    import ctypes
+
+    from tf2_gnn_amd import _lib
+
+    lib = _lib.load()
+    for fn, struct in ((lib.tfgnn_mp_forward, _lib.MpForwardArgs), (lib.tfgnn_mp_backward, _lib.MpBackwardArgs)):
+        a = struct()
+        a.struct_size = ctypes.sizeof(struct) - 8  # a binding built against another header
+        assert fn(ctypes.byref(a), None) == -1 and b"struct_size" in lib.tfgnn_last_error()
+        a.struct_size = ctypes.sizeof(struct)
+        a.kind = 7
+        assert fn(ctypes.byref(a), None) == -1 and b"unknown layer kind" in lib.tfgnn_last_error()
+        a.kind = 0
+        assert fn(ctypes.byref(a), None) == -1 and b"NULL pointer" in lib.tfgnn_last_error()
+        assert fn(None, None) == -1

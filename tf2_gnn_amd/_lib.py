@@ -321,6 +321,12 @@ _SIGNATURES = [
     ),
 ]
 
+# layer-level entry points (include/tfgnn.h, round 6): the argument structs travel by pointer
+_SIGNATURES += [
+    ("tfgnn_mp_forward", c_int, [c_void_p, c_void_p]),
+    ("tfgnn_mp_backward", c_int, [c_void_p, c_void_p]),
+]
+
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 ABI_VERSION = 4  # include/tfgnn.h TFGNN_ABI_VERSION
 
@@ -329,6 +335,37 @@ class AuxJob(ctypes.Structure):
     """tfgnn_aux_job (include/tfgnn.h): one small pass of a merged launch"""
 
     _fields_ = [("kind", c_int), ("num_blocks", ctypes.c_uint), ("payload", ctypes.c_ubyte * 248)]
+
+
+class MpForwardArgs(ctypes.Structure):
+    """tfgnn_mp_forward_args (include/tfgnn.h), field for field"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_size_t), ("kind", c_int), ("graph", c_void_p), ("view", c_int), ("x", c_void_p), ("ldx", c_int64),
+        ("in_dim", c_int), ("hidden_dim", c_int), ("row_scale", c_void_p), ("w", c_void_p), ("wt_sp", c_void_p),
+        ("ld_wt_sp_bytes", c_int64), ("wt_inv_scale", c_void_p), ("agg_sp", c_void_p), ("agg_inv_scale", c_void_p), ("bias", c_void_p),
+        ("act", c_int), ("dropout_rate", ctypes.c_float), ("dropout_seed", ctypes.c_uint64), ("tile_kmask", c_void_p),
+        ("row_map", c_void_p), ("out", c_void_p), ("ld_out", c_int64), ("out_sp", c_void_p), ("ld_out_sp_bytes", c_int64),
+        ("out_inv_scale", c_void_p), ("extra_jobs", c_void_p), ("num_extra_jobs", c_int), ("workspace", c_void_p),
+        ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class MpBackwardArgs(ctypes.Structure):
+    """tfgnn_mp_backward_args (include/tfgnn.h), field for field"""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_size_t), ("kind", c_int), ("graph", c_void_p), ("d_pre", c_void_p), ("ld_d_pre", c_int64),
+        ("in_dim", c_int), ("hidden_dim", c_int), ("edge_weight", c_void_p), ("w", c_void_p), ("wh_sp", c_void_p),
+        ("ld_wh_sp_bytes", c_int64), ("wh_inv_scale", c_void_p), ("g_sp", c_void_p), ("g_inv_scale", c_void_p), ("dx", c_void_p),
+        ("ld_dx", c_int64), ("accumulate", c_int), ("mul", c_void_p), ("ld_mul", c_int64), ("act_of_saved", c_int), ("saved", c_void_p),
+        ("ld_saved", c_int64), ("saved_scale", ctypes.c_float), ("dropout_rate", ctypes.c_float), ("dropout_seed", ctypes.c_uint64),
+        ("dx_sp", c_void_p), ("ld_dx_sp_bytes", c_int64), ("dx_inv_scale", c_void_p), ("tile_kmask", c_void_p), ("a_rows", c_void_p),
+        ("row_map", c_void_p), ("dw", c_void_p), ("x_sp", c_void_p), ("ld_x_sp_bytes", c_int64), ("x_inv_scale", c_void_p),
+        ("tn_workspace", c_void_p), ("tn_workspace_bytes", ctypes.c_size_t), ("extra_jobs", c_void_p), ("num_extra_jobs", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
 
 _lib = None
 

@@ -427,24 +427,33 @@ class GNN_Edge_MLP(MessagePassing):
             rmap = g.array(ops.G_PATTERN_NODE_BY_DST) if skip else None
             # (a gather that leaves the zero rows of skipped blocks unwritten - 38 % of the operand's 154 MB at the benchmark
             #  batch - measured no gain in round 5, 2.370 vs 2.368 ms per step: the gather's time is its reads.  Removed.)
-            A_sp = ops.graph_gather_sp(g, ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED, X, row_scale=row_scale,
-                                       rows_per_operand_row=L, defer_combine=True)
-            Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H), defer=True))
+            view = ops.VIEW_BY_DST_TYPED_PATTERN if skip else ops.VIEW_BY_DST_TYPED
             gelu_split = fuse_act == "gelu"
             want_split = getattr(self, "_want_split_output", False) or getattr(self, "_always_split_output", False)
             drop = getattr(self, "_fused_output_dropout", None)  # (rate, seed) of the NEXT layer's input dropout (GNN stack)
             out_scale = 1.0
-            if drop is not None and not gelu_split and H in (128, 256, 320) and type(self)._finish is GNN_Edge_MLP._finish:
-                # this layer's output is only ever read through that dropout: apply the mask in the product's epilogue and
-                # write the dropped result in both forms (fp32 for the next gather, SP16 for its weight-gradient product)
-                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, dropout=drop, tile_kmask=kmask, row_map=rmap)
+            # this layer's output is only ever read through that dropout: apply the mask in the product's epilogue and write the
+            # dropped result in both forms (fp32 for the next gather, SP16 for its weight-gradient product)
+            fuse_drop = drop is not None and not gelu_split and H in (128, 256, 320) and type(self)._finish is GNN_Edge_MLP._finish
+            # (a split result: the consumer finds it with sp_rows_of)
+            split_out = fuse_drop or (want_split and not gelu_split and H in (128, 256, 320))
+            if ops.mp_entry_enabled() and Din == D:
+                # round 6: gather + weight split + merged small passes + product in ONE library call (tfgnn_mp_forward) - the
+                # kernels and arguments of the op-level route below, without Python between the launches
+                pre, _ = ops.mp_forward(g, view, X, W, row_scale=row_scale, act=None if gelu_split else fuse_act,
+                                        dropout=drop if fuse_drop else None, tile_kmask=kmask, row_map=rmap, want_split=split_out)
+            else:
+                A_sp = ops.graph_gather_sp(g, view, X, row_scale=row_scale, rows_per_operand_row=L, defer_combine=True)
+                Wt_sp = ops.sp_weight_operand(W, "cols", lambda: ops.sp_split_cols(W.view(L * Din, H), defer=True))
+                if fuse_drop:
+                    pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, dropout=drop, tile_kmask=kmask, row_map=rmap)
+                elif split_out:
+                    pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, tile_kmask=kmask, row_map=rmap)
+                else:
+                    pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act, tile_kmask=kmask, row_map=rmap)
+            if fuse_drop:
                 self._fused_output_dropout_done = True
                 out_scale = 1.0 - float(drop[0])
-            elif want_split and not gelu_split and H in (128, 256, 320):
-                # the consumer finds the split form with sp_rows_of
-                pre, _ = ops.sp_gemm_nt_split(A_sp, Wt_sp, act=fuse_act, tile_kmask=kmask, row_map=rmap)
-            else:
-                pre = ops.sp_gemm_nt(A_sp, Wt_sp, act=None if gelu_split else fuse_act, tile_kmask=kmask, row_map=rmap)
             ctx = {"path": "A", "A": None, "fused_act": fuse_act, "f16x2": True, "out_scale": out_scale}
             if gelu_split:
                 ctx["pre"] = pre
@@ -483,11 +492,32 @@ class GNN_Edge_MLP(MessagePassing):
         W = mlps.kernels[0]  # [L, D, H]
         import os
 
+        overlap = ops.env("TFGNN_TN_OVERLAP", "0") == "1"
+        if ops.mp_entry_enabled() and not overlap:
+            # round 6: the whole pass in ONE library call (tfgnn_mp_backward): gather over the by-source buckets, the rows form of
+            # the kernels when stale, the merged small passes, dX = G W^T with its epilogue, dW = X^T G - the op-level sequence below
+            skip = {}
+            if _skip_empty_blocks(L, H) and V > 0:
+                node_at = g.array(ops.G_PATTERN_NODE_BY_SRC)
+                skip = dict(tile_kmask=g.array(ops.G_PATTERN_TILEMASK_BY_SRC), a_rows=node_at, row_map=node_at)
+            epi = getattr(self, "_out_epilogue", None)
+            acc = getattr(self, "_dx_accumulate", None)
+            kw = {}
+            if acc is not None:
+                kw = dict(out=acc[0], accumulate=True, out_mul=acc[1])
+                self._dx_accumulate = None  # consumed
+            elif epi is not None:
+                kw = dict(out_mul=epi[0], act_grad=epi[1], want_split=bool(getattr(self, "_want_split_input_grad", False)) and D in (128, 256, 320))
+                self._out_epilogue = None  # consumed
+            X_sp = ops.sp_rows_of(X)  # written by the dropout kernel when X came out of one
+            dX, _, dW = ops.mp_backward(g, d_agg.contiguous(), W, X_sp, edge_weight=ew_s, skip=skip, **kw)
+            mlps.grads = [dW]
+            mlps.publish_grads()
+            return dX
         G_sp = ops.graph_gather_sp(g, ops.VIEW_BY_SRC_TYPED, d_agg.contiguous(), edge_weight=ew_s, rows_per_operand_row=L,
                                    defer_combine=True)
         # the weight gradient dW = X^T G is off the critical path of the backward pass: its two small passes (per-k factors,
         # split reduction) run on the library's second stream beside the big kernels around them
-        overlap = ops.env("TFGNN_TN_OVERLAP", "0") == "1"
         tn = None
         if overlap:
             dW = torch.empty_like(W)

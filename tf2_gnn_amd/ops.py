@@ -1673,6 +1673,191 @@ def graph_gather_sp(graph: "Graph", view: int, inp: torch.Tensor, *, col=None, e
     return SplitOperand(data, inv, num_rows // R, R * width, width)
 
 
+# ---- layer-level entry points (include/tfgnn.h tfgnn_mp_forward / tfgnn_mp_backward, csrc/mp_layer.hip) --------------------------
+def mp_entry_enabled() -> bool:
+    """The aggregate-first layers drive ONE C call per pass (default) instead of the op-level calls it is made of
+    (TFGNN_MP_ENTRY=0: the op-level route - same kernels, same arguments, bit-identical results)."""
+    return env("TFGNN_MP_ENTRY", "1") != "0"
+
+
+def _take_pending_jobs():
+    """What ``aux_defer`` holds for the current stream, handed to a layer-level call that launches it with its own small passes.
+    -> (ctypes array | None, count, callbacks to run after the call, keep-alive)"""
+    with _AUX_LOCK:
+        batch = list(_AUX_PENDING)
+        del _AUX_PENDING[:]
+        _AUX_URGENT[0] = False
+    live = [j for j, _, _ in batch if j.kind != 0 and j.num_blocks != 0]
+    arr = (_lib.AuxJob * len(live))(*live) if live else None
+    return arr, len(live), [t for _, _, t in batch if t is not None], batch
+
+
+def _fresh_weight_operand(w: torch.Tensor, kind: str, rows: int, cols: int):
+    """-> (operand, stale): the cached split form of weight ``w`` or a new, still EMPTY one registered in the cache - the
+    layer-level call that receives ``stale`` = True builds it in its merged small-pass launch."""
+    made = []
+
+    def build():
+        made.append(True)
+        return SplitOperand(torch.empty((rows, cols * 4), dtype=torch.uint8, device=w.device),
+                            torch.empty((rows, 1), dtype=torch.float32, device=w.device), rows, cols, cols)
+
+    return sp_weight_operand(w, kind, build), bool(made)
+
+
+def mp_forward(graph: "Graph", view: int, x: torch.Tensor, W: torch.Tensor, *, row_scale=None, act=ACT_NONE, dropout=None,
+               tile_kmask=None, row_map=None, want_split: bool = False, want_fp32: bool = True):
+    """One aggregate-first message-passing layer forward in ONE library call (tfgnn_mp_forward): gather of the source rows per
+    (node, type) bucket written as the split operand, W^T split when its cached form is stale, the small passes merged, the
+    product with its epilogue.  W: stacked kernels [L, D, H].  -> (out [V, H] | None, split form of out | None)."""
+    lib = _lib.load()
+    _require_dev(x, torch.float32, "x")
+    L, D, H = (int(v) for v in W.shape)
+    V = graph.num_nodes
+    if L != graph.num_edge_types or x.shape[1] != D or not W.is_contiguous():
+        raise ValueError("mp_forward: W must be the contiguous [L, D, H] stack of the graph's edge types and of x's width")
+    x, ldx = _rowmajor(x, "x")
+    dev = x.device
+    graph.ensure(_VIEW_PARTS[view])
+    wt, stale = _fresh_weight_operand(W, "cols", H, L * D)
+    agg = torch.empty((V, L * D * 4), dtype=torch.uint8, device=dev)
+    agg_inv = torch.empty((V, L), dtype=torch.float32, device=dev)
+    out = torch.empty((V, H), dtype=torch.float32, device=dev) if want_fp32 else None
+    op = None
+    if want_split:
+        bn = sp_tile_width(H)
+        op = SplitOperand(torch.empty((V, H * 4), dtype=torch.uint8, device=dev),
+                          torch.empty((V, max(1, H // max(bn, 1))), dtype=torch.float32, device=dev), V, H, bn if bn else H)
+    ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, view, D)
+    ws = _workspace(dev, ws_bytes) if ws_bytes else None
+    rate, seed = dropout if dropout is not None else (0.0, 0)
+    _ensure_splitk_workspace(dev, V)
+    stream = _stream()  # (launches what was deferred as urgent before this layer: its inputs may depend on it)
+    jobs, njobs, after, keep = _take_pending_jobs()
+    a = _lib.MpForwardArgs()
+    a.struct_size = ctypes.sizeof(_lib.MpForwardArgs)
+    a.kind = 0
+    a.graph = graph._h
+    a.view = int(view)
+    a.x, a.ldx, a.in_dim, a.hidden_dim = x.data_ptr(), ldx, D, H
+    a.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    a.w = W.data_ptr() if stale else None
+    a.wt_sp, a.ld_wt_sp_bytes, a.wt_inv_scale = wt.data.data_ptr(), wt.data.stride(0), wt.inv_scale.data_ptr()
+    a.agg_sp, a.agg_inv_scale = agg.data_ptr(), agg_inv.data_ptr()
+    a.bias = None
+    a.act = act_id(act)
+    a.dropout_rate, a.dropout_seed = float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.tile_kmask = _tile_kmask(tile_kmask, V).data_ptr() if tile_kmask is not None else None
+    a.row_map = _row_map(row_map, V).data_ptr() if row_map is not None else None
+    a.out, a.ld_out = (out.data_ptr(), H) if out is not None else (None, 0)
+    if op is not None:
+        a.out_sp, a.ld_out_sp_bytes, a.out_inv_scale = op.data.data_ptr(), op.data.stride(0), op.inv_scale.data_ptr()
+    a.extra_jobs = ctypes.cast(jobs, ctypes.c_void_p) if jobs is not None else None
+    a.num_extra_jobs = njobs
+    a.workspace, a.workspace_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+    _lib.check(lib.tfgnn_mp_forward(ctypes.byref(a), stream))
+    del keep
+    for then in after:
+        then()
+    if out is not None and op is not None:
+        _remember_split_rows(out, op)
+    return out, op
+
+
+def mp_backward(graph: "Graph", d_pre: torch.Tensor, W: torch.Tensor, x_sp: Optional[SplitOperand], *, edge_weight=None, out=None,
+                accumulate: bool = False, out_mul=None, act_grad=None, want_split: bool = False, skip=None,
+                need_weight_grad: bool = True):
+    """The backward pass of that layer in ONE library call (tfgnn_mp_backward): the gather of ``d_pre`` over the by-source buckets
+    as a split operand, the rows form of the kernels when stale, d(node states) = epilogue(G W^T) - ``out`` / ``accumulate`` /
+    ``out_mul`` / ``act_grad`` as in ``sp_gemm_nt``; ``skip`` = dict(tile_kmask, a_rows, row_map) of the by-source pattern order -
+    and the kernel gradients dW [L, D, H] = X^T G_l from the layer input's split form ``x_sp``.
+    -> (dX [V, D], split form of dX | None, dW | None)."""
+    lib = _lib.load()
+    _require_dev(d_pre, torch.float32, "d_pre")
+    L, D, H = (int(v) for v in W.shape)
+    V = graph.num_nodes
+    if L != graph.num_edge_types or d_pre.shape[1] != H or not W.is_contiguous():
+        raise ValueError("mp_backward: W must be the contiguous [L, D, H] stack of the graph's edge types, d_pre [V, H]")
+    d_pre, ldg = _rowmajor(d_pre, "d_pre")
+    dev = d_pre.device
+    graph.ensure(_VIEW_PARTS[VIEW_BY_SRC_TYPED])
+    wh, stale = _fresh_weight_operand(W, "rows", D, L * H)
+    g_sp = torch.empty((V, L * H * 4), dtype=torch.uint8, device=dev)
+    g_inv = torch.empty((V, L), dtype=torch.float32, device=dev)
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs out")
+        out = torch.empty((V, D), dtype=torch.float32, device=dev)
+    out2, ldc = _rowmajor(out, "out")
+    if out2 is not out or tuple(out.shape) != (V, D):
+        raise ValueError(f"out must be [{V},{D}] with unit inner stride")
+    op = None
+    if want_split:
+        if accumulate:
+            raise ValueError("mp_backward: the split result needs no accumulation")
+        bn = sp_tile_width(D)
+        op = SplitOperand(torch.empty((V, D * 4), dtype=torch.uint8, device=dev),
+                          torch.empty((V, max(1, D // max(bn, 1))), dtype=torch.float32, device=dev), V, D, bn if bn else D)
+    out_mul, act_grad, dropout, saved_scale = _native_epilogue(out_mul, act_grad, None, 1.0)
+    act_name, saved = act_grad if act_grad is not None else (None, None)
+    rate, seed = dropout if dropout is not None else (0.0, 0)
+    dW = torch.empty_like(W) if need_weight_grad else None
+    ws_bytes = lib.tfgnn_graph_gather_workspace_bytes(graph._h, VIEW_BY_SRC_TYPED, H)
+    ws = _workspace(dev, ws_bytes) if ws_bytes else None
+    tn_ws, tn_ptr, tn_len = None, None, 0
+    if need_weight_grad:
+        if x_sp is None or x_sp.scale_block != x_sp.cols or x_sp.rows != V or x_sp.cols != D:
+            raise ValueError("mp_backward: the kernel gradients need the layer input as a split operand with one scale per row")
+        tn_bytes = lib.tfgnn_sp_gemm_tn_workspace_bytes(L * H, D, V, L * H, H)
+        if tn_bytes:
+            # (its own buffer: the gather's workspace above is the shared one of this stream)
+            tn_ws = torch.empty(tn_bytes + 256, dtype=torch.uint8, device=dev)
+            off = (-tn_ws.data_ptr()) % 256
+            tn_ptr, tn_len = tn_ws.data_ptr() + off, tn_ws.numel() - off
+    _ensure_splitk_workspace(dev, V)
+    stream = _stream()
+    jobs, njobs, after, keep = _take_pending_jobs()
+    skip = skip or {}
+    a = _lib.MpBackwardArgs()
+    a.struct_size = ctypes.sizeof(_lib.MpBackwardArgs)
+    a.kind = 0
+    a.graph = graph._h
+    a.d_pre, a.ld_d_pre, a.in_dim, a.hidden_dim = d_pre.data_ptr(), ldg, D, H
+    a.edge_weight = edge_weight.data_ptr() if edge_weight is not None else None
+    a.w = W.data_ptr() if stale else None
+    a.wh_sp, a.ld_wh_sp_bytes, a.wh_inv_scale = wh.data.data_ptr(), wh.data.stride(0), wh.inv_scale.data_ptr()
+    a.g_sp, a.g_inv_scale = g_sp.data_ptr(), g_inv.data_ptr()
+    a.dx, a.ld_dx, a.accumulate = out.data_ptr(), ldc, int(bool(accumulate))
+    if out_mul is not None:
+        a.mul, a.ld_mul = out_mul.data_ptr(), out_mul.stride(0)
+    a.act_of_saved = act_id(act_name)
+    if saved is not None:
+        a.saved, a.ld_saved = saved.data_ptr(), saved.stride(0)
+    a.saved_scale = float(saved_scale)
+    a.dropout_rate, a.dropout_seed = float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF
+    if op is not None:
+        a.dx_sp, a.ld_dx_sp_bytes, a.dx_inv_scale = op.data.data_ptr(), op.data.stride(0), op.inv_scale.data_ptr()
+    for name, check in (("tile_kmask", _tile_kmask), ("a_rows", _row_map), ("row_map", _row_map)):
+        t = skip.get(name)
+        if t is not None:
+            setattr(a, name, check(t, V).data_ptr())
+    if dW is not None:
+        a.dw = dW.data_ptr()
+        a.x_sp, a.ld_x_sp_bytes, a.x_inv_scale = x_sp.data.data_ptr(), x_sp.data.stride(0), x_sp.inv_scale.data_ptr()
+        a.tn_workspace, a.tn_workspace_bytes = tn_ptr, tn_len
+    a.extra_jobs = ctypes.cast(jobs, ctypes.c_void_p) if jobs is not None else None
+    a.num_extra_jobs = njobs
+    a.workspace, a.workspace_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+    _lib.check(lib.tfgnn_mp_backward(ctypes.byref(a), stream))
+    del keep, tn_ws
+    for then in after:
+        then()
+    torch.autograd.graph.increment_version(out)
+    if op is not None:
+        _remember_split_rows(out, op)
+    return out, op, dW
+
+
 @_writes_out
 def sp_gemm_tn(a: SplitOperand, b: SplitOperand, *, a_cols=None, b_cols=None, out: Optional[torch.Tensor] = None,
                scatter=None, accumulate: bool = False, defer_reduce: bool = False, wide: bool = False) -> torch.Tensor:
