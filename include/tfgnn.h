@@ -810,6 +810,15 @@ int tfgnn_sp_split_rows_job(const float* d_src, int64_t ld, int64_t seg_len, int
                             const float* d_fixed_inv_scale, tfgnn_aux_job* job);
 int tfgnn_sp_split_cols_job(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
                             float* d_inv_scale, tfgnn_aux_job* job);
+/* tfgnn_sp_split_cols for LONG K (round 6; the stacked kernels of many relations, BASELINE configs[4]: [40 * 512, 512]): the
+ * one-pass job lets each of its K slices take the column maxima over all of K itself - 64-byte row pieces, the matrix read 8
+ * times.  Two jobs instead: *maxima_job (whole rows, each byte once, per-slab maxima into d_colmax_workspace,
+ * tfgnn_sp_split_cols_two_pass_bytes(K, N) bytes; 0 = K is short, the one-pass job is used and *maxima_job is empty) must run
+ * in an EARLIER launch than *split_job.  Same operand, bit for bit (a maximum does not depend on the order). */
+size_t tfgnn_sp_split_cols_two_pass_bytes(int64_t K, int64_t N);
+int tfgnn_sp_split_cols_jobs(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                             float* d_inv_scale, float* d_colmax_workspace, size_t workspace_bytes, tfgnn_aux_job* maxima_job,
+                             tfgnn_aux_job* split_job);
 /* tfgnn_graph_gather_reduce_sp; the combine pass of the long buckets comes back in *combine_job (kind 0: none) */
 int tfgnn_graph_gather_reduce_sp_deferred(const tfgnn_graph* graph, int view, const int32_t* d_col_override,
                                           const float* d_edge_weight, const float* d_row_scale, const float* d_in,

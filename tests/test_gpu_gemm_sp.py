@@ -819,3 +819,26 @@ def test_tile_mask_needs_block_scales_that_tile_k(dev):
         ops.sp_gemm_nt(a, w, tile_kmask=mask[:1])
     with pytest.raises(ValueError, match="row_map"):
         ops.sp_gemm_nt(a, w, row_map=torch.zeros(5, dtype=torch.int32, device=dev))
+
+
+@pytest.mark.parametrize("K,N", [(4096, 512), (20480, 512), (2560, 320), (1296, 128), (1280, 256)])
+def test_two_pass_split_of_a_long_kernel_stack_equals_the_one_pass_split(dev, K, N):
+    """Round 6 (BASELINE configs[4]): the deferred transposed split of a long [K, N] stack of kernels takes its column maxima in a
+    pass of its own (a job of one merged launch) and converts in the next launch - every byte read once instead of once per K
+    slice.  The operand and its scales must be the one-pass split's, bit for bit; K <= 1280 keeps the one-pass job."""
+    from tf2_gnn_amd import _lib, ops
+
+    gen = torch.Generator().manual_seed(K + N)
+    w = (torch.randn((K, N), generator=gen) * torch.logspace(-3, 2, N).unsqueeze(0)).to(dev)
+    w[5::7, 3] = 0.0
+    w[:, 8] = 0.0  # an all-zero column: the marker scale
+    assert (_lib.load().tfgnn_sp_split_cols_two_pass_bytes(K, N) > 0) == (K > 1280)
+    ref = ops.sp_split_cols(w)
+    got = ops.sp_split_cols(w, defer=True).synced()
+    torch.cuda.synchronize()
+    assert torch.equal(got.inv_scale, ref.inv_scale) and torch.equal(got.data, ref.data)
+    # and as a consumer meets it: the product right behind the deferred split
+    a = ops.sp_split_rows(torch.randn((300, K), generator=gen).to(dev))
+    out_ref = ops.sp_gemm_nt(a, ref)
+    out = ops.sp_gemm_nt(a, ops.sp_split_cols(w, defer=True))
+    assert torch.equal(out, out_ref)

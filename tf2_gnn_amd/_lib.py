@@ -278,6 +278,9 @@ _SIGNATURES = [
         [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     ),
     ("tfgnn_sp_split_cols_job", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    ("tfgnn_sp_split_cols_two_pass_bytes", c_size_t, [c_int64, c_int64]),
+    ("tfgnn_sp_split_cols_jobs", c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p,
+                                         c_void_p]),
     (
         "tfgnn_graph_gather_reduce_sp_deferred",
         c_int,

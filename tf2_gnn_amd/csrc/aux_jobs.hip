@@ -50,7 +50,12 @@ __global__ void __launch_bounds__(256) aux_jobs_kernel(AuxJobTable table) {
     }
     case AUX_SPLIT_COLS: {
       const AuxSplitCols a = aux_payload<AuxSplitCols>(j);
-      sp_split_cols_body(a.src, a.ld, a.K, a.N, a.dst, a.ld_dst, a.inv, b % a.ncx, b / a.ncx, a.ncy);
+      sp_split_cols_body(a.src, a.ld, a.K, a.N, a.dst, a.ld_dst, a.inv, b % a.ncx, b / a.ncx, a.ncy, a.colmax_parts, a.nparts);
+      break;
+    }
+    case AUX_COL_ABSMAX: {
+      const AuxColAbsmax a = aux_payload<AuxColAbsmax>(j);
+      col_absmax_body(a, b);
       break;
     }
     case AUX_TN_REDUCE: {

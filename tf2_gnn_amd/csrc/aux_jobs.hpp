@@ -15,7 +15,7 @@
 
 namespace tfgnn {
 
-enum AuxKind { AUX_NONE = 0, AUX_SPLIT_ROWS = 1, AUX_SPLIT_COLS = 2, AUX_TN_REDUCE = 3, AUX_COMBINE_SP = 4, AUX_TN_FACTORS = 5, AUX_KIND_END = 6 };
+enum AuxKind { AUX_NONE = 0, AUX_SPLIT_ROWS = 1, AUX_SPLIT_COLS = 2, AUX_TN_REDUCE = 3, AUX_COMBINE_SP = 4, AUX_TN_FACTORS = 5, AUX_COL_ABSMAX = 6, AUX_KIND_END = 7 };
 
 struct AuxSplitRows {
   const float* src;
@@ -33,7 +33,22 @@ struct AuxSplitCols {
   int64_t ld_dst;
   float* inv;
   unsigned ncx, ncy;
+  // round 6 (long K: stacked kernels of many relations): the column maxima come from a pass of their own (AUX_COL_ABSMAX in an
+  // EARLIER launch) as nparts slabs [nparts][N]; NULL: every workgroup takes them over all of K itself
+  const float* colmax_parts;
+  int nparts;
 };
+// |x| maxima of the columns of a row-major [K, N] matrix over nparts row slabs: part[s][n] = max over the rows of slab s.
+// One workgroup per (slab, chunk of 1024 columns); thread t owns the float4 column group t of its chunk, rows in sequence
+// (whole rows are read: coalesced, each byte once - the column-strip workgroups of the conversion read 64-byte row pieces).
+struct AuxColAbsmax {
+  const float* src;
+  int64_t ld, K, N;
+  float* part;
+  int nparts;
+  unsigned nchunks;
+};
+static_assert(sizeof(AuxColAbsmax) <= sizeof(((tfgnn_aux_job*)0)->payload), "tfgnn_aux_job payload too small");
 struct AuxTnReduce {
   const float* partial;
   int splits;
@@ -131,9 +146,37 @@ __device__ __forceinline__ void sp_split_rows_body(const float* __restrict__ src
 // [K, N] -> the [N, K] K-contiguous operand of the NT product), one scale per dst row.  Workgroup (x, y): 16 dst rows, the
 // y-th slice of K; every workgroup takes the column maxima over ALL k itself (a weight matrix is L2 resident), so the
 // slices need no second launch.
+__device__ __forceinline__ void col_absmax_body(const AuxColAbsmax& a, unsigned block) {
+  const unsigned s = block / a.nchunks, chunk = block - s * a.nchunks;
+  const int64_t per = (a.K + a.nparts - 1) / a.nparts;
+  const int64_t k0 = (int64_t)s * per, k1 = k0 + per < a.K ? k0 + per : a.K;
+  const int64_t c = ((int64_t)chunk * 256 + threadIdx.x) * 4;  // N % 4 == 0
+  if (c >= a.N) return;
+  const float* p = a.src + c;
+  float4 mx = {0.f, 0.f, 0.f, 0.f};
+  int64_t k = k0;
+  for (; k + 8 <= k1; k += 8) {  // eight rows in flight
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (k + u) * a.ld);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      mx.x = fmaxf(mx.x, fabsf(v[u].x)); mx.y = fmaxf(mx.y, fabsf(v[u].y));
+      mx.z = fmaxf(mx.z, fabsf(v[u].z)); mx.w = fmaxf(mx.w, fabsf(v[u].w));
+    }
+  }
+  for (; k < k1; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(p + k * a.ld);
+    mx.x = fmaxf(mx.x, fabsf(v.x)); mx.y = fmaxf(mx.y, fabsf(v.y));
+    mx.z = fmaxf(mx.z, fabsf(v.z)); mx.w = fmaxf(mx.w, fabsf(v.w));
+  }
+  *reinterpret_cast<float4*>(a.part + (int64_t)s * a.N + c) = mx;
+}
+
 __device__ __forceinline__ void sp_split_cols_body(const float* __restrict__ src, int64_t ld, int64_t K, int64_t N,
                                                    uint8_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ inv,
-                                                   unsigned bx, unsigned by, unsigned ny) {
+                                                   unsigned bx, unsigned by, unsigned ny, const float* __restrict__ colmax_parts = nullptr,
+                                                   int nparts = 0) {
   __shared__ float red[64][4];
   __shared__ float tile[2][16][65];
   __shared__ float sc[16];
@@ -146,7 +189,16 @@ __device__ __forceinline__ void sp_split_cols_body(const float* __restrict__ src
   const bool in_regs = nv <= NV;
   float4 v[NV];
   float4 mx = {0.f, 0.f, 0.f, 0.f};
-  if (in_regs) {
+  if (!in_regs && colmax_parts) {
+    // the maxima were taken by a pass of their own (col_absmax_body): this thread reduces the slabs kq, kq + 64, .. of its four
+    // columns; the reduction below then runs over the 64 threads with the same nq as for the direct pass.  (max is exact and
+    // order-free: the same scales, bit for bit, as the pass over all of K.)
+    if (ok)
+      for (int sl = kq; sl < nparts; sl += 64) {
+        const float4 u = *reinterpret_cast<const float4*>(colmax_parts + (int64_t)sl * N + n0 + nq);
+        mx.x = fmaxf(mx.x, u.x); mx.y = fmaxf(mx.y, u.y); mx.z = fmaxf(mx.z, u.z); mx.w = fmaxf(mx.w, u.w);
+      }
+  } else if (in_regs) {
     // all of the strip's rows in flight at once (round 4: the loop below waited for four loads at a time - 15 us of latency
     // for 80 KB), kept for the conversion: nothing is read twice
 #pragma unroll

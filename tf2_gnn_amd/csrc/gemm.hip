@@ -376,7 +376,9 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, size_t workspace_byte
     const int64_t want = splitk_want(tiles, K);
     int64_t max_by_k = K / (4 * BK);
     int64_t s = want < max_by_k ? want : max_by_k;
-    int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4 + 1));
+    // (exact division: with "+ 1" a workspace of exactly tfgnn_gemm_workspace_bytes() bytes allowed one split fewer than a larger
+    //  one - the same product then summed in another order depending on which buffer the caller happened to hold: round 6)
+    int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4));
     if (s > max_by_ws) s = max_by_ws;
     if (s > 1) {
       p.k_chunk = ceil_div(ceil_div(K, s), BK) * BK;
@@ -523,7 +525,15 @@ extern "C" size_t tfgnn_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   // upper bound over both staging variants
   GemmPlan p1 = plan_gemm(M, N, K, (size_t)1 << 40, true);
   GemmPlan p2 = plan_gemm(M, N, K, (size_t)1 << 40, false);
-  const int s = std::max(p1.splits, p2.splits);
+  int64_t s = std::max(p1.splits, p2.splits);
+  // ... and over the split-operand kernels of the other GEMM modes (gemm_x3_try: 128-row tiles of up to 320 columns): with
+  // exactly this many bytes every mode takes the split count it would take with any larger buffer - the summation order of a
+  // product does not depend on which workspace the caller holds (round 6: a captured step and its eager twin differed in the
+  // last bit of a weight gradient because their streams' workspaces had different sizes)
+  if (K >= 1024) {
+    const int64_t tiles_min = ceil_div(M, 128) * ceil_div(N, 320);
+    if (tiles_min < 192) s = std::max<int64_t>(s, std::min<int64_t>(splitk_want(tiles_min, K), K / 128));
+  }
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
 }
 

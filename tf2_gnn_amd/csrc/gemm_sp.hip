@@ -1510,6 +1510,9 @@ static int splitk_admit(hipStream_t s) {
 // (Helper workgroups for the heavy tiles of a masked product - round 5, measured a loss: 112 / 101 us against 90 us per forward
 //  product, NOTEBOOK 10 - were removed in round 6 together with their export.)
 
+// row slabs of the column-maxima pass of a long [K, N] kernel stack: ~160 rows each, at most 256
+static int sp_colmax_parts(int64_t K) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, K / 160)); }
+
 static int sp_tile_width(int64_t N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
 // one int in host memory mapped into the device's address space: the factor pass of the weight-gradient product stores 1
@@ -2113,8 +2116,37 @@ int tfgnn_sp_split_cols_job(const float* d_src, int64_t ld, int64_t K, int64_t N
                 "tfgnn_sp_split_cols_job: K must be a multiple of 16, N and ld multiples of 4");
   TFGNN_REQUIRE(ld_sp_bytes >= K * 4 && ld_sp_bytes % 64 == 0 && (uintptr_t)d_sp % 64 == 0, "tfgnn_sp_split_cols_job: bad SP16 leading dimension / alignment");
   AuxSplitCols a{d_src, ld, K, N, (uint8_t*)d_sp, ld_sp_bytes, d_inv_scale, (unsigned)ceil_div(N, 16),
-                 (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, K / 128))};
+                 (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, K / 128)), nullptr, 0};
   aux_job_set(job, AUX_SPLIT_COLS, a.ncx * a.ncy, a);
+  return TFGNN_OK;
+}
+
+size_t tfgnn_sp_split_cols_two_pass_bytes(int64_t K, int64_t N) {
+  // worth it where the one-pass conversion cannot keep a column strip in registers (K > 1280) and re-reads it per K slice
+  if (K <= 1280 || N <= 0 || N % 4) return 0;
+  return (size_t)sp_colmax_parts(K) * (size_t)N * 4;
+}
+
+int tfgnn_sp_split_cols_jobs(const float* d_src, int64_t ld, int64_t K, int64_t N, void* d_sp, int64_t ld_sp_bytes,
+                             float* d_inv_scale, float* d_colmax_workspace, size_t workspace_bytes, tfgnn_aux_job* maxima_job,
+                             tfgnn_aux_job* split_job) {
+  TFGNN_REQUIRE(maxima_job && split_job, "tfgnn_sp_split_cols_jobs: null job");
+  int rc = tfgnn_sp_split_cols_job(d_src, ld, K, N, d_sp, ld_sp_bytes, d_inv_scale, split_job);
+  if (rc) return rc;
+  maxima_job->kind = AUX_NONE;
+  maxima_job->num_blocks = 0;
+  const size_t need = tfgnn_sp_split_cols_two_pass_bytes(K, N);
+  if (!need) return TFGNN_OK;  // the one-pass job
+  TFGNN_REQUIRE(d_colmax_workspace && workspace_bytes >= need && (uintptr_t)d_colmax_workspace % 16 == 0,
+                "tfgnn_sp_split_cols_jobs: the maxima need %zu bytes of 16-byte aligned workspace", need);
+  const int nparts = sp_colmax_parts(K);
+  AuxColAbsmax m{d_src, ld, K, N, d_colmax_workspace, nparts, (unsigned)ceil_div(N, 1024)};
+  aux_job_set(maxima_job, AUX_COL_ABSMAX, (unsigned)nparts * m.nchunks, m);
+  AuxSplitCols a{};
+  memcpy(&a, split_job->payload, sizeof(a));
+  a.colmax_parts = d_colmax_workspace;
+  a.nparts = nparts;
+  aux_job_set(split_job, AUX_SPLIT_COLS, a.ncx * a.ncy, a);
   return TFGNN_OK;
 }
 

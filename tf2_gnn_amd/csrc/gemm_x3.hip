@@ -1427,7 +1427,9 @@ int gemm_x3_try(int nprod, int trans_a, int trans_b, int64_t M, int64_t N, int64
     int64_t want = splitk_want(tiles, K);
     const int64_t max_by_k = K / 128;
     if (want > max_by_k) want = max_by_k;
-    const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4 + 1));
+    // (exact division: with "+ 1" a workspace of exactly tfgnn_gemm_workspace_bytes() bytes allowed one split fewer than a larger
+    //  one - the same product then summed in another order depending on which buffer the caller happened to hold: round 6)
+    const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)(M * N) * 4));
     if (want > max_by_ws) want = max_by_ws;
     if (want > 1 && (uintptr_t)workspace % 16 == 0) {
       g.k_chunk = ceil_div(ceil_div(K, want), X3_BK) * X3_BK;

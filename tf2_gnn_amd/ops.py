@@ -92,7 +92,7 @@ def _raw_stream() -> int:
 def _stream() -> int:
     """The launch stream of a library call.  Every wrapper evaluates this right before its C call, which makes it the one
     place where deferred small passes (``aux_defer``) that the coming kernel may depend on are launched first."""
-    if _AUX_PENDING and _AUX_URGENT[0]:
+    while _AUX_PENDING and _AUX_URGENT[0]:  # (a launched job may chain an urgent one behind it: the two-pass weight split)
         aux_flush(everything=False)
     return _raw_stream()
 
@@ -1349,6 +1349,17 @@ def sp_split_cols(w: torch.Tensor, defer: bool = False, out: Optional[SplitOpera
         data = torch.empty((N, K * 4), dtype=torch.uint8, device=w.device)
         inv = torch.empty((N, 1), dtype=torch.float32, device=w.device)
     if defer and aux_enabled():
+        two_pass = lib.tfgnn_sp_split_cols_two_pass_bytes(K, N)
+        if two_pass:
+            # long K (the stacked kernels of many relations): the column maxima as a pass of their own in THIS merged launch, the
+            # conversion - which then reads every byte once instead of once per K slice - in the next one (the chained job is
+            # deferred as urgent: ``_stream()`` launches it before the consumer's kernel)
+            cm = torch.empty(two_pass, dtype=torch.uint8, device=w.device)
+            mjob, sjob = _lib.AuxJob(), _lib.AuxJob()
+            _lib.check(lib.tfgnn_sp_split_cols_jobs(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), _ptr(cm), two_pass,
+                                                    ctypes.byref(mjob), ctypes.byref(sjob)))
+            aux_defer(mjob, keep=(w, cm), then=lambda: aux_defer(sjob, keep=(w, data, inv, cm)))
+            return SplitOperand(data, inv, N, K, K)
         job = _lib.AuxJob()
         _lib.check(lib.tfgnn_sp_split_cols_job(_ptr(w), ld, K, N, _ptr(data), data.stride(0), _ptr(inv), ctypes.byref(job)))
         aux_defer(job, keep=(w, data, inv))
