@@ -352,7 +352,7 @@ def compact_line(result, detail_path=None):
             if e.get("cpu_baseline"):
                 row["cpu_value"] = e["cpu_baseline"].get("value")
             if e.get("products_per_step"):
-                row["products_per_step"] = {k: v for k, v in e["products_per_step"].items() if v and k in ("sp_nt", "sp_tn", "x3", "fp32")}
+                row["products_per_step"] = {k: v for k, v in e["products_per_step"].items() if v and k in ("sp_nt", "sp_tn", "stream_f16x2", "x3", "fp32")}
             if e.get("guard"):
                 row["guard_stage"] = e["guard"].get("stage")
             if e.get("host_ms_per_step") is not None:
@@ -403,10 +403,11 @@ def emit(result, workload, write_file=True):
 # --------------------------------------------------------------------------------------------------------------------
 def products_from_counts(c0, c1, steps):
     """tfgnn_launch_counts differences -> launches per step by product family.  ``x3`` = the exact bf16x3 kernels (gemm_x3s /
-    x3p / x3k; ``x3_stream`` is the x3k share), ``fp32`` = gemm_mfma_kernel, ``sp_nt`` / ``sp_tn`` = the split-operand products."""
+    x3p / x3k; ``x3_stream`` is the x3k share), ``stream_f16x2`` = the streaming kernel in the f16x2 arithmetic (3 products, operands
+    split on the fly), ``fp32`` = gemm_mfma_kernel, ``sp_nt`` / ``sp_tn`` = the split-operand products."""
     d = {k: (c1[k] - c0[k]) / float(steps) for k in c1}
-    return {"sp_nt": d["sp_nt"], "sp_tn": d["sp_tn"], "x3": d["gemm_bf16x3"], "x3_stream": d["gemm_stream"], "fp32": d["gemm_fp32"],
-            "gather_sp": d["gather_sp"], "gather": d["gather"]}
+    return {"sp_nt": d["sp_nt"], "sp_tn": d["sp_tn"], "x3": d["gemm_bf16x3"], "stream_f16x2": d["stream_f16x2"],
+            "x3_stream": d["gemm_stream"] - d["stream_f16x2"], "fp32": d["gemm_fp32"], "gather_sp": d["gather_sp"], "gather": d["gather"]}
 
 
 def rccl_info(dist, dev, world):

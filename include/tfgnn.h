@@ -77,7 +77,9 @@ typedef enum {
   TFGNN_KFAM_FUSED_NT = 6,    /* reserved (the gather-producing product was measured and not shipped) */
   TFGNN_KFAM_GEMM_STREAM = 7, /* gemm_x3k_kernel: bf16x3 products with the weight block resident in LDS (short K,
                                  very many rows); every such launch also counts as TFGNN_KFAM_GEMM_BF16X3 */
-  TFGNN_KFAM_COUNT = 8
+  TFGNN_KFAM_STREAM_F16X2 = 8, /* gemm_x3k_kernel in the f16x2 arithmetic (round 6: mode f16x2; 3 products, operands split on the fly);
+                                  such a launch counts here and as TFGNN_KFAM_GEMM_STREAM, NOT as TFGNN_KFAM_GEMM_BF16X3 */
+  TFGNN_KFAM_COUNT = 9
 } tfgnn_kernel_family;
 int tfgnn_launch_counts(int64_t* out_counts, int n);
 

@@ -82,9 +82,9 @@ def launch_counts():
 
     from tf2_gnn_amd import _lib
 
-    buf = (ctypes.c_int64 * 8)()
-    _lib.check(_lib.load().tfgnn_launch_counts(buf, 8))
-    names = ["gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream"]
+    buf = (ctypes.c_int64 * 9)()
+    _lib.check(_lib.load().tfgnn_launch_counts(buf, 9))
+    names = ["gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream", "stream_f16x2"]
     return dict(zip(names, list(buf)))
 
 

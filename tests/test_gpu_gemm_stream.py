@@ -10,7 +10,9 @@ from tests.helpers import KernelsUsed, assert_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bf16x3", "bf16x3_9"])
+# (f16x2, round 6: the same streaming kernel in the f16x2 arithmetic - operands split on the fly into two fp16 pieces under a
+#  power-of-two scale per row of A / column of B, 3 piece products; counted as kernel family stream_f16x2)
+@pytest.fixture(params=["bf16x3", "bf16x3_9", "f16x2"])
 def x3_mode(request):
     from tf2_gnn_amd import ops
 
@@ -76,7 +78,7 @@ def test_streaming_kernel_against_fp64(dev, x3_mode, case):
             ref = ref * dact * (1.0 if mask is None else mask.double())
             if "accumulate" in epi:
                 ref = ref + C_full[:, :N].double()
-    assert k.delta["gemm_stream"] == 1, k.delta
+    assert k.delta["gemm_stream"] == 1 and k.delta["stream_f16x2"] == (1 if x3_mode == "f16x2" else 0), k.delta
     assert res.data_ptr() == out_view.data_ptr()
     scale = max(1.0, 0.2 * float(K) ** 0.5)
     assert_close(res.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"streaming {x3_mode} {case}")
@@ -99,7 +101,8 @@ def test_streaming_kernel_special_values_stay_in_their_rows(dev, x3_mode):
     # inf * b is +inf in fp32; the split evaluation also multiplies inf by b's lower pieces, and where such a piece is exactly
     # zero inf * 0 = nan joins the sum (tests/test_gpu_bf16x3_mode.py): non-finite everywhere, +inf almost everywhere
     assert (~torch.isfinite(out[7])).all()
-    assert (out[7][torch.isinf(out[7])] > 0).all() and float(torch.isnan(out[7]).float().mean()) < 0.2
+    if x3_mode != "f16x2":  # (the round-to-nearest split of f16x2 has lower pieces of either sign: inf * l_b may be -inf, the sum nan)
+        assert (out[7][torch.isinf(out[7])] > 0).all() and float(torch.isnan(out[7]).float().mean()) < 0.2
     assert torch.isnan(out[M - 1]).all()
     assert torch.equal(out[12345], torch.zeros(N))
     keep = torch.ones(M, dtype=torch.bool)
@@ -158,6 +161,7 @@ def test_gathered_rows_product(dev, x3_mode, M, V, K, N, tb, epi):
         res = ops.gemm_gathered(X.to(dev), idx.to(torch.int32).to(dev), B.to(dev), trans_b=tb, bias=None if bias is None else bias.to(dev),
                                 act=act, out=out, accumulate=acc)
     assert k.delta["gemm_stream"] == (1 if streaming else 0), k.delta
+    assert k.delta["stream_f16x2"] == (1 if streaming and x3_mode == "f16x2" else 0), k.delta
     scale = max(1.0, 0.2 * float(K) ** 0.5)
     assert_close(res.cpu() / scale, (ref / scale).float(), tol=1e-5, what=f"gathered product {x3_mode} {(M, V, K, N, tb, epi)}")
 
@@ -185,3 +189,31 @@ def test_gathered_rows_product_reads_an_out_of_range_index_as_a_zero_row(dev, x3
         keep[pos] = False
         assert torch.equal(res[pos].cpu(), torch.zeros(N)), pos
     assert torch.equal(res.cpu()[keep], ref.cpu()[keep])
+
+
+@pytest.mark.parametrize("tb", [False, True])
+def test_streaming_kernel_f16x2_arithmetic_over_wide_dynamic_range(dev, tb):
+    """The f16x2 form scales every ROW of the streamed operand and every COLUMN of the resident one by its own power of two:
+    rows 2^+-30 apart, columns 2^+-20 apart and entries far below their row's maximum must all come out to fp32 accuracy,
+    relative to sum_k |a||b| of the entry (the yardstick of the other split-operand products, tests/test_gpu_gemm_sp.py)."""
+    from tf2_gnn_amd import ops
+
+    M, K, N = 70000, 128, 256
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn((M, K), generator=g) * torch.exp2(torch.randint(-30, 31, (M, 1), generator=g).float())
+    A[:, ::5] *= 2.0 ** -12  # entries far below the row maximum
+    B = torch.randn((N, K) if tb else (K, N), generator=g) * 0.2
+    colscale = torch.exp2(torch.randint(-20, 21, (N,), generator=g).float())
+    B = B * (colscale.unsqueeze(1) if tb else colscale.unsqueeze(0))
+    prev = ops.set_gemm_mode("f16x2")
+    try:
+        with KernelsUsed() as k:
+            out = ops.gemm(A.to(dev), B.to(dev), trans_b=tb).cpu()
+        assert k.delta["stream_f16x2"] == 1, k.delta
+    finally:
+        ops.set_gemm_mode(prev)
+    Bm = B.double().t() if tb else B.double()
+    ref = A.double() @ Bm
+    mag = A.double().abs() @ Bm.abs()
+    err = float(((out.double() - ref).abs() / mag).max())
+    assert err <= 2e-6, err

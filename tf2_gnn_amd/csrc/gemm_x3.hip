@@ -24,11 +24,13 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "sp16.hpp"
 
 namespace tfgnn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
@@ -958,11 +960,22 @@ __device__ __forceinline__ void x3k_request(uint4v (&dst)[3], const unsigned (&a
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(addr[1]), "n"(OFF) : "memory");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(addr[2]), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void x3k_request(uint4v (&dst)[2], const unsigned (&addr)[2]) {  // two planes: the f16x2 form
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(addr[0]), "n"(OFF) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(addr[1]), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void x3k_wait_all_but_3(uint4v (&b)[3]) {  // the three reads of the group BEFORE the last request
   asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2])::"memory");
 }
+__device__ __forceinline__ void x3k_wait_all_but_3(uint4v (&b)[2]) {  // (two planes: all but the last request's two reads)
+  asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b[0]), "+v"(b[1])::"memory");
+}
 __device__ __forceinline__ void x3k_wait_all(uint4v (&b)[3]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2])::"memory");
+}
+__device__ __forceinline__ void x3k_wait_all(uint4v (&b)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1])::"memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void x3k_static_for(F&& f) {
@@ -976,9 +989,18 @@ constexpr int XK_PS = 36;  // row stride (floats) of a wave's 32 x 32 epilogue p
 // MODE: 0 plain epilogue (bias, activation), 1 + gradient factors / accumulate, 2 GRU gate math (three column tiles: z | r | h
 // of 32 units per workgroup; B in the regrouped layout of tfgnn_gemm_gru)
 constexpr int XK_PLAIN = 0, XK_EXTRAS = 1, XK_GRU = 2;
+// NPROD = 3 (round 6): the f16x2 arithmetic of gemm_sp.hip inside this kernel - what mode f16x2 runs for the products that have
+// no split PRODUCER (the per-edge and Dense products of QM9-sized batches: 3 MFMAs per k-step and column tile instead of 6).
+// B is split when the workgroup fills its block: two fp16 planes under one power-of-two scale per column; a lane scales the
+// K / 2 values of its row half by the power of two of the ROW maximum (one exchange with lane ^ 32), splits them into
+// h = fp16(xs), l = fp16(xs - h) and multiplies l_a h_b + h_a l_b + h_a h_b (each product exact in fp32); the two scales leave
+// in the epilogue.  Same error class as the other f16x2 products (gemm_sp.hip: >= 22 significand bits per value); no spread
+// guard is needed - the scales belong to the rows / columns of the RESULT, not to k.
 template <int NPROD, int KS, int MODE>
 __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor, int ncb, int spx) {
   constexpr bool EXTRAS = MODE == XK_EXTRAS;
+  constexpr bool F16 = NPROD == 3;
+  constexpr int NPL = F16 ? 2 : 3;  // operand planes
   constexpr int CT = MODE == XK_GRU ? 3 : 4, COLS = CT * 32;  // column tiles / columns per workgroup
   constexpr int K = KS * 16, ROWB = 2 * K + 16, PLANE_B = COLS * ROWB;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -999,7 +1021,66 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   };
 
   // ---- fill: B[:, n0 .. n0 + 127] -> planes[p][n][k] (bf16, k natural order) ---------------------------------
-  if (!b_kmajor) {  // B given as [N, K] (K-contiguous)
+  float* const lds_f32 = reinterpret_cast<float*>(lds + NPL * PLANE_B);  // [patches 8 x 32 x XK_PS | bias COLS | (F16) col inv COLS | col max COLS]
+  if constexpr (F16) {
+    float* colinv = lds_f32 + XK_WAVES * 32 * XK_PS + COLS;
+    unsigned* colmax = reinterpret_cast<unsigned*>(colinv + COLS);
+    if (tid < COLS) colmax[tid] = 0u;
+    __syncthreads();
+    // column maxima (non-negative floats order like their bit patterns: an LDS atomic maximum, order-free)
+    if (!b_kmajor) {
+      for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
+        const int n = idx / (K / 4), kq = idx - n * (K / 4);
+        const float4 v = *reinterpret_cast<const float4*>(g.B + b_row(n) * g.ldb + kq * 4);
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (!(m == m)) m = __builtin_inff();  // a NaN in the column: no scaling (sp_scale_for_max), the result is NaN anyway
+        atomicMax(colmax + n, __float_as_uint(m));
+      }
+    } else {
+      for (int idx = tid; idx < K * (COLS / 4); idx += XK_NT) {
+        const int k = idx / (COLS / 4), nq = idx - k * (COLS / 4);
+        const float4 v = *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n0 + nq * 4);
+        const float e[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicMax(colmax + nq * 4 + q, __float_as_uint(e[q] == e[q] ? e[q] : __builtin_inff()));
+      }
+    }
+    __syncthreads();
+    if (tid < COLS) {
+      float iv;
+      const float sc = sp_scale_for_max(__uint_as_float(colmax[tid]), &iv);
+      colinv[tid] = iv;
+      colmax[tid] = __float_as_uint(sc);  // from here on: the column's scale
+    }
+    __syncthreads();
+    const float* colscale = reinterpret_cast<const float*>(colmax);
+    if (!b_kmajor) {
+      for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
+        const int n = idx / (K / 4), kq = idx - n * (K / 4);
+        const float4 v = *reinterpret_cast<const float4*>(g.B + b_row(n) * g.ldb + kq * 4);
+        const float sc = colscale[n];
+        _Float16 h[4], l[4];
+        sp_split(v.x * sc, h[0], l[0]); sp_split(v.y * sc, h[1], l[1]); sp_split(v.z * sc, h[2], l[2]); sp_split(v.w * sc, h[3], l[3]);
+        typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<half4v*>(lds + n * ROWB + kq * 8) = half4v{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<half4v*>(lds + PLANE_B + n * ROWB + kq * 8) = half4v{l[0], l[1], l[2], l[3]};
+      }
+    } else {
+      for (int idx = tid; idx < K * (COLS / 4); idx += XK_NT) {
+        const int k = idx / (COLS / 4), nq = idx - k * (COLS / 4);
+        const float4 v = *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n0 + nq * 4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          _Float16 h, l;
+          sp_split(e[q] * colscale[nq * 4 + q], h, l);
+          _Float16* d = reinterpret_cast<_Float16*>(lds + (nq * 4 + q) * ROWB + k * 2);
+          d[0] = h;
+          d[PLANE_B / 2] = l;
+        }
+      }
+    }
+  } else if (!b_kmajor) {  // B given as [N, K] (K-contiguous)
     for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
       const int n = idx / (K / 4), kq = idx - n * (K / 4);
       const float4 v = *reinterpret_cast<const float4*>(g.B + b_row(n) * g.ldb + kq * 4);
@@ -1021,7 +1102,7 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
       }
     }
   }
-  if (g.bias && tid < COLS) reinterpret_cast<float*>(lds + 3 * PLANE_B)[XK_WAVES * 32 * XK_PS + tid] = g.bias[b_row(tid)];
+  if (g.bias && tid < COLS) lds_f32[XK_WAVES * 32 * XK_PS + tid] = g.bias[b_row(tid)];
   __syncthreads();
 
   const int ntiles = (int)((g.M + 31) / 32);  // M * lda < 2^30 (launch site): rows, tiles and blocks fit 32 bits
@@ -1053,16 +1134,17 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   // sits right in front of its MFMAs and the LDS latency is paid 4 K/16 times per tile (the multiply side alone took 198 us
   // of a 320 us kernel, twice the time of its MFMAs).  A request's registers reach the MFMAs through the "+v" operands of the
   // wait, so neither can move above it.
-  unsigned b_addr[3];
+  unsigned b_addr[NPL];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
-  uint4v bq[2][3];
+  for (int p = 0; p < NPL; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
+  uint4v bq[2][NPL];
   auto b_request = [&](auto group_c) {  // group = step * CT + column tile
     constexpr int grp = decltype(group_c)::value;
     x3k_request<(grp % CT) * 32 * ROWB + (grp / CT) * 16>(bq[grp & 1], b_addr);
   };
-  float* patch = reinterpret_cast<float*>(lds + 3 * PLANE_B) + wave * 32 * XK_PS;
-  const float* lds_bias = reinterpret_cast<const float*>(lds + 3 * PLANE_B) + XK_WAVES * 32 * XK_PS;  // [128], filled above
+  float* patch = lds_f32 + wave * 32 * XK_PS;
+  const float* lds_bias = lds_f32 + XK_WAVES * 32 * XK_PS;  // [128], filled above
+  const float* lds_colinv = lds_bias + COLS;                // (F16) 2^-e of the columns
   float4 araw[2 * KS];
   int blk = stream;
   {
@@ -1083,11 +1165,49 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     // requests are pending only inside the step code below (VALU + MFMA, no spill code: the compiler does not know that the
     // registers of an asm read are still in flight - around the epilogue it spilled them and saved the OLD contents)
+    // F16: the power-of-two scale of this lane's row - the maximum over its K / 2 values and, through lane ^ 32, the other half
+    float a_scale = 1.f, a_inv = 1.f;
+    if constexpr (F16) {
+      float mx = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        const float4 v = araw[i];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        bad = bad || !(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w);
+      }
+      if (bad) mx = __builtin_inff();  // a NaN in the row: no scaling, the row is NaN anyway (fmaxf drops NaNs)
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      a_scale = sp_scale_for_max(mx, &a_inv);
+    }
     b_request(std::integral_constant<int, 0>{});
     x3k_static_for<0, KS>([&](auto j_c) {
       constexpr int j = decltype(j_c)::value;
       const float4 x0 = araw[2 * j], x1 = araw[2 * j + 1];
       const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      if constexpr (F16) {
+        half8v ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 hh, ll;
+          sp_split(xs[e] * a_scale, hh, ll);
+          ah[e] = hh;
+          al[e] = ll;
+        }
+        x3k_static_for<0, CT>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value, cur = (j * CT + c) & 1;
+          if constexpr (j * CT + c + 1 < CT * KS) {
+            b_request(std::integral_constant<int, j * CT + c + 1>{});
+            x3k_wait_all_but_3(bq[cur]);
+          } else {
+            x3k_wait_all(bq[cur]);  // last group of the tile: nothing stays pending across the epilogue
+          }
+          const half8v bh = __builtin_bit_cast(half8v, bq[cur][0]), bl = __builtin_bit_cast(half8v, bq[cur][1]);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[c], 0, 0, 0);  // smallest terms first
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[c], 0, 0, 0);
+        });
+      } else {
       unsigned h[8], m[8], l[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) split3(xs[e], h[e], m[e], l[e]);
@@ -1102,9 +1222,11 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
         } else {
           x3k_wait_all(bq[cur]);  // last group of the tile: nothing stays pending across the epilogue
         }
-        acc[c] = mfma_group<NPROD>(acc[c], ah, am, al, __builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, bq[cur][1]),
-                                   __builtin_bit_cast(bf16x8, bq[cur][2]));
+        if constexpr (!F16)
+          acc[c] = mfma_group<NPROD>(acc[c], ah, am, al, __builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, bq[cur][1]),
+                                     __builtin_bit_cast(bf16x8, bq[cur][NPL - 1]));
       });
+      }
       // the next tile's values, one burst of whole 128-byte lines per lane every four steps (with two loads per step a line
       // stays half-read for four steps while the other seven waves push it out of the 32 KB L1)
       if ((j & 3) == 3 || j == KS - 1) {
@@ -1116,6 +1238,17 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
     if (tile >= ntiles) continue;
     // ---- epilogue, straight from the accumulator layout: register r of lane (li, kg) is element
     // (row (r & 3) + 8 (r >> 2) + 4 kg, column li) of its 32 x 32 block ------------------------------------------
+    if constexpr (F16) {  // the two power-of-two scales leave: row r's from the lane that holds row r, the column's from LDS
+      float rf[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rf[r] = __shfl(a_inv, (r & 3) + 8 * (r >> 2) + 4 * kg, 64);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float ci = lds_colinv[c * 32 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] *= rf[r] * ci;
+      }
+    }
     if (g.bias) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -1279,12 +1412,13 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
 template <int NPROD, int MODE>
 static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int spx, dim3 grid, hipStream_t s) {
   constexpr int COLS = MODE == XK_GRU ? 96 : 128;
-  const size_t lds_bytes = (size_t)3 * COLS * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4;
+  constexpr int NPL = NPROD == 3 ? 2 : 3, EXTRA = NPROD == 3 ? 2 * COLS * 4 : 0;  // (f16x2 form: column scales + maxima)
+  const size_t lds_bytes = (size_t)NPL * COLS * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4 + EXTRA;
 #define TFGNN_X3K_CASE(KSV)                                                                                                   \
   case KSV: {                                                                                                                 \
     static const bool raised = [] {                                                                                           \
       (void)hipFuncSetAttribute((const void*)gemm_x3k_kernel<NPROD, KSV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                3 * COLS * (2 * KSV * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4);                       \
+                                NPL * COLS * (2 * KSV * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + COLS * 4 + EXTRA);             \
       return true;                                                                                                            \
     }();                                                                                                                      \
     (void)raised;                                                                                                             \
@@ -1298,6 +1432,14 @@ static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int sp
     default: break;
   }
 #undef TFGNN_X3K_CASE
+}
+
+int gemm_f16x2_mode();
+// mode f16x2 (while its guard has not demoted it): the streaming kernel multiplies in the f16x2 arithmetic, 3 products instead of
+// 6 (TFGNN_X3K_F16=0: the exact bf16x3 form, for A/B runs)
+static bool x3k_f16_arithmetic(int nprod) {
+  static const bool on = [] { const char* e = getenv("TFGNN_X3K_F16"); return !e || atoi(e) != 0; }();
+  return on && nprod == 6 && gemm_f16x2_mode() == 1;
 }
 
 static int64_t x3k_min_rows() {
@@ -1318,12 +1460,16 @@ static int gemm_x3k_try(int nprod, int trans_b, const X3Args& g, hipStream_t s) 
   const int ncb = (int)(g.N / XK_COLS);
   if (ncb > 32) return 0;
   const int spx = 32 / ncb;  // row streams per XCD (32 CUs each)
-  count_launch(TFGNN_KFAM_GEMM_BF16X3);
+  const bool f16 = x3k_f16_arithmetic(nprod);
+  count_launch(f16 ? TFGNN_KFAM_STREAM_F16X2 : TFGNN_KFAM_GEMM_BF16X3);
   count_launch(TFGNN_KFAM_GEMM_STREAM);
   dim3 grid((unsigned)(8 * spx * ncb));
   const bool extras = g.mul || g.saved || g.accumulate;  // the plain forward kernels carry none of that code
   const int ks = (int)(g.K / 16), bkm = trans_b ? 0 : 1;
-  if (nprod >= 9) {
+  if (f16) {
+    if (extras) launch_x3k_ks<3, XK_EXTRAS>(g, ks, bkm, ncb, spx, grid, s);
+    else launch_x3k_ks<3, XK_PLAIN>(g, ks, bkm, ncb, spx, grid, s);
+  } else if (nprod >= 9) {
     if (extras) launch_x3k_ks<9, XK_EXTRAS>(g, ks, bkm, ncb, spx, grid, s);
     else launch_x3k_ks<9, XK_PLAIN>(g, ks, bkm, ncb, spx, grid, s);
   } else {
@@ -1339,10 +1485,12 @@ static int gemm_x3k_gru_try(int nprod, const X3Args& g, hipStream_t s) {
   const int H = g.gru_H;
   if (!on || !x3k_shape_ok(g) || H % 64 || H / 32 > 32 || g.ldc % 4) return 0;
   const int ncb = H / 32, spx = 32 / ncb;
-  count_launch(TFGNN_KFAM_GEMM_BF16X3);
+  const bool f16 = x3k_f16_arithmetic(nprod);
+  count_launch(f16 ? TFGNN_KFAM_STREAM_F16X2 : TFGNN_KFAM_GEMM_BF16X3);
   count_launch(TFGNN_KFAM_GEMM_STREAM);
   dim3 grid((unsigned)(8 * spx * ncb));
-  if (nprod >= 9) launch_x3k_ks<9, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
+  if (f16) launch_x3k_ks<3, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
+  else if (nprod >= 9) launch_x3k_ks<9, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
   else launch_x3k_ks<6, XK_GRU>(g, (int)(g.K / 16), 0, ncb, spx, grid, s);
   return 1;
 }

@@ -687,7 +687,7 @@ def rearm_spread_guard() -> None:
     _lib.load().tfgnn_sp_spread_flag(1)
 
 
-KERNEL_FAMILIES = ("gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream")
+KERNEL_FAMILIES = ("gemm_fp32", "gemm_bf16x3", "sp_nt", "sp_tn", "gather_sp", "gather", "fused_nt", "gemm_stream", "stream_f16x2")
 
 
 def launch_counts() -> dict:
