@@ -707,6 +707,11 @@ def main():
                     help="no device work: spawn / rendezvous (gloo) / sharding / collectives only - the CPU test of the N > 1 launch path")
     args = ap.parse_args()
 
+    if os.environ.get("TFGNN_BENCH_WATCHDOG"):  # debugging aid: every process dumps its Python stacks if it still runs after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["TFGNN_BENCH_WATCHDOG"]), repeat=False, file=sys.stderr)
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
 
@@ -883,6 +888,11 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / nb
+            if world > 1:
+                # every rank must take the SAME decisions here: with --allreduce-grads a step holds a collective, and a rank that
+                # settles one batch earlier than its peer leaves it alone in that collective (round 6: the two-rank test hung
+                # about every other run - one rank at the barrier of timed(), the other in allreduce_gradients of a settle step)
+                dt = parallel.reduce_max(dt, dist, dev)
             ms_guess[0] = 1000.0 * dt
             if trace:
                 print(f"settle batch {i}: {1000 * dt:.3f} ms/step", file=sys.stderr)

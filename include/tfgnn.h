@@ -456,6 +456,14 @@ int tfgnn_activation_backward_mul(int act, const float* d_dy, const float* d_sav
 int tfgnn_gemm_gru(int64_t V, int H, int64_t K, const float* d_x, int64_t ld_x, const float* d_kernel_t,
                    const float* d_bias, const float* d_mh, const float* d_h, float* d_h_new, float* d_gates,
                    void* stream);
+/* tfgnn_gemm_gru2 (round 6; mode f16x2, H = K in {64, 128}, >= 65536 rows: QM9-sized batches): BOTH products of the cell in the
+ * kernel - h' = GRU(x @ kernel + bias[0], h @ recurrent_kernel + bias[1], h) - so that mh [V, 3H] is neither written by a
+ * product of its own nor read back.  Both kernels transposed and regrouped as for tfgnn_gemm_gru (d_recurrent_bias likewise,
+ * nullable).  d_mh_out (nullable, [V, 3H]): only the candidate third (columns 2H .. 3H) is written - all the backward pass
+ * reads of mh (tfgnn_gru_gates_backward*).  TFGNN_ERR_UNSUPPORTED otherwise: callers use tfgnn_gemm + tfgnn_gemm_gru. */
+int tfgnn_gemm_gru2(int64_t V, int H, const float* d_x, int64_t ld_x, const float* d_kernel_t, const float* d_bias,
+                    const float* d_h, const float* d_recurrent_kernel_t, const float* d_recurrent_bias, float* d_h_new,
+                    float* d_gates, float* d_mh_out, void* stream);
 int tfgnn_gru_gates_forward(const float* d_mx, const float* d_mh, const float* d_h, float* d_h_new,
                             float* d_gates, int64_t V, int H, void* stream);
 int tfgnn_gru_gates_backward(const float* d_dh_new, const float* d_gates, const float* d_mh,

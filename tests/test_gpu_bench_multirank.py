@@ -14,11 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(extra):
-    env = dict(os.environ, TFGNN_BENCH_SINGLE_DEVICE="1")
+    # (TFGNN_BENCH_WATCHDOG: every process of a run that is still alive after 100 s dumps its Python stacks to stderr - a hang
+    #  then fails with the place it hangs at instead of a bare timeout)
+    env = dict(os.environ, TFGNN_BENCH_SINGLE_DEVICE="1", TFGNN_BENCH_WATCHDOG="100")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-alt-mode", *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                              "--no-alt-mode", *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode("utf-8", "replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        raise AssertionError("bench.py " + " ".join(extra) + " hung; stacks after 100 s:\n" + err[-6000:])
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout

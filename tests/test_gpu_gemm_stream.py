@@ -217,3 +217,40 @@ def test_streaming_kernel_f16x2_arithmetic_over_wide_dynamic_range(dev, tb):
     mag = A.double().abs() @ Bm.abs()
     err = float(((out.double() - ref).abs() / mag).max())
     assert err <= 2e-6, err
+
+
+@pytest.mark.parametrize("V,H", [(70001, 128), (65536 + 40, 64)])
+def test_gru_cell_with_both_products_in_the_kernel(dev, V, H):
+    """tfgnn_gemm_gru2 (round 6): h' = GRUCell(x, h) with x @ kernel AND h @ recurrent_kernel inside the gate kernel (mode f16x2,
+    QM9-sized row counts) against the fp64 cell ([ext] TF2 GRUCell, reset_after: oracle gru_cell); the gates saved for the
+    backward pass and the one third of mh it reads (the candidate part h U_h + b_h) against fp64 too."""
+    from oracle import tf2gnn_oracle as orc
+    from tf2_gnn_amd import ops
+
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn((V, H), generator=g) * torch.exp2(torch.randint(-6, 7, (V, 1), generator=g).float())
+    h = torch.tanh(torch.randn((V, H), generator=g))
+    kernel = (torch.rand((H, 3 * H), generator=g) * 2 - 1) * (6.0 / (4 * H)) ** 0.5
+    recurrent = torch.linalg.qr(torch.randn((3 * H, H), generator=g))[0].t().contiguous()
+    bias = torch.randn((2, 3 * H), generator=g) * 0.1
+    prev = ops.set_gemm_mode("f16x2")
+    try:
+        with KernelsUsed() as k:
+            res = ops.gemm_gru2(x.to(dev), kernel.to(dev), bias[0].to(dev), h.to(dev), recurrent.to(dev), bias[1].to(dev))
+        assert res is not None and k.delta["stream_f16x2"] == 1 and k.delta["gemm_stream"] == 1, k.delta
+        ops.set_gemm_mode("bf16x3")
+        assert ops.gemm_gru2(x.to(dev), kernel.to(dev), bias[0].to(dev), h.to(dev), recurrent.to(dev), bias[1].to(dev)) is None
+    finally:
+        ops.set_gemm_mode(prev)
+    h_new, gates, mh = (t.cpu() for t in res)
+    x64, h64, k64, r64, b64 = x.double(), h.double(), kernel.double(), recurrent.double(), bias.double()
+    ref = orc.gru_cell(x64, h64, k64, r64, b64)
+    assert_close(h_new, ref.float(), tol=1e-5, what=f"gru2 h' V={V} H={H}")
+    mx, mh64 = x64 @ k64 + b64[0], h64 @ r64 + b64[1]
+    z = torch.sigmoid(mx[:, :H] + mh64[:, :H])
+    r = torch.sigmoid(mx[:, H:2 * H] + mh64[:, H:2 * H])
+    c = torch.tanh(mx[:, 2 * H:] + r * mh64[:, 2 * H:])
+    assert_close(gates[:, :H], z.float(), tol=1e-5, what="gru2 z")
+    assert_close(gates[:, H:2 * H], r.float(), tol=1e-5, what="gru2 r")
+    assert_close(gates[:, 2 * H:], c.float(), tol=1e-5, what="gru2 candidate")
+    assert_close(mh[:, 2 * H:], mh64[:, 2 * H:].float(), tol=1e-5, what="gru2 candidate part of mh")

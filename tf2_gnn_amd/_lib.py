@@ -115,6 +115,8 @@ _SIGNATURES = [
         c_int,
         [c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    ("tfgnn_gemm_gru2", c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
     ("tfgnn_gru_gates_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     (
         "tfgnn_gru_gates_backward",

@@ -430,6 +430,8 @@ int gemm_x3_try_grouped_k(int nprod, int num_groups, const int32_t* group_off, i
 
 int gemm_f16x2_mode();
 void gemm_f16x2_set(int on);
+int gemm_x3_gru2(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t lda, const float* Bt, const float* bias, const float* h,
+                 const float* B2t, const float* bias2, float* h_new, float* gates, float* mh_out, hipStream_t s);
 int gemm_x3_gathered_supported(int nprod, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t a_rows);
 }  // namespace tfgnn
 
@@ -513,6 +515,23 @@ extern "C" int tfgnn_gemm_gru(int64_t V, int H, int64_t K, const float* d_x, int
   TFGNN_REQUIRE(ld_x >= K, "bad leading dimension");
   const int nprod = gemm_x3_mode();
   if (nprod && gemm_x3_gru(nprod, V, H, K, d_x, ld_x, d_kernel_t, d_bias, d_mh, d_h, d_h_new, d_gates, (hipStream_t)stream)) {
+    TFGNN_LAUNCH_CHECK();
+    return TFGNN_OK;
+  }
+  return TFGNN_ERR_UNSUPPORTED;
+}
+
+extern "C" int tfgnn_gemm_gru2(int64_t V, int H, const float* d_x, int64_t ld_x, const float* d_kernel_t, const float* d_bias,
+                               const float* d_h, const float* d_recurrent_kernel_t, const float* d_recurrent_bias, float* d_h_new,
+                               float* d_gates, float* d_mh_out, void* stream) {
+  using namespace tfgnn;
+  TFGNN_REQUIRE(V >= 0 && H >= 0, "negative size");
+  if (V == 0 || H == 0) return TFGNN_OK;
+  TFGNN_REQUIRE(d_x && d_kernel_t && d_h && d_recurrent_kernel_t && d_h_new, "NULL pointer");
+  TFGNN_REQUIRE(ld_x >= H, "bad leading dimension");
+  const int nprod = gemm_x3_mode();
+  if (nprod && gemm_x3_gru2(nprod, V, H, H, d_x, ld_x, d_kernel_t, d_bias, d_h, d_recurrent_kernel_t, d_recurrent_bias, d_h_new, d_gates,
+                            d_mh_out, (hipStream_t)stream)) {
     TFGNN_LAUNCH_CHECK();
     return TFGNN_OK;
   }

@@ -1409,6 +1409,226 @@ __global__ void __launch_bounds__(XK_NT) gemm_x3k_kernel(X3Args g, int b_kmajor,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// GRUCell with BOTH of its products in the kernel (round 6; ggnn.py:84-87): h' = GRU(x W + b_0, h U + b_1, h).
+// The GRU form above still read mh = h U + b_1 - a [V, 3H] tensor another product had written: 3.5 GB per layer at the QM9 size
+// for something that is consumed once.  Here a workgroup keeps the [z | r | h] column blocks of its 32 units of BOTH kernels in
+// LDS (f16x2 planes: 2 x 192 columns x (2 K + 16) bytes = 104 KB at K = 128; the three bf16 planes of the exact form would not
+// fit - this kernel exists in the f16x2 arithmetic only) and a tile of 32 rows is multiplied twice: the rows of x against W
+// (while the rows of h stream into the registers the consumed values leave), then the rows of h against U (while the next
+// tile's x streams in).  The gate math needs of mh only its candidate third: written to the last third of d_mh_out's rows for
+// the backward pass (tfgnn_gru_gates_backward* read nothing else of it).  K = H (GGNN: message width = state width).
+template <int KS>
+__global__ void __launch_bounds__(XK_NT) gemm_x3k_gru2_kernel(X3Args g, const float* __restrict__ B2, const float* __restrict__ bias2,
+                                                             float* __restrict__ mh_out, int ncb, int spx) {
+  constexpr int CT = 3, COLS = 2 * CT * 32;  // 96 columns of W + 96 of U
+  constexpr int K = KS * 16, ROWB = 2 * K + 16, PLANE_B = COLS * ROWB;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned cb = slot % (unsigned)ncb, stream_local = slot / (unsigned)ncb;
+  if ((int)stream_local >= spx) return;
+  const int stream = (int)(stream_local * 8 + xcd), nstreams = spx * 8;
+  // row of the regrouped kernels ([3H, K], blocks of 192 rows = [z 64 | r 64 | h 64] of 64 units) behind column n < 96
+  auto b_row = [&](int n) -> int64_t { return (int64_t)(cb >> 1) * 192 + (n >> 5) * 64 + (cb & 1) * 32 + (n & 31); };
+  float* const lds_f32 = reinterpret_cast<float*>(lds + 2 * PLANE_B);  // [patches | bias 192 | col inv 192 | col max 192]
+  float* lds_bias = lds_f32 + XK_WAVES * 32 * XK_PS;
+  float* colinv = lds_bias + COLS;
+  unsigned* colmax = reinterpret_cast<unsigned*>(colinv + COLS);
+  if (tid < COLS) colmax[tid] = 0u;
+  __syncthreads();
+  for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
+    const int n = idx / (K / 4), kq = idx - n * (K / 4);
+    const float* src = n < 96 ? g.B + b_row(n) * g.ldb : B2 + b_row(n - 96) * (int64_t)K;
+    const float4 v = *reinterpret_cast<const float4*>(src + kq * 4);
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (!(m == m)) m = __builtin_inff();
+    atomicMax(colmax + n, __float_as_uint(m));
+  }
+  __syncthreads();
+  if (tid < COLS) {
+    float iv;
+    const float sc = sp_scale_for_max(__uint_as_float(colmax[tid]), &iv);
+    colinv[tid] = iv;
+    colmax[tid] = __float_as_uint(sc);
+    const float* bsrc = tid < 96 ? g.bias : bias2;
+    lds_bias[tid] = bsrc ? bsrc[b_row(tid < 96 ? tid : tid - 96)] : 0.f;
+  }
+  __syncthreads();
+  {
+    const float* colscale = reinterpret_cast<const float*>(colmax);
+    for (int idx = tid; idx < COLS * (K / 4); idx += XK_NT) {
+      const int n = idx / (K / 4), kq = idx - n * (K / 4);
+      const float* src = n < 96 ? g.B + b_row(n) * g.ldb : B2 + b_row(n - 96) * (int64_t)K;
+      const float4 v = *reinterpret_cast<const float4*>(src + kq * 4);
+      const float sc = colscale[n];
+      _Float16 h[4], l[4];
+      sp_split(v.x * sc, h[0], l[0]); sp_split(v.y * sc, h[1], l[1]); sp_split(v.z * sc, h[2], l[2]); sp_split(v.w * sc, h[3], l[3]);
+      typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<half4v*>(lds + n * ROWB + kq * 8) = half4v{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<half4v*>(lds + PLANE_B + n * ROWB + kq * 8) = half4v{l[0], l[1], l[2], l[3]};
+    }
+  }
+  __syncthreads();
+
+  const int ntiles = (int)((g.M + 31) / 32);
+  const int nblocks = (ntiles + XK_WAVES - 1) / XK_WAVES;
+  const int Mi = (int)g.M;
+  const int H = g.gru_H;
+  const unsigned a_row_bytes = (unsigned)g.lda * 4u, h_row_bytes = (unsigned)H * 4u, lane_bytes = (unsigned)kg * (K / 2) * 4u;
+  auto row_of = [&](int tile) {
+    const int row = tile * 32 + li;
+    return row < Mi ? row : Mi - 1;
+  };
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)(unsigned)(g.M * g.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.gru_h, 0, (int)(unsigned)(g.M * (int64_t)H * 4), 0x00020000);
+  auto a_load = [&](unsigned off, int i) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + i * 16, 0, 0)); };
+  auto h_load = [&](unsigned off, int i) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + i * 16, 0, 0)); };
+  unsigned b_addr[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) b_addr[p] = (unsigned)(uintptr_t)(x3k_lds_void*)lds + p * PLANE_B + li * ROWB + kg * K;
+  uint4v bq[2][2];
+  float* patch = lds_f32 + wave * 32 * XK_PS;
+  float4 araw[2 * KS];
+  int blk = stream;
+  {
+    const int t0 = blk * XK_WAVES + wave;
+    const unsigned ao = __umul24((unsigned)row_of(t0 < ntiles ? t0 : ntiles - 1), a_row_bytes) + lane_bytes;
+#pragma unroll
+    for (int j = 0; j < 2 * KS; ++j) araw[j] = a_load(ao, j);
+  }
+  // one product of the tile: the values in araw against column tiles PH * 3 .. PH * 3 + 2 into acc; the registers a step has
+  // consumed are refilled from the other operand (PH = 0: this tile's rows of h; PH = 1: the next tile's rows of x)
+  auto row_scale = [&](float& inv) {
+    float mx = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) {
+      const float4 v = araw[i];
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      bad = bad || !(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w);
+    }
+    if (bad) mx = __builtin_inff();
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    return sp_scale_for_max(mx, &inv);
+  };
+  for (; blk < nblocks; blk += nstreams) {
+    const int tile = blk * XK_WAVES + wave;
+    int next = (blk + nstreams) * XK_WAVES + wave;
+    if (next >= ntiles) next = ntiles - 1;
+    const unsigned ho = __umul24((unsigned)row_of(tile < ntiles ? tile : ntiles - 1), h_row_bytes) + lane_bytes;
+    const unsigned no = __umul24((unsigned)row_of(next), a_row_bytes) + lane_bytes;
+    floatx16 acc[2][CT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][c][r] = 0.f;
+    float a_inv[2];
+    x3k_static_for<0, 2>([&](auto ph_c) {
+      constexpr int PH = decltype(ph_c)::value;
+      const float a_scale = row_scale(a_inv[PH]);
+      x3k_request<(PH * 96) * ROWB>(bq[0], b_addr);
+      x3k_static_for<0, KS>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        const float4 x0 = araw[2 * j], x1 = araw[2 * j + 1];
+        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        half8v ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 hh, ll;
+          sp_split(xs[e] * a_scale, hh, ll);
+          ah[e] = hh;
+          al[e] = ll;
+        }
+        x3k_static_for<0, CT>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value, grp = j * CT + c, cur = grp & 1;
+          if constexpr (grp + 1 < CT * KS) {
+            constexpr int nxt = grp + 1;
+            x3k_request<(PH * 96 + (nxt % CT) * 32) * ROWB + (nxt / CT) * 16>(bq[nxt & 1], b_addr);
+            x3k_wait_all_but_3(bq[cur]);
+          } else {
+            x3k_wait_all(bq[cur]);
+          }
+          const half8v bh = __builtin_bit_cast(half8v, bq[cur][0]), bl = __builtin_bit_cast(half8v, bq[cur][1]);
+          acc[PH][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[PH][c], 0, 0, 0);
+          acc[PH][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[PH][c], 0, 0, 0);
+          acc[PH][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[PH][c], 0, 0, 0);
+        });
+        if ((j & 3) == 3 || j == KS - 1) {
+#pragma unroll
+          for (int i = 2 * (j & ~3); i <= 2 * j + 1; ++i) araw[i] = PH == 0 ? h_load(ho, i) : a_load(no, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    if (tile >= ntiles) continue;
+    // ---- the two scales and the biases, in the accumulator layout ----
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float rf[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rf[r] = __shfl(a_inv[p], (r & 3) + 8 * (r >> 2) + 4 * kg, 64);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float ci = colinv[p * 96 + c * 32 + li], bias = lds_bias[p * 96 + c * 32 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][c][r] = acc[p][c][r] * (rf[r] * ci) + bias;
+      }
+    }
+    // ---- gate math: a 32 x 32 block through the patch puts four units of one row into a lane ----
+    auto to_rows = [&](const floatx16& a, float4 (&out)[4]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * XK_PS + li] = a[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const float4*>(patch + ((lane >> 3) + 8 * q) * XK_PS + (lane & 7) * 4);
+      __builtin_amdgcn_wave_barrier();
+    };
+    float4 z[4], r[4], t0[4], t1[4];
+    to_rows(acc[0][0], t0);
+    to_rows(acc[1][0], t1);
+#define X3K_SIG(d, a, b) d.x = 1.f / (1.f + expf(-(a.x + b.x))); d.y = 1.f / (1.f + expf(-(a.y + b.y))); \
+                         d.z = 1.f / (1.f + expf(-(a.z + b.z))); d.w = 1.f / (1.f + expf(-(a.w + b.w)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { X3K_SIG(z[q], t0[q], t1[q]) }
+    to_rows(acc[0][1], t0);
+    to_rows(acc[1][1], t1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { X3K_SIG(r[q], t0[q], t1[q]) }
+#undef X3K_SIG
+    to_rows(acc[0][2], t0);  // x_h
+    to_rows(acc[1][2], t1);  // h_h
+    const int64_t unit = (int64_t)cb * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t row = (int64_t)tile * 32 + (lane >> 3) + 8 * q;
+      if (row < g.M) {
+        const float4 hv = *reinterpret_cast<const float4*>(g.gru_h + row * H + unit);
+        const float4 xh = t0[q], hc = t1[q];
+        float4 c, o;
+#define X3K_GRU1(e)                         \
+        c.e = tanhf(xh.e + r[q].e * hc.e);  \
+        o.e = z[q].e * hv.e + (1.f - z[q].e) * c.e;
+        X3K_GRU1(x) X3K_GRU1(y) X3K_GRU1(z) X3K_GRU1(w)
+#undef X3K_GRU1
+        *reinterpret_cast<float4*>(g.C + row * g.ldc + unit) = o;
+        if (g.gru_gates) {
+          float* pg = g.gru_gates + row * 3 * H + unit;
+          *reinterpret_cast<float4*>(pg) = z[q];
+          *reinterpret_cast<float4*>(pg + H) = r[q];
+          *reinterpret_cast<float4*>(pg + 2 * H) = c;
+        }
+        if (mh_out) *reinterpret_cast<float4*>(mh_out + row * 3 * H + 2 * H + unit) = hc;
+      }
+    }
+  }
+}
+
 template <int NPROD, int MODE>
 static void launch_x3k_ks(const X3Args& g, int ks, int b_kmajor, int ncb, int spx, dim3 grid, hipStream_t s) {
   constexpr int COLS = MODE == XK_GRU ? 96 : 128;
@@ -1659,6 +1879,47 @@ int gemm_x3_gru(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t 
   count_launch(TFGNN_KFAM_GEMM_BF16X3);
   if (nprod >= 9) hipLaunchKernelGGL((gemm_x3s_kernel<false, 9, 3, 1>), grid, dim3(X3_NT), 0, s, g);
   else hipLaunchKernelGGL((gemm_x3s_kernel<false, 6, 3, 1>), grid, dim3(X3_NT), 0, s, g);
+  return 1;
+}
+
+// GRUCell with both products in the streaming kernel (gemm_x3k_gru2_kernel): 1 = taken.  Mode f16x2 only, K == H in {64, 128},
+// QM9-sized row counts (x3k_shape_ok).
+int gemm_x3_gru2(int nprod, int64_t M, int H, int64_t K, const float* A, int64_t lda, const float* Bt, const float* bias, const float* h,
+                 const float* B2t, const float* bias2, float* h_new, float* gates, float* mh_out, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("TFGNN_X3_STREAM_GRU2"); return !e || atoi(e) != 0; }();  // 0: A/B probe
+  if (!on || !x3k_f16_arithmetic(nprod) || K != H || (H != 64 && H != 128) || M < 1 || lda % 4 != 0) return 0;
+  for (const void* ptr : {(const void*)A, (const void*)Bt, (const void*)B2t, (const void*)h, (const void*)h_new})
+    if ((uintptr_t)ptr % 16) return 0;
+  if ((bias && (uintptr_t)bias % 16) || (bias2 && (uintptr_t)bias2 % 16) || (gates && (uintptr_t)gates % 16) || (mh_out && (uintptr_t)mh_out % 16))
+    return 0;
+  X3Args g{};
+  g.M = M; g.N = 3 * (int64_t)H; g.K = K; g.A = A; g.lda = lda; g.B = Bt; g.ldb = K; g.C = h_new; g.ldc = H;
+  g.bias = bias; g.act = TFGNN_ACT_NONE; g.splits = 1; g.k_chunk = ceil_div(K, X3_BK) * X3_BK;
+  g.gru_mh = nullptr; g.gru_h = h; g.gru_gates = gates; g.gru_H = H;
+  if (!x3k_shape_ok(g) || M * (int64_t)H >= (1ll << 30) - 2048) return 0;
+  const int ncb = H / 32, spx = 32 / ncb;
+  count_launch(TFGNN_KFAM_STREAM_F16X2);
+  count_launch(TFGNN_KFAM_GEMM_STREAM);
+  dim3 grid((unsigned)(8 * spx * ncb));
+  const int ks = (int)(K / 16);
+  const size_t lds_bytes = (size_t)2 * 192 * (2 * ks * 16 + 16) + XK_WAVES * 32 * XK_PS * 4 + 3 * 192 * 4;
+  if (ks == 8) {
+    static const bool raised = [] {
+      (void)hipFuncSetAttribute((const void*)gemm_x3k_gru2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * 192 * (2 * 128 + 16) + XK_WAVES * 32 * XK_PS * 4 + 3 * 192 * 4);
+      return true;
+    }();
+    (void)raised;
+    hipLaunchKernelGGL((gemm_x3k_gru2_kernel<8>), grid, dim3(XK_NT), lds_bytes, s, g, B2t, bias2, mh_out, ncb, spx);
+  } else {
+    static const bool raised = [] {
+      (void)hipFuncSetAttribute((const void*)gemm_x3k_gru2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * 192 * (2 * 64 + 16) + XK_WAVES * 32 * XK_PS * 4 + 3 * 192 * 4);
+      return true;
+    }();
+    (void)raised;
+    hipLaunchKernelGGL((gemm_x3k_gru2_kernel<4>), grid, dim3(XK_NT), lds_bytes, s, g, B2t, bias2, mh_out, ncb, spx);
+  }
   return 1;
 }
 

@@ -67,6 +67,13 @@ class GGNN(GNN_Edge_MLP):
     def _finish(self, agg, X, ctx, training):
         ru = self._recurrent_unit
         b = ru["bias"].value
+        # round 6 (QM9-sized batches, mode f16x2): both products of the cell inside the gate kernel - mh = h U + b_1 is neither
+        # written by a product of its own nor read back; of it the backward pass needs the candidate third only
+        both = ops.gemm_gru2(agg, ru["kernel"].value, b[0], X, ru["recurrent_kernel"].value, b[1])
+        if both is not None:
+            h_new, gates, mh = both
+            ctx.update({"agg": agg, "mh": mh, "gates": gates, "out": h_new})
+            return h_new
         mh = ops.gemm(X, ru["recurrent_kernel"].value, bias=b[1])
         fused = ops.gemm_gru(agg, ru["kernel"].value, b[0], mh, X)  # mx stays on chip (bf16x3 modes, H % 64 == 0)
         if fused is not None:

@@ -920,6 +920,31 @@ def gemm_gru(x, kernel, bias, mh, h, save_gates: bool = True):
     return h_new, gates
 
 
+def gemm_gru2(x, kernel, bias, h, recurrent_kernel, recurrent_bias):
+    """The whole GRUCell forward in ONE kernel (tfgnn_gemm_gru2): h' = GRU(x @ kernel + bias, h @ recurrent_kernel +
+    recurrent_bias, h) - mh is neither produced by a product of its own nor read back (3.5 GB per layer at the QM9 size).
+    -> (h', gates [V, 3H], mh [V, 3H] of which ONLY the candidate third is written: all the backward pass reads), or None when
+    the library has no such kernel (mode other than f16x2, H not in {64, 128}, fewer than 65536 rows)."""
+    H = h.shape[1]
+    if get_gemm_mode() != GEMM_F16X2 or H not in (64, 128) or kernel.shape[0] != H or h.shape[0] < 65536:
+        return None
+    lib = _lib.load()
+    x, ldx = _rowmajor(x, "x")
+    h = h.contiguous()
+    kt, bp = gru_kernel_regrouped(kernel, bias)
+    rt, rbp = gru_kernel_regrouped(recurrent_kernel, recurrent_bias)
+    V = x.shape[0]
+    h_new = torch.empty_like(h)
+    gates = torch.empty((V, 3 * H), dtype=torch.float32, device=h.device)
+    mh = torch.empty((V, 3 * H), dtype=torch.float32, device=h.device)
+    rc = lib.tfgnn_gemm_gru2(V, H, _ptr(x), ldx, _ptr(kt), _ptr(bp), _ptr(h), _ptr(rt), _ptr(rbp), _ptr(h_new), _ptr(gates), _ptr(mh),
+                             _stream())
+    if rc == -4:
+        return None
+    _lib.check(rc)
+    return h_new, gates, mh
+
+
 def gru_gates_backward(dh_new, gates, mh, h):
     lib = _lib.load()
     V, H = h.shape
