@@ -1262,7 +1262,7 @@ def _pmc_traffic(workload, name):
     if name is None:
         return None, None
     root = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r05", "r04", "r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
+    for tag in ("r06", "r05", "r04", "r03", "r02"):  # the newest collection that has this workload (tools/pmc_collect.sh)
         path = os.path.join(root, "profiles", f"{tag}_pmc_traffic_{workload}.json")
         try:
             with open(path) as f:
