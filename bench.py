@@ -55,7 +55,7 @@ GEMM_MODE_NOTES = {
     "f16x2": "f16x2: the layers' products on pre-split operands - every fp32 value scaled by a power of two per row and split "
     "into two fp16 pieces by round-to-nearest (22+ significand bits), 3 piece products (each exact in fp32), fp32 accumulate "
     "on v_mfma_f32_32x32x16_f16, the gather writes the split operand; fp32 in/out; error vs fp64 measured at or below the "
-    "fp32-MFMA kernel's (profiles/parity_r05.json - every parity check of the suite in this mode, tools/mfma_acc_probe.hip); "
+    "fp32-MFMA kernel's (profiles/parity_r06.json - every parity check of the suite in this mode, tools/mfma_acc_probe.hip); "
     "products without a split producer run as bf16x3; the library default since round 3",
 }
 

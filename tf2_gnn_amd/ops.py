@@ -1791,7 +1791,12 @@ def mp_forward(graph: "Graph", view: int, x: torch.Tensor, W: torch.Tensor, *, r
     a.extra_jobs = ctypes.cast(jobs, ctypes.c_void_p) if jobs is not None else None
     a.num_extra_jobs = njobs
     a.workspace, a.workspace_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
-    _lib.check(lib.tfgnn_mp_forward(ctypes.byref(a), stream))
+    try:
+        _lib.check(lib.tfgnn_mp_forward(ctypes.byref(a), stream))
+    except Exception:
+        if stale:  # the cache holds an operand this call was to fill: forget it
+            notify_weights_changed(W)
+        raise
     del keep
     for then in after:
         then()
@@ -1884,7 +1889,12 @@ def mp_backward(graph: "Graph", d_pre: torch.Tensor, W: torch.Tensor, x_sp: Opti
     a.extra_jobs = ctypes.cast(jobs, ctypes.c_void_p) if jobs is not None else None
     a.num_extra_jobs = njobs
     a.workspace, a.workspace_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
-    _lib.check(lib.tfgnn_mp_backward(ctypes.byref(a), stream))
+    try:
+        _lib.check(lib.tfgnn_mp_backward(ctypes.byref(a), stream))
+    except Exception:
+        if stale:
+            notify_weights_changed(W)
+        raise
     del keep, tn_ws
     for then in after:
         then()
