@@ -7,7 +7,7 @@ WL=${2:-}
 STEPS=${3:-20}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py ${WL:+--workload $WL} --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-mode --no-roofline --no-other-configs > $O/bench.json 2> $O/err.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py ${WL:+--workload $WL} --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-mode --no-roofline --no-other-configs --no-settle > $O/bench.json 2> $O/err.log
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
 python - <<PY
