@@ -28,6 +28,9 @@ def _bench(extra):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
+    # the driver's contract for N > 1 too: the LAST stdout line is the short object, the complete record precedes it
+    last = [l for l in out.stdout.splitlines() if l.strip()][-1]
+    assert last == lines[0] and len(last) < 4096 and any(l.startswith("BENCH_DETAIL {") for l in out.stdout.splitlines())
     return json.loads(lines[0])
 
 
@@ -38,6 +41,10 @@ def test_two_ranks_shard_the_molecule_batch_through_the_hip_path():
     assert sum(two["config"]["edges_per_rank"]) == one["config"]["edges_per_rank"][0]  # the same batch, split by graph
     assert two["value"] > 0 and one["value"] > 0
     assert "all-reduce" in two["config"]["collectives_per_step"]
+    # what the communicator is made of travels in the line (the first real RCCL run will say "nccl" and a version here)
+    assert two["config"]["rccl"]["backend"] == "gloo" and two["config"]["rccl"]["world_size_reported"] == 2
+    assert len(two["config"]["ms_per_step_per_rank"]) == 2 and len(two["config"]["allreduce_ms_per_step_per_rank"]) == 2
+    assert two["config"]["products_per_step"]["gather"] + two["config"]["products_per_step"]["gather_sp"] > 0
 
 
 def test_two_replica_ranks_for_the_single_graph_workload():

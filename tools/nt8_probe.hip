@@ -3,6 +3,7 @@
 //   V0  4 waves x (64 x 160), 7 DMAs per wave and step            = the shipped geometry (yardstick inside this harness)
 //   V1  4 waves x (64 x 160), DMAs issued every OTHER step for two steps: both 64-byte halves of a 128-byte line back to back
 //   V2  8 waves x (32 x 160) (two per SIMD, <= 256 registers), the same pair issue: 7 DMAs per wave every other step
+//   V3  256 x 320 tile, 8 waves x (64 x 160), two per SIMD, accumulators in architectural VGPRs (see below)
 // Plain epilogue (accumulators stored straight from registers) in all three, so only differences between variants and the
 // slope over K (us per k16 step) mean anything.  Results are checked against a host evaluation on sampled entries.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/nt8_probe.hip -o tools/_probe/nt8_probe && tools/_probe/nt8_probe
@@ -226,10 +227,164 @@ __global__ void __launch_bounds__(kThreads<TM>, 1) nt_probe_kernel(Args g) {
 }
 
 
-// (A fourth shape - 256 x 320 tile, 8 waves x 64 x 160 with ONE fragment set, 36 KB per k16 step for twice the flops - was
-//  written and does not build at two waves per SIMD: it needs 160 accumulator registers + ~90 others of the 256 a wave may
-//  have, and hipcc (ROCm 7.2) splits that budget evenly - 128 VGPRs + 128 AGPRs: 712 spilled dwords in the main loop;
-//  amdgpu_num_vgpr(96) makes it 96 + 96 and 1220.  At one wave per SIMD a 256-row tile needs 320 accumulators.  NOTEBOOK 11.)
+// ---------------------------------------------------------------------------------------------------------------------
+// V3: 256 x 320 tile, 8 waves x (64 x 160), two waves per SIMD: ONE fragment set per wave (a wave reads the fragments of a step,
+// waits, multiplies; the other wave of the SIMD fills its gaps), four ring stages of 36 KB.  The weight operand is streamed once
+// per 256 rows: 36 KB per k16 step for twice the flops of the 28 KB of the 128-row tile.  The accumulators are ARCHITECTURAL
+// VGPRs ("+v": gfx950 MFMAs take them) - with AGPR accumulators hipcc splits the 256 registers of a wave evenly (128 + 128) and
+// spills 712 dwords.  With 118 row tiles at M = 30 000 it needs a K split (2 x 118 workgroups) to fill the chip: M = 60 000 at
+// K = 640 times the two halves' main loops (the hand-off of a 328 KB slab per tile comes on top).
+constexpr int BM3 = 256, ROWS3 = BM3 + BN, STG3 = ROWS3 * 64, NST3 = 4, UNITS_A3 = BM3 / 16;
+
+struct Loop3 {
+  half8 (&fa)[2][2];    // [row tile][plane]
+  half8 (&fb)[TNW][2];
+  floatx16 (&acc)[2][TNW];
+  unsigned (&a_addr)[NST3][2], (&b_addr)[NST3][2];
+  unsigned (&voff)[5];
+  unsigned (&ubase)[5];
+  uint4v rs_a, rs_b;
+  unsigned lds_base;
+  int nsteps;
+  __device__ __forceinline__ Loop3(half8 (&fa_)[2][2], half8 (&fb_)[TNW][2], floatx16 (&acc_)[2][TNW], unsigned (&aa)[NST3][2],
+                                   unsigned (&ba)[NST3][2], unsigned (&vo)[5], unsigned (&ub)[5])
+      : fa(fa_), fb(fb_), acc(acc_), a_addr(aa), b_addr(ba), voff(vo), ubase(ub) {}
+  template <int I, int ST>
+  __device__ __forceinline__ void read_one() {
+    if constexpr (I < 4) {
+      constexpr int t = I >> 1, p = I & 1;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[t][p]) : "v"(a_addr[ST][p]), "n"(t * 2048) : "memory");
+    } else {
+      constexpr int c = (I - 4) >> 1, p = (I - 4) & 1;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[c][p]) : "v"(b_addr[ST][p]), "n"(c * 2048) : "memory");
+    }
+  }
+  template <int I, int ST>
+  __device__ __forceinline__ void read_all() {
+    if constexpr (I < 14) {
+      read_one<I, ST>();
+      read_all<I + 1, ST>();
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ void mfma_one() {
+    constexpr int prod = I / (2 * TNW), j = I % (2 * TNW), t = j / TNW, c = j % TNW;
+    constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[t][c]) : "v"(fa[t][pa]), "v"(fb[c][pb]));
+  }
+  template <int J, int ST>
+  __device__ __forceinline__ void dma_one(int tgt) {  // unit J of this wave for step tgt into stage ST
+    const int src_step = tgt < nsteps ? tgt : nsteps - 1;
+    const unsigned m0v = lds_base + (unsigned)(ST * STG3) + ubase[J];
+    const unsigned so = (unsigned)src_step * 64u;
+    if (J < 2)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff[J]), "s"(rs_a), "s"(so) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff[J]), "s"(rs_b), "s"(so) : "memory");
+  }
+  template <int J, int ST>
+  __device__ __forceinline__ void dma_all(int tgt) {
+    if constexpr (J < 5) {
+      dma_one<J, ST>(tgt);
+      dma_all<J + 1, ST>(tgt);
+    }
+  }
+  template <int S, int I>
+  __device__ __forceinline__ void items(int sbase) {
+    if constexpr (I < 30) {
+      mfma_one<I>();
+      if constexpr (I >= 4 && I < 24 && (I - 4) % 4 == 0) dma_one<(I - 4) / 4, ((S + 3) % NST3)>(sbase + S + 3);
+      items<S, I + 1>(sbase);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void step(int sbase) {
+    read_all<0, (S % NST3)>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    items<S, 0>(sbase);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // steps s+2, s+3 may be in flight; s+1 has landed
+    __builtin_amdgcn_s_barrier();
+  }
+  template <int S>
+  __device__ __forceinline__ void steps(int sbase) {
+    if constexpr (S < NST3) {
+      if (sbase + S < nsteps) step<S>(sbase);
+      steps<S + 1>(sbase);
+    }
+  }
+};
+
+__global__ void __launch_bounds__(512, 1) nt_probe_kernel_v3(Args g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t row0 = (int64_t)blockIdx.x * BM3;
+  const int nsteps = g.K >> 4;
+  auto make_rsrc = [](const uint8_t* p, int64_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return uint4v{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+  };
+  const int64_t rows_a = g.M - row0 < BM3 ? g.M - row0 : BM3;
+  half8 r_fa[2][2];
+  half8 r_fb[TNW][2];
+  floatx16 r_acc[2][TNW];
+  unsigned r_aa[NST3][2], r_ba[NST3][2], r_vo[5], r_ub[5];
+  Loop3 L(r_fa, r_fb, r_acc, r_aa, r_ba, r_vo, r_ub);
+  L.rs_a = make_rsrc(g.A + row0 * g.lda, rows_a * g.lda);
+  L.rs_b = make_rsrc(g.B, (int64_t)BN * g.ldb);
+  L.lds_base = (unsigned)(uintptr_t)(lds_void*)lds;
+  L.nsteps = nsteps;
+  const int drow = lane >> 2;
+  const int dq = (lane & 3) ^ ((drow >> 2) & 3);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    // A units 2w, 2w+1; B units: waves 0..3 take 3 (3w .. 3w+2), waves 4..7 take 2 (12 + 2(w-4) ..) and repeat their first one
+    // (a duplicate fetch: 40 instead of 36 KB per step - the probe overstates the traffic of a build that branches instead)
+    int unit;
+    bool is_a = u < 2;
+    if (is_a) unit = 2 * wave + u;
+    else if (wave < 4) unit = 3 * wave + (u - 2);
+    else unit = 12 + 2 * (wave - 4) + ((u - 2) % 2);
+    const int tr = unit * 16 + drow;
+    L.voff[u] = (unsigned)(tr * (is_a ? g.lda : g.ldb) + dq * 16);
+    L.ubase[u] = (unsigned)__builtin_amdgcn_readfirstlane((is_a ? unit : UNITS_A3 + unit) * 1024);
+  }
+  const int fi = lane & 31, kg = lane >> 5;
+  const int sw = (fi >> 2) & 3;
+#pragma unroll
+  for (int st = 0; st < NST3; ++st)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      L.a_addr[st][p] = (unsigned)(st * STG3 + (wm * 64 + fi) * 64 + (((p * 2 + kg) ^ sw) * 16));
+      L.b_addr[st][p] = (unsigned)(st * STG3 + BM3 * 64 + (wn * 32 * TNW + fi) * 64 + (((p * 2 + kg) ^ sw) * 16));
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L.acc[t][c][r] = 0.f;
+  L.dma_all<0, 0>(0);
+  L.dma_all<0, 1>(1);
+  L.dma_all<0, 2>(2);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < nsteps; s += NST3) L.steps<0>(s);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < TNW; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (row < g.M) g.C[row * g.ldc + wn * 32 * TNW + c * 32 + fi] = L.acc[t][c][r];
+      }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 static void pack_sp16(const std::vector<float>& x, int64_t rows, int K, std::vector<uint8_t>& out, int64_t pitch) {
@@ -334,6 +489,17 @@ int main(int argc, char** argv) {
       t[1][ki] = run<2, true>("V1 4 waves x 64x160, pair issue (128-B lines)", a, 40, cA, cB, check);
       t[2][ki] = run<1, true>("V2 8 waves x 32x160, pair issue (128-B lines)", a, 40, cA, cB, check);
     }
+  // V3 (256-row tile): the whole product on 118 workgroups, and the two K halves' main loops as 2 M rows at K = 640 (236 workgroups)
+  {
+    std::vector<float> none;
+    Args a{dA, pitch, dB, pitch, dC, BN, M, 1280};
+    run_kernel(nt_probe_kernel_v3, NST3 * STG3, BM3, 512, "V3 8 waves x 64x160, 256-row tile (M rows)", a, 40, hA, hB, true);
+    for (int rep = 0; rep < 2; ++rep)
+      for (int K : {1280, 640, 160}) {
+        Args b{dA, pitch, dB, pitch, dC, BN, M, K};
+        run_kernel(nt_probe_kernel_v3, NST3 * STG3, BM3, 512, "V3 256-row tile (M rows)", b, 40, none, none, false);
+      }
+  }
   const char* names[3] = {"V0", "V1", "V2"};
   for (int v = 0; v < 3; ++v)
     printf("%s: %.3f us per k16 step (slope K=160..1280), fixed %.1f us; K=1280 launch %.1f us\n", names[v], (t[v][0] - t[v][2]) / 70.0,
