@@ -413,7 +413,7 @@ def products_from_counts(c0, c1, steps):
 def rccl_info(dist, dev, world):
     """What the communicator of an N > 1 run is made of: backend, the world size IT reports, the RCCL
     version torch was built against, the device name.  None at N == 1."""
-    if dist is None or world == 1:
+    if dist is None:
         return None
     info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
             "device": torch.cuda.get_device_name(dev) if dev is not None else "cpu"}
@@ -888,7 +888,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / nb
-            if world > 1:
+            if dist is not None:
                 # every rank must take the SAME decisions here: with --allreduce-grads a step holds a collective, and a rank that
                 # settles one batch earlier than its peer leaves it alone in that collective (round 6: the two-rank test hung
                 # about every other run - one rank at the barrier of timed(), the other in allreduce_gradients of a settle step)
@@ -980,7 +980,7 @@ def main():
                         "the same batch every step (re-bucketed per step; its rows stay warm in the Infinity Cache: the optimistic "
                         "case - see --distinct-batches)"),
             "collectives_per_step": ("1 bucketed all-reduce of the weight gradients (--allreduce-grads)"
-                                     if (args.allreduce_grads and world > 1) else "none (graph-sharded batches / replicas)"),
+                                     if (args.allreduce_grads and dist is not None) else "none (graph-sharded batches / replicas)"),
             "edges_per_rank": gathered[:, 0].tolist(),
             "ms_per_step_per_rank": ms_per_step_per_rank,
             "allreduce_ms_per_step_per_rank": allreduce_ms_per_rank,

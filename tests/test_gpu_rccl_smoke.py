@@ -20,3 +20,22 @@ def test_parallel_helpers_run_on_rccl_with_one_rank():
                          timeout=240)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "backend nccl world 1" in out.stdout and "rccl smoke ok" in out.stdout, out.stdout
+
+
+def test_bench_flow_on_rccl_with_one_rank():
+    """bench.py's N > 1 flow - rank-consistent settle loop, barrier, MAX of the step time, all-gather of the per-rank counts, the
+    per-step gradient all-reduce - with a communicator of ONE rank on the real backend (TFGNN_FORCE_PROCESS_GROUP=1): the line then
+    says which backend and RCCL version carried it."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TFGNN_FORCE_PROCESS_GROUP="1", TFGNN_BENCH_WATCHDOG="150")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TFGNN_BENCH_SINGLE_DEVICE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-alt-mode", "--no-roofline", "--allreduce-grads"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    rccl = line["config"]["rccl"]
+    assert rccl["backend"] == "nccl" and rccl["world_size_reported"] == 1 and rccl["rccl_version"][0].isdigit(), rccl
+    assert "all-reduce" in line["config"]["collectives_per_step"] and len(line["config"]["allreduce_ms_per_step_per_rank"]) == 1

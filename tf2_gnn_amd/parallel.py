@@ -22,7 +22,9 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
     Returns (rank, world_size, dist-or-None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world <= 1:
+    # TFGNN_FORCE_PROCESS_GROUP=1: a communicator of ONE rank - every collective of the N > 1 path then runs through the real
+    # backend on a single-GPU box (tests/test_gpu_rccl_smoke.py: bench.py's whole flow on RCCL)
+    if world <= 1 and os.environ.get("TFGNN_FORCE_PROCESS_GROUP") != "1":
         return rank, 1, None
     import torch.distributed as dist
 
@@ -31,6 +33,9 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("WORLD_SIZE", str(max(world, 1)))
+        os.environ.setdefault("RANK", str(rank))
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = device  # binds the communicator to this rank's GPU at once (no lazy device guess)
@@ -40,7 +45,7 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
             if not kwargs or dist.is_initialized():
                 raise
             dist.init_process_group(backend=backend)  # a torch / RCCL build without eager init: lazy binding
-    return rank, world, dist
+    return rank, max(world, 1), dist
 
 
 def partition_graphs(cost_per_graph: Sequence[int], world_size: int) -> List[List[int]]:
