@@ -190,6 +190,7 @@ struct GatherArgs {
   float* inv_out;          // [rows] 2^-e of every output row (not written when fixed_inv is given)
   const float* fixed_inv;  // nullable: one caller-chosen 2^-e for the whole tensor
   tfgnn_aux_job* combine_job;  // host pointer, nullable: receive the combine pass as a job instead of launching it
+  int multi_code;  // host only: 10 R + U = the short rows go R to a lane group, U edges of each per round (gather_rows_block_multi: 21); 0: one row per group
 };
 
 // scale of one output row from the maximum over its LANES lanes (lanes of one group are contiguous)
@@ -403,6 +404,140 @@ __device__ __forceinline__ void gather_rows_block(const GatherArgs& a, unsigned 
   }
 }
 
+// Short rows (round 6): a lane group takes R rows AT ONCE and walks them side by side, U edges of each per round.  A bucket of
+// a molecule batch holds 0 - 4 edges: with one row per group the chain of dependent loads (row list -> row pointers -> columns
+// -> source rows) is walked once per row with at most its own few source rows in flight at the end - the node-view gathers of
+// the per-edge messages of configs[3] moved 2.3 GB in 0.83 ms (0.35 of the HBM peak) with every CU full of waiting waves.
+// Here the R chains of a group advance together (R x U x VPL 16-byte loads in flight per lane) and loads past the end of a row
+// are not issued (the one-row walk re-reads the row's last edge up to UNROLL - 1 times).  Every row still adds its edges in CSR
+// order with the same arithmetic: results are bit-identical to gather_rows_block.  MODE_SUM, one feature window.
+template <int LPR, int VPL, int VEC, bool SP, int R, int U>
+__device__ __forceinline__ void gather_rows_block_multi(const GatherArgs& a, unsigned row_block) {
+  using V = typename VecT<VEC>::type;
+  constexpr int GROUPS_PER_BLOCK = 256 / LPR;
+  const int tid = threadIdx.x;
+  const int group = tid / LPR;
+  const int gl = tid % LPR;
+  const int64_t nslots = a.short_rows ? a.num_short : a.num_rows;
+  const int64_t slot0 = (int64_t)row_block * (GROUPS_PER_BLOCK * R) + group;  // row r of the group: slot0 + r * GROUPS_PER_BLOCK
+  const int f0 = gl * VEC;
+  bool live[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) live[i] = (f0 + i * LPR * VEC) < a.width;
+  int64_t row[R];
+  bool on[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t slot = slot0 + (int64_t)r * GROUPS_PER_BLOCK;
+    on[r] = slot < nslots;
+    row[r] = on[r] ? (a.short_rows ? (int64_t)a.short_rows[slot] : slot) : 0;
+  }
+  int32_t beg[R], len[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    beg[r] = a.rowptr[row[r]];
+    len[r] = a.rowptr[row[r] + 1] - beg[r];
+  }
+  int64_t orow[R];
+  float rs[R];
+  int32_t maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    orow[r] = a.out_row_map ? (int64_t)a.out_row_map[row[r]] : row[r];
+    rs[r] = a.row_scale ? a.row_scale[row[r]] : 1.f;
+    // (rows of the item kernels; compact output: empty buckets have no row)
+    if ((a.long_threshold > 0 && len[r] > a.long_threshold) || orow[r] < 0) on[r] = false;
+    if (!on[r]) len[r] = 0;
+    maxlen = len[r] > maxlen ? len[r] : maxlen;
+  }
+  float acc[R][VPL][VEC];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[r][i][c] = 0.f;
+
+  for (int32_t j = 0; j < maxlen; j += U) {
+    int32_t idx[R][U];
+    float w[R][U];
+    bool ok[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[r][u] = j + u < len[r];
+        idx[r][u] = 0;
+        w[r][u] = 1.f;
+        if (ok[r][u]) {
+          const int32_t e = beg[r] + j + u;
+          idx[r][u] = a.col[e];
+          if (a.ew) w[r][u] = a.ew[e];
+        }
+      }
+    V v[R][U][VPL];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[r][u]) {
+          const float* src = a.in + (int64_t)idx[r][u] * a.ld_in + f0;
+#pragma unroll
+          for (int i = 0; i < VPL; ++i)
+            if (live[i]) v[r][u][i] = vload<VEC>(src + i * LPR * VEC);
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[r][u]) {
+#pragma unroll
+          for (int i = 0; i < VPL; ++i)
+            if (live[i]) {
+              float x[VEC];
+              vunpack<VEC>(v[r][u][i], x);
+#pragma unroll
+              for (int c = 0; c < VEC; ++c) {
+                float m = w[r][u] * x[c];
+                acc[r][i][c] += m;
+              }
+            }
+        }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!on[r]) continue;
+    if constexpr (SP) {
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          acc[r][i][c] *= rs[r];
+          if (live[i]) mx = fmaxf(mx, fabsf(acc[r][i][c]));
+        }
+      const float sc = sp_row_scale<LPR>(a, mx, orow[r], gl == 0);
+      uint8_t* drow = a.out_sp + orow[r] * a.ld_out_sp;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i)
+        if (live[i])
+          sp_store4(drow, f0 + i * LPR * VEC,
+                    make_float4(acc[r][i][0], acc[r][i][VEC > 1 ? 1 : 0], acc[r][i][VEC > 2 ? 2 : 0], acc[r][i][VEC > 3 ? 3 : 0]), sc);
+    } else {
+      float* dst = a.out + orow[r] * a.ld_out + f0;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i)
+        if (live[i]) {
+          float o[VEC];
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) o[c] = act_apply(a.post_act, acc[r][i][c] * rs[r]);
+          vstore<VEC>(dst + i * LPR * VEC, o);
+        }
+    }
+  }
+}
+
 // one workgroup per item (a run of <= item_chunk_edges edges of a long row)
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 __device__ __forceinline__ void gather_item_block(const GatherArgs& a, int item, unsigned window,
@@ -544,6 +679,24 @@ __global__ void __launch_bounds__(256) csr_gather_reduce_kernel(GatherArgs a, in
     gather_rows_block<LPR, VPL, VEC, UNROLL, MODE, SP>(a, unit - (unsigned)num_items, window);
 }
 
+// the same launch with the short rows R to a lane group (one feature window, plain sums)
+template <int LPR, int VPL, int VEC, int UNROLL, bool SP, int R, int U>
+__global__ void __launch_bounds__(256) csr_gather_reduce_multi_kernel(GatherArgs a, int num_items) {
+  __shared__ float red[256 / LPR][LPR * VPL * VEC];
+  const unsigned unit = blockIdx.x;
+  if ((int)unit < num_items)
+    gather_item_block<LPR, VPL, VEC, UNROLL, MODE_SUM, SP>(a, (int)unit, 0, red);
+  else
+    gather_rows_block_multi<LPR, VPL, VEC, SP, R, U>(a, unit - (unsigned)num_items);
+}
+
+template <int LPR, int VPL, int VEC, int UNROLL, bool SP, int R, int U>
+static void launch_multi(GatherArgs a, int num_items, hipStream_t s) {
+  const unsigned units = (unsigned)(num_items + ceil_div(a.short_rows ? a.num_short : a.num_rows, (256 / LPR) * R));
+  a.total_units = units;
+  hipLaunchKernelGGL((csr_gather_reduce_multi_kernel<LPR, VPL, VEC, UNROLL, SP, R, U>), dim3(units, 1), dim3(256), 0, s, a, num_items);
+}
+
 template <int LPR, int VPL, int VEC, int UNROLL, int MODE, bool SP = false>
 static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   constexpr int GROUPS_PER_BLOCK = 256 / LPR;
@@ -552,13 +705,25 @@ static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
   const unsigned units = (unsigned)(num_items + ceil_div(a.short_rows ? a.num_short : a.num_rows, GROUPS_PER_BLOCK));
   dim3 block(256);
   a.total_units = units;
+  bool multi_done = false;
+  if constexpr (MODE == MODE_SUM && VEC == 4 && LPR * VPL <= 128) {
+    if (a.multi_code > 10 && windows == 1 && (!SP || a.width <= 2048)) {
+      a.xcd_units_pad = 0;
+      multi_done = true;
+      switch (a.multi_code) {
+        case 21: launch_multi<LPR, VPL, VEC, UNROLL, SP, 2, 1>(a, num_items, s); break;
+        default: multi_done = false; break;
+      }
+    }
+  }
   if constexpr (SP) {
     if (windows != 1 || a.width > 2048) {
       set_error("SP16 gather output needs the whole row in one feature window (width %d)", a.width);
       return TFGNN_ERR_UNSUPPORTED;
     }
     a.xcd_units_pad = 0;
-    hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE, true>), dim3(units, 1), block, 0, s, a, num_items);
+    if (!multi_done)
+      hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE, true>), dim3(units, 1), block, 0, s, a, num_items);
     TFGNN_LAUNCH_CHECK();
     if (a.num_multi > 0) {
       if (a.combine_job) {  // the caller launches the combine pass itself, together with other small passes
@@ -570,7 +735,8 @@ static int launch_mode(GatherArgs a, int num_items, hipStream_t s) {
     }
     return TFGNN_OK;
   }
-  if (a.xcd_units_pad && windows > 1) {
+  if (multi_done) {
+  } else if (a.xcd_units_pad && windows > 1) {
     a.xcd_units_pad = (units + 7u) & ~7u;
     hipLaunchKernelGGL((csr_gather_reduce_kernel<LPR, VPL, VEC, UNROLL, MODE>), dim3(a.xcd_units_pad * windows), block, 0, s,
                        a, num_items);
@@ -603,6 +769,9 @@ static int launch_variant(const GatherArgs& a, int mode, int num_items, hipStrea
   }
   return launch_mode<LPR, VPL, VEC, UNROLL, MODE_GENERAL>(a, num_items, s);
 }
+
+// average edges per walked row up to which the short rows go two to a lane group
+constexpr double kMultiAvgLen = 1.5;
 
 static int gather_dispatch(GatherArgs a, int num_items, hipStream_t s) {
   int mode = MODE_SUM;
@@ -768,6 +937,20 @@ static int graph_gather_impl(const tfgnn_graph* g, int view, const int32_t* d_co
     // compact output: the empty buckets have no row, and they close the length-ordered list - no lane groups for them
     // (configs[4]: 452 517 of 6.8 M by-source buckets are non-empty; walking all of them was 0.85 M workgroups with nothing to do)
     if (compact_nz >= 0) a.num_short = std::max<int64_t>(0, (int64_t)p.num_short - (gv.num_rows - compact_nz));
+  }
+  {
+    // short rows side by side (gather_rows_block_multi) when the rows the row workgroups walk hold <= 1.5 edges on average -
+    // the (node, type) buckets of a molecule batch (0.6): tools/gather_short_probe.py, 128k molecules, H = 128: typed by-target
+    // view 1109 -> 948 us, typed by-source view with SP16 output 1257 -> 1132 us with two rows per group and one edge of each
+    // per round; four rows, or two edges per round: 1070 - 1277 / 1156 - 1306 us; a persistent grid (4 - 16 workgroups per CU
+    // walking the units): no better.  The node views (3 edges per row) run at 5.0 - 5.2 TB/s either way and keep one row per
+    // group.  TFGNN_GATHER_MULTI = 1: off; 21: every plain-sum launch (tests)
+    const char* multi_env = getenv("TFGNN_GATHER_MULTI");  // (read per call: the tests compare the two shapes in one process)
+    const int multi_knob = multi_env ? atoi(multi_env) : 0;
+    const int64_t nslots = a.short_rows ? a.num_short : a.num_rows;
+    a.multi_code = 0;
+    if (multi_knob > 10) a.multi_code = multi_knob;
+    else if (multi_knob == 0 && nslots > 0 && !a.is_max && ew_heads == 1 && (double)g->E <= kMultiAvgLen * (double)nslots) a.multi_code = 21;
   }
   count_launch(d_out_sp ? TFGNN_KFAM_GATHER_SP : TFGNN_KFAM_GATHER);
   return gather_dispatch(a, p.num_items, (hipStream_t)stream);
