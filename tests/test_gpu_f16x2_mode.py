@@ -278,19 +278,42 @@ def test_a_tripped_guard_recomputes_the_first_backward_passes_of_a_stack_on_the_
     gnn(inp, training=True)
     gnn.backward(torch.randn((V, H), generator=gen).to(dev))
     assert gnn.guard_tripped_last_backward is False and ops.get_gemm_mode() == ops.GEMM_F16X2
-    # after the warm-up passes a trip is only REPORTED (one pass late) unless the periodic check is on
+    # after the warm-up passes a trip is only REPORTED, one pass late.  Round 6: the next query of the mode then walks the
+    # stack's staged policy one step (ops._f16x2_on -> GNN._on_late_guard_trip) instead of taking the whole mode off the split
+    # operands, re-arms the guard and has the stack's next passes checked synchronously again
+    gnn._guard_sync_passes = 0
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        gnn(inp, training=True)
+        gnn.backward(dOut)  # unchecked: whatever its products report is seen by a later query of the mode, maybe inside the pass
+        torch.cuda.synchronize()
+        assert ops.get_gemm_mode() == ops.GEMM_F16X2
+    assert any("not checked synchronously" in str(x.message) for x in w2)
+    assert _lib.load().tfgnn_sp_spread_flag(0) == 0 and gnn._guard_sync_passes == 3 and gnn.guard_state()["stage"] == "1a"
+    gnn(inp, training=True)
+    gnn.backward(dOut)  # checked again: recomputed stage by stage until nothing trips
+    assert gnn.guard_tripped_last_backward is True
+    for v, b in zip(gnn.trainable_variables, exact):
+        scale = max(float(b.abs().max()), 1e-30)
+        assert float((v.grad - b).abs().max()) / scale <= 1e-5, v.name
+    # the periodic check: every second pass is checked synchronously (and recomputed) whatever the warm-up count says
+    ops.set_gemm_mode("f16x2")
+    gnn(inp, training=True)
+    gnn.backward(torch.randn((V, H), generator=gen).to(dev))  # (a quiet, checked pass: the re-armed stack's policy starts over)
     gnn._guard_sync_passes = 0
     gnn.guard_check_every = 2
+    gnn._backward_passes = 0
+    ops._LATE_TRIP_POLICIES.clear()  # (the periodic check alone: without a staged policy a late trip demotes the mode on sight)
     for i in range(2):
         gnn(inp, training=True)
         gnn.backward(dOut)
-        if i == 0:  # unchecked pass: the flag as it stood when the pass was enqueued
+        if i == 0:
             assert gnn.guard_tripped_last_backward is False
             torch.cuda.synchronize()
             assert _lib.load().tfgnn_sp_spread_flag(0) == 1
             ops.set_gemm_mode("f16x2")  # (the host may or may not have demoted the mode on sight: arm it for the checked pass)
             assert gnn._guard_sync_passes == 0
-    assert gnn.guard_tripped_last_backward is True  # every second pass is checked synchronously and recomputed
+    assert gnn.guard_tripped_last_backward is True
     for v, b in zip(gnn.trainable_variables, exact):
         scale = max(float(b.abs().max()), 1e-30)
         assert float((v.grad - b).abs().max()) / scale <= 1e-5, v.name

@@ -463,8 +463,9 @@ def test_grouped_products_on_split_operands(dev, sizes, H):
 def test_gemm_tn_wide_range_form(dev, K, M, N, sb):
     """tfgnn_sp_gemm_tn_wide (round 5): per-k factors on BOTH operands' fragments.  Same numbers as the one-factor product on
     ordinary operands; with each operand's row scales spread over 2^18 (their products over 2^36 - the one-factor form flags
-    that and loses the small rows) the result stays within 2e-6 of sum |a||b| per entry and the guard stays quiet; a row 2^30
-    below the rest of its operand still trips it.  Also transposed scatter and accumulation."""
+    that and loses the small rows) or one operand's alone over 2^36 (round 6: the two factors share a pair's deficit) the
+    result stays within 2e-6 of sum |a||b| per entry and the guard stays quiet; a row 2^60 below the rest of its operand
+    still trips it.  Also transposed scatter and accumulation."""
     from tf2_gnn_amd import _lib, ops
 
     lib = _lib.load()
@@ -512,8 +513,23 @@ def test_gemm_tn_wide_range_form(dev, K, M, N, sb):
         finally:
             ops.TN_WIDE_MAX_ROWS = keep
         assert float(((out2.cpu().double() - ref).abs() / mag).max()) <= 2e-6
-    # one operand row 2^30 below its neighbours: reported
+    # ONE operand's rows spread over 2^36, the other's over 2^4 (attention-pooled gradients against node states: configs[2] /
+    # configs[3]): the deficit of a pair of rows is split between the two factors (round 6), nothing is lost, the guard is quiet
+    sa36 = torch.exp2(torch.randint(-36, 1, (K, 1), generator=gen).float())
+    a4, b4 = a * sa36, b * torch.exp2(torch.randint(-4, 1, (K, 1), generator=gen).float())
+    a4[2::9] = 0.0
+    assert rel(run(a4, b4), a4, b4) <= 2e-6
+    a5, b5 = a * torch.exp2(torch.randint(-4, 1, (K, 1), generator=gen).float()), b * sa36  # ... and the other way round
+    b5[1::13] = 0.0
+    assert rel(run(a5, b5), a5, b5) <= 2e-6
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 0 and ops.get_gemm_mode() == ops.GEMM_F16X2
+    # a row 2^30 below its neighbours is carried by both factors (2^15 each): still quiet; 2^60 below: reported
     a3 = a.clone()
+    a3[5] *= 2.0 ** -30
+    assert rel(run(a3, b), a3, b) <= 2e-6
+    torch.cuda.synchronize()
+    assert lib.tfgnn_sp_spread_flag(0) == 0
     a3[5] *= 2.0 ** -30
     run(a3, b)
     torch.cuda.synchronize()

@@ -991,10 +991,12 @@ __global__ void __launch_bounds__(1024) sp_tn_factors_kernel(const float* __rest
 // stages are in flight; the ring loses the 1 KB factor slot per stage and wave 0 its extra DMA per step.
 constexpr int SP_TN_FTAB_BYTES = 20480;
 constexpr int64_t SP_TN_FIK_MAX_CHUNK = (SP_TN_FTAB_BYTES / 128 - 2) * 16;  // rows of K per split: one zeroed step + 128 B of scratch
-// BSC (round 5, "wide range"): BOTH operands' fragments are scaled by per-k factors of their own - F_a[b][k] = inv_a[k, b] /
-// max_k inv_a[., b], F_b[k] = inv_b[k] / max_k inv_b - instead of ONE combined factor on the A fragments.  A row keeps >= 16
-// bits while each of its two factors is >= 2^-22, whatever their product is: the scale products of the per-relation weight
+// BSC (round 5, "wide range"): BOTH operands' fragments are scaled by per-k factors - instead of ONE combined factor on the A
+// fragments.  A row keeps >= 16 bits while each of its two factors is >= 2^-22: the scale products of the per-relation weight
 // gradients of an un-normalised RGIN stack spread over 2^25 (2^19 and 2^21 per operand) and trip the combined-factor guard.
+// Round 5 gave each operand its own deficit (F_a[b][k] = inv_a[k, b] / max_k inv_a[., b], F_b[k] = inv_b[k] / max_k inv_b);
+// since round 6 the deficit of the PAIR is split evenly between the two (see the table's computation in the kernel): 2^44 of
+// spread in the scale products of a K range, wherever it comes from.
 // 2 TNW more packed multiplies per fragment set and step; the factor table takes 160 bytes per step (k_chunk <= 2016).
 constexpr int64_t SP_TN_BSC_MAX_CHUNK = (SP_TN_FTAB_BYTES / 160 - 2) * 16;
 template <int TNW, bool FIK, bool BSC = false>
@@ -1328,22 +1330,60 @@ __global__ void __launch_bounds__(SP_NT, 1) gemm_sp_tn_kernel(SpTnArgs g) {
     for (int64_t k = tid; k < kpad; k += SP_NT) {
       const float ib = (k < krows && g.inv_b) ? g.inv_b[k0 + k] : 1.f;
       if constexpr (BSC) {
-        const float fbv = k < krows ? ib * frefb : 0.f;
-        ftab[(k >> 4) * FH + 64 + (k & 15)] = (_Float16)fbv;
-        // a non-zero row of B more than 2^22 below the largest of the range (>= 16 bits are left above that)
-        wide |= k < krows && fbv < 2.384185791015625e-07f && ib > 1.2e-38f;
-      }
+        // BALANCED factors (round 6): what counts is the product F_a[j][k] F_b[k] = 2^-(e_a + e_b), not who carries it.  With
+        // each operand scaled by its OWN deficit a row 2^-25 below its operand's largest loses bits (and trips the guard at
+        // 2^-22) even when the other operand's row needs no scaling at all - the attention-pooled gradients of configs[2] /
+        // configs[3] are spread like that, and their weight gradients went back to the exact bf16x3 kernels.  The deficit of
+        // the pair is split evenly instead: F_b = 2^-floor(e / 2), F_a[j] = 2^-(e_a[j] + e_b - floor(e / 2)) with e = e_b + the
+        // smallest e_a of the tile's non-zero blocks at k - powers of two, exact; a pair 2^-26 below the range's largest keeps
+        // every bit of its high pieces (2^-13 each), the absolute error of a row's term shrinks with the row (<= 2^-25 - e/2
+        // of the largest term: a scaled low piece's rounding times the OTHER, scaled, operand) instead of staying 2^-25, and
+        // the guard's 2^-22 per factor is reached at 2^-44 for the pair.
+        float fa[4], famax = 0.f;
+        bool anz[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float f = 0.f, ia = 0.f;
-        if (j < nb && k < krows) {
-          ia = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j];
-          f = BSC ? ia * fref[j] : ia * ib * fref[j];  // powers of two: exact
+        for (int j = 0; j < 4; ++j) {
+          fa[j] = 0.f;
+          anz[j] = false;
+          if (j < nb && k < krows) {
+            const float ia = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j];
+            fa[j] = ia * fref[j];  // powers of two: exact
+            anz[j] = ia > 1.2e-38f;  // (all-zero rows carry the marker 2^-126)
+            if (anz[j]) famax = fmaxf(famax, fa[j]);
+          }
         }
-        ftab[(k >> 4) * FH + j * 16 + (k & 15)] = (_Float16)f;
-        // the spread guard (see sp_tn_factors_kernel), relative to the largest scale (product) of THIS K range
-        if constexpr (BSC) wide |= j < nb && k < krows && f < 2.384185791015625e-07f && ia > 1.2e-38f;
-        else wide |= sp_row_too_small(f, ia, ib);
+        const bool bnz = k < krows && ib > 1.2e-38f;
+        const float fbv = k < krows ? ib * frefb : 0.f;
+        float fb2 = fbv, up = 1.f;  // up = fbv / fb2: what B hands over to A
+        if (bnz && famax > 0.f) {
+          const unsigned ex = (__float_as_uint(famax * fbv) >> 23) & 0xffu;  // the pair's product 2^(ex - 127) <= 1
+          if (ex > 0u && ex <= 127u) {
+            const unsigned tb = (127u - ex) >> 1;
+            fb2 = __uint_as_float((127u - tb) << 23);
+            up = fbv * __uint_as_float((127u + tb) << 23);
+          }
+        }
+        ftab[(k >> 4) * FH + 64 + (k & 15)] = (_Float16)fb2;
+        // a pair of non-zero rows whose share of the deficit is more than 2^22 (>= 16 bits are left above that)
+        wide |= bnz && famax > 0.f && fb2 < 2.384185791015625e-07f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f = fa[j] * up;
+          ftab[(k >> 4) * FH + j * 16 + (k & 15)] = (_Float16)f;
+          wide |= anz[j] && bnz && f < 2.384185791015625e-07f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f = 0.f, ia = 0.f;
+          if (j < nb && k < krows) {
+            ia = g.inv_a[(k0 + k) * g.a_nblk + blk_first + j];
+            f = ia * ib * fref[j];  // powers of two: exact
+          }
+          ftab[(k >> 4) * FH + j * 16 + (k & 15)] = (_Float16)f;
+          // the spread guard (see sp_tn_factors_kernel), relative to the largest scale (product) of THIS K range
+          wide |= sp_row_too_small(f, ia, ib);
+        }
       }
     }
     if (g.spread_flag && __any(wide) && lane == 0) *g.spread_flag = 1;

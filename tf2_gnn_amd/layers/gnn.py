@@ -112,6 +112,9 @@ class GNN:
         self.guard_check_every = int(ops.env("TFGNN_GUARD_CHECK_EVERY", "0"))
         self.guard_tripped_last_backward: Optional[bool] = None
         self._backward_passes = 0
+        self._unchecked_split_passes = 0  # backward passes in mode f16x2 since the last synchronous check (late trips: below)
+        self._late_trip_pass = -1         # the backward pass whose late trip moved the policy (one step per pass)
+        self._late_trip_hook = ops.register_late_trip_policy(self)
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
         self._dense_demoted_epoch = -1  # ops.REARM_EPOCH at that moment: set_gemm_mode("f16x2") re-arms this stack as well
         self._tn_demoted_epoch = None   # the same for stage 2 (per-relation weight gradients of the message-passing layers)
@@ -475,6 +478,8 @@ class GNN:
                 periodic = False
             if not (was_f16x2 and (self._guard_sync_passes > 0 or periodic)):
                 self.guard_tripped_last_backward = bool(was_f16x2 and ops.f16x2_guard_flag_async())
+                if was_f16x2:
+                    self._unchecked_split_passes += 1
                 return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
             # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
             # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
@@ -489,6 +494,7 @@ class GNN:
             if self._guard_sync_passes > 0:
                 self._guard_sync_passes -= 1
             self.guard_tripped_last_backward = False
+            self._unchecked_split_passes = 0
             with ops.hold_spread_guard():
                 result = self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
                 for attempt in range(4):
@@ -530,6 +536,22 @@ class GNN:
         if self._backward_passes and ops.get_gemm_mode() != ops.GEMM_F16X2:
             stage = "3" if stage != "none" or ops.f16x2_guard_flag_async() else stage
         return {"tripped": self.guard_tripped_last_backward, "stage": stage, "checked_passes_left": self._guard_sync_passes}
+
+    def _on_late_guard_trip(self) -> Optional[str]:
+        """A backward pass that was NOT checked synchronously tripped the spread guard (ops._f16x2_on sees the flag some time
+        later - possibly while that pass is still being enqueued).  Instead of losing the whole mode, a stack that ran such
+        passes walks its staged policy one step - one step per pass, however many of its products report - and has its next
+        passes checked (and recomputed when they trip) again.  -> what changed kernels, None: nothing left / not involved."""
+        if self._unchecked_split_passes == 0:
+            return None
+        if self._late_trip_pass == self._backward_passes:
+            return "(this stack's policy has moved a step for that pass already)"
+        what = self._demote_fragile_weight_gradients()
+        if what:
+            self._late_trip_pass = self._backward_passes
+            self._guard_sync_passes = max(self._guard_sync_passes, self._guard_sync_passes_init)
+            self.guard_tripped_last_backward = True
+        return what
 
     def _demote_fragile_weight_gradients(self) -> Optional[str]:
         """The stages of the spread guard's policy before the whole mode is demoted: the weight-gradient products whose operand

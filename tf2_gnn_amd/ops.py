@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
+import weakref
 import os
 from typing import Optional, Sequence
 
@@ -615,8 +616,28 @@ _spread_warned = [False]
 def _f16x2_on() -> bool:
     """Is the library in mode f16x2 (include/tfgnn.h TFGNN_GEMM_F16X2)?  The library itself holds the mode and demotes it when
     the spread guard of the split weight-gradient product trips (tfgnn_gemm_get_mode); this mirror only warns once."""
-    if _GUARD_HOLD[0] and _f16x2[0]:
+    if (_GUARD_HOLD[0] or _in_late_trip[0]) and _f16x2[0]:
         return True  # a caller that checks the guard synchronously at the end of its pass decides what a trip demotes
+    if _f16x2[0] and env("TFGNN_GUARD_IGNORE", "0") == "1":
+        return True  # PROBING ONLY (what would a workload cost if its products stayed on split operands): results unguarded
+    if _f16x2[0] and _LATE_TRIP_POLICIES and _lib.load().tfgnn_sp_spread_flag(0) and not capturing():
+        # A pass that was not checked synchronously tripped the guard.  Before the library takes the whole mode off the split
+        # operands (tfgnn_gemm_get_mode, sticky), the stacks that ran such passes walk their staged policy one step each
+        # (GNN._on_late_guard_trip: only the weight-gradient products whose operand rows are spread change kernels) and have
+        # their next passes checked synchronously again; the guard is re-armed.  The tripping pass itself is not recomputed.
+        _in_late_trip[0] = True
+        try:
+            handled = [w for w in (fn() for fn in list(_LATE_TRIP_POLICIES.values())) if w]
+            if handled:
+                rearm_spread_guard()
+                import warnings
+
+                warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread beyond the range of the split-operand "
+                              "product that ran, in a pass that was not checked synchronously (its gradients may have lost "
+                              "low-order rows): " + "; ".join(handled) + "; the next passes are checked again")
+                return True
+        finally:
+            _in_late_trip[0] = False
     on = _lib.load().tfgnn_gemm_get_mode() == GEMM_F16X2
     if _f16x2[0] and not on and not _spread_warned[0] and _lib.load().tfgnn_sp_spread_flag(0):
         _spread_warned[0] = True
@@ -653,6 +674,29 @@ def get_gemm_mode() -> int:
 
 
 _GUARD_HOLD = [0]
+_in_late_trip = [False]
+_LATE_TRIP_POLICIES = weakref.WeakValueDictionary()  # id -> bound-method holder of the stacks with a staged guard policy
+
+
+class _LateTripHook:
+    """Keeps a stack's policy callable reachable through a weak dictionary: the hook lives as long as its owner does."""
+
+    def __init__(self, owner):
+        self._owner = weakref.ref(owner)
+
+    def __call__(self):
+        o = self._owner()
+        return o._on_late_guard_trip() if o is not None else None
+
+
+def register_late_trip_policy(owner) -> "_LateTripHook":
+    """``owner._on_late_guard_trip() -> Optional[str]`` is asked when an unchecked pass trips the spread guard (``_f16x2_on``).
+    The caller keeps the returned hook alive (an attribute of the owner)."""
+    hook = _LateTripHook(owner)
+    _LATE_TRIP_POLICIES[id(hook)] = hook
+    return hook
+
+
 REARM_EPOCH = [0]  # times the f16x2 mode was (re-)armed by set_gemm_mode("f16x2")
 
 
