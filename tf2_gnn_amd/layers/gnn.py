@@ -113,6 +113,7 @@ class GNN:
         self.guard_tripped_last_backward: Optional[bool] = None
         self._backward_passes = 0
         self._unchecked_split_passes = 0  # backward passes in mode f16x2 since the last synchronous check (late trips: below)
+        self._unchecked_epoch = -1        # ops.REARM_EPOCH at the last of them
         self._late_trip_pass = -1         # the backward pass whose late trip moved the policy (one step per pass)
         self._late_trip_hook = ops.register_late_trip_policy(self)
         self._dense_split_ok = True  # cleared when the spread guard trips on this stack's Dense products (backward())
@@ -480,6 +481,7 @@ class GNN:
                 self.guard_tripped_last_backward = bool(was_f16x2 and ops.f16x2_guard_flag_async())
                 if was_f16x2:
                     self._unchecked_split_passes += 1
+                    self._unchecked_epoch = ops.REARM_EPOCH[0]
                 return self._backward_walk(ctx, g, g_is_pre, g_last, extras, need_input_grad)
             # The spread guard of the split weight-gradient products reports through a host-visible flag WITHOUT a stream
             # synchronisation: a pass that trips it has produced its gradients by the time the host notices.  For the
@@ -542,8 +544,8 @@ class GNN:
         later - possibly while that pass is still being enqueued).  Instead of losing the whole mode, a stack that ran such
         passes walks its staged policy one step - one step per pass, however many of its products report - and has its next
         passes checked (and recomputed when they trip) again.  -> what changed kernels, None: nothing left / not involved."""
-        if self._unchecked_split_passes == 0:
-            return None
+        if self._unchecked_split_passes == 0 or self._unchecked_epoch != ops.REARM_EPOCH[0]:
+            return None  # (no unchecked pass of this stack since the mode was last armed: somebody else's products)
         if self._late_trip_pass == self._backward_passes:
             return "(this stack's policy has moved a step for that pass already)"
         what = self._demote_fragile_weight_gradients()
