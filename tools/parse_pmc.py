@@ -40,12 +40,14 @@ res = {"calibration": {"known_bytes_each_way": known, "fetch_raw_bytes": cal_f, 
 # traffic keys of bench.py's roofline blocks -> substrings of the kernel name
 NEEDLES = (
     ("gather", ("csr_gather_reduce_kernel", ", 0, false>")), ("gather_sp", ("csr_gather_reduce_kernel", ", 0, true>")),
+    # (round 6: buckets of <= 1.5 edges on average - molecule batches - go two to a lane group: another kernel name)
+    ("gather", ("csr_gather_reduce_multi_kernel", ", false, 2, 1>")), ("gather_sp", ("csr_gather_reduce_multi_kernel", ", true, 2, 1>")),
     ("gather_heads", ("csr_gather_reduce_kernel", ", 1, false>")),
     ("gemm", "gemm_mfma_kernel"), ("gemm_bf16x3", "gemm_x3s_kernel"), ("gemm_bf16x3_pipelined", "gemm_x3p_kernel"),
     ("gemm_sp_nt", "gemm_sp_nt_kernel"), ("gemm_sp_tn", "gemm_sp_tn_kernel"), ("gemm_stream", "gemm_x3k_kernel"),
 )
 for name, needle in NEEDLES:
-    if pick(fetch, needle) is None or pick(write, needle) is None:
+    if pick(fetch, needle) is None or pick(write, needle) is None or name in res:
         continue
     f, w = pick(fetch, needle) * 1024.0, pick(write, needle) * 1024.0
     res[name] = {"kernel": [k for k in fetch if all(n in k for n in ((needle,) if isinstance(needle, str) else needle))][0][:160],

@@ -25,7 +25,7 @@ for wl in "$WLS".split():
                 vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, c in vals.items():
-        if not any(n in k for n in ("gemm_sp_nt_kernel", "gemm_sp_tn_kernel", "gemm_x3", "gemm_mfma_kernel", "csr_gather_reduce_kernel")):
+        if not any(n in k for n in ("gemm_sp_nt_kernel", "gemm_sp_tn_kernel", "gemm_x3", "gemm_mfma_kernel", "csr_gather_reduce_")):
             continue
         e = {n: sum(v) / len(v) for n, v in c.items()}
         if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
