@@ -718,10 +718,12 @@ int tfgnn_sp_gather_rows(const void* d_src_sp, int64_t ld_src_bytes, const float
                          const int32_t* d_index, int64_t rows, int64_t src_rows, int64_t cols, void* d_dst_sp, int64_t ld_dst_bytes,
                          float* d_dst_inv_scale, void* stream);
 
-/* tfgnn_sp_gemm_tn with a WIDER operand range (round 5): both operands' fragments carry per-k factors of their own (inv_a /
- * its maximum over the K range, inv_b / its maximum) instead of one combined factor on A.  A row keeps >= 16 bits while EACH of
- * its two scales lies within 2^22 of the largest of its K range (ranges of <= 2016 rows, factors computed in the kernel), whatever
- * their product is; the spread flag is set beyond that.  For products whose rows are un-normalised sums on both sides (the
+/* tfgnn_sp_gemm_tn with a WIDER operand range (round 5): both operands' fragments carry per-k factors instead of one combined
+ * factor on A.  Round 6: the two factors of row k share the deficit of the PAIR - (inv_a[k] / its maximum over the K range) x
+ * (inv_b[k] / its maximum) = 2^-e is applied as 2^-ceil(e / 2) on A and 2^-floor(e / 2) on B (per scale block of A: the block
+ * with the smallest deficit sets B's share) - so a row pair keeps >= 16 bits while its scale PRODUCT lies within 2^44 of the
+ * largest of its K range (ranges of <= 2016 rows, factors computed in the kernel), whichever operand the spread comes from;
+ * the spread flag is set beyond that (for pairs of non-zero rows).  For products whose rows are un-normalised sums on both sides (the
  * per-relation weight gradients of RGIN at arxiv scale: row scales over 2^19 and 2^21, their products over 2^25 - the combined
  * factor of tfgnn_sp_gemm_tn trips its 2^20 guard there).  Costs 2 (N / 32) packed multiplies more per k16 step (~+25 %) and
  * more K ranges (workspace: tfgnn_sp_gemm_tn_wide_workspace_bytes).  reduce_job non-NULL: the split reduction as a job of
