@@ -112,6 +112,12 @@ struct SpArgs {
   float* ws_partial;    // [tiles][S - 1][4 waves x 2 x TNW x 16 x 64 floats]
   unsigned* ws_flags;   // [tiles][S - 1], zero when the kernel starts (split 0 clears what it consumed)
   int* ws_timeout;      // host-mapped: set to 1 if a reducer gave up waiting (never expected; the result is then wrong)
+  // XCD-aware tile order (round 6, products over several column tiles: N = 512 / 1024).  Workgroup b runs on XCD b % 8; with
+  // the column tile as the fast index the two (four) column tiles of a row tile sat on DIFFERENT XCDs and each fetched the
+  // row tile's A rows over the fabric (counters, configs[4]: 2 132 MB fetched per grouped launch for 927 MB of A).  xcd_per
+  // != 0: tile = (b % 8) * xcd_per + b / 8 - an XCD walks whole row tiles, their column tiles back to back - and workgroups
+  // past xcd_total leave at once (the grid is padded to 8 xcd_per).  Set by launch_sp_nt (never together with ksplit).
+  unsigned xcd_per, xcd_total;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -393,6 +399,10 @@ __global__ void __launch_bounds__(SP_NT, (TNW == 2 ? 2 : 1)) gemm_sp_nt_kernel(S
   const int wm = wave >> 1, wn = wave & 1;
   // K split: the producers (splits S-1 .. 1) take the low block ids - they are dispatched first -, the reducers (split 0) last
   unsigned bid = blockIdx.x;
+  if (g.xcd_per) {
+    bid = (blockIdx.x & 7u) * g.xcd_per + (blockIdx.x >> 3);
+    if (bid >= g.xcd_total) return;  // (the whole workgroup: no barrier has been met)
+  }
   int split = 0;
   int S = g.ksplit;
   if (S > 1) {
@@ -1450,8 +1460,16 @@ static int sp_tn_splits(int64_t M, int64_t N, int64_t K, int bn) {
 }
 
 template <int TNW>
-static void launch_sp_nt(const SpArgs& g, dim3 grid, hipStream_t s) {
+static void launch_sp_nt(const SpArgs& g_in, dim3 grid, hipStream_t s) {
   using G = SpGeo<TNW>;
+  SpArgs g = g_in;
+  g.xcd_per = g.xcd_total = 0;
+  static const bool xcd_order = [] { const char* e = getenv("TFGNN_SP_NT_XCD"); return !(e && atoi(e) == 0); }();
+  if (xcd_order && g.n_tiles > 1 && g.ksplit <= 1 && grid.y == 1 && grid.z == 1 && grid.x >= 16) {
+    g.xcd_total = grid.x;
+    g.xcd_per = (grid.x + 7u) / 8u;
+    grid.x = g.xcd_per * 8u;
+  }
   const bool ablk = g.a_inv && g.a_nblk > 1;
   const bool grad = g.mul || g.saved;
   count_launch(TFGNN_KFAM_SP_NT);

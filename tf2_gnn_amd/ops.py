@@ -620,26 +620,30 @@ def _f16x2_on() -> bool:
         return True  # a caller that checks the guard synchronously at the end of its pass decides what a trip demotes
     if _f16x2[0] and env("TFGNN_GUARD_IGNORE", "0") == "1":
         return True  # PROBING ONLY (what would a workload cost if its products stayed on split operands): results unguarded
-    if _f16x2[0] and _LATE_TRIP_POLICIES and _lib.load().tfgnn_sp_spread_flag(0) and not capturing():
-        # A pass that was not checked synchronously tripped the guard.  Before the library takes the whole mode off the split
-        # operands (tfgnn_gemm_get_mode, sticky), the stacks that ran such passes walk their staged policy one step each
-        # (GNN._on_late_guard_trip: only the weight-gradient products whose operand rows are spread change kernels) and have
-        # their next passes checked synchronously again; the guard is re-armed.  The tripping pass itself is not recomputed.
+    lib = _lib.load()
+    on = lib.tfgnn_gemm_get_mode() == GEMM_F16X2  # (the library takes the mode off - sticky - when it finds the flag up)
+    if _f16x2[0] and not on and _LATE_TRIP_POLICIES and lib.tfgnn_sp_spread_flag(0) and not capturing():
+        # A pass that was not checked synchronously tripped the guard, and the library has just taken the whole mode off the split
+        # operands for it.  If the stacks that ran such passes still have a stage of their policy to give (GNN._on_late_guard_trip:
+        # only the weight-gradient products whose operand rows are spread change kernels, one stage per pass), the mode goes back
+        # on - tfgnn_gemm_set_mode waits for the device and clears the flag - and those stacks' next passes are checked
+        # synchronously again.  The tripping pass itself is not recomputed.  (ONE read of the flag decides - the library's: a
+        # look at the flag here followed by the library's own could straddle the moment the device raises it.)
         _in_late_trip[0] = True
         try:
             handled = [w for w in (fn() for fn in list(_LATE_TRIP_POLICIES.values())) if w]
             if handled:
-                rearm_spread_guard()
+                aux_flush()
+                _lib.check(lib.tfgnn_gemm_set_mode(GEMM_F16X2))
+                on = True
                 import warnings
 
                 warnings.warn("tf2_gnn_amd: operand rows of a weight-gradient product spread beyond the range of the split-operand "
                               "product that ran, in a pass that was not checked synchronously (its gradients may have lost "
                               "low-order rows): " + "; ".join(handled) + "; the next passes are checked again")
-                return True
         finally:
             _in_late_trip[0] = False
-    on = _lib.load().tfgnn_gemm_get_mode() == GEMM_F16X2
-    if _f16x2[0] and not on and not _spread_warned[0] and _lib.load().tfgnn_sp_spread_flag(0):
+    if _f16x2[0] and not on and not _spread_warned[0] and lib.tfgnn_sp_spread_flag(0):
         _spread_warned[0] = True
         import warnings
 
