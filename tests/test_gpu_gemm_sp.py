@@ -858,3 +858,46 @@ def test_two_pass_split_of_a_long_kernel_stack_equals_the_one_pass_split(dev, K,
     out_ref = ops.sp_gemm_nt(a, ref)
     out = ops.sp_gemm_nt(a, ops.sp_split_cols(w, defer=True))
     assert torch.equal(out, out_ref)
+
+
+def test_xcd_aware_tile_order_of_products_over_several_column_tiles_is_bit_identical(dev):
+    """Round 6 (csrc/gemm_sp.hip, SpArgs::xcd_per): products over two or four column tiles (configs[4] N = 512, rgat N = 1024)
+    hand their tiles to the XCDs in whole row tiles - a row tile's column tiles run on ONE XCD instead of each fetching the
+    row tile's A rows over the fabric.  Same tiles, same arithmetic: the result does not depend on the order
+    (TFGNN_SP_NT_XCD=0 restores the old one; the switch is read once per process, hence the two child processes)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import hashlib, torch\n"
+        "from tf2_gnn_amd import ops\n"
+        "dev = torch.device('cuda', 0)\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "h = hashlib.sha256()\n"
+        "for M, N, K in ((3000, 512, 512), (2500, 1024, 256), (130, 512, 96), (4000, 256, 320)):\n"
+        "    a = ops.sp_split_rows(torch.randn((M, K), generator=g).to(dev))\n"
+        "    b = ops.sp_split_rows((torch.randn((N, K), generator=g) * 0.05).to(dev))\n"
+        "    h.update(ops.sp_gemm_nt(a, b, act='relu').cpu().numpy().tobytes())\n"
+        "sizes = [300, 0, 129, 1000, 77]\n"
+        "off = [0]\n"
+        "for n in sizes: off.append(off[-1] + n)\n"
+        "H = 512\n"
+        "X = torch.randn((off[-1], H), generator=g)\n"
+        "W = torch.randn((len(sizes), H, H), generator=g) * 0.05\n"
+        "groups = ops.RowGroups(off, dev)\n"
+        "wt = ops.sp_split_rows(W.transpose(1, 2).contiguous().view(len(sizes) * H, H).to(dev))\n"
+        "y, y_sp = ops.sp_gemm_nt_grouped(ops.sp_split_rows(X.to(dev)), wt, groups, act='relu', want_split=True)\n"
+        "h.update(y.cpu().numpy().tobytes()); h.update(y_sp.data.cpu().numpy().tobytes()); h.update(y_sp.inv_scale.cpu().numpy().tobytes())\n"
+        "print('DIGEST', h.hexdigest())\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for knob in ("0", "1"):
+        env = dict(os.environ, TFGNN_SP_NT_XCD=knob, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        digests.append([ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
+    assert hashlib.sha256(b"").hexdigest() not in digests[0]
